@@ -1,0 +1,48 @@
+"""The C restatement (oracle/vq_ref.c) against fixture G1 and against itself."""
+import numpy as np
+import torch
+
+from conftest import load_golden
+from oracle import nn as O
+from oracle import vq
+
+
+def test_fsq_c_matches_reference_g1():
+    g = load_golden("g1_fsq.npz")
+    levels = g["levels"].tolist()
+    codes, idx = vq.fsq_forward(g["z"], levels)
+    np.testing.assert_array_equal(idx, g["idx"])
+    np.testing.assert_array_equal(codes, g["codes"])
+    np.testing.assert_array_equal(vq.fsq_decode(np.arange(1000), levels), g["decode_all"])
+    g2 = load_golden("g1b_fsq_idx16k.npz")
+    _, idx2 = vq.fsq_forward(g2["z"], levels)
+    np.testing.assert_array_equal(idx2, g2["idx"].astype(np.int32))
+
+
+def test_fsq_is_l2_argmin_over_implicit_codebook():
+    """SURVEY section 8a row Q3 pin (i): on the FSQ grid the generic L2 nearest
+    neighbour search reproduces the FSQ index (away from rounding boundaries)."""
+    g = load_golden("g1_fsq.npz")
+    x = g["bounded_norm"].reshape(-1, 4)
+    idx = vq.l2_argmin(x, g["implicit_codebook"], threads=4)
+    ref = g["idx"].reshape(-1)
+    safe = g["margin"].reshape(-1, 4).min(axis=1) > 1e-4
+    np.testing.assert_array_equal(idx[safe], ref[safe])
+    assert safe.mean() > 0.99
+
+
+def test_l2_argmin_is_a_true_minimiser():
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((300, 64)).astype(np.float32)
+    cb = rng.standard_normal((257, 64)).astype(np.float32)
+    idx, dist = vq.l2_argmin(x, cb, threads=2, return_dist=True)
+    d2 = ((x[:, None, :].astype(np.float64) - cb[None].astype(np.float64)) ** 2).sum(-1)
+    best = d2.min(axis=1)
+    chosen = d2[np.arange(300), idx]
+    assert np.all(chosen <= best * (1 + 1e-5) + 1e-5)
+    # ties -> lowest index
+    cb2 = np.concatenate([cb[:5], cb[:5]], 0)
+    idx2 = vq.l2_argmin(cb[:5], cb2)
+    np.testing.assert_array_equal(idx2, np.arange(5))
+    # thread split does not change the answer
+    np.testing.assert_array_equal(vq.l2_argmin(x, cb, threads=1), idx)
