@@ -1,0 +1,281 @@
+/* mqgan_hip.h - C ABI of libmqgan_hip.so: the MI355X (gfx950) kernels behind the
+ * MQGAN PreEncoder VQ-GAN training / encode / decode hot path.
+ *
+ * The reference (ZDisket/MQGAN) is pure Python on PyTorch and has no FFI of its
+ * own; each entry point below therefore cites the
+ * reference Python code whose arithmetic it replaces, and INTEGRATION.md shows
+ * the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter name ends in _host
+ *   - fp32 activations are channels-last: 1-D maps (B, T, C), 2-D maps (N, H, W, C)
+ *   - frame masks are uint8, (B, T), 1 = padded (the reference's True = padded)
+ *   - `stream` is a hipStream_t (pass 0 for the null stream); calls are
+ *     asynchronous, allocate nothing, and never synchronise, so they can be
+ *     captured into a hipGraph
+ *   - return value: 0 on success, non-zero on failure; mq_last_error() then
+ *     returns a description (thread-local).  Shapes are validated on the host
+ *     before any launch; a rejected call launches nothing.
+ */
+#ifndef MQGAN_HIP_H
+#define MQGAN_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *mqStream; /* hipStream_t */
+
+int mq_abi_version(void);
+const char *mq_last_error(void);
+
+/* ------------------------------------------------------------------ quantiser
+ * FSQ (reference quantizer.py:109-114 bound, :128-140 quantize, :39-42 round_ste,
+ * :177-181 codes_to_indices, :183-205 indices_to_codes).  d <= 8 levels.  The
+ * per-dimension constants are computed on the host as the reference does
+ * (quantizer.py:68-72,111-113,132) and passed by value. */
+typedef struct {
+    int d;
+    int levels[8];
+    int half_width[8];
+    int basis[8];
+    float half_l[8];
+    float offset[8];
+    float shift[8];
+    /* thresh[j][k], k < levels[j]-1: smallest float z for which dimension j quantises to level >= k+1
+     * under the reference arithmetic (found on the host by bisection, mqgan_amd/quantizer.py). */
+    float thresh[8][8];
+} mqFsqDesc;
+
+/* z (n, d) -> codes (n, d) [nullable], idx (n) int32 [nullable] */
+int mq_fsq_forward(const mqFsqDesc *desc_host, const float *z, int64_t n, float *codes, int32_t *idx, mqStream stream);
+/* straight-through gradient: dz = dcodes * half_l * (1 - tanh^2(z + shift)) / half_width */
+int mq_fsq_backward(const mqFsqDesc *desc_host, const float *z, const float *dcodes, int64_t n, float *dz,
+                    mqStream stream);
+/* idx (n) int64 -> codes (n, d) */
+int mq_fsq_decode(const mqFsqDesc *desc_host, const int64_t *idx, int64_t n, float *codes, mqStream stream);
+
+/* Generic L2 nearest neighbour (no reference code, arithmetic
+ * defined in oracle/vq_ref.c): cnorm[k] = fma-chain_d c[k][d]^2; idx[n] = argmin_k
+ * fma(-2, fma-chain_d x[n][d]*c[k][d], cnorm[k]), ties to the lowest k.
+ * Requires d % 4 == 0.  best_dist nullable. */
+int mq_l2_codebook_norms(const float *codebook, int k, int d, float *cnorm, mqStream stream);
+size_t mq_l2_argmin_workspace(int64_t n);
+int mq_l2_argmin(const float *x, const float *codebook, const float *cnorm, int64_t n, int k, int d, int32_t *idx,
+                 float *best_dist, void *workspace, mqStream stream);
+/* codebook EMA update (row Q3, parity unpinned): cluster_size = decay*cluster_size + (1-decay)*count_k;
+ * embed_sum = decay*embed_sum + (1-decay)*sum_{n: idx[n]==k} x[n]; codebook = embed_sum / smoothed(cluster_size).
+ * counts_ws (k + 4) and sums_ws (k*d) are scratch (zeroed by the call). */
+int mq_codebook_ema_update(const float *x, const int32_t *idx, int64_t n, int k, int d, float decay, float eps,
+                           float *cluster_size, float *embed_sum, float *codebook, float *counts_ws, float *sums_ws,
+                           mqStream stream);
+
+/* ------------------------------------------------------------------ convolutions
+ * Implicit-GEMM convolution on f32 MFMA (v_mfma_f32_32x32x2_f32), NHWC.  Replaces
+ * every nn.Conv1d / nn.Conv2d / nn.Linear on the path: ResidualBlock1D convs
+ * (attentions.py:490-495,522), UNetRefiner convs (preencoder.py:51-53,86-130,165),
+ * discriminator convs (discriminators.py:139-167), Linear projections
+ * (preencoder.py:321,334,336,354,356).  1-D convs are H = R = 1; Linear is R = S = 1.
+ *   x  (N, H, W, C)   w (groups, K, R, S, C)   bias (groups, K)   y (N, P, Q, K)
+ * `groups` splits the BATCH (N % groups == 0): images of group g use filter bank g
+ * (this is how the eight independent band discriminators run as one launch,
+ * discriminators.py:280-311).  pad_h/pad_w are the top/left paddings; P, Q are given
+ * explicitly so that causal (left-only) padding is expressible (attentions.py:471-474). */
+typedef struct {
+    int N, H, W, C;
+    int K, R, S;
+    int P, Q;
+    int stride_h, stride_w;
+    int pad_h, pad_w;
+    int dil_h, dil_w;
+    int groups;
+} mqConvDesc;
+
+int mq_conv_fprop(const mqConvDesc *desc_host, const float *x, const float *w_krsc, const float *bias, float *y,
+                  mqStream stream);
+/* dx (N,H,W,C) = conv_transpose(dy (N,P,Q,K)); weights given as (groups, C, R, S, K) */
+int mq_conv_dgrad(const mqConvDesc *desc_host, const float *dy, const float *w_crsk, float *dx, mqStream stream);
+/* dw (groups, K, R, S, C); split-K over pixels with a deterministic slab reduction.
+ * workspace: mq_conv_wgrad_workspace() bytes (may be 0 -> pass NULL). */
+size_t mq_conv_wgrad_workspace(const mqConvDesc *desc_host);
+int mq_conv_wgrad(const mqConvDesc *desc_host, const float *x, const float *dy, float *dw_krsc, void *workspace,
+                  size_t workspace_bytes, mqStream stream);
+/* out[c] = sum_r x[r][c]  (bias gradients; deterministic two-stage).  workspace: 64*cols floats. */
+int mq_colsum(const float *x, int64_t rows, int cols, float *out, float *workspace, mqStream stream);
+
+/* ------------------------------------------------------------------ weight preparation
+ * Effective conv weights, produced in the two layouts the implicit GEMM reads.
+ * mode 0: plain weight  (nn.Linear / nn.Conv*)           w = v
+ * mode 1: weight norm   (torch weight_norm, both APIs)    w = g * v / ||v||_(per out channel)
+ * v is in the reference's layout (K, C, R*S) ; g is (K).  inv_norm (K) is saved for backward. */
+int mq_weight_prep(int mode, const float *v, const float *g, int K, int C, int RS, float *w_krsc, float *w_crsk,
+                   float *inv_norm, mqStream stream);
+/* dw_krsc -> dv (K, C, RS) and, mode 1, dg (K) */
+int mq_weight_prep_bwd(int mode, const float *dw_krsc, const float *v, const float *g, const float *inv_norm, int K,
+                       int C, int RS, float *dv, float *dg, mqStream stream);
+/* Legacy spectral norm (torch.nn.utils.spectral_norm, discriminators.py:139,162):
+ * optional one power iteration (training mode) updating u (K), v (C*RS) in place, then
+ * sigma = u^T W v and w = W / sigma in both layouts.  sigma_out (1).  scratch: K + C*RS floats. */
+int mq_spectral_prep(const float *w_orig, float *u, float *v, int K, int C, int RS, int power_iteration, float eps,
+                     float *w_krsc, float *w_crsk, float *sigma_out, float *scratch, mqStream stream);
+/* dW_orig = dW/sigma - (sum(dW * W_orig) / sigma^2) * u v^T ; scratch: 1 + 256 floats */
+int mq_spectral_prep_bwd(const float *dw_krsc, const float *w_orig, const float *u, const float *v,
+                         const float *sigma, int K, int C, int RS, float *dw_orig, float *scratch, mqStream stream);
+
+/* ------------------------------------------------------------------ fused ConvBlock2D
+ * preencoder.py:277-301 as instantiated at :322,:351: 1-channel C0 x T image ->
+ * weight-normed depthwise 5x5 -> mask -> 1x1 conv 1->C0 -> mask -> APTx(1,1,.5) ->
+ * Dropout(p) -> 1x1 conv C0->1, i.e. per pixel  y = b2 + sum_k w2[k]*drop*aptx(w1[k]*v + b1[k]).
+ * x, y, v, dv: (B, T, C0).  The (B, C0, C0, T) intermediate of the reference is never
+ * materialised.  Padded frames come out as b2 (reference quirk).
+ * wdw: 25 effective depthwise taps [i over channel axis][j over time]; scalars by pointer. */
+typedef struct {
+    const float *wdw;   /* 25 */
+    const float *bdw;   /* 1  */
+    const float *w1;    /* C0 effective point-wise weights */
+    const float *b1;    /* C0 */
+    const float *w2;    /* C0 conv_out weights */
+    const float *b2;    /* 1 */
+} mqCb2dWeights;
+
+int mq_convblock2d_fwd(const mqCb2dWeights *w_host, const float *x, const uint8_t *mask, int B, int T, int C0,
+                       float p_drop, uint64_t seed, float *y, float *v_save, mqStream stream);
+/* grads: dx (B,T,C0); dwdw (25), dbdw (1), dw1 (C0), db1 (C0), dw2 (C0), db2 (1).
+ * workspace bytes: mq_convblock2d_bwd_workspace(B, T, C0). */
+size_t mq_convblock2d_bwd_workspace(int B, int T, int C0);
+int mq_convblock2d_bwd(const mqCb2dWeights *w_host, const float *x, const float *v_save, const float *dy,
+                       const uint8_t *mask, int B, int T, int C0, float p_drop, uint64_t seed, float *dx, float *dwdw,
+                       float *dbdw, float *dw1, float *db1, float *dw2, float *db2, void *workspace, mqStream stream);
+
+/* ------------------------------------------------------------------ pointwise
+ * One fused elementwise pass:  t = h (+ r_pre);  mask_pre: t = 0 on padded frames;
+ * a = act(t);  a = dropout(a);  a += r_post;  mask_post: a = 0 on padded frames.
+ * act: 0 none, 1 APTx (alpha=1; beta, gamma read from device pointers, attentions.py:34-35),
+ * 2 LeakyReLU(0.2) (discriminators.py:170).
+ * rows x C tensors; the frame-mask index of row m is (m / d1) * d2 + (m % d3). */
+typedef struct {
+    int64_t rows;
+    int C;
+    int act;
+    int mask_pre, mask_post;
+    int64_t d1, d2, d3;
+    float p_drop;
+    uint64_t seed;
+} mqPointwiseDesc;
+
+int mq_pointwise_fwd(const mqPointwiseDesc *desc_host, const float *h, const float *r_pre, const float *r_post,
+                     const uint8_t *mask, const float *beta, const float *gamma, float *out, mqStream stream);
+/* dt (gradient wrt h and r_pre), dr_post is dout after mask_post (written to dpost if non-null);
+ * dbeta/dgamma (1 each, nullable) need workspace of 2*1024 floats. */
+int mq_pointwise_bwd(const mqPointwiseDesc *desc_host, const float *dout, const float *h, const float *r_pre,
+                     const uint8_t *mask, const float *beta, const float *gamma, float *dt, float *dpost,
+                     float *dbeta, float *dgamma, float *workspace, mqStream stream);
+
+/* frame masks */
+int mq_sequence_mask(const int32_t *lengths, int B, int T, uint8_t *mask, mqStream stream);           /* preencoder.py:15-24 */
+/* max-pool (padding stays padded) along T with window = stride, optional ceil mode
+ * (preencoder.py:63-65, discriminators.py:223-229); frames past Tin count as `pad_value`. */
+int mq_mask_pool(const uint8_t *in, int B, int Tin, int Tout, int stride, uint8_t *out, mqStream stream);
+int mq_mask_upsample2(const uint8_t *in, int B, int Tin, uint8_t *out, mqStream stream);              /* preencoder.py:68-70 */
+
+/* UNet data movement (preencoder.py:105-130): time-only avg-pool /2, nearest x2 fused with
+ * the channel concat, and their backward passes.  x (N, T, F, C). */
+int mq_avgpool_t2_fwd(const float *x, int N, int T, int F, int C, float *y, mqStream stream);
+int mq_avgpool_t2_bwd(const float *dy, int N, int T, int F, int C, float *dx, mqStream stream);
+/* out (N, 2T, F, C1+C2) = cat(upsample2(x (N,T,F,C1)), skip (N,2T,F,C2)) */
+int mq_upcat_fwd(const float *x, const float *skip, int N, int T, int F, int C1, int C2, float *out, mqStream stream);
+int mq_upcat_bwd(const float *dout, int N, int T, int F, int C1, int C2, float *dx, float *dskip, mqStream stream);
+/* band split for the multi-bin discriminator (discriminators.py:298, 211):
+ * x (B, T, F) -> out (n_bins*B, F/n_bins, T): out[j*B+b][f][t] = x[b][t][j*bs+f]; bwd is the inverse. */
+int mq_band_split_fwd(const float *x, int B, int T, int F, int n_bins, float *out, mqStream stream);
+int mq_band_split_bwd(const float *dout, int B, int T, int F, int n_bins, float *dx, mqStream stream);
+/* y[r][0:C1] = a[r], y[r][C1:C1+C2] = b[r] */
+int mq_concat2(const float *a, const float *b, int64_t rows, int C1, int C2, float *y, mqStream stream);
+int mq_axpby(const float *a, const float *b, float alpha, float beta_, int64_t n, float *out, mqStream stream);
+
+/* ------------------------------------------------------------------ CBAM1D / SE
+ * attentions.py:217-273, 310-365, 393-419 incl. the no-op-mask quirk. */
+/* per (b, c): max over ALL t (with argmax), mean over VALID t.  x (B, T, C). */
+int mq_cam_pool(const float *x, const uint8_t *mask, int B, int T, int C, float *maxv, int32_t *argmax_t, float *avgv,
+                mqStream stream);
+/* gate (B, C) = sigmoid(a + b) */
+int mq_sigmoid_add(const float *a, const float *b, int64_t n, float *out, mqStream stream);
+/* da = dout * out * (1 - out) */
+int mq_sigmoid_add_bwd(const float *dout, const float *out, int64_t n, float *da, mqStream stream);
+int mq_relu_fwd(const float *x, int64_t n, float *y, mqStream stream);
+int mq_relu_bwd(const float *dy, const float *y, int64_t n, float *dx, mqStream stream);
+/* SAM: feat (B, T, 2) = [max_c, mean_c] of gate*x, with arg-max channel */
+int mq_sam_pool(const float *x, const float *gate, int B, int T, int C, float *feat, int32_t *argmax_c,
+                mqStream stream);
+/* s = sigmoid(conv_k7(feat)) ; out = s*gate*x + x.  w7: (2, ks) as in Conv1d(2,1,ks).weight[0] */
+int mq_sam_apply(const float *x, const float *gate, const float *feat, const float *w7, int ks, int B, int T, int C,
+                 float *s_save, float *out, mqStream stream);
+/* backward of the whole CBAM given dout: produces dx (B,T,C), dgate (B,C), dw7 (2*ks).
+ * workspace: mq_cbam_bwd_workspace bytes */
+size_t mq_cbam_bwd_workspace(int B, int T, int C, int ks);
+int mq_cbam_bwd(const float *dout, const float *x, const float *gate, const float *feat, const int32_t *argmax_c,
+                const float *s_save, const float *w7, int ks, int B, int T, int C, float *dx, float *dgate, float *dw7,
+                void *workspace, mqStream stream);
+/* (dgate then flows through mq_sigmoid_add_bwd and the two MLP linears back to dmax / davg)
+ * adds the pooling gradients into dx: dx[b, argmax_t[b,c], c] += dmax[b,c]; dx[b,t,c] += davg[b,c]/count_b (valid t) */
+int mq_cam_pool_bwd(const float *dmax, const float *davg, const int32_t *argmax_t, const uint8_t *mask, int B, int T,
+                    int C, float *dx, mqStream stream);
+
+/* masked SE (discriminators.py:40-67): squeeze (B, C) = sum over valid (h, w) / max(count, 1).
+ * x (B, H, W, C); the padded mask is per (b, w) (time on W). */
+int mq_se_squeeze(const float *x, const uint8_t *mask, int B, int H, int W, int C, float *squeeze, mqStream stream);
+int mq_se_scale_fwd(const float *x, const float *excite, int B, int HW, int C, float *y, mqStream stream);
+/* dx = dy*excite ; dexcite (B,C) = sum_p dy*x.  mq_se_squeeze_bwd then ADDS dsq[b,c]/count on valid pixels. */
+int mq_se_scale_bwd(const float *dy, const float *x, const float *excite, int B, int HW, int C, float *dx,
+                    float *dexcite, mqStream stream);
+int mq_se_squeeze_bwd(const float *dsq, const uint8_t *mask, int B, int H, int W, int C, float *dx_accum,
+                      mqStream stream);
+
+/* ------------------------------------------------------------------ losses
+ * MaskedMelLoss("mse") (losses.py:146-182): loss = mean_g( sum_g / (count_g + 1e-12) ), for
+ * group sizes g1 and g2 at once: out[0] = loss(g1), out[1] = loss(g2).  x, y (B, T, C). */
+/* workspace: 64*C floats */
+int mq_mel_loss_fwd(const float *x, const float *y, const int32_t *lengths, int B, int T, int C, int g1, int g2,
+                    float *out2, float *workspace, mqStream stream);
+/* dx = (w1 * dloss(g1) + w2 * dloss(g2)) * gout[0] */
+int mq_mel_loss_bwd(const float *x, const float *y, const int32_t *lengths, int B, int T, int C, int g1, int g2,
+                    float w1, float w2, const float *gout, float *dx, mqStream stream);
+/* LSGANLoss (losses.py:5-116).  Logits are single-channel maps (B, H, W); `padded` is the
+ * discriminator's padded-patch mask (B, W), 1 = padded (constant along H); the loss mask is its
+ * complement, as train.py:385,395 passes it.  state (4 floats): ema_real, ema_fake, initialised
+ * flag, unused - one state is shared by all nine discriminators (train.py:216).
+ * discriminator_loss: out[0] = 0.5*(mse(real,1)+mse(fake,0)) + lecam, EMA updated first.
+ * saved: 4 floats kept for backward. */
+int mq_lsgan_d_fwd(const float *real, const float *fake, const uint8_t *padded, int B, int H, int W, float decay,
+                   float *state, float *out, float *saved, mqStream stream);
+int mq_lsgan_d_bwd(const float *real, const float *fake, const uint8_t *padded, int B, int H, int W, const float *saved,
+                   const float *gout, float *dreal, float *dfake, mqStream stream);
+int mq_lsgan_g_fwd(const float *fake, const uint8_t *padded, int B, int H, int W, float *out, float *saved,
+                   mqStream stream);
+int mq_lsgan_g_bwd(const float *fake, const uint8_t *padded, int B, int H, int W, const float *saved, const float *gout,
+                   float *dfake, mqStream stream);
+/* masked_mae (train.py:38-45): pred/target (B, H, W, C), padded mask (B, W).  out2: [loss, valid count];
+ * workspace: 512 floats. */
+int mq_masked_mae_fwd(const float *pred, const float *target, const uint8_t *padded, int B, int H, int W, int C,
+                      float *out2, float *workspace, mqStream stream);
+int mq_masked_mae_bwd(const float *pred, const float *target, const uint8_t *padded, int B, int H, int W, int C,
+                      const float *out2, const float *gout, float *dpred, mqStream stream);
+
+/* ------------------------------------------------------------------ optimiser
+ * clip_grad_norm_ + Adam on flat arenas (train.py:401-407,485-492; torch.optim.Adam
+ * defaults eps=1e-8, no weight decay, no amsgrad).
+ * mq_sumsq: out[0] = sum g^2 (deterministic two-stage; workspace 1024 floats). */
+int mq_sumsq(const float *g, int64_t n, float *out, float *workspace, mqStream stream);
+/* clip coefficient read on device: coef = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)); max_norm <= 0 disables.
+ * step_host is the 1-based Adam step.  grad_scale multiplies the gradients first (1 / world size after a
+ * SUM all-reduce; 1 otherwise); sumsq is the squared norm of the UNSCALED arena. */
+int mq_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, double lr, double beta1,
+                 double beta2, double eps, int step_host, const float *sumsq, float max_norm, float grad_scale,
+                 mqStream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MQGAN_HIP_H */

@@ -1,0 +1,151 @@
+"""ctypes binding of libmqgan_hip.so (C ABI: include/mqgan_hip.h).
+
+There is no CPU fallback: if the library is missing, or a tensor is not a
+contiguous fp32/int HIP tensor, the call raises.  PyTorch only supplies device
+memory and the current HIP stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmqgan_hip.so")
+_lib = None
+
+
+class MqganHipError(RuntimeError):
+    pass
+
+
+class FsqDesc(C.Structure):
+    _fields_ = [("d", C.c_int), ("levels", C.c_int * 8), ("half_width", C.c_int * 8), ("basis", C.c_int * 8),
+                ("half_l", C.c_float * 8), ("offset", C.c_float * 8), ("shift", C.c_float * 8),
+                ("thresh", (C.c_float * 8) * 8)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("N", "H", "W", "C", "K", "R", "S", "P", "Q", "stride_h", "stride_w", "pad_h",
+                                       "pad_w", "dil_h", "dil_w", "groups")]
+
+
+class Cb2dWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("wdw", "bdw", "w1", "b1", "w2", "b2")]
+
+
+class PointwiseDesc(C.Structure):
+    _fields_ = [("rows", C.c_int64), ("C", C.c_int), ("act", C.c_int), ("mask_pre", C.c_int), ("mask_post", C.c_int),
+                ("d1", C.c_int64), ("d2", C.c_int64), ("d3", C.c_int64), ("p_drop", C.c_float), ("seed", C.c_uint64)]
+
+
+_P, _I, _L, _F, _D, _Z, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t, C.c_uint64
+
+# name -> (restype, argtypes); every symbol declared in include/mqgan_hip.h
+SIGNATURES = {
+    "mq_abi_version": (C.c_int, []),
+    "mq_last_error": (C.c_char_p, []),
+    "mq_fsq_forward": (_I, [C.POINTER(FsqDesc), _P, _L, _P, _P, _P]),
+    "mq_fsq_backward": (_I, [C.POINTER(FsqDesc), _P, _P, _L, _P, _P]),
+    "mq_fsq_decode": (_I, [C.POINTER(FsqDesc), _P, _L, _P, _P]),
+    "mq_l2_codebook_norms": (_I, [_P, _I, _I, _P, _P]),
+    "mq_l2_argmin_workspace": (_Z, [_L]),
+    "mq_l2_argmin": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _P]),
+    "mq_codebook_ema_update": (_I, [_P, _P, _L, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P]),
+    "mq_conv_fprop": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
+    "mq_conv_dgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
+    "mq_conv_wgrad_workspace": (_Z, [C.POINTER(ConvDesc)]),
+    "mq_conv_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _Z, _P]),
+    "mq_colsum": (_I, [_P, _L, _I, _P, _P, _P]),
+    "mq_weight_prep": (_I, [_I, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "mq_weight_prep_bwd": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "mq_spectral_prep": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P]),
+    "mq_spectral_prep_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "mq_convblock2d_fwd": (_I, [C.POINTER(Cb2dWeights), _P, _P, _I, _I, _I, _F, _U64, _P, _P, _P]),
+    "mq_convblock2d_bwd_workspace": (_Z, [_I, _I, _I]),
+    "mq_convblock2d_bwd": (_I, [C.POINTER(Cb2dWeights), _P, _P, _P, _P, _I, _I, _I, _F, _U64, _P, _P, _P, _P, _P, _P, _P,
+                                _P, _P]),
+    "mq_pointwise_fwd": (_I, [C.POINTER(PointwiseDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mq_pointwise_bwd": (_I, [C.POINTER(PointwiseDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mq_sequence_mask": (_I, [_P, _I, _I, _P, _P]),
+    "mq_mask_pool": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "mq_mask_upsample2": (_I, [_P, _I, _I, _P, _P]),
+    "mq_avgpool_t2_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "mq_avgpool_t2_bwd": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "mq_upcat_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "mq_upcat_bwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "mq_band_split_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "mq_band_split_bwd": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "mq_concat2": (_I, [_P, _P, _L, _I, _I, _P, _P]),
+    "mq_axpby": (_I, [_P, _P, _F, _F, _L, _P, _P]),
+    "mq_cam_pool": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "mq_sigmoid_add": (_I, [_P, _P, _L, _P, _P]),
+    "mq_sigmoid_add_bwd": (_I, [_P, _P, _L, _P, _P]),
+    "mq_relu_fwd": (_I, [_P, _L, _P, _P]),
+    "mq_relu_bwd": (_I, [_P, _P, _L, _P, _P]),
+    "mq_sam_pool": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
+    "mq_sam_apply": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "mq_cbam_bwd_workspace": (_Z, [_I, _I, _I, _I]),
+    "mq_cbam_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "mq_cam_pool_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "mq_se_squeeze": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "mq_se_scale_fwd": (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    "mq_se_scale_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "mq_se_squeeze_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "mq_mel_loss_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "mq_mel_loss_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P]),
+    "mq_lsgan_d_fwd": (_I, [_P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P]),
+    "mq_lsgan_d_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "mq_lsgan_g_fwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
+    "mq_lsgan_g_bwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "mq_masked_mae_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "mq_masked_mae_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "mq_sumsq": (_I, [_P, _L, _P, _P, _P]),
+    "mq_adam_step": (_I, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _I, _P, _F, _F, _P]),
+}
+
+
+def load():
+    """Load the shared library (once) and type every entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MqganHipError(
+            f"{LIB_PATH} not found: the HIP kernels are not built.  Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or `make -C mqgan_amd/csrc`).  mqgan_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().mq_last_error().decode("utf-8", "replace")
+        raise MqganHipError(f"{what}: {msg}" if what else msg)
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, dtype=None, allow_none=False):
+    """Device pointer of a contiguous HIP tensor (validated)."""
+    if t is None:
+        if allow_none:
+            return C.c_void_p(0)
+        raise MqganHipError("required tensor is None")
+    if not t.is_cuda:
+        raise MqganHipError("mqgan_amd ops need HIP device tensors (got a CPU tensor); there is no CPU path")
+    if not t.is_contiguous():
+        raise MqganHipError(f"tensor of shape {tuple(t.shape)} is not contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise MqganHipError(f"expected dtype {dtype}, got {t.dtype}")
+    return C.c_void_p(t.data_ptr())
+
+
+def fptr(t, allow_none=False):
+    return ptr(t, torch.float32, allow_none)

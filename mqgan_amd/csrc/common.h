@@ -1,0 +1,156 @@
+// Shared device/host helpers for libmqgan_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mqgan_hip.h"
+
+namespace mq {
+
+// ----------------------------------------------------------------------------- errors
+extern thread_local char g_err[512];
+
+inline int fail(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+inline int fail(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+#define MQ_REQUIRE(cond, ...)                      \
+    do {                                           \
+        if (!(cond)) return ::mq::fail(__VA_ARGS__); \
+    } while (0)
+
+#define MQ_LAUNCH_CHECK(name)                                                              \
+    do {                                                                                   \
+        hipError_t e_ = hipGetLastError();                                                 \
+        if (e_ != hipSuccess) return ::mq::fail("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+inline hipStream_t S(mqStream s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// grid for a grid-stride elementwise kernel: enough blocks to fill 256 CUs x 8, no more
+inline int ew_grid(int64_t work_items, int block)
+{
+    int64_t g = cdiv(work_items, block);
+    if (g > 256 * 8) g = 256 * 8;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ----------------------------------------------------------------------------- wave64 reductions (DPP)
+// sum over the 64 lanes, result valid in lane 63 (row_bcast form, gfx9 family).
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf, bool BOUND_CTRL = false>
+__device__ __forceinline__ float dpp_mov(float old, float v)
+{
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK,
+                                           BANK_MASK, BOUND_CTRL));
+}
+
+// full wave sum, every lane gets the total
+__device__ __forceinline__ float wave_sum(float v)
+{
+    v += dpp_mov<0xB1>(0.f, v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(0.f, v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(0.f, v);  // row_half_mirror
+    v += dpp_mov<0x140>(0.f, v);  // row_mirror  -> every lane of a 16-row holds the row sum
+    // across the four rows of 16: use ds_swizzle-free readlane of lanes 0,16,32,48
+    float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+__device__ __forceinline__ float wave_max(float v)
+{
+    v = fmaxf(v, dpp_mov<0xB1>(v, v));
+    v = fmaxf(v, dpp_mov<0x4E>(v, v));
+    v = fmaxf(v, dpp_mov<0x141>(v, v));
+    v = fmaxf(v, dpp_mov<0x140>(v, v));
+    float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
+// block-wide sum for blockDim.x = NT (multiple of 64); result valid in every thread.
+// `red` is LDS scratch of NT/64 floats.  Deterministic (fixed order).
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float *red)
+{
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) t += red[i];
+    return t;
+}
+
+// ----------------------------------------------------------------------------- counter-based RNG for dropout
+// Philox4x32-7 (the shortest variant that passes BigCrush); key = seed, counter = (group index, stream id).
+__device__ __forceinline__ uint4 philox4x32_7(uint2 key, uint4 ctr)
+{
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        uint32_t hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
+        uint32_t hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
+        ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+        key.x += W0;
+        key.y += W1;
+    }
+    return ctr;
+}
+
+// Dropout keep-scale for 8 consecutive elements [8*group, 8*group+8): each 32-bit word gives two
+// 16-bit uniforms; drop iff u16 < thresh16 where thresh16 = round(p * 65536).
+struct Drop8 {
+    uint4 r;
+    __device__ __forceinline__ Drop8() : r(make_uint4(~0u, ~0u, ~0u, ~0u)) {}   // keeps everything
+    __device__ __forceinline__ Drop8(uint64_t seed, uint64_t group)
+    {
+        r = philox4x32_7(make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)),
+                         make_uint4((uint32_t)group, (uint32_t)(group >> 32), 0x6d71u, 0u));
+    }
+    __device__ __forceinline__ bool keep(int e, uint32_t thresh16) const
+    {
+        uint32_t w = (e >> 1) == 0 ? r.x : (e >> 1) == 1 ? r.y : (e >> 1) == 2 ? r.z : r.w;
+        uint32_t u = (e & 1) ? (w >> 16) : (w & 0xffffu);
+        return u >= thresh16;
+    }
+};
+
+__host__ __device__ inline uint32_t drop_thresh16(float p)
+{
+    float t = p * 65536.0f + 0.5f;
+    return t < 0.f ? 0u : (t > 65535.f ? 65535u : (uint32_t)t);
+}
+// the keep probability actually realised (so that the scale is exact for the realised p)
+__host__ __device__ inline float drop_scale(float p)
+{
+    return 65536.0f / (65536.0f - (float)drop_thresh16(p));
+}
+
+// ----------------------------------------------------------------------------- APTx
+// aptx(x) = (1 + tanh(b x)) * g * x = 2*sigmoid(2 b x) * g * x   (no cancellation for any x)
+__device__ __forceinline__ float aptx_s(float bx)  // s = 1 + tanh(bx)
+{
+    return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * bx));
+}
+
+}  // namespace mq

@@ -1,0 +1,335 @@
+// Fused ConvBlock2D (reference preencoder.py:277-301 as used at :322 / :351).
+//
+// The reference inflates a (B, C0, T) map to (B, C0, C0, T) (17 GB fp32 at B=32, C0=T=512) and runs
+// ~10 elementwise passes over it.  Here each pixel (b, t, c) keeps its C0-wide hidden vector in
+// registers: HBM traffic is one read of x and one write of y (8 B / pixel), the work is C0
+// tanh-class evaluations per pixel on the VALU / transcendental pipes.
+//
+//   v      = bdw + sum_{i,j} wdw[i][j] * x[b, t + j - 2, c + i - 2]          (i: channel axis, j: time)
+//   v      = 0 on padded frames;  h_k = w1[k] * v + b1[k], also 0 on padded frames
+//   y      = b2 + sum_k w2[k] * drop_k * aptx(h_k)                            aptx(h) = (1 + tanh h) * 0.5 * h
+#include "common.h"
+
+namespace mq {
+
+constexpr int CB_TT = 4;     // time steps per block tile
+constexpr int CB_TC = 64;    // channels per block tile (fwd)
+
+__device__ __forceinline__ uint64_t cb_group(int64_t pixel, int k, int groups_per_pixel)
+{
+    return (uint64_t)pixel * (uint64_t)groups_per_pixel + (uint64_t)(k >> 3);
+}
+
+__global__ __launch_bounds__(256) void cb2d_fwd_kernel(const float *__restrict__ x, const uint8_t *__restrict__ mask,
+                                                       const float *__restrict__ wdw, const float *__restrict__ bdw,
+                                                       const float *__restrict__ w1, const float *__restrict__ b1,
+                                                       const float *__restrict__ w2, const float *__restrict__ b2, int B, int T,
+                                                       int C0, uint32_t thresh16, float scale, uint64_t seed,
+                                                       float *__restrict__ y, float *__restrict__ v_save)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *sw1 = sm, *sb1 = sm + C0, *sw2 = sm + 2 * C0;
+    float *xt = sm + 3 * C0;                       // [(CB_TT+4)][(CB_TC+4)]
+    __shared__ float swd[25];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z, t0 = blockIdx.y * CB_TT, c0 = blockIdx.x * CB_TC;
+    for (int i = tid; i < C0; i += 256) {
+        sw1[i] = w1[i];
+        sb1[i] = b1[i];
+        sw2[i] = w2[i];
+    }
+    if (tid < 25) swd[tid] = wdw[tid];
+    for (int i = tid; i < (CB_TT + 4) * (CB_TC + 4); i += 256) {
+        const int tt = i / (CB_TC + 4), cc = i - tt * (CB_TC + 4);
+        const int t = t0 + tt - 2, c = c0 + cc - 2;
+        xt[i] = (t >= 0 && t < T && c >= 0 && c < C0) ? x[((size_t)b * T + t) * C0 + c] : 0.f;
+    }
+    __syncthreads();
+    const int tt = tid >> 6, tc = tid & 63;
+    const int t = t0 + tt, c = c0 + tc;
+    if (t >= T || c >= C0) return;
+    const int64_t pixel = ((int64_t)b * T + t) * C0 + c;
+    const bool padded = mask[(size_t)b * T + t] != 0;
+    const float bias2 = b2[0];
+    if (padded) {
+        y[pixel] = bias2;
+        if (v_save) v_save[pixel] = 0.f;
+        return;
+    }
+    float v = bdw[0];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) v = fmaf(swd[i * 5 + j], xt[(tt + j) * (CB_TC + 4) + tc + i], v);
+    if (v_save) v_save[pixel] = v;
+    const int gpp = (C0 + 7) >> 3;
+    float acc = bias2;
+    for (int k0 = 0; k0 < C0; k0 += 8) {
+        Drop8 rng;
+        if (thresh16) rng = Drop8(seed, cb_group(pixel, k0, gpp));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + e;
+            if (k < C0) {
+                const float h = fmaf(sw1[k], v, sb1[k]);
+                float a = aptx_s(h) * 0.5f * h;
+                if (thresh16) a = rng.keep(e, thresh16) ? a * scale : 0.f;
+                acc = fmaf(sw2[k], a, acc);
+            }
+        }
+    }
+    y[pixel] = acc;
+}
+
+// Backward pass 1: per-pixel MLP backward.  Thread = channel c, CB_TT consecutive time steps.
+// Produces dv (masked) and per-block partials of dw1, db1, dw2 (3*C0) and db2.
+__global__ __launch_bounds__(256) void cb2d_bwd_mlp_kernel(const float *__restrict__ v_save, const float *__restrict__ dy,
+                                                           const uint8_t *__restrict__ mask, const float *__restrict__ w1,
+                                                           const float *__restrict__ b1, const float *__restrict__ w2, int B, int T,
+                                                           int C0, uint32_t thresh16, float scale, uint64_t seed,
+                                                           float *__restrict__ dv, float *__restrict__ part, int ntiles_c,
+                                                           int ntiles_t)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *sw1 = sm, *sb1 = sm + C0, *sw2 = sm + 2 * C0;
+    float *wacc = sm + 3 * C0;                     // [4 waves][3][C0]
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < C0; i += 256) {
+        sw1[i] = w1[i];
+        sb1[i] = b1[i];
+        sw2[i] = w2[i];
+    }
+    for (int i = tid; i < 12 * C0; i += 256) wacc[i] = 0.f;
+    __syncthreads();
+    float *my = wacc + wave * 3 * C0;
+    const int gpp = (C0 + 7) >> 3;
+    float db2 = 0.f;
+    const int64_t ntiles = (int64_t)B * ntiles_t * ntiles_c;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int ct = (int)(tile % ntiles_c);
+        const int64_t r = tile / ntiles_c;
+        const int tt_ = (int)(r % ntiles_t), b = (int)(r / ntiles_t);
+        const int c = ct * 256 + tid;
+        const int t0 = tt_ * CB_TT;
+        float v[CB_TT], g[CB_TT], dva[CB_TT];
+        bool on[CB_TT];
+        int64_t pix[CB_TT];
+#pragma unroll
+        for (int p = 0; p < CB_TT; ++p) {
+            const int t = t0 + p;
+            const bool inb = (c < C0) && (t < T);
+            pix[p] = inb ? ((int64_t)b * T + t) * C0 + c : 0;
+            g[p] = inb ? dy[pix[p]] : 0.f;
+            db2 += g[p];
+            on[p] = inb && (mask[(size_t)b * T + t] == 0);
+            v[p] = on[p] ? v_save[pix[p]] : 0.f;
+            dva[p] = 0.f;
+        }
+        for (int k0 = 0; k0 < C0; k0 += 8) {
+            Drop8 rng[CB_TT];
+            if (thresh16) {
+#pragma unroll
+                for (int p = 0; p < CB_TT; ++p) rng[p] = Drop8(seed, cb_group(pix[p], k0, gpp));
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = k0 + e;
+                if (k >= C0) break;
+                const float wk1 = sw1[k], bk1 = sb1[k], wk2 = sw2[k];
+                float s_w2 = 0.f, s_w1 = 0.f, s_b1 = 0.f;
+#pragma unroll
+                for (int p = 0; p < CB_TT; ++p) {
+                    const float h = fmaf(wk1, v[p], bk1);
+                    const float s = aptx_s(h);
+                    float keep = 1.0f;
+                    if (thresh16) keep = rng[p].keep(e, thresh16) ? scale : 0.f;
+                    const float gk = on[p] ? g[p] * keep : 0.f;
+                    const float a = s * 0.5f * h;
+                    const float dh = gk * wk2 * 0.5f * (s + h * s * (2.0f - s));
+                    s_w2 = fmaf(gk, a, s_w2);
+                    s_w1 = fmaf(dh, v[p], s_w1);
+                    s_b1 += dh;
+                    dva[p] = fmaf(dh, wk1, dva[p]);
+                }
+                s_w2 = wave_sum(s_w2);
+                s_w1 = wave_sum(s_w1);
+                s_b1 = wave_sum(s_b1);
+                if (lane == 0) {
+                    my[k] += s_w1;
+                    my[C0 + k] += s_b1;
+                    my[2 * C0 + k] += s_w2;
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < CB_TT; ++p)
+            if (c < C0 && t0 + p < T) dv[pix[p]] = dva[p];
+    }
+    db2 = block_sum<256>(db2, red);
+    __syncthreads();
+    float *out = part + (size_t)blockIdx.x * (3 * C0 + 1);
+    for (int i = tid; i < 3 * C0; i += 256) out[i] = (wacc[i] + wacc[3 * C0 + i]) + (wacc[6 * C0 + i] + wacc[9 * C0 + i]);
+    if (tid == 0) out[3 * C0] = db2;
+}
+
+// Backward pass 2: transpose of the 5x5 stencil (dx) + its 25 weight gradients and bias gradient.
+__global__ __launch_bounds__(256) void cb2d_bwd_stencil_kernel(const float *__restrict__ x, const float *__restrict__ dv,
+                                                               const float *__restrict__ wdw, int B, int T, int C0,
+                                                               float *__restrict__ dx, float *__restrict__ part, int ntiles_c,
+                                                               int ntiles_t)
+{
+    __shared__ float dvt[(CB_TT + 4) * (CB_TC + 4)];
+    __shared__ float xt[(CB_TT + 4) * (CB_TC + 4)];
+    __shared__ float swd[25];
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    if (tid < 25) swd[tid] = wdw[tid];
+    float gw[26];
+#pragma unroll
+    for (int i = 0; i < 26; ++i) gw[i] = 0.f;
+    const int tt = tid >> 6, tc = tid & 63;
+    const int64_t ntiles = (int64_t)B * ntiles_t * ntiles_c;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int ct = (int)(tile % ntiles_c);
+        const int64_t r = tile / ntiles_c;
+        const int tt_ = (int)(r % ntiles_t), b = (int)(r / ntiles_t);
+        const int t0 = tt_ * CB_TT, c0 = ct * CB_TC;
+        __syncthreads();
+        for (int i = tid; i < (CB_TT + 4) * (CB_TC + 4); i += 256) {
+            const int a = i / (CB_TC + 4), cc = i - a * (CB_TC + 4);
+            const int t = t0 + a - 2, c = c0 + cc - 2;
+            const bool inb = t >= 0 && t < T && c >= 0 && c < C0;
+            const size_t o = ((size_t)b * T + (inb ? t : 0)) * C0 + (inb ? c : 0);
+            dvt[i] = inb ? dv[o] : 0.f;
+            xt[i] = inb ? x[o] : 0.f;
+        }
+        __syncthreads();
+        const int t = t0 + tt, c = c0 + tc;
+        if (t < T && c < C0) {
+            // dx[t][c] = sum_{i,j} w[i][j] * dv[t - (j-2)][c - (i-2)]
+            float a = 0.f;
+            const float d0 = dvt[(tt + 2) * (CB_TC + 4) + tc + 2];
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    a = fmaf(swd[i * 5 + j], dvt[(tt + 4 - j) * (CB_TC + 4) + tc + 4 - i], a);
+                    gw[i * 5 + j] = fmaf(d0, xt[(tt + j) * (CB_TC + 4) + tc + i], gw[i * 5 + j]);
+                }
+            gw[25] += d0;
+            dx[((size_t)b * T + t) * C0 + c] = a;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 26; ++i) {
+        const float s = block_sum<256>(gw[i], red);
+        if (tid == 0) part[(size_t)blockIdx.x * 26 + i] = s;
+    }
+}
+
+// sums `nparts` rows of `width` floats
+__global__ void cb2d_reduce_kernel(const float *__restrict__ part, int nparts, int width, float *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= width) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * width + i];
+    out[i] = s;
+}
+
+struct CbPlan {
+    int ntc_mlp, ntt, grid_mlp, ntc_st, grid_st;
+    size_t off_dv, off_p1, off_p2, off_r1, off_r2, total;
+};
+static CbPlan cb_plan(int B, int T, int C0)
+{
+    CbPlan p;
+    p.ntc_mlp = (int)cdiv(C0, 256);
+    p.ntt = (int)cdiv(T, CB_TT);
+    p.ntc_st = (int)cdiv(C0, CB_TC);
+    int64_t t1 = (int64_t)B * p.ntt * p.ntc_mlp, t2 = (int64_t)B * p.ntt * p.ntc_st;
+    p.grid_mlp = (int)(t1 < 1024 ? t1 : 1024);
+    p.grid_st = (int)(t2 < 1024 ? t2 : 1024);
+    size_t o = 0;
+    p.off_dv = o; o += (size_t)B * T * C0;
+    p.off_p1 = o; o += (size_t)p.grid_mlp * (3 * C0 + 1);
+    p.off_p2 = o; o += (size_t)p.grid_st * 26;
+    p.off_r1 = o; o += (size_t)3 * C0 + 1;
+    p.off_r2 = o; o += 32;
+    p.total = o * sizeof(float);
+    return p;
+}
+
+__global__ void cb2d_scatter_kernel(const float *__restrict__ r1, const float *__restrict__ r2, int C0, float *dw1, float *db1,
+                                    float *dw2, float *db2, float *dwdw, float *dbdw)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < C0) {
+        dw1[i] = r1[i];
+        db1[i] = r1[C0 + i];
+        dw2[i] = r1[2 * C0 + i];
+    }
+    if (i == 0) {
+        db2[0] = r1[3 * C0];
+        dbdw[0] = r2[25];
+    }
+    if (i < 25) dwdw[i] = r2[i];
+}
+
+}  // namespace mq
+
+using namespace mq;
+
+static int cb_check(const mqCb2dWeights *w, int B, int T, int C0, float p, const char *who)
+{
+    MQ_REQUIRE(w && w->wdw && w->bdw && w->w1 && w->b1 && w->w2 && w->b2, "%s: null weight pointer", who);
+    MQ_REQUIRE(B > 0 && T > 0 && C0 > 0 && B <= 65535 && cdiv(T, CB_TT) <= 65535, "%s: bad shape", who);
+    MQ_REQUIRE(C0 <= 1024, "%s: C0=%d exceeds the LDS budget (1024)", who, C0);
+    MQ_REQUIRE(p >= 0.f && p < 1.f, "%s: dropout p out of range", who);
+    return 0;
+}
+
+extern "C" int mq_convblock2d_fwd(const mqCb2dWeights *w, const float *x, const uint8_t *mask, int B, int T, int C0, float p_drop,
+                                  uint64_t seed, float *y, float *v_save, mqStream stream)
+{
+    if (cb_check(w, B, T, C0, p_drop, "mq_convblock2d_fwd")) return 1;
+    MQ_REQUIRE(x && mask && y, "mq_convblock2d_fwd: null pointer");
+    const size_t shm = (size_t)(3 * C0 + (CB_TT + 4) * (CB_TC + 4)) * sizeof(float);
+    dim3 grid((unsigned)cdiv(C0, CB_TC), (unsigned)cdiv(T, CB_TT), B);
+    hipLaunchKernelGGL(cb2d_fwd_kernel, grid, dim3(256), shm, S(stream), x, mask, w->wdw, w->bdw, w->w1, w->b1, w->w2, w->b2, B, T,
+                       C0, p_drop > 0.f ? drop_thresh16(p_drop) : 0u, p_drop > 0.f ? drop_scale(p_drop) : 1.0f, seed, y, v_save);
+    MQ_LAUNCH_CHECK("mq_convblock2d_fwd");
+    return 0;
+}
+
+extern "C" size_t mq_convblock2d_bwd_workspace(int B, int T, int C0)
+{
+    if (B <= 0 || T <= 0 || C0 <= 0) return 0;
+    return cb_plan(B, T, C0).total;
+}
+
+extern "C" int mq_convblock2d_bwd(const mqCb2dWeights *w, const float *x, const float *v_save, const float *dy, const uint8_t *mask,
+                                  int B, int T, int C0, float p_drop, uint64_t seed, float *dx, float *dwdw, float *dbdw, float *dw1,
+                                  float *db1, float *dw2, float *db2, void *workspace, mqStream stream)
+{
+    if (cb_check(w, B, T, C0, p_drop, "mq_convblock2d_bwd")) return 1;
+    MQ_REQUIRE(x && v_save && dy && mask && dx && dwdw && dbdw && dw1 && db1 && dw2 && db2 && workspace,
+               "mq_convblock2d_bwd: null pointer");
+    const CbPlan p = cb_plan(B, T, C0);
+    float *ws = reinterpret_cast<float *>(workspace);
+    float *dv = ws + p.off_dv, *p1 = ws + p.off_p1, *p2 = ws + p.off_p2, *r1 = ws + p.off_r1, *r2 = ws + p.off_r2;
+    const uint32_t th = p_drop > 0.f ? drop_thresh16(p_drop) : 0u;
+    const float sc = p_drop > 0.f ? drop_scale(p_drop) : 1.0f;
+    hipStream_t st = S(stream);
+    const size_t shm = (size_t)(15 * C0) * sizeof(float);
+    hipLaunchKernelGGL(cb2d_bwd_mlp_kernel, dim3(p.grid_mlp), dim3(256), shm, st, v_save, dy, mask, w->w1, w->b1, w->w2, B, T, C0, th,
+                       sc, seed, dv, p1, p.ntc_mlp, p.ntt);
+    hipLaunchKernelGGL(cb2d_bwd_stencil_kernel, dim3(p.grid_st), dim3(256), 0, st, x, dv, w->wdw, B, T, C0, dx, p2, p.ntc_st, p.ntt);
+    hipLaunchKernelGGL(cb2d_reduce_kernel, dim3((unsigned)cdiv(3 * C0 + 1, 256)), dim3(256), 0, st, p1, p.grid_mlp, 3 * C0 + 1, r1);
+    hipLaunchKernelGGL(cb2d_reduce_kernel, dim3(1), dim3(256), 0, st, p2, p.grid_st, 26, r2);
+    hipLaunchKernelGGL(cb2d_scatter_kernel, dim3((unsigned)cdiv(C0 > 32 ? C0 : 32, 256)), dim3(256), 0, st, r1, r2, C0, dw1, db1, dw2,
+                       db2, dwdw, dbdw);
+    MQ_LAUNCH_CHECK("mq_convblock2d_bwd");
+    return 0;
+}

@@ -1,0 +1,143 @@
+// f32-MFMA "NT" GEMM core shared by the implicit-GEMM convolutions and the L2 nearest-neighbour
+// search: C[m][n] = sum_k A[m][k] * B[n][k], both operands K-contiguous per row.
+//
+// Block = 256 threads = 4 waves; block tile BM(=128) x BN x BK(=16); each wave owns TM x TN tiles of
+// 32x32 computed with v_mfma_f32_32x32x2_f32 (exact f32, k-ordered fma chain).  Operands are staged
+// global -> registers -> LDS (double buffered, one barrier per K-step); the global loads of step t+1
+// are issued before the MFMAs of step t.
+//
+// LDS image: rows of BK floats padded to LD = 18 (2 x odd: the 32 lanes of a ds_read_b64 then cover
+// all 64 banks).  Inside each aligned group of 4 k's the middle two are swapped when written,
+// (k0,k2,k1,k3), so that lane half h reads ONE float2 at offset 4q+2h = (k = 4q+h, k = 4q+2+h): the
+// operands of MFMA steps 2q and 2q+1.  Every accumulator therefore sums k in natural order, which
+// the nearest-neighbour search relies on for bit-exactness against oracle/vq_ref.c.
+#pragma once
+#include "common.h"
+
+namespace mq {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int GEMM_BM = 128;
+constexpr int GEMM_BK = 16;
+constexpr int GEMM_LD = 18;
+
+template <int BN>
+struct GemmCfg {
+    static constexpr int WM = (BN == 32) ? 4 : 2;       // waves along M
+    static constexpr int WN = 4 / WM;                   // waves along N
+    static constexpr int TM = GEMM_BM / WM / 32;        // 32x32 tiles per wave along M
+    static constexpr int TN = BN / WN / 32;
+    static constexpr int A_SLOTS = GEMM_BM / 64;        // float4 loads per thread for the A tile
+    static constexpr int B_SLOTS = (BN >= 64) ? BN / 64 : 1;
+    static constexpr int LDS_FLOATS = 2 * (GEMM_BM + BN) * GEMM_LD;
+};
+
+__device__ __forceinline__ void lds_store_k4(float *dst, float4 v)
+{
+    *reinterpret_cast<float2 *>(dst) = make_float2(v.x, v.z);
+    *reinterpret_cast<float2 *>(dst + 2) = make_float2(v.y, v.w);
+}
+
+// ALoad / BLoad: .prepare(k0) once per K-step (k0 = first k of the step), then .load(slot) -> float4 of
+// k = k0 + 4*(tid&3) .. +3 for tile row (tid>>2) + 64*slot.  Out-of-range elements must come back as 0.
+template <int BN, class ALoad, class BLoad>
+__device__ __forceinline__ void nt_gemm_mainloop(ALoad &la, BLoad &lb, int nk, float *smem,
+                                                 f32x16 (&acc)[GemmCfg<BN>::TM][GemmCfg<BN>::TN])
+{
+    using Cfg = GemmCfg<BN>;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+    const int li = lane & 31, lh = lane >> 5;
+    float *As = smem;
+    float *Bs = smem + 2 * GEMM_BM * GEMM_LD;
+    const int ld_row = tid >> 2, ld_kq = tid & 3;
+    const bool b_active = (BN >= 64) || (tid < BN * 4);
+
+    float4 ra[Cfg::A_SLOTS], rb[Cfg::B_SLOTS];
+    la.prepare(0);
+    lb.prepare(0);
+#pragma unroll
+    for (int j = 0; j < Cfg::A_SLOTS; ++j) ra[j] = la.load(j);
+#pragma unroll
+    for (int j = 0; j < Cfg::B_SLOTS; ++j) rb[j] = b_active ? lb.load(j) : make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < Cfg::A_SLOTS; ++j) lds_store_k4(&As[(ld_row + 64 * j) * GEMM_LD + 4 * ld_kq], ra[j]);
+    if (b_active) {
+#pragma unroll
+        for (int j = 0; j < Cfg::B_SLOTS; ++j) lds_store_k4(&Bs[(ld_row + 64 * j) * GEMM_LD + 4 * ld_kq], rb[j]);
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = (kt + 1 < nk);
+        if (more) {
+            la.prepare((kt + 1) * GEMM_BK);
+            lb.prepare((kt + 1) * GEMM_BK);
+#pragma unroll
+            for (int j = 0; j < Cfg::A_SLOTS; ++j) ra[j] = la.load(j);
+#pragma unroll
+            for (int j = 0; j < Cfg::B_SLOTS; ++j) rb[j] = b_active ? lb.load(j) : make_float4(0, 0, 0, 0);
+        }
+        const float *Ac = As + cur * GEMM_BM * GEMM_LD + (wm * Cfg::TM * 32 + li) * GEMM_LD + 2 * lh;
+        const float *Bc = Bs + cur * BN * GEMM_LD + (wn * Cfg::TN * 32 + li) * GEMM_LD + 2 * lh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float2 a[Cfg::TM], b[Cfg::TN];
+#pragma unroll
+            for (int t = 0; t < Cfg::TM; ++t) a[t] = *reinterpret_cast<const float2 *>(Ac + t * 32 * GEMM_LD + 4 * q);
+#pragma unroll
+            for (int t = 0; t < Cfg::TN; ++t) b[t] = *reinterpret_cast<const float2 *>(Bc + t * 32 * GEMM_LD + 4 * q);
+#pragma unroll
+            for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < Cfg::TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].x, b[tn].x, acc[tm][tn], 0, 0, 0);
+#pragma unroll
+            for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < Cfg::TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].y, b[tn].y, acc[tm][tn], 0, 0, 0);
+        }
+        if (more) {
+            float *An = As + (cur ^ 1) * GEMM_BM * GEMM_LD;
+            float *Bn = Bs + (cur ^ 1) * BN * GEMM_LD;
+#pragma unroll
+            for (int j = 0; j < Cfg::A_SLOTS; ++j) lds_store_k4(&An[(ld_row + 64 * j) * GEMM_LD + 4 * ld_kq], ra[j]);
+            if (b_active) {
+#pragma unroll
+                for (int j = 0; j < Cfg::B_SLOTS; ++j)
+                    lds_store_k4(&Bn[(ld_row + 64 * j) * GEMM_LD + 4 * ld_kq], rb[j]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// row / column of accumulator register r of tile (tm, tn) inside the block tile
+template <int BN>
+__device__ __forceinline__ int acc_row(int tm, int r)
+{
+    using Cfg = GemmCfg<BN>;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    return (wave / Cfg::WN) * Cfg::TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+}
+template <int BN>
+__device__ __forceinline__ int acc_col(int tn)
+{
+    using Cfg = GemmCfg<BN>;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    return (wave % Cfg::WN) * Cfg::TN * 32 + tn * 32 + (lane & 31);
+}
+
+// Bijective XCD-aware remap of a linear block id (guide T1): blocks that are consecutive after the
+// remap run on the same XCD (round-robin dispatch), so they share that XCD's L2.
+__device__ __forceinline__ int xcd_remap(int lin, int total)
+{
+    const int q = total >> 3, r = total & 7, x = lin & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (lin >> 3);
+}
+
+}  // namespace mq

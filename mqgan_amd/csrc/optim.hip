@@ -1,0 +1,86 @@
+// clip_grad_norm_ + Adam on flat fp32 arenas (train.py:401-407, 485-492).
+// One launch for the squared norm (two-stage, deterministic) and one for the update; the clip
+// coefficient never leaves the device.
+#include "common.h"
+
+namespace mq {
+
+__global__ void sumsq_partial_kernel(const float *__restrict__ g, int64_t n, float *__restrict__ part)
+{
+    __shared__ float red[4];
+    float s = 0.f;
+    const int64_t n4 = n >> 2;
+    const float4 *g4 = reinterpret_cast<const float4 *>(g);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = g4[i];
+        s = fmaf(v.x, v.x, s);
+        s = fmaf(v.y, v.y, s);
+        s = fmaf(v.z, v.z, s);
+        s = fmaf(v.w, v.w, s);
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s = fmaf(g[i], g[i], s);
+    s = block_sum<256>(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ void sumsq_final_kernel(const float *__restrict__ part, int nb, float *__restrict__ out)
+{
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 256) s += part[i];
+    s = block_sum<256>(s, red);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+// torch.optim.Adam (single-tensor path) op order:
+//   g *= clip_coef ; m.lerp_(g, 1-b1) ; v = v*b2 + (1-b2) g*g ; denom = sqrt(v)/sqrt(bc2) + eps ; p -= (lr/bc1) * m/denom
+__global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, int64_t n,
+                            float step_size, float beta1, float beta2, float eps, float bc2_sqrt, const float *__restrict__ sumsq,
+                            float max_norm, float grad_scale)
+{
+    // grad_scale turns all-reduced SUMS into means (1 / world size) without an extra pass
+    float coef = grad_scale;
+    if (max_norm > 0.f && sumsq) {
+        const float tn = sqrtf(sumsq[0]) * grad_scale;
+        coef = fminf(max_norm / (tn + 1e-6f), 1.0f) * grad_scale;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * coef;
+        const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);
+        const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - step_size * (mi / denom);
+    }
+}
+
+}  // namespace mq
+
+using namespace mq;
+
+extern "C" int mq_sumsq(const float *g, int64_t n, float *out, float *workspace, mqStream stream)
+{
+    MQ_REQUIRE(g && out && workspace && n > 0, "mq_sumsq: bad arguments");
+    MQ_REQUIRE((uintptr_t)g % 16 == 0, "mq_sumsq: g must be 16-byte aligned");
+    int nb = ew_grid(n / 4 + 1, 256);
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, S(stream), g, n, workspace);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, S(stream), workspace, nb, out);
+    MQ_LAUNCH_CHECK("mq_sumsq");
+    return 0;
+}
+
+extern "C" int mq_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, double lr, double beta1,
+                            double beta2, double eps, int step_host, const float *sumsq, float max_norm, float grad_scale,
+                            mqStream stream)
+{
+    MQ_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step_host >= 1, "mq_adam_step: bad arguments");
+    const double bc1 = 1.0 - pow(beta1, (double)step_host);
+    const double bc2 = 1.0 - pow(beta2, (double)step_host);
+    const float step_size = (float)(lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S(stream), param, grad, exp_avg, exp_avg_sq, n, step_size, (float)beta1,
+                       (float)beta2, (float)eps, bc2_sqrt, sumsq, max_norm, grad_scale);
+    MQ_LAUNCH_CHECK("mq_adam_step");
+    return 0;
+}

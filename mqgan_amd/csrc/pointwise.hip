@@ -1,0 +1,572 @@
+// Elementwise / data-movement kernels: fused mask+activation+dropout(+residual), frame masks,
+// UNet pool / upsample+concat, band split, small helpers.  All HBM-bound: float4 per lane where the
+// channel count allows, grid-stride over at most 2048 blocks.
+#include "common.h"
+
+namespace mq {
+
+struct PwParams {
+    int64_t rows;
+    int C;
+    int act, mask_pre, mask_post;
+    int64_t d1, d2, d3;
+    uint32_t thresh16;
+    float scale;
+    uint64_t seed;
+};
+
+__device__ __forceinline__ float act_fwd(int act, float t, float beta, float gamma)
+{
+    if (act == 1) return aptx_s(beta * t) * gamma * t;
+    if (act == 2) return t > 0.f ? t : 0.2f * t;
+    return t;
+}
+// returns f'(t); accumulates d/dbeta, d/dgamma (per unit upstream gradient) into gb, gg
+__device__ __forceinline__ float act_bwd(int act, float t, float beta, float gamma, float g, float &gb, float &gg)
+{
+    if (act == 1) {
+        const float s = aptx_s(beta * t);
+        const float ss = s * (2.0f - s);          // = 1 - tanh^2
+        gb += g * gamma * t * t * ss;
+        gg += g * s * t;
+        return gamma * (s + t * beta * ss);
+    }
+    if (act == 2) return t > 0.f ? 1.0f : 0.2f;
+    return 1.0f;
+}
+
+// one thread = one group of 8 consecutive flat elements (= one Philox call)
+template <bool VEC8>
+__global__ void pointwise_fwd_kernel(PwParams p, const float *__restrict__ h, const float *__restrict__ rpre,
+                                     const float *__restrict__ rpost, const uint8_t *__restrict__ mask,
+                                     const float *__restrict__ beta_p, const float *__restrict__ gamma_p, float *__restrict__ out)
+{
+    const int64_t total = p.rows * p.C;
+    const int64_t ngroups = (total + 7) >> 3;
+    const float beta = beta_p ? beta_p[0] : 1.0f, gamma = gamma_p ? gamma_p[0] : 0.5f;
+    for (int64_t gidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gidx < ngroups; gidx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e0 = gidx << 3;
+        float t[8], a[8];
+        bool pad[8];
+        if (VEC8) {
+            const float4 x0 = *reinterpret_cast<const float4 *>(h + e0), x1 = *reinterpret_cast<const float4 *>(h + e0 + 4);
+            t[0] = x0.x; t[1] = x0.y; t[2] = x0.z; t[3] = x0.w; t[4] = x1.x; t[5] = x1.y; t[6] = x1.z; t[7] = x1.w;
+            if (rpre) {
+                const float4 r0 = *reinterpret_cast<const float4 *>(rpre + e0), r1 = *reinterpret_cast<const float4 *>(rpre + e0 + 4);
+                t[0] += r0.x; t[1] += r0.y; t[2] += r0.z; t[3] += r0.w; t[4] += r1.x; t[5] += r1.y; t[6] += r1.z; t[7] += r1.w;
+            }
+            bool pd = false;
+            if (mask) {
+                const int64_t m = e0 / p.C;
+                pd = mask[(m / p.d1) * p.d2 + (m % p.d3)] != 0;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pad[i] = pd;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int64_t e = e0 + i;
+                t[i] = 0.f;
+                pad[i] = false;
+                if (e < total) {
+                    t[i] = h[e] + (rpre ? rpre[e] : 0.f);
+                    if (mask) {
+                        const int64_t m = e / p.C;
+                        pad[i] = mask[(m / p.d1) * p.d2 + (m % p.d3)] != 0;
+                    }
+                }
+            }
+        }
+        const bool use_drop = p.thresh16 != 0;
+        Drop8 rng;
+        if (use_drop) rng = Drop8(p.seed, (uint64_t)gidx);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float tv = (p.mask_pre && pad[i]) ? 0.f : t[i];
+            float av = act_fwd(p.act, tv, beta, gamma);
+            if (use_drop) av = rng.keep(i, p.thresh16) ? av * p.scale : 0.f;
+            a[i] = av;
+        }
+        if (VEC8) {
+            if (rpost) {
+                const float4 r0 = *reinterpret_cast<const float4 *>(rpost + e0), r1 = *reinterpret_cast<const float4 *>(rpost + e0 + 4);
+                a[0] += r0.x; a[1] += r0.y; a[2] += r0.z; a[3] += r0.w; a[4] += r1.x; a[5] += r1.y; a[6] += r1.z; a[7] += r1.w;
+            }
+            if (p.mask_post && pad[0]) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a[i] = 0.f;
+            }
+            *reinterpret_cast<float4 *>(out + e0) = make_float4(a[0], a[1], a[2], a[3]);
+            *reinterpret_cast<float4 *>(out + e0 + 4) = make_float4(a[4], a[5], a[6], a[7]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int64_t e = e0 + i;
+                if (e < total) {
+                    float av = a[i] + (rpost ? rpost[e] : 0.f);
+                    if (p.mask_post && pad[i]) av = 0.f;
+                    out[e] = av;
+                }
+            }
+        }
+    }
+}
+
+template <bool VEC8>
+__global__ void pointwise_bwd_kernel(PwParams p, const float *__restrict__ dout, const float *__restrict__ h,
+                                     const float *__restrict__ rpre, const uint8_t *__restrict__ mask,
+                                     const float *__restrict__ beta_p, const float *__restrict__ gamma_p, float *__restrict__ dt,
+                                     float *__restrict__ dpost, float *__restrict__ part)
+{
+    __shared__ float red[4];
+    const int64_t total = p.rows * p.C;
+    const int64_t ngroups = (total + 7) >> 3;
+    const float beta = beta_p ? beta_p[0] : 1.0f, gamma = gamma_p ? gamma_p[0] : 0.5f;
+    float gb = 0.f, gg = 0.f;
+    for (int64_t gidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gidx < ngroups; gidx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e0 = gidx << 3;
+        float t[8], g[8];
+        bool pad[8], live[8];
+        if (VEC8) {
+            const float4 x0 = *reinterpret_cast<const float4 *>(h + e0), x1 = *reinterpret_cast<const float4 *>(h + e0 + 4);
+            t[0] = x0.x; t[1] = x0.y; t[2] = x0.z; t[3] = x0.w; t[4] = x1.x; t[5] = x1.y; t[6] = x1.z; t[7] = x1.w;
+            if (rpre) {
+                const float4 r0 = *reinterpret_cast<const float4 *>(rpre + e0), r1 = *reinterpret_cast<const float4 *>(rpre + e0 + 4);
+                t[0] += r0.x; t[1] += r0.y; t[2] += r0.z; t[3] += r0.w; t[4] += r1.x; t[5] += r1.y; t[6] += r1.z; t[7] += r1.w;
+            }
+            const float4 g0 = *reinterpret_cast<const float4 *>(dout + e0), g1 = *reinterpret_cast<const float4 *>(dout + e0 + 4);
+            g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
+            bool pd = false;
+            if (mask) {
+                const int64_t m = e0 / p.C;
+                pd = mask[(m / p.d1) * p.d2 + (m % p.d3)] != 0;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { pad[i] = pd; live[i] = true; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int64_t e = e0 + i;
+                t[i] = 0.f; g[i] = 0.f; pad[i] = false;
+                live[i] = e < total;
+                if (live[i]) {
+                    t[i] = h[e] + (rpre ? rpre[e] : 0.f);
+                    g[i] = dout[e];
+                    if (mask) {
+                        const int64_t m = e / p.C;
+                        pad[i] = mask[(m / p.d1) * p.d2 + (m % p.d3)] != 0;
+                    }
+                }
+            }
+        }
+        const bool use_drop = p.thresh16 != 0;
+        Drop8 rng;
+        if (use_drop) rng = Drop8(p.seed, (uint64_t)gidx);
+        float po[8], dv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float gv = (p.mask_post && pad[i]) ? 0.f : g[i];
+            po[i] = gv;
+            if (use_drop) gv = rng.keep(i, p.thresh16) ? gv * p.scale : 0.f;
+            const bool mp = p.mask_pre && pad[i];
+            const float tv = mp ? 0.f : t[i];
+            float b_ = 0.f, g_ = 0.f;
+            const float d = act_bwd(p.act, tv, beta, gamma, gv, b_, g_);
+            if (live[i]) { gb += b_; gg += g_; }
+            dv[i] = mp ? 0.f : gv * d;
+        }
+        if (VEC8) {
+            *reinterpret_cast<float4 *>(dt + e0) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+            *reinterpret_cast<float4 *>(dt + e0 + 4) = make_float4(dv[4], dv[5], dv[6], dv[7]);
+            if (dpost) {
+                *reinterpret_cast<float4 *>(dpost + e0) = make_float4(po[0], po[1], po[2], po[3]);
+                *reinterpret_cast<float4 *>(dpost + e0 + 4) = make_float4(po[4], po[5], po[6], po[7]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (live[i]) {
+                    dt[e0 + i] = dv[i];
+                    if (dpost) dpost[e0 + i] = po[i];
+                }
+        }
+    }
+    if (part) {
+        gb = block_sum<256>(gb, red);
+        gg = block_sum<256>(gg, red);
+        if (threadIdx.x == 0) {
+            part[blockIdx.x] = gb;
+            part[gridDim.x + blockIdx.x] = gg;
+        }
+    }
+}
+
+__global__ void pw_final_kernel(const float *__restrict__ part, int nblocks, float *__restrict__ dbeta, float *__restrict__ dgamma)
+{
+    __shared__ float red[4];
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 256) {
+        a += part[i];
+        b += part[nblocks + i];
+    }
+    a = block_sum<256>(a, red);
+    b = block_sum<256>(b, red);
+    if (threadIdx.x == 0) {
+        if (dbeta) dbeta[0] = a;
+        if (dgamma) dgamma[0] = b;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ masks
+__global__ void sequence_mask_kernel(const int32_t *__restrict__ len, int B, int T, uint8_t *__restrict__ mask)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * T) return;
+    const int b = i / T, t = i - b * T;
+    mask[i] = t >= len[b] ? 1 : 0;
+}
+__global__ void mask_pool_kernel(const uint8_t *__restrict__ in, int B, int Tin, int Tout, int stride, uint8_t *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * Tout) return;
+    const int b = i / Tout, t = i - b * Tout;
+    uint8_t m = 0;
+    for (int j = 0; j < stride; ++j) {
+        const int s = t * stride + j;
+        if (s < Tin) m |= in[b * Tin + s];
+    }
+    out[i] = m;
+}
+__global__ void mask_upsample2_kernel(const uint8_t *__restrict__ in, int B, int Tin, uint8_t *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * Tin * 2) return;
+    const int b = i / (2 * Tin), t = i - b * 2 * Tin;
+    out[i] = in[b * Tin + (t >> 1)];
+}
+
+// ------------------------------------------------------------------------------------------ UNet data movement
+// x (N, T, F, C) viewed as (N, T, FC)
+__global__ void avgpool_t2_fwd_kernel(const float *__restrict__ x, int64_t N, int T, int64_t FC, float *__restrict__ y)
+{
+    const int To = T / 2;
+    const int64_t total = N * To * FC;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t fc = i % FC, r = i / FC;
+        const int64_t t = r % To, n = r / To;
+        const float *p = x + ((n * T + 2 * t) * FC + fc);
+        y[i] = (p[0] + p[FC]) * 0.5f;
+    }
+}
+__global__ void avgpool_t2_bwd_kernel(const float *__restrict__ dy, int64_t N, int T, int64_t FC, float *__restrict__ dx)
+{
+    const int To = T / 2;
+    const int64_t total = N * T * FC;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t fc = i % FC, r = i / FC;
+        const int64_t t = r % T, n = r / T;
+        dx[i] = 0.5f * dy[(n * To + (t >> 1)) * FC + fc];
+    }
+}
+// out (N, 2T, F, C1+C2)
+__global__ void upcat_fwd_kernel(const float *__restrict__ x, const float *__restrict__ skip, int64_t N, int T, int F, int C1,
+                                 int C2, float *__restrict__ out)
+{
+    const int Co = C1 + C2;
+    const int64_t total = N * 2 * T * F * Co;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Co);
+        const int64_t r = i / Co;           // (n, t2, f)
+        const int64_t f = r % F, r2 = r / F;
+        const int64_t t2 = r2 % (2 * T), n = r2 / (2 * T);
+        out[i] = c < C1 ? x[((n * T + (t2 >> 1)) * F + f) * C1 + c] : skip[r * C2 + (c - C1)];
+    }
+}
+__global__ void upcat_bwd_x_kernel(const float *__restrict__ dout, int64_t N, int T, int F, int C1, int C2, float *__restrict__ dx)
+{
+    const int Co = C1 + C2;
+    const int64_t total = N * T * F * C1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C1);
+        const int64_t r = i / C1;
+        const int64_t f = r % F, r2 = r / F;
+        const int64_t t = r2 % T, n = r2 / T;
+        const int64_t o = ((n * 2 * T + 2 * t) * F + f) * Co + c;
+        dx[i] = dout[o] + dout[o + (int64_t)F * Co];
+    }
+}
+__global__ void upcat_bwd_skip_kernel(const float *__restrict__ dout, int64_t rows, int C1, int C2, float *__restrict__ dskip)
+{
+    const int Co = C1 + C2;
+    const int64_t total = rows * C2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C2);
+        const int64_t r = i / C2;
+        dskip[i] = dout[r * Co + C1 + c];
+    }
+}
+__global__ void concat2_kernel(const float *__restrict__ a, const float *__restrict__ b, int64_t rows, int C1, int C2,
+                               float *__restrict__ y)
+{
+    const int Co = C1 + C2;
+    const int64_t total = rows * Co;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Co);
+        const int64_t r = i / Co;
+        y[i] = c < C1 ? a[r * C1 + c] : b[r * C2 + (c - C1)];
+    }
+}
+__global__ void axpby_kernel(const float *__restrict__ a, const float *__restrict__ b, float alpha, float beta, int64_t n,
+                             float *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
+}
+
+// (B, T, F) <-> (n_bins*B, F/n_bins, T) through a 32x32 LDS tile.  FWD: x -> out ; !FWD: dout -> dx.
+template <bool FWD>
+__global__ void band_split_kernel(const float *__restrict__ src, int B, int T, int F, int n_bins, float *__restrict__ dst)
+{
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, t0 = blockIdx.x * 32, f0 = blockIdx.y * 32;
+    const int bs = F / n_bins;
+    const int tx = threadIdx.x, ty = threadIdx.y;   // (32, 8)
+    if (FWD) {
+        for (int j = ty; j < 32; j += 8) {
+            const int t = t0 + j, f = f0 + tx;
+            tile[j][tx] = (t < T && f < F) ? src[((size_t)b * T + t) * F + f] : 0.f;
+        }
+        __syncthreads();
+        for (int j = ty; j < 32; j += 8) {
+            const int f = f0 + j, t = t0 + tx;
+            if (f < F && t < T) {
+                const size_t row = ((size_t)(f / bs) * B + b) * bs + (f % bs);
+                dst[row * T + t] = tile[tx][j];
+            }
+        }
+    } else {
+        for (int j = ty; j < 32; j += 8) {
+            const int f = f0 + j, t = t0 + tx;
+            float v = 0.f;
+            if (f < F && t < T) {
+                const size_t row = ((size_t)(f / bs) * B + b) * bs + (f % bs);
+                v = src[row * T + t];
+            }
+            tile[j][tx] = v;
+        }
+        __syncthreads();
+        for (int j = ty; j < 32; j += 8) {
+            const int t = t0 + j, f = f0 + tx;
+            if (t < T && f < F) dst[((size_t)b * T + t) * F + f] = tile[tx][j];
+        }
+    }
+}
+
+__global__ void sigmoid_add_kernel(const float *__restrict__ a, const float *__restrict__ b, int64_t n, float *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float z = a[i] + (b ? b[i] : 0.f);
+        out[i] = 1.0f / (1.0f + __expf(-z));
+    }
+}
+__global__ void sigmoid_bwd_kernel(const float *__restrict__ dout, const float *__restrict__ out, int64_t n, float *__restrict__ da)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        da[i] = dout[i] * out[i] * (1.0f - out[i]);
+}
+__global__ void relu_fwd_kernel(const float *__restrict__ x, int64_t n, float *__restrict__ y)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = fmaxf(x[i], 0.f);
+}
+__global__ void relu_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y, int64_t n, float *__restrict__ dx)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dx[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+static int make_pw(const mqPointwiseDesc *d, PwParams &p, const char *who)
+{
+    MQ_REQUIRE(d && d->rows > 0 && d->C > 0, "%s: bad shape", who);
+    MQ_REQUIRE(d->act >= 0 && d->act <= 2, "%s: unknown activation %d", who, d->act);
+    MQ_REQUIRE(d->p_drop >= 0.f && d->p_drop < 1.f, "%s: dropout p out of range", who);
+    p.rows = d->rows; p.C = d->C; p.act = d->act; p.mask_pre = d->mask_pre; p.mask_post = d->mask_post;
+    p.d1 = d->d1 > 0 ? d->d1 : 1; p.d2 = d->d2; p.d3 = d->d3 > 0 ? d->d3 : 1;
+    p.thresh16 = d->p_drop > 0.f ? drop_thresh16(d->p_drop) : 0u;
+    p.scale = d->p_drop > 0.f ? drop_scale(d->p_drop) : 1.0f;
+    p.seed = d->seed;
+    return 0;
+}
+static bool al16(const void *q) { return q == nullptr || ((uintptr_t)q % 16) == 0; }
+
+}  // namespace mq
+
+using namespace mq;
+
+extern "C" int mq_pointwise_fwd(const mqPointwiseDesc *d, const float *h, const float *r_pre, const float *r_post,
+                                const uint8_t *mask, const float *beta, const float *gamma, float *out, mqStream stream)
+{
+    PwParams p;
+    if (make_pw(d, p, "mq_pointwise_fwd")) return 1;
+    MQ_REQUIRE(h && out, "mq_pointwise_fwd: null pointer");
+    MQ_REQUIRE(mask || !(p.mask_pre || p.mask_post), "mq_pointwise_fwd: mask flags set but mask is null");
+    const int64_t groups = (p.rows * p.C + 7) / 8;
+    const bool vec = (p.C % 8 == 0) && al16(h) && al16(r_pre) && al16(r_post) && al16(out);
+    const int grid = ew_grid(groups, 256);
+    if (vec)
+        hipLaunchKernelGGL((pointwise_fwd_kernel<true>), dim3(grid), dim3(256), 0, S(stream), p, h, r_pre, r_post, mask, beta,
+                           gamma, out);
+    else
+        hipLaunchKernelGGL((pointwise_fwd_kernel<false>), dim3(grid), dim3(256), 0, S(stream), p, h, r_pre, r_post, mask, beta,
+                           gamma, out);
+    MQ_LAUNCH_CHECK("mq_pointwise_fwd");
+    return 0;
+}
+
+extern "C" int mq_pointwise_bwd(const mqPointwiseDesc *d, const float *dout, const float *h, const float *r_pre,
+                                const uint8_t *mask, const float *beta, const float *gamma, float *dt, float *dpost, float *dbeta,
+                                float *dgamma, float *workspace, mqStream stream)
+{
+    PwParams p;
+    if (make_pw(d, p, "mq_pointwise_bwd")) return 1;
+    MQ_REQUIRE(dout && h && dt, "mq_pointwise_bwd: null pointer");
+    MQ_REQUIRE(mask || !(p.mask_pre || p.mask_post), "mq_pointwise_bwd: mask flags set but mask is null");
+    const bool want_bg = dbeta || dgamma;
+    MQ_REQUIRE(!want_bg || workspace, "mq_pointwise_bwd: dbeta/dgamma need a workspace");
+    const int64_t groups = (p.rows * p.C + 7) / 8;
+    const bool vec = (p.C % 8 == 0) && al16(h) && al16(r_pre) && al16(dout) && al16(dt) && al16(dpost);
+    int grid = ew_grid(groups, 256);
+    if (grid > 1024) grid = 1024;
+    float *part = want_bg ? workspace : nullptr;
+    if (vec)
+        hipLaunchKernelGGL((pointwise_bwd_kernel<true>), dim3(grid), dim3(256), 0, S(stream), p, dout, h, r_pre, mask, beta,
+                           gamma, dt, dpost, part);
+    else
+        hipLaunchKernelGGL((pointwise_bwd_kernel<false>), dim3(grid), dim3(256), 0, S(stream), p, dout, h, r_pre, mask, beta,
+                           gamma, dt, dpost, part);
+    if (want_bg) hipLaunchKernelGGL(pw_final_kernel, dim3(1), dim3(256), 0, S(stream), part, grid, dbeta, dgamma);
+    MQ_LAUNCH_CHECK("mq_pointwise_bwd");
+    return 0;
+}
+
+extern "C" int mq_sequence_mask(const int32_t *lengths, int B, int T, uint8_t *mask, mqStream stream)
+{
+    MQ_REQUIRE(lengths && mask && B > 0 && T > 0, "mq_sequence_mask: bad arguments");
+    hipLaunchKernelGGL(sequence_mask_kernel, dim3((unsigned)cdiv((int64_t)B * T, 256)), dim3(256), 0, S(stream), lengths, B, T, mask);
+    MQ_LAUNCH_CHECK("mq_sequence_mask");
+    return 0;
+}
+extern "C" int mq_mask_pool(const uint8_t *in, int B, int Tin, int Tout, int stride, uint8_t *out, mqStream stream)
+{
+    MQ_REQUIRE(in && out && B > 0 && Tin > 0 && Tout > 0 && stride > 0, "mq_mask_pool: bad arguments");
+    MQ_REQUIRE((int64_t)(Tout - 1) * stride < Tin, "mq_mask_pool: Tout=%d too large for Tin=%d stride=%d", Tout, Tin, stride);
+    hipLaunchKernelGGL(mask_pool_kernel, dim3((unsigned)cdiv((int64_t)B * Tout, 256)), dim3(256), 0, S(stream), in, B, Tin, Tout,
+                       stride, out);
+    MQ_LAUNCH_CHECK("mq_mask_pool");
+    return 0;
+}
+extern "C" int mq_mask_upsample2(const uint8_t *in, int B, int Tin, uint8_t *out, mqStream stream)
+{
+    MQ_REQUIRE(in && out && B > 0 && Tin > 0, "mq_mask_upsample2: bad arguments");
+    hipLaunchKernelGGL(mask_upsample2_kernel, dim3((unsigned)cdiv((int64_t)B * Tin * 2, 256)), dim3(256), 0, S(stream), in, B, Tin,
+                       out);
+    MQ_LAUNCH_CHECK("mq_mask_upsample2");
+    return 0;
+}
+
+extern "C" int mq_avgpool_t2_fwd(const float *x, int N, int T, int F, int C, float *y, mqStream stream)
+{
+    MQ_REQUIRE(x && y && N > 0 && T > 0 && T % 2 == 0 && F > 0 && C > 0, "mq_avgpool_t2_fwd: bad arguments (T must be even)");
+    const int64_t FC = (int64_t)F * C;
+    hipLaunchKernelGGL(avgpool_t2_fwd_kernel, dim3(ew_grid((int64_t)N * (T / 2) * FC, 256)), dim3(256), 0, S(stream), x, (int64_t)N,
+                       T, FC, y);
+    MQ_LAUNCH_CHECK("mq_avgpool_t2_fwd");
+    return 0;
+}
+extern "C" int mq_avgpool_t2_bwd(const float *dy, int N, int T, int F, int C, float *dx, mqStream stream)
+{
+    MQ_REQUIRE(dy && dx && N > 0 && T > 0 && T % 2 == 0 && F > 0 && C > 0, "mq_avgpool_t2_bwd: bad arguments (T must be even)");
+    const int64_t FC = (int64_t)F * C;
+    hipLaunchKernelGGL(avgpool_t2_bwd_kernel, dim3(ew_grid((int64_t)N * T * FC, 256)), dim3(256), 0, S(stream), dy, (int64_t)N, T, FC,
+                       dx);
+    MQ_LAUNCH_CHECK("mq_avgpool_t2_bwd");
+    return 0;
+}
+extern "C" int mq_upcat_fwd(const float *x, const float *skip, int N, int T, int F, int C1, int C2, float *out, mqStream stream)
+{
+    MQ_REQUIRE(x && skip && out && N > 0 && T > 0 && F > 0 && C1 > 0 && C2 > 0, "mq_upcat_fwd: bad arguments");
+    hipLaunchKernelGGL(upcat_fwd_kernel, dim3(ew_grid((int64_t)N * 2 * T * F * (C1 + C2), 256)), dim3(256), 0, S(stream), x, skip,
+                       (int64_t)N, T, F, C1, C2, out);
+    MQ_LAUNCH_CHECK("mq_upcat_fwd");
+    return 0;
+}
+extern "C" int mq_upcat_bwd(const float *dout, int N, int T, int F, int C1, int C2, float *dx, float *dskip, mqStream stream)
+{
+    MQ_REQUIRE(dout && dx && dskip && N > 0 && T > 0 && F > 0 && C1 > 0 && C2 > 0, "mq_upcat_bwd: bad arguments");
+    hipLaunchKernelGGL(upcat_bwd_x_kernel, dim3(ew_grid((int64_t)N * T * F * C1, 256)), dim3(256), 0, S(stream), dout, (int64_t)N, T,
+                       F, C1, C2, dx);
+    hipLaunchKernelGGL(upcat_bwd_skip_kernel, dim3(ew_grid((int64_t)N * 2 * T * F * C2, 256)), dim3(256), 0, S(stream), dout,
+                       (int64_t)N * 2 * T * F, C1, C2, dskip);
+    MQ_LAUNCH_CHECK("mq_upcat_bwd");
+    return 0;
+}
+extern "C" int mq_concat2(const float *a, const float *b, int64_t rows, int C1, int C2, float *y, mqStream stream)
+{
+    MQ_REQUIRE(a && b && y && rows > 0 && C1 > 0 && C2 > 0, "mq_concat2: bad arguments");
+    hipLaunchKernelGGL(concat2_kernel, dim3(ew_grid(rows * (C1 + C2), 256)), dim3(256), 0, S(stream), a, b, rows, C1, C2, y);
+    MQ_LAUNCH_CHECK("mq_concat2");
+    return 0;
+}
+extern "C" int mq_axpby(const float *a, const float *b, float alpha, float beta_, int64_t n, float *out, mqStream stream)
+{
+    MQ_REQUIRE(a && out && n > 0, "mq_axpby: bad arguments");
+    hipLaunchKernelGGL(axpby_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S(stream), a, b, alpha, beta_, n, out);
+    MQ_LAUNCH_CHECK("mq_axpby");
+    return 0;
+}
+extern "C" int mq_band_split_fwd(const float *x, int B, int T, int F, int n_bins, float *out, mqStream stream)
+{
+    MQ_REQUIRE(x && out && B > 0 && T > 0 && F > 0 && n_bins > 0 && F % n_bins == 0, "mq_band_split_fwd: bad arguments");
+    MQ_REQUIRE(B <= 65535, "mq_band_split_fwd: B too large");
+    hipLaunchKernelGGL((band_split_kernel<true>), dim3((unsigned)cdiv(T, 32), (unsigned)cdiv(F, 32), B), dim3(32, 8), 0, S(stream), x,
+                       B, T, F, n_bins, out);
+    MQ_LAUNCH_CHECK("mq_band_split_fwd");
+    return 0;
+}
+extern "C" int mq_band_split_bwd(const float *dout, int B, int T, int F, int n_bins, float *dx, mqStream stream)
+{
+    MQ_REQUIRE(dout && dx && B > 0 && T > 0 && F > 0 && n_bins > 0 && F % n_bins == 0, "mq_band_split_bwd: bad arguments");
+    MQ_REQUIRE(B <= 65535, "mq_band_split_bwd: B too large");
+    hipLaunchKernelGGL((band_split_kernel<false>), dim3((unsigned)cdiv(T, 32), (unsigned)cdiv(F, 32), B), dim3(32, 8), 0, S(stream),
+                       dout, B, T, F, n_bins, dx);
+    MQ_LAUNCH_CHECK("mq_band_split_bwd");
+    return 0;
+}
+extern "C" int mq_sigmoid_add(const float *a, const float *b, int64_t n, float *out, mqStream stream)
+{
+    MQ_REQUIRE(a && out && n > 0, "mq_sigmoid_add: bad arguments");
+    hipLaunchKernelGGL(sigmoid_add_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S(stream), a, b, n, out);
+    MQ_LAUNCH_CHECK("mq_sigmoid_add");
+    return 0;
+}
+extern "C" int mq_sigmoid_add_bwd(const float *dout, const float *out, int64_t n, float *da, mqStream stream)
+{
+    MQ_REQUIRE(dout && out && da && n > 0, "mq_sigmoid_add_bwd: bad arguments");
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S(stream), dout, out, n, da);
+    MQ_LAUNCH_CHECK("mq_sigmoid_add_bwd");
+    return 0;
+}
+extern "C" int mq_relu_fwd(const float *x, int64_t n, float *y, mqStream stream)
+{
+    MQ_REQUIRE(x && y && n > 0, "mq_relu_fwd: bad arguments");
+    hipLaunchKernelGGL(relu_fwd_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S(stream), x, n, y);
+    MQ_LAUNCH_CHECK("mq_relu_fwd");
+    return 0;
+}
+extern "C" int mq_relu_bwd(const float *dy, const float *y, int64_t n, float *dx, mqStream stream)
+{
+    MQ_REQUIRE(dy && y && dx && n > 0, "mq_relu_bwd: bad arguments");
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S(stream), dy, y, n, dx);
+    MQ_LAUNCH_CHECK("mq_relu_bwd");
+    return 0;
+}

@@ -1,0 +1,360 @@
+// Vector-quantiser kernels for gfx950: FSQ (the reference's quantiser) and the generic L2
+// nearest-neighbour search + codebook EMA (north-star micro-benchmark shapes).
+#include "gemm_core.h"
+
+namespace mq {
+
+// ------------------------------------------------------------------------------------------ FSQ
+// Index search by thresholds: the reference pipeline  z -> rint(f32(f32(tanh(z+shift))*half_l) - offset)
+// is a monotone step function of z with L-1 jumps.  The host finds, by bisection over float bit
+// patterns with exactly that arithmetic (tanh evaluated in double), the smallest float theta_k with
+// level >= k, and the kernel just counts  z >= theta_k.  No transcendental, pure streaming, and
+// bit-identical to oracle/vq_ref.c by construction.
+struct FsqDev {
+    int d;
+    int nthr[8];       // levels - 1
+    int half_width[8];
+    int basis[8];
+    float thresh[8][8];
+    float half_l[8];
+    float shift[8];
+};
+
+template <int D>
+__global__ void fsq_forward_kernel(const float *__restrict__ z, int64_t n, FsqDev p, float *__restrict__ codes,
+                                   int32_t *__restrict__ idx)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float zv[D], cv[D];
+        if (D == 4) {
+            const float4 t = reinterpret_cast<const float4 *>(z)[i];
+            zv[0] = t.x; zv[1] = t.y; zv[2] = t.z; zv[3] = t.w;
+        } else {
+            for (int j = 0; j < p.d; ++j) zv[j] = z[i * p.d + j];
+        }
+        int id = 0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            if (D != 4 && j >= p.d) break;
+            int lvl = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k < p.nthr[j]) lvl += (zv[j] >= p.thresh[j][k]) ? 1 : 0;
+            const int q = lvl - p.half_width[j];
+            cv[j] = (float)q / (float)p.half_width[j];
+            id += lvl * p.basis[j];
+        }
+        if (codes) {
+            if (D == 4)
+                reinterpret_cast<float4 *>(codes)[i] = make_float4(cv[0], cv[1], cv[2], cv[3]);
+            else
+                for (int j = 0; j < p.d; ++j) codes[i * p.d + j] = cv[j];
+        }
+        if (idx) idx[i] = id;
+    }
+}
+
+__global__ void fsq_backward_kernel(const float *__restrict__ z, const float *__restrict__ dc, int64_t total, FsqDev p,
+                                    float *__restrict__ dz)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % p.d);
+        const float x = z[i] + p.shift[j];
+        const float e = __expf(-2.0f * fabsf(x));
+        const float r = __builtin_amdgcn_rcpf(1.0f + e);
+        const float sech2 = 4.0f * e * r * r;                       // 1 - tanh^2, no cancellation
+        dz[i] = dc[i] * (p.half_l[j] * sech2 / (float)p.half_width[j]);
+    }
+}
+
+__global__ void fsq_decode_kernel(const int64_t *__restrict__ idx, int64_t n, FsqDev p, float *__restrict__ codes)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t id = idx[i];
+        for (int j = 0; j < p.d; ++j) {
+            const int l = (int)((id / p.basis[j]) % (p.nthr[j] + 1));
+            codes[i * p.d + j] = (float)(l - p.half_width[j]) / (float)p.half_width[j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ L2 nearest neighbour
+__global__ void codebook_norms_kernel(const float *__restrict__ c, int k, int d, float *__restrict__ cn)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= k) return;
+    float acc = 0.f;
+    for (int t = 0; t < d; ++t) acc = fmaf(c[(size_t)j * d + t], c[(size_t)j * d + t], acc);
+    cn[j] = acc;
+}
+
+struct DenseALoader {   // rows of x, K-contiguous; same contract as the conv loaders
+    const float *__restrict__ x;
+    int64_t n;
+    int64_t m0;
+    int d, kbase;
+    __device__ __forceinline__ void prepare(int k0) { kbase = k0 + 4 * (threadIdx.x & 3); }
+    __device__ __forceinline__ float4 load(int j) const
+    {
+        const int64_t m = m0 + (threadIdx.x >> 2) + 64 * j;
+        if (m >= n || kbase >= d) return make_float4(0.f, 0.f, 0.f, 0.f);
+        return *reinterpret_cast<const float4 *>(x + m * d + kbase);
+    }
+};
+struct DenseCLoader {
+    const float *__restrict__ c;
+    int k, c0, d, kbase;
+    __device__ __forceinline__ void prepare(int k0) { kbase = k0 + 4 * (threadIdx.x & 3); }
+    __device__ __forceinline__ float4 load(int j) const
+    {
+        const int r = c0 + (threadIdx.x >> 2) + 64 * j;
+        if (r >= k || kbase >= d) return make_float4(0.f, 0.f, 0.f, 0.f);
+        return *reinterpret_cast<const float4 *>(c + (size_t)r * d + kbase);
+    }
+};
+
+__device__ __forceinline__ unsigned long long pack_dist_idx(float dist, int idx)
+{
+    unsigned u = __builtin_bit_cast(unsigned, dist);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);      // order-preserving map float -> uint
+    return ((unsigned long long)u << 32) | (unsigned)idx;
+}
+
+// grid (row tiles, code splits).  Each block: 128 rows x its range of 128-code tiles.
+__global__ __launch_bounds__(256) void l2_argmin_kernel(const float *__restrict__ x, const float *__restrict__ cb,
+                                                        const float *__restrict__ cn, int64_t n, int k, int d,
+                                                        int tiles_per_split, unsigned long long *__restrict__ packed)
+{
+    constexpr int BN = 128;
+    using Cfg = GemmCfg<BN>;
+    __shared__ __attribute__((aligned(16))) float smem[Cfg::LDS_FLOATS];
+    const int64_t m0 = (int64_t)blockIdx.x * GEMM_BM;
+    const int ntiles = (k + BN - 1) / BN;
+    const int t_begin = blockIdx.y * tiles_per_split;
+    const int t_end = min(ntiles, t_begin + tiles_per_split);
+    const int nk = (d + GEMM_BK - 1) / GEMM_BK;
+
+    float best[Cfg::TM][16];
+    int bidx[Cfg::TM][16];
+#pragma unroll
+    for (int a = 0; a < Cfg::TM; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            best[a][r] = INFINITY;
+            bidx[a][r] = 0x7fffffff;
+        }
+
+    for (int t = t_begin; t < t_end; ++t) {
+        DenseALoader la{x, n, m0, d, 0};
+        DenseCLoader lb{cb, k, t * BN, d, 0};
+        f32x16 acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+        for (int a = 0; a < Cfg::TM; ++a)
+#pragma unroll
+            for (int b = 0; b < Cfg::TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        nt_gemm_mainloop<BN>(la, lb, nk, smem, acc);
+#pragma unroll
+        for (int tn = 0; tn < Cfg::TN; ++tn) {
+            const int col = t * BN + acc_col<BN>(tn);
+            if (col < k) {
+                const float cnv = cn[col];
+#pragma unroll
+                for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float dist = fmaf(-2.0f, acc[tm][tn][r], cnv);
+                        if (dist < best[tm][r]) {       // strict: lowest index wins ties inside a lane
+                            best[tm][r] = dist;
+                            bidx[tm][r] = col;
+                        }
+                    }
+            }
+        }
+    }
+    // reduce over the 32 lanes that hold different columns of the same row, then one atomic per row
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            unsigned long long p = pack_dist_idx(best[tm][r], bidx[tm][r]);
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) {
+                const unsigned long long o = __shfl_xor(p, off, 64);
+                p = o < p ? o : p;
+            }
+            const int64_t m = m0 + acc_row<BN>(tm, r);
+            if ((lane & 31) == 0 && m < n) atomicMin(&packed[m], p);
+        }
+}
+
+__global__ void l2_unpack_kernel(const unsigned long long *__restrict__ packed, int64_t n, int32_t *__restrict__ idx,
+                                 float *__restrict__ dist)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long p = packed[i];
+        idx[i] = (int32_t)(p & 0xffffffffu);
+        if (dist) {
+            unsigned u = (unsigned)(p >> 32);
+            u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+            dist[i] = __builtin_bit_cast(float, u);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ codebook EMA
+__global__ void ema_accumulate_kernel(const float *__restrict__ x, const int32_t *__restrict__ idx, int64_t n, int d,
+                                      float *__restrict__ counts, float *__restrict__ sums)
+{
+    // one wave per row: lanes stride the feature dim
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave; i < n; i += nwaves) {
+        const int c = idx[i];
+        if (lane == 0) atomicAdd(&counts[c], 1.0f);
+        for (int t = lane; t < d; t += 64) atomicAdd(&sums[(size_t)c * d + t], x[i * d + t]);
+    }
+}
+__global__ void ema_sizes_kernel(const float *__restrict__ counts, int k, float decay, float *__restrict__ cluster_size,
+                                 float *__restrict__ total)
+{
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int j = threadIdx.x; j < k; j += blockDim.x) {
+        const float v = cluster_size[j] * decay + (1.0f - decay) * counts[j];
+        cluster_size[j] = v;
+        s += v;
+    }
+    s = block_sum<1024>(s, red);
+    if (threadIdx.x == 0) total[0] = s;
+}
+__global__ void ema_codebook_kernel(const float *__restrict__ sums, const float *__restrict__ cluster_size,
+                                    const float *__restrict__ total, int k, int d, float decay, float eps,
+                                    float *__restrict__ embed_sum, float *__restrict__ codebook)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)k * d) return;
+    const int j = (int)(i / d);
+    const float es = embed_sum[i] * decay + (1.0f - decay) * sums[i];
+    embed_sum[i] = es;
+    const float ntot = total[0];
+    const float smoothed = (cluster_size[j] + eps) / (ntot + (float)k * eps) * ntot;   // Laplace smoothing
+    codebook[i] = es / smoothed;
+}
+
+static int to_dev(const mqFsqDesc *h, FsqDev &p, const float (*thresh)[8], const char *who)
+{
+    MQ_REQUIRE(h && h->d >= 1 && h->d <= 8, "%s: d must be 1..8", who);
+    p.d = h->d;
+    for (int j = 0; j < 8; ++j) {
+        const bool on = j < h->d;
+        MQ_REQUIRE(!on || (h->levels[j] >= 2 && h->levels[j] <= 9), "%s: levels[%d]=%d out of range 2..9", who, j,
+                   h->levels[j]);
+        p.nthr[j] = on ? h->levels[j] - 1 : 0;
+        p.half_width[j] = on ? h->half_width[j] : 1;
+        p.basis[j] = on ? h->basis[j] : 0;
+        p.half_l[j] = on ? h->half_l[j] : 0.f;
+        p.shift[j] = on ? h->shift[j] : 0.f;
+        for (int k = 0; k < 8; ++k) p.thresh[j][k] = (on && thresh) ? thresh[j][k] : INFINITY;
+    }
+    return 0;
+}
+
+}  // namespace mq
+
+using namespace mq;
+
+extern "C" int mq_fsq_forward(const mqFsqDesc *desc, const float *z, int64_t n, float *codes, int32_t *idx,
+                              mqStream stream)
+{
+    FsqDev p;
+    if (to_dev(desc, p, desc ? desc->thresh : nullptr, "mq_fsq_forward")) return 1;
+    MQ_REQUIRE(z && n >= 0 && (codes || idx), "mq_fsq_forward: bad arguments");
+    if (n == 0) return 0;
+    const int grid = ew_grid(n, 256);
+    if (p.d == 4 && (uintptr_t)z % 16 == 0 && (uintptr_t)codes % 16 == 0)
+        hipLaunchKernelGGL((fsq_forward_kernel<4>), dim3(grid), dim3(256), 0, S(stream), z, n, p, codes, idx);
+    else
+        hipLaunchKernelGGL((fsq_forward_kernel<8>), dim3(grid), dim3(256), 0, S(stream), z, n, p, codes, idx);
+    MQ_LAUNCH_CHECK("mq_fsq_forward");
+    return 0;
+}
+
+extern "C" int mq_fsq_backward(const mqFsqDesc *desc, const float *z, const float *dcodes, int64_t n, float *dz,
+                               mqStream stream)
+{
+    FsqDev p;
+    if (to_dev(desc, p, nullptr, "mq_fsq_backward")) return 1;
+    MQ_REQUIRE(z && dcodes && dz && n >= 0, "mq_fsq_backward: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(fsq_backward_kernel, dim3(ew_grid(n * p.d, 256)), dim3(256), 0, S(stream), z, dcodes, n * p.d, p,
+                       dz);
+    MQ_LAUNCH_CHECK("mq_fsq_backward");
+    return 0;
+}
+
+extern "C" int mq_fsq_decode(const mqFsqDesc *desc, const int64_t *idx, int64_t n, float *codes, mqStream stream)
+{
+    FsqDev p;
+    if (to_dev(desc, p, nullptr, "mq_fsq_decode")) return 1;
+    MQ_REQUIRE(idx && codes && n >= 0, "mq_fsq_decode: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(fsq_decode_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S(stream), idx, n, p, codes);
+    MQ_LAUNCH_CHECK("mq_fsq_decode");
+    return 0;
+}
+
+extern "C" int mq_l2_codebook_norms(const float *codebook, int k, int d, float *cnorm, mqStream stream)
+{
+    MQ_REQUIRE(codebook && cnorm && k > 0 && d > 0, "mq_l2_codebook_norms: bad arguments");
+    hipLaunchKernelGGL(codebook_norms_kernel, dim3((unsigned)cdiv(k, 256)), dim3(256), 0, S(stream), codebook, k, d,
+                       cnorm);
+    MQ_LAUNCH_CHECK("mq_l2_codebook_norms");
+    return 0;
+}
+
+extern "C" size_t mq_l2_argmin_workspace(int64_t n) { return (size_t)(n > 0 ? n : 0) * sizeof(unsigned long long); }
+
+extern "C" int mq_l2_argmin(const float *x, const float *codebook, const float *cnorm, int64_t n, int k, int d,
+                            int32_t *idx, float *best_dist, void *workspace, mqStream stream)
+{
+    MQ_REQUIRE(x && codebook && cnorm && idx && workspace, "mq_l2_argmin: null pointer");
+    MQ_REQUIRE(n >= 0 && k > 0 && d > 0 && d % 4 == 0, "mq_l2_argmin: need n >= 0, k > 0, d %% 4 == 0 (d=%d)", d);
+    MQ_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)codebook % 16 == 0, "mq_l2_argmin: x / codebook must be 16-byte aligned");
+    if (n == 0) return 0;
+    hipError_t e = hipMemsetAsync(workspace, 0xFF, (size_t)n * 8, S(stream));
+    MQ_REQUIRE(e == hipSuccess, "mq_l2_argmin: memset failed: %s", hipGetErrorString(e));
+    const int row_tiles = (int)cdiv(n, GEMM_BM);
+    const int ntiles = (int)cdiv(k, 128);
+    int splits = (int)cdiv(768, row_tiles);
+    if (splits > ntiles) splits = ntiles;
+    if (splits < 1) splits = 1;
+    const int tps = (int)cdiv(ntiles, splits);
+    splits = (int)cdiv(ntiles, tps);
+    hipLaunchKernelGGL(l2_argmin_kernel, dim3(row_tiles, splits), dim3(256), 0, S(stream), x, codebook, cnorm, n, k, d, tps,
+                       reinterpret_cast<unsigned long long *>(workspace));
+    hipLaunchKernelGGL(l2_unpack_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S(stream),
+                       reinterpret_cast<const unsigned long long *>(workspace), n, idx, best_dist);
+    MQ_LAUNCH_CHECK("mq_l2_argmin");
+    return 0;
+}
+
+extern "C" int mq_codebook_ema_update(const float *x, const int32_t *idx, int64_t n, int k, int d, float decay, float eps,
+                                      float *cluster_size, float *embed_sum, float *codebook, float *counts_ws,
+                                      float *sums_ws, mqStream stream)
+{
+    MQ_REQUIRE(x && idx && cluster_size && embed_sum && codebook && counts_ws && sums_ws, "mq_codebook_ema_update: null pointer");
+    MQ_REQUIRE(n > 0 && k > 0 && d > 0, "mq_codebook_ema_update: bad sizes");
+    hipMemsetAsync(counts_ws, 0, ((size_t)k + 4) * sizeof(float), S(stream));   // +4: slot k holds the total
+    hipMemsetAsync(sums_ws, 0, (size_t)k * d * sizeof(float), S(stream));
+    hipLaunchKernelGGL(ema_accumulate_kernel, dim3(ew_grid(n * 64, 256)), dim3(256), 0, S(stream), x, idx, n, d, counts_ws,
+                       sums_ws);
+    hipLaunchKernelGGL(ema_sizes_kernel, dim3(1), dim3(1024), 0, S(stream), counts_ws, k, decay, cluster_size, counts_ws + k);
+    hipLaunchKernelGGL(ema_codebook_kernel, dim3((unsigned)cdiv((int64_t)k * d, 256)), dim3(256), 0, S(stream), sums_ws,
+                       cluster_size, counts_ws + k, k, d, decay, eps, embed_sum, codebook);
+    MQ_LAUNCH_CHECK("mq_codebook_ema_update");
+    return 0;
+}

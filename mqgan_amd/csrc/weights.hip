@@ -1,0 +1,214 @@
+// Effective-weight preparation for the implicit GEMM: layout change (reference (K, C, R*S) ->
+// KRSC and CRSK) fused with weight norm / spectral norm, plus the matching backward passes.
+#include "common.h"
+
+namespace mq {
+
+// one block per output channel k.  v (K, C, RS).
+__global__ void weight_prep_kernel(int mode, const float *__restrict__ v, const float *__restrict__ g, int K, int C, int RS,
+                                   float *__restrict__ w_krsc, float *__restrict__ w_crsk, float *__restrict__ inv_norm)
+{
+    __shared__ float red[4];
+    const int k = blockIdx.x;
+    const int fan = C * RS;
+    const float *vk = v + (size_t)k * fan;
+    float scale = 1.0f;
+    if (mode == 1) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < fan; i += 256) s += vk[i] * vk[i];
+        s = block_sum<256>(s, red);
+        const float inv = 1.0f / sqrtf(s);
+        if (threadIdx.x == 0 && inv_norm) inv_norm[k] = inv;
+        scale = g[k] * inv;
+    }
+    for (int i = threadIdx.x; i < fan; i += 256) {
+        const int c = i / RS, rs = i - c * RS;
+        const float w = vk[i] * scale;
+        if (w_krsc) w_krsc[((size_t)k * RS + rs) * C + c] = w;
+        if (w_crsk) w_crsk[((size_t)c * RS + rs) * K + k] = w;
+    }
+}
+
+__global__ void weight_prep_bwd_kernel(int mode, const float *__restrict__ dw_krsc, const float *__restrict__ v,
+                                       const float *__restrict__ g, const float *__restrict__ inv_norm, int K, int C, int RS,
+                                       float *__restrict__ dv, float *__restrict__ dg)
+{
+    __shared__ float red[4];
+    const int k = blockIdx.x;
+    const int fan = C * RS;
+    const float *vk = v + (size_t)k * fan;
+    if (mode == 0) {
+        for (int i = threadIdx.x; i < fan; i += 256) {
+            const int c = i / RS, rs = i - c * RS;
+            dv[(size_t)k * fan + i] = dw_krsc[((size_t)k * RS + rs) * C + c];
+        }
+        return;
+    }
+    float dot = 0.f;
+    for (int i = threadIdx.x; i < fan; i += 256) {
+        const int c = i / RS, rs = i - c * RS;
+        dot += dw_krsc[((size_t)k * RS + rs) * C + c] * vk[i];
+    }
+    dot = block_sum<256>(dot, red);
+    const float inv = inv_norm[k], gk = g[k];
+    if (threadIdx.x == 0) dg[k] = dot * inv;
+    if (fan == 1) {   // w = g * sign(v): the gradient wrt v is exactly zero (reference: measured 0)
+        if (threadIdx.x == 0) dv[k] = 0.f;
+        return;
+    }
+    const float a = gk * inv, b = gk * dot * inv * inv * inv;
+    for (int i = threadIdx.x; i < fan; i += 256) {
+        const int c = i / RS, rs = i - c * RS;
+        dv[(size_t)k * fan + i] = a * dw_krsc[((size_t)k * RS + rs) * C + c] - b * vk[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ spectral norm
+// t[j] = sum_k W[k][j] * u[k]      (grid over j)
+__global__ void sn_wt_u_kernel(const float *__restrict__ W, const float *__restrict__ u, int K, int fan, float *__restrict__ t)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= fan) return;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += W[(size_t)k * fan + j] * u[k];
+    t[j] = s;
+}
+// s[k] = sum_j W[k][j] * v[j]      (block per k)
+__global__ void sn_w_v_kernel(const float *__restrict__ W, const float *__restrict__ v, int fan, float *__restrict__ s)
+{
+    __shared__ float red[4];
+    const int k = blockIdx.x;
+    float a = 0.f;
+    for (int j = threadIdx.x; j < fan; j += 256) a += W[(size_t)k * fan + j] * v[j];
+    a = block_sum<256>(a, red);
+    if (threadIdx.x == 0) s[k] = a;
+}
+// out = in / max(||in||, eps)   (single block of 1024)
+__global__ void sn_normalize_kernel(const float *__restrict__ in, int n, float eps, float *__restrict__ out)
+{
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) s += in[i] * in[i];
+    s = block_sum<1024>(s, red);
+    const float inv = 1.0f / fmaxf(sqrtf(s), eps);
+    for (int i = threadIdx.x; i < n; i += 1024) out[i] = in[i] * inv;
+}
+// sigma = dot(u, s)   (single block)
+__global__ void sn_sigma_kernel(const float *__restrict__ u, const float *__restrict__ s, int K, float *__restrict__ sigma)
+{
+    __shared__ float red[16];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < K; i += 1024) a += u[i] * s[i];
+    a = block_sum<1024>(a, red);
+    if (threadIdx.x == 0) sigma[0] = a;
+}
+__global__ void sn_scale_kernel(const float *__restrict__ W, const float *__restrict__ sigma, int K, int C, int RS,
+                                float *__restrict__ w_krsc, float *__restrict__ w_crsk)
+{
+    const int fan = C * RS;
+    const int64_t n = (int64_t)K * fan;
+    const float inv = 1.0f / sigma[0];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i / fan), r = (int)(i - (int64_t)k * fan);
+        const int c = r / RS, rs = r - c * RS;
+        const float w = W[i] * inv;
+        if (w_krsc) w_krsc[((size_t)k * RS + rs) * C + c] = w;
+        if (w_crsk) w_crsk[((size_t)c * RS + rs) * K + k] = w;
+    }
+}
+// partial[b] = sum over a slice of dW (KRSC) * W (KCRS)
+__global__ void sn_bwd_dot_kernel(const float *__restrict__ dw_krsc, const float *__restrict__ W, int K, int C, int RS,
+                                  float *__restrict__ partial)
+{
+    __shared__ float red[4];
+    const int fan = C * RS;
+    const int64_t n = (int64_t)K * fan;
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int k = (int)(i / fan), r = (int)(i - (int64_t)k * fan);
+        const int c = r / RS, rs = r - c * RS;
+        s += dw_krsc[((size_t)k * RS + rs) * C + c] * W[i];
+    }
+    s = block_sum<256>(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ void sn_bwd_apply_kernel(const float *__restrict__ dw_krsc, const float *__restrict__ u, const float *__restrict__ v,
+                                    const float *__restrict__ sigma, const float *__restrict__ partial, int nparts, int K,
+                                    int C, int RS, float *__restrict__ dW)
+{
+    const int fan = C * RS;
+    const int64_t n = (int64_t)K * fan;
+    float dot = 0.f;
+    for (int i = 0; i < nparts; ++i) dot += partial[i];
+    const float inv = 1.0f / sigma[0];
+    const float coef = dot * inv * inv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i / fan), r = (int)(i - (int64_t)k * fan);
+        const int c = r / RS, rs = r - c * RS;
+        dW[i] = dw_krsc[((size_t)k * RS + rs) * C + c] * inv - coef * u[k] * v[r];
+    }
+}
+
+}  // namespace mq
+
+using namespace mq;
+
+extern "C" int mq_weight_prep(int mode, const float *v, const float *g, int K, int C, int RS, float *w_krsc, float *w_crsk,
+                              float *inv_norm, mqStream stream)
+{
+    MQ_REQUIRE(v && K > 0 && C > 0 && RS > 0 && (w_krsc || w_crsk), "mq_weight_prep: bad arguments");
+    MQ_REQUIRE(mode == 0 || (mode == 1 && g && inv_norm), "mq_weight_prep: mode 1 needs g and inv_norm");
+    hipLaunchKernelGGL(weight_prep_kernel, dim3(K), dim3(256), 0, S(stream), mode, v, g, K, C, RS, w_krsc, w_crsk, inv_norm);
+    MQ_LAUNCH_CHECK("mq_weight_prep");
+    return 0;
+}
+
+extern "C" int mq_weight_prep_bwd(int mode, const float *dw_krsc, const float *v, const float *g, const float *inv_norm,
+                                  int K, int C, int RS, float *dv, float *dg, mqStream stream)
+{
+    MQ_REQUIRE(dw_krsc && v && dv && K > 0 && C > 0 && RS > 0, "mq_weight_prep_bwd: bad arguments");
+    MQ_REQUIRE(mode == 0 || (mode == 1 && g && inv_norm && dg), "mq_weight_prep_bwd: mode 1 needs g, inv_norm, dg");
+    hipLaunchKernelGGL(weight_prep_bwd_kernel, dim3(K), dim3(256), 0, S(stream), mode, dw_krsc, v, g, inv_norm, K, C, RS, dv,
+                       dg);
+    MQ_LAUNCH_CHECK("mq_weight_prep_bwd");
+    return 0;
+}
+
+extern "C" int mq_spectral_prep(const float *w_orig, float *u, float *v, int K, int C, int RS, int power_iteration, float eps,
+                                float *w_krsc, float *w_crsk, float *sigma_out, float *scratch, mqStream stream)
+{
+    MQ_REQUIRE(w_orig && u && v && sigma_out && scratch && K > 0 && C > 0 && RS > 0, "mq_spectral_prep: bad arguments");
+    const int fan = C * RS;
+    float *t = scratch;        // fan
+    float *s = scratch + fan;  // K
+    hipStream_t st = S(stream);
+    if (power_iteration) {
+        hipLaunchKernelGGL(sn_wt_u_kernel, dim3((unsigned)cdiv(fan, 128)), dim3(128), 0, st, w_orig, u, K, fan, t);
+        hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(1024), 0, st, t, fan, eps, v);
+        hipLaunchKernelGGL(sn_w_v_kernel, dim3(K), dim3(256), 0, st, w_orig, v, fan, s);
+        hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(1024), 0, st, s, K, eps, u);
+    } else {
+        hipLaunchKernelGGL(sn_w_v_kernel, dim3(K), dim3(256), 0, st, w_orig, v, fan, s);
+    }
+    hipLaunchKernelGGL(sn_sigma_kernel, dim3(1), dim3(1024), 0, st, u, s, K, sigma_out);
+    hipLaunchKernelGGL(sn_scale_kernel, dim3(ew_grid((int64_t)K * fan, 256)), dim3(256), 0, st, w_orig, sigma_out, K, C, RS,
+                       w_krsc, w_crsk);
+    MQ_LAUNCH_CHECK("mq_spectral_prep");
+    return 0;
+}
+
+extern "C" int mq_spectral_prep_bwd(const float *dw_krsc, const float *w_orig, const float *u, const float *v,
+                                    const float *sigma, int K, int C, int RS, float *dw_orig, float *scratch, mqStream stream)
+{
+    MQ_REQUIRE(dw_krsc && w_orig && u && v && sigma && dw_orig && scratch && K > 0 && C > 0 && RS > 0,
+               "mq_spectral_prep_bwd: bad arguments");
+    const int64_t n = (int64_t)K * C * RS;
+    int nparts = (int)cdiv(n, 256 * 16);
+    if (nparts > 256) nparts = 256;
+    if (nparts < 1) nparts = 1;
+    hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(nparts), dim3(256), 0, S(stream), dw_krsc, w_orig, K, C, RS, scratch);
+    hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S(stream), dw_krsc, u, v, sigma, scratch,
+                       nparts, K, C, RS, dw_orig);
+    MQ_LAUNCH_CHECK("mq_spectral_prep_bwd");
+    return 0;
+}

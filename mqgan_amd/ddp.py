@@ -1,0 +1,146 @@
+"""Data-parallel gradient exchange for one process per GPU (torch.distributed: backend "nccl" is
+RCCL over xGMI on ROCm; "gloo" on CPU for tests).
+
+Design (MI355X-first, not a port of torch DDP):
+  * parameters and gradients of a model live in two flat fp32 arenas (FlatArena), so the optimiser,
+    the gradient norm and the all-reduce all work on a handful of large contiguous ranges;
+  * GradReducer cuts the gradient arena into a few large buckets (default 32 MiB: a ring all-reduce
+    over xGMI is per-link bound, few large messages beat many small ones) in REVERSE registration
+    order, launches an asynchronous all-reduce for a bucket as soon as every gradient in it has been
+    accumulated (post-accumulate-grad hooks, i.e. while backward is still running; the collective
+    runs on the process group's own HIP stream), and waits for all of them before the clip/Adam
+    kernels read the arena;
+  * parameters that never receive a gradient (``hidden_proj.*``: its only consumer is detached,
+    reference preencoder.py:413-415) do not block a bucket: whatever is still pending is flushed by
+    ``finish()``.
+"""
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class FlatArena:
+    """Re-homes the parameters of ``modules`` into one flat buffer and gives every parameter a
+    gradient view into a second flat buffer (zeroed, never None)."""
+
+    def __init__(self, modules: Iterable[torch.nn.Module], align: int = 4):
+        self.params: List[torch.nn.Parameter] = []
+        seen = set()
+        for m in modules:
+            for p in m.parameters():
+                if id(p) not in seen:
+                    seen.add(id(p))
+                    self.params.append(p)
+        if not self.params:
+            raise ValueError("FlatArena: no parameters")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        self.offsets, n = [], 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += (p.numel() + align - 1) // align * align          # keep every tensor 16-byte aligned
+        self.numel = n
+        self.flat_param = torch.zeros(n, dtype=dt, device=dev)
+        self.flat_grad = torch.zeros(n, dtype=dt, device=dev)
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                view = self.flat_param[o:o + p.numel()].view_as(p)
+                view.copy_(p)
+                p.data = view
+                p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+        for p, o in zip(self.params, self.offsets):               # re-attach if something reset .grad to None
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
+                p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+
+    def rebind(self):
+        """After load_state_dict / .to(): make sure parameters still alias the arena."""
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                if p.data.data_ptr() != self.flat_param.data_ptr() + 4 * o:
+                    view = self.flat_param[o:o + p.numel()].view_as(p)
+                    view.copy_(p.data)
+                    p.data = view
+
+
+class GradReducer:
+    def __init__(self, arena: FlatArena, process_group=None, bucket_bytes: int = 32 << 20, average: bool = False):
+        self.arena = arena
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.average = average
+        self.buckets = []                      # (start, end) element ranges of flat_grad, reverse order
+        self.param_bucket = {}
+        cap = max(1, bucket_bytes // 4)
+        end = arena.numel
+        cur_start, members = end, []
+        for p, o in reversed(list(zip(arena.params, arena.offsets))):
+            cur_start = o
+            members.append(p)
+            if end - cur_start >= cap:
+                self._add_bucket(cur_start, end, members)
+                end, members = cur_start, []
+        if members:
+            self._add_bucket(cur_start, end, members)
+        self._pending = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+        self._handles = []
+        self._hooks = []
+        self.enabled = self.world > 1
+        if self.enabled:
+            for p in arena.params:
+                if p.requires_grad:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def _add_bucket(self, start, end, members):
+        b = len(self.buckets)
+        self.buckets.append((start, end, len(members)))
+        for p in members:
+            self.param_bucket[id(p)] = b
+
+    def start(self):
+        """Call before backward."""
+        self._pending = [n for (_, _, n) in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._handles = []
+
+    def _launch(self, b):
+        s, e, _ = self.buckets[b]
+        self._launched[b] = True
+        self._handles.append(dist.all_reduce(self.arena.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def _on_grad(self, p):
+        if not self.enabled:
+            return
+        b = self.param_bucket[id(p)]
+        self._pending[b] -= 1
+        if self._pending[b] == 0 and not self._launched[b]:
+            self._launch(b)
+
+    def finish(self):
+        """Call after backward: flush buckets that are still waiting (parameters without gradient),
+        wait for every collective.  The arena then holds SUMS over ranks; the 1 / world factor is
+        applied inside the clip / Adam kernel (``grad_scale``) unless ``average`` asks for it here."""
+        if not self.enabled:
+            return
+        for b in range(len(self.buckets)):
+            if not self._launched[b]:
+                self._launch(b)
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+        if self.average:
+            self.arena.flat_grad.mul_(1.0 / self.world)
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
+def broadcast_arena(arena: FlatArena, src: int = 0, process_group=None):
+    """Make every replica start from rank ``src``'s weights."""
+    if dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        dist.broadcast(arena.flat_param, src=src, group=process_group)

@@ -1,0 +1,154 @@
+"""Patch and multi-bin discriminators with the reference's API and state_dict keys (reference
+discriminators.py:10-67, 70-242, 245-311) on the HIP kernels.
+
+Both run through one code path: the (H = mel, W = time) single-channel image of every band is
+stacked along the batch and each conv is ONE batch-grouped implicit-GEMM launch (groups = number of
+bands; 1 for the patch discriminator), instead of eight small independent networks.
+"""
+from typing import List, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .nn_base import ConvParams
+
+
+class ChannelSELayerMasked(nn.Module):
+    """discriminators.py:10-67 (keys fc1.*, fc2.*)."""
+
+    def __init__(self, num_channels: int, reduction_ratio: int = 2):
+        super().__init__()
+        reduced = max(1, num_channels // reduction_ratio)
+        self.fc1 = ConvParams(reduced, num_channels, ())
+        self.fc2 = ConvParams(num_channels, reduced, ())
+
+
+def _layer_strides(stride, n_convs):
+    if isinstance(stride, int):
+        ls = [(1, stride)] * n_convs
+    elif isinstance(stride, tuple) and len(stride) == 2:
+        ls = [stride] * n_convs
+    else:
+        assert len(stride) == n_convs, "stride list must match kernel_sizes"
+        ls = [tuple(s) for s in stride]
+    return ls[:-1] + [(1, 1)]                      # the logits conv is always stride 1 (discriminators.py:165)
+
+
+class MelSpectrogramPatchDiscriminator2D(nn.Module):
+    def __init__(self, mel_channels: int, hidden_channels: list = (64, 128, 256, 512), kernel_sizes: list = (7, 5, 5, 3, 3),
+                 stride: Union[int, Tuple[int, int], List[Tuple[int, int]]] = (2, 2), lengthwise_only=False):
+        super().__init__()
+        assert len(kernel_sizes) == len(hidden_channels) + 1, "kernel_sizes must be hidden_channels len + 1"
+        if lengthwise_only:
+            raise NotImplementedError("lengthwise_only discriminators are not used by train.py")
+        self.mel_channels = mel_channels
+        n = len(kernel_sizes)
+        self.ret_features_map = [False, False] + [True] * (n - 3) + [False]
+        self.strides = _layer_strides(stride, n)
+        self.convs = nn.ModuleList()
+        in_ch = 1
+        for out_ch, k in zip(list(hidden_channels) + [1], kernel_sizes):
+            k1, k2 = (k, k) if not isinstance(k, (tuple, list)) else k
+            self.convs.append(ConvParams(out_ch, in_ch, (k1, k2), "sn", init="normal02"))
+            in_ch = out_ch
+        self.se_block = ChannelSELayerMasked(hidden_channels[-1], 8)
+
+    # reference API: (B, T, F), (B,) -> logits (B,1,H,W), patch_mask bool True = valid [, features]
+    def forward(self, x, x_lengths, return_features: bool = False):
+        logits, mask, feats = run_discriminators([self], x, x_lengths, return_features)
+        B, H, W, _ = logits.shape
+        valid = (~mask.bool())[:, None, None, :].expand(B, 1, H, W)
+        if return_features:
+            fl = [(f.permute(0, 3, 1, 2), m.bool()[:, None, None, :].expand(f.shape[0], 1, f.shape[1], f.shape[2]))
+                  for f, m in feats]
+            return logits.permute(0, 3, 1, 2), valid, fl
+        return logits.permute(0, 3, 1, 2), valid
+
+
+class MultiBinDiscriminator(nn.Module):
+    def __init__(self, mel_channels: int, n_bins: int = 4, hidden_channels: list = (64, 128, 256, 512),
+                 kernel_sizes: list = (7, 5, 5, 3, 3), n_no_strides: int = 2):
+        super().__init__()
+        assert mel_channels % n_bins == 0, "mel_channels must divide n_bins"
+        self.n_bins = n_bins
+        strides = [(1, 1) if i < n_no_strides else (1, 2) for i in range(len(kernel_sizes))]
+        self.discriminators = nn.ModuleList([
+            MelSpectrogramPatchDiscriminator2D(mel_channels // n_bins, hidden_channels=list(hidden_channels),
+                                               kernel_sizes=[(3, ks) for ks in kernel_sizes], stride=strides)
+            for _ in range(n_bins)])
+
+    def forward(self, x, x_lengths, return_features: bool = False):
+        logits, mask, feats = run_discriminators(list(self.discriminators), x, x_lengths, return_features)
+        G = self.n_bins
+        B = logits.shape[0] // G
+        H, W = logits.shape[1], logits.shape[2]
+        valid = (~mask[:B].bool())[:, None, None, :].expand(B, 1, H, W)
+        outs = [logits[j * B:(j + 1) * B].permute(0, 3, 1, 2) for j in range(G)]
+        masks = [valid for _ in range(G)]
+        if return_features:
+            fl = [[(f[j * B:(j + 1) * B].permute(0, 3, 1, 2),
+                    m[:B].bool()[:, None, None, :].expand(B, 1, f.shape[1], f.shape[2])) for f, m in feats] for j in range(G)]
+            return outs, masks, fl
+        return outs, masks
+
+
+def _stacked(bands, get, need_crsk=True, power_iteration=False, detach=False):
+    """Effective weights of the same layer of every band, stacked along the group axis."""
+    ws = [get(b).effective(need_crsk=need_crsk, power_iteration=power_iteration) for b in bands]
+    if len(ws) == 1:
+        w_krsc, w_crsk = ws[0]
+        bias = get(bands[0]).bias
+    else:
+        w_krsc = torch.cat([w[0] for w in ws], dim=0)
+        w_crsk = torch.cat([w[1] for w in ws], dim=0) if need_crsk else None
+        bias = torch.cat([get(b).bias for b in bands], dim=0)
+    if detach:
+        w_krsc, bias = w_krsc.detach(), bias.detach()
+    return w_krsc, w_crsk, bias
+
+
+def run_discriminators(bands: List[MelSpectrogramPatchDiscriminator2D], x, x_lengths, return_features=False,
+                       need_input_grad=None, detach_params=False):
+    """Shared forward.  x (B, T, F) -> logits (G*B, H, W, 1) channels-last, padded mask uint8 (G*B, W) and
+    [(feature (G*B, H, W, C), padded mask (G*B, W))].  G = len(bands); band j owns rows [jB, (j+1)B).
+    ``detach_params``: treat the weights as constants (generator step: no discriminator weight gradients)."""
+    G = len(bands)
+    d0 = bands[0]
+    B, T, Fq = x.shape
+    training = d0.training
+    need_dx = x.requires_grad if need_input_grad is None else need_input_grad
+    mask = ops.sequence_mask(x_lengths.to(x.device), T)                       # discriminators.py:184-193
+    if G > 1:
+        mask = mask.repeat(G, 1)
+    out = ops.BandSplitFn.apply(x.contiguous(), G)                            # (G*B, F/G, T, 1)  (:211, :298)
+    feats = []
+    n = len(d0.convs)
+    for i in range(n):
+        N, H, W, Cin = out.shape
+        if i == n - 1:                                                        # masked SE before the logits conv (:216-217)
+            sq = ops.SeSqueezeFn.apply(out, mask)                             # (G*B, C)
+            w1k, w1c, b1 = _stacked(bands, lambda d: d.se_block.fc1, detach=detach_params)
+            w2k, w2c, b2 = _stacked(bands, lambda d: d.se_block.fc2, detach=detach_params)
+            r = b1.numel() // G
+            h = ops.conv(sq.view(N, 1, 1, Cin), w1k, w1c, b1, ops.conv_desc(N, 1, 1, Cin, r, 1, 1, groups=G))
+            h = ops.ReluFn.apply(h)
+            e = ops.conv(h, w2k, w2c, b2, ops.conv_desc(N, 1, 1, r, Cin, 1, 1, groups=G))
+            e = ops.SigmoidAddFn.apply(e.view(N, Cin), None)
+            out = ops.SeScaleFn.apply(out, e)
+        conv_i = d0.convs[i]
+        kh, kw = conv_i.ksize
+        sh, sw = d0.strides[i]
+        first = (i == 0)
+        wk, wc, bias = _stacked(bands, lambda d: d.convs[i], need_crsk=(need_dx or not first), power_iteration=training,
+                                detach=detach_params)
+        desc = ops.conv_desc(N, H, W, Cin, conv_i.cout, kh, kw, stride=(sh, sw), pad=((kh - 1) // 2, (kw - 1) // 2), groups=G)
+        out = ops.conv(out, wk, wc, bias, desc)
+        if sh > 1 or sw > 1:                                                  # ceil-mode max-pool of the mask (:223-229)
+            if sw > 1:
+                mask = ops.mask_pool(mask, sw, ceil_mode=True)
+        P, Q = out.shape[1], out.shape[2]
+        out = ops.pointwise(out, act=ops.ACT_LEAKY, mask=mask, mask_post=True, dmap=(P * Q, Q, Q))   # (:219, :232)
+        if return_features and d0.ret_features_map[i]:
+            feats.append((out, mask))
+    return out, mask, feats

@@ -1,0 +1,139 @@
+"""Parameter containers with the reference's state_dict key names, producing the effective
+weights the implicit-GEMM kernels read.
+
+Three flavours appear in the reference checkpoint layout:
+  * new-API weight norm  -> ``<name>.bias``, ``<name>.parametrizations.weight.original0`` (g),
+                            ``...original1`` (v)            (preencoder.py:53,248; attentions.py:500-501)
+  * legacy weight norm   -> ``<name>.bias``, ``<name>.weight_g``, ``<name>.weight_v``   (attentions.py:469)
+  * legacy spectral norm -> ``<name>.bias``, ``<name>.weight_orig`` + buffers ``weight_u``, ``weight_v``
+                                                                                (discriminators.py:139,162)
+  * plain                -> ``<name>.weight``, ``<name>.bias``
+Weights keep the reference's (K, C, *kernel) shapes; the kernels' KRSC / CRSK images are produced on
+the fly by mq_weight_prep / mq_spectral_prep (fused with the normalisation).
+"""
+import math
+from typing import Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def _fan_in(shape) -> int:
+    n = 1
+    for s in shape[1:]:
+        n *= s
+    return n
+
+
+def _default_init(shape):
+    """PyTorch's default Conv/Linear init: kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(fan_in), 1/sqrt(fan_in))."""
+    bound = 1.0 / math.sqrt(_fan_in(shape))
+    w = torch.empty(shape).uniform_(-bound, bound)
+    b = torch.empty(shape[0]).uniform_(-bound, bound)
+    return w, b
+
+
+class _WNOriginals(nn.Module):
+    def __init__(self, g, v):
+        super().__init__()
+        self.original0 = nn.Parameter(g)
+        self.original1 = nn.Parameter(v)
+
+
+class _Parametrizations(nn.Module):
+    def __init__(self, g, v):
+        super().__init__()
+        self.weight = _WNOriginals(g, v)
+
+
+class ConvParams(nn.Module):
+    """Weights of one conv / linear layer.  ``flavour`` in {"plain", "wn", "wn_legacy", "sn"}."""
+
+    def __init__(self, cout: int, cin: int, ksize: Sequence[int], flavour: str = "plain", bias: bool = True,
+                 init: str = "default"):
+        super().__init__()
+        shape = (cout, cin) + tuple(ksize)
+        self.flavour = flavour
+        self.cout, self.cin, self.ksize = cout, cin, tuple(ksize)
+        w, b = _default_init(shape)
+        if init == "normal02":                      # discriminators.py:176-181
+            w = torch.randn(shape) * 0.02
+            b = torch.zeros(cout)
+        if flavour == "sn":
+            # state_dict order of the reference: bias, weight_orig, then buffers weight_u, weight_v
+            self.bias = nn.Parameter(b) if bias else None
+            self.weight_orig = nn.Parameter(w)
+            u = torch.nn.functional.normalize(torch.randn(cout), dim=0, eps=1e-12)
+            v = torch.nn.functional.normalize(torch.randn(_fan_in(shape)), dim=0, eps=1e-12)
+            self.register_buffer("weight_u", u)
+            self.register_buffer("weight_v", v)
+        elif flavour == "wn":
+            self.bias = nn.Parameter(b) if bias else None
+            g = w.flatten(1).norm(dim=1).view(cout, *([1] * (len(shape) - 1)))
+            self.parametrizations = _Parametrizations(g, w)
+        elif flavour == "wn_legacy":
+            self.bias = nn.Parameter(b) if bias else None
+            self.weight_g = nn.Parameter(w.flatten(1).norm(dim=1).view(cout, *([1] * (len(shape) - 1))))
+            self.weight_v = nn.Parameter(w)
+        else:
+            self.weight = nn.Parameter(w)
+            self.bias = nn.Parameter(b) if bias else None
+
+    # effective weights in the kernels' layouts -------------------------------------------------
+    def effective(self, need_crsk: bool = True, power_iteration: bool = False):
+        if self.flavour == "plain":
+            return ops.weight_prep(self.weight, None, need_crsk)
+        if self.flavour == "wn":
+            p = self.parametrizations.weight
+            return ops.weight_prep(p.original1, p.original0, need_crsk)
+        if self.flavour == "wn_legacy":
+            return ops.weight_prep(self.weight_v, self.weight_g, need_crsk)
+        return ops.spectral_prep(self.weight_orig, self.weight_u, self.weight_v, power_iteration, need_crsk)
+
+    def fold_weight_norm_(self):
+        """strip_weight_norm (preencoder.py:507-514) for the legacy flavour: weight_g/weight_v -> weight."""
+        if self.flavour != "wn_legacy":
+            return
+        with torch.no_grad():
+            v, g = self.weight_v, self.weight_g
+            w = v * (g / v.flatten(1).norm(dim=1).view(-1, *([1] * (v.dim() - 1))))
+        del self.weight_g, self.weight_v
+        bias = self.bias
+        del self.bias
+        self.weight = nn.Parameter(w)
+        self.bias = bias
+        self.flavour = "plain"
+
+
+def linear(x: torch.Tensor, p: ConvParams, need_dx: bool = True) -> torch.Tensor:
+    """nn.Linear on the last dim of a channels-last tensor, as a 1x1 implicit GEMM."""
+    cin = x.shape[-1]
+    rows = x.numel() // cin
+    w_krsc, w_crsk = p.effective(need_crsk=need_dx)
+    d = ops.conv_desc(1, 1, rows, cin, p.cout, 1, 1)
+    y = ops.conv(x.reshape(1, 1, rows, cin), w_krsc, w_crsk, p.bias, d)
+    return y.view(*x.shape[:-1], p.cout)
+
+
+def conv1d(x: torch.Tensor, p: ConvParams, causal: bool, dilation: int = 1) -> torch.Tensor:
+    """x (B, T, Cin) -> (B, T, Cout); "same" padding (odd k) or causal left padding d*(k-1)."""
+    B, T, cin = x.shape
+    k = p.ksize[0]
+    pad = dilation * (k - 1) if causal else dilation * (k // 2)
+    w_krsc, w_crsk = p.effective()
+    d = ops.conv_desc(B, 1, T, cin, p.cout, 1, k, pad=(0, pad), dil=(1, dilation), out_hw=(1, T))
+    return ops.conv(x.view(B, 1, T, cin), w_krsc, w_crsk, p.bias, d).view(B, T, p.cout)
+
+
+def conv2d(x: torch.Tensor, p: ConvParams, stride=(1, 1), pad: Optional[Tuple[int, int]] = None, need_dx: bool = True,
+           power_iteration: bool = False) -> torch.Tensor:
+    """x (N, H, W, Cin) -> (N, P, Q, Cout), padding (k-1)//2 per dim unless given."""
+    N, H, W, cin = x.shape
+    kh, kw = p.ksize
+    if pad is None:
+        pad = ((kh - 1) // 2, (kw - 1) // 2)
+    w_krsc, w_crsk = p.effective(need_crsk=need_dx, power_iteration=power_iteration)
+    d = ops.conv_desc(N, H, W, cin, p.cout, kh, kw, stride=tuple(stride), pad=pad)
+    return ops.conv(x, w_krsc, w_crsk, p.bias, d)

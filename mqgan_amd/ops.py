@@ -1,0 +1,743 @@
+"""Python face of the C ABI: thin wrappers + torch.autograd.Function glue.
+
+PyTorch supplies device memory, the HIP stream and the autograd tape; every
+arithmetic step on activations and gradients is a kernel of libmqgan_hip.so.
+Layouts are channels-last: (B, T, C) for 1-D maps, (N, H, W, C) for 2-D maps;
+frame masks are uint8 (B, T) with 1 = padded.
+"""
+import ctypes as C
+import itertools
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, Cb2dWeights, PointwiseDesc, check, fptr, ptr, stream
+
+F32 = torch.float32
+
+
+def L():
+    return _lib.load()
+
+
+def _empty(shape, like, dtype=F32):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+def _ws_bytes(nbytes, like):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=like.device)
+
+
+# ----------------------------------------------------------------------------- dropout seeds
+_seed_counter = itertools.count(1)
+_base_seed = 0x5DEECE66D
+
+
+def manual_seed(seed: int, rank: int = 0):
+    """Seed the counter-based dropout RNG (per-rank offset for data parallel runs)."""
+    global _seed_counter, _base_seed
+    _base_seed = (int(seed) * 0x9E3779B97F4A7C15 + rank * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+    _seed_counter = itertools.count(1)
+
+
+def next_seed() -> int:
+    return (_base_seed + next(_seed_counter) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+
+
+# ----------------------------------------------------------------------------- convolution
+def conv_desc(N, H, W, Cin, K, R, S, stride=(1, 1), pad=(0, 0), dil=(1, 1), groups=1, out_hw=None) -> ConvDesc:
+    if out_hw is None:
+        P = (H + 2 * pad[0] - dil[0] * (R - 1) - 1) // stride[0] + 1
+        Q = (W + 2 * pad[1] - dil[1] * (S - 1) - 1) // stride[1] + 1
+    else:
+        P, Q = out_hw
+    return ConvDesc(N=N, H=H, W=W, C=Cin, K=K, R=R, S=S, P=P, Q=Q, stride_h=stride[0], stride_w=stride[1], pad_h=pad[0],
+                    pad_w=pad[1], dil_h=dil[0], dil_w=dil[1], groups=groups)
+
+
+def _desc_key(d: ConvDesc):
+    return tuple(getattr(d, f[0]) for f in ConvDesc._fields_)
+
+
+def _desc_from_key(k) -> ConvDesc:
+    return ConvDesc(*k)
+
+
+class KernelTimer:
+    """HIP-event timing of individual kernel launches on the current stream (bench.py's roofline leg).
+    Enabled by assigning an instance to ``ops.TIMER``; adds two event records per timed launch."""
+
+    def __init__(self):
+        self.records = []          # (tag, algorithmic flops, start event, end event)
+
+    def run(self, tag, flops, fn):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        self.records.append((tag, flops, s, e))
+
+    def summary(self):
+        """tag -> dict(launches, flops, ms).  Call after torch.cuda.synchronize()."""
+        out = {}
+        for tag, flops, s, e in self.records:
+            d = out.setdefault(tag, {"launches": 0, "flops": 0.0, "ms": 0.0})
+            d["launches"] += 1
+            d["flops"] += flops
+            d["ms"] += s.elapsed_time(e)
+        return out
+
+
+TIMER: Optional[KernelTimer] = None
+
+
+def _timed(tag, flops, fn):
+    if TIMER is None:
+        fn()
+    else:
+        TIMER.run(tag, flops, fn)
+
+
+def _conv_tag(kind, d: ConvDesc):
+    """Name of the kernel instantiation the C side picks (igemm.hip: launch_nt / mq_conv_wgrad)."""
+    if kind == "wgrad":
+        vec = d.C % 4 == 0 and d.K % 4 == 0
+        return f"conv_wgrad_kernel<{str(vec).lower()}>"
+    ncols, ic = (d.K, d.C) if kind == "fprop" else (d.C, d.K)
+    bn = 128 if ncols > 64 else (64 if ncols > 32 else 32)
+    return f"conv_nt_kernel<{bn}, {str(kind == 'dgrad').lower()}, {str(ic % 4 == 0).lower()}>"
+
+
+def _conv_flops(d: ConvDesc):
+    return 2.0 * d.N * d.P * d.Q * d.K * d.C * d.R * d.S
+
+
+def colsum(x2d: torch.Tensor) -> torch.Tensor:
+    rows, cols = x2d.shape
+    out = _empty((cols,), x2d)
+    ws = _empty((64 * cols,), x2d)
+    check(L().mq_colsum(fptr(x2d), rows, cols, fptr(out), fptr(ws), stream()), "mq_colsum")
+    return out
+
+
+class ConvFn(torch.autograd.Function):
+    """y = conv(x, w) + bias on the implicit-GEMM kernels.  ``w_krsc`` (groups*K, R, S, C) carries the
+    gradient; ``w_crsk`` is the same weights in the dgrad layout (no gradient of its own)."""
+
+    @staticmethod
+    def forward(ctx, x, w_krsc, w_crsk, bias, key):
+        d = _desc_from_key(key)
+        y = _empty((d.N, d.P, d.Q, d.K), x)
+        _timed(_conv_tag("fprop", d), _conv_flops(d), lambda: check(
+            L().mq_conv_fprop(C.byref(d), fptr(x), fptr(w_krsc), fptr(bias, True), fptr(y), stream()), "mq_conv_fprop"))
+        ctx.key = key
+        ctx.w_shape = tuple(w_krsc.shape)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, w_crsk if w_crsk is not None else w_krsc)
+        ctx.have_crsk = w_crsk is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        d = _desc_from_key(ctx.key)
+        x, w_crsk = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if not ctx.have_crsk:
+                raise _lib.MqganHipError("conv backward wrt the input needs the CRSK weights")
+            dx = torch.empty_like(x)
+            _timed(_conv_tag("dgrad", d), _conv_flops(d), lambda: check(
+                L().mq_conv_dgrad(C.byref(d), fptr(dy), fptr(w_crsk), fptr(dx), stream()), "mq_conv_dgrad"))
+        if ctx.needs_input_grad[1]:
+            dw = _empty(ctx.w_shape, x)      # (groups*K, R*S, C) == KRSC
+            nbytes = L().mq_conv_wgrad_workspace(C.byref(d))
+            ws = _ws_bytes(nbytes, x)
+            _timed(_conv_tag("wgrad", d), _conv_flops(d), lambda: check(
+                L().mq_conv_wgrad(C.byref(d), fptr(x), fptr(dy), fptr(dw), ptr(ws), nbytes, stream()), "mq_conv_wgrad"))
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            rows_per_group = (d.N // d.groups) * d.P * d.Q
+            if d.groups == 1:
+                db = colsum(dy.view(-1, d.K))
+            else:
+                db = torch.cat([colsum(dy.view(d.groups, rows_per_group, d.K)[g]) for g in range(d.groups)])
+        return dx, dw, None, db, None
+
+
+def conv(x, w_krsc, w_crsk, bias, desc: ConvDesc):
+    return ConvFn.apply(x, w_krsc, w_crsk, bias, _desc_key(desc))
+
+
+# ----------------------------------------------------------------------------- weight preparation
+class WeightPrepFn(torch.autograd.Function):
+    """(v (K, C, *ks), g (K,...) or None) -> (w_krsc (K, RS, C), w_crsk (C, RS, K)).  mode 1 = weight norm."""
+
+    @staticmethod
+    def forward(ctx, v, g, need_crsk):
+        K, Cin = v.shape[0], v.shape[1]
+        RS = v.numel() // (K * Cin)
+        mode = 0 if g is None else 1
+        w_krsc = _empty((K, RS, Cin), v)
+        w_crsk = _empty((Cin, RS, K), v) if need_crsk else None
+        inv = _empty((K,), v) if mode else None
+        check(L().mq_weight_prep(mode, fptr(v), fptr(g, True), K, Cin, RS, fptr(w_krsc), fptr(w_crsk, True), fptr(inv, True),
+                                 stream()), "mq_weight_prep")
+        ctx.mode, ctx.dims = mode, (K, Cin, RS)
+        ctx.save_for_backward(v, g, inv)
+        if w_crsk is not None:
+            ctx.mark_non_differentiable(w_crsk)
+        return w_krsc, w_crsk
+
+    @staticmethod
+    def backward(ctx, dw_krsc, _unused):
+        v, g, inv = ctx.saved_tensors
+        K, Cin, RS = ctx.dims
+        dv = torch.empty_like(v)
+        dg = torch.empty_like(g) if ctx.mode else None
+        check(L().mq_weight_prep_bwd(ctx.mode, fptr(dw_krsc.contiguous()), fptr(v), fptr(g, True), fptr(inv, True), K, Cin, RS,
+                                     fptr(dv), fptr(dg, True), stream()), "mq_weight_prep_bwd")
+        return dv, dg, None
+
+
+def weight_prep(v, g=None, need_crsk=True):
+    return WeightPrepFn.apply(v, g, need_crsk)
+
+
+class SpectralPrepFn(torch.autograd.Function):
+    """Legacy spectral norm: (weight_orig, u, v) -> (w_krsc, w_crsk); u, v updated in place when
+    ``power_iteration``."""
+
+    @staticmethod
+    def forward(ctx, w_orig, u, v, power_iteration, need_crsk):
+        K, Cin = w_orig.shape[0], w_orig.shape[1]
+        RS = w_orig.numel() // (K * Cin)
+        w_krsc = _empty((K, RS, Cin), w_orig)
+        w_crsk = _empty((Cin, RS, K), w_orig) if need_crsk else None
+        sigma = _empty((1,), w_orig)
+        scratch = _empty((K + Cin * RS + 8,), w_orig)
+        check(L().mq_spectral_prep(fptr(w_orig), fptr(u), fptr(v), K, Cin, RS, int(bool(power_iteration)), 1e-12, fptr(w_krsc),
+                                   fptr(w_crsk, True), fptr(sigma), fptr(scratch), stream()), "mq_spectral_prep")
+        ctx.dims = (K, Cin, RS)
+        # u, v as used for sigma (after the power iteration); clone so later iterations do not disturb backward
+        ctx.save_for_backward(w_orig, u.clone() if power_iteration else u, v.clone() if power_iteration else v, sigma)
+        if w_crsk is not None:
+            ctx.mark_non_differentiable(w_crsk)
+        return w_krsc, w_crsk
+
+    @staticmethod
+    def backward(ctx, dw_krsc, _unused):
+        w_orig, u, v, sigma = ctx.saved_tensors
+        K, Cin, RS = ctx.dims
+        dw = torch.empty_like(w_orig)
+        scratch = _empty((264,), w_orig)
+        check(L().mq_spectral_prep_bwd(fptr(dw_krsc.contiguous()), fptr(w_orig), fptr(u), fptr(v), fptr(sigma), K, Cin, RS,
+                                       fptr(dw), fptr(scratch), stream()), "mq_spectral_prep_bwd")
+        return dw, None, None, None, None
+
+
+def spectral_prep(w_orig, u, v, power_iteration, need_crsk=True):
+    return SpectralPrepFn.apply(w_orig, u, v, power_iteration, need_crsk)
+
+
+# ----------------------------------------------------------------------------- pointwise
+ACT_NONE, ACT_APTX, ACT_LEAKY = 0, 1, 2
+
+
+class PointwiseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, r_pre, r_post, mask, beta, gamma, cfg):
+        act, mask_pre, mask_post, dmap, p_drop, seed = cfg
+        Cc = h.shape[-1]
+        rows = h.numel() // Cc
+        d = PointwiseDesc(rows=rows, C=Cc, act=act, mask_pre=int(mask_pre), mask_post=int(mask_post), d1=dmap[0], d2=dmap[1],
+                          d3=dmap[2], p_drop=float(p_drop), seed=seed)
+        out = torch.empty_like(h)
+        check(L().mq_pointwise_fwd(C.byref(d), fptr(h), fptr(r_pre, True), fptr(r_post, True), ptr(mask, torch.uint8, True),
+                                   fptr(beta, True), fptr(gamma, True), fptr(out), stream()), "mq_pointwise_fwd")
+        ctx.cfg = cfg
+        ctx.save_for_backward(h, r_pre, mask, beta, gamma)
+        ctx.has_post = r_post is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, r_pre, mask, beta, gamma = ctx.saved_tensors
+        act, mask_pre, mask_post, dmap, p_drop, seed = ctx.cfg
+        Cc = h.shape[-1]
+        rows = h.numel() // Cc
+        d = PointwiseDesc(rows=rows, C=Cc, act=act, mask_pre=int(mask_pre), mask_post=int(mask_post), d1=dmap[0], d2=dmap[1],
+                          d3=dmap[2], p_drop=float(p_drop), seed=seed)
+        dout = dout.contiguous()
+        dt = torch.empty_like(h)
+        dpost = torch.empty_like(h) if (ctx.has_post and ctx.needs_input_grad[2]) else None
+        want_b = beta is not None and ctx.needs_input_grad[4]
+        want_g = gamma is not None and ctx.needs_input_grad[5]
+        dbeta = torch.empty_like(beta) if want_b else None
+        dgamma = torch.empty_like(gamma) if want_g else None
+        ws = _empty((2 * 1024,), h) if (want_b or want_g) else None
+        check(L().mq_pointwise_bwd(C.byref(d), fptr(dout), fptr(h), fptr(r_pre, True), ptr(mask, torch.uint8, True),
+                                   fptr(beta, True), fptr(gamma, True), fptr(dt), fptr(dpost, True), fptr(dbeta, True),
+                                   fptr(dgamma, True), fptr(ws, True), stream()), "mq_pointwise_bwd")
+        return dt, (dt if r_pre is not None else None), dpost, None, dbeta, dgamma, None
+
+
+def pointwise(h, *, act=ACT_NONE, r_pre=None, r_post=None, mask=None, mask_pre=False, mask_post=False, dmap=(1, 1, 1),
+              beta=None, gamma=None, p_drop=0.0, training=False):
+    """t = h (+ r_pre); [mask_pre]; act; dropout; (+ r_post); [mask_post].  ``dmap`` = (d1, d2, d3): the mask
+    index of row m is (m // d1) * d2 + (m % d3)."""
+    p = float(p_drop) if training else 0.0
+    seed = next_seed() if p > 0 else 0
+    return PointwiseFn.apply(h, r_pre, r_post, mask, beta, gamma, (act, bool(mask_pre), bool(mask_post), tuple(dmap), p, seed))
+
+
+# ----------------------------------------------------------------------------- masks (no grad)
+def sequence_mask(lengths: torch.Tensor, T: int) -> torch.Tensor:
+    lengths = lengths.to(torch.int32).contiguous()
+    B = lengths.numel()
+    m = torch.empty((B, T), dtype=torch.uint8, device=lengths.device)
+    check(L().mq_sequence_mask(ptr(lengths, torch.int32), B, T, ptr(m), stream()), "mq_sequence_mask")
+    return m
+
+
+def mask_pool(mask: torch.Tensor, stride: int, ceil_mode: bool) -> torch.Tensor:
+    B, Tin = mask.shape
+    Tout = -(-Tin // stride) if ceil_mode else Tin // stride
+    out = torch.empty((B, Tout), dtype=torch.uint8, device=mask.device)
+    check(L().mq_mask_pool(ptr(mask, torch.uint8), B, Tin, Tout, stride, ptr(out), stream()), "mq_mask_pool")
+    return out
+
+
+def mask_upsample2(mask: torch.Tensor) -> torch.Tensor:
+    B, Tin = mask.shape
+    out = torch.empty((B, 2 * Tin), dtype=torch.uint8, device=mask.device)
+    check(L().mq_mask_upsample2(ptr(mask, torch.uint8), B, Tin, ptr(out), stream()), "mq_mask_upsample2")
+    return out
+
+
+# ----------------------------------------------------------------------------- UNet data movement
+class AvgPoolT2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        N, T, Fq, Cc = x.shape
+        y = _empty((N, T // 2, Fq, Cc), x)
+        check(L().mq_avgpool_t2_fwd(fptr(x), N, T, Fq, Cc, fptr(y), stream()), "mq_avgpool_t2_fwd")
+        ctx.shape = (N, T, Fq, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, T, Fq, Cc = ctx.shape
+        dx = _empty(ctx.shape, dy)
+        check(L().mq_avgpool_t2_bwd(fptr(dy.contiguous()), N, T, Fq, Cc, fptr(dx), stream()), "mq_avgpool_t2_bwd")
+        return dx
+
+
+class UpCatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, skip):
+        N, T, Fq, C1 = x.shape
+        C2 = skip.shape[-1]
+        if tuple(skip.shape[:3]) != (N, 2 * T, Fq):
+            raise _lib.MqganHipError(f"upcat: skip {tuple(skip.shape)} does not match upsampled {(N, 2 * T, Fq)}")
+        out = _empty((N, 2 * T, Fq, C1 + C2), x)
+        check(L().mq_upcat_fwd(fptr(x), fptr(skip), N, T, Fq, C1, C2, fptr(out), stream()), "mq_upcat_fwd")
+        ctx.dims = (N, T, Fq, C1, C2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        N, T, Fq, C1, C2 = ctx.dims
+        dx = _empty((N, T, Fq, C1), dout)
+        ds = _empty((N, 2 * T, Fq, C2), dout)
+        check(L().mq_upcat_bwd(fptr(dout.contiguous()), N, T, Fq, C1, C2, fptr(dx), fptr(ds), stream()), "mq_upcat_bwd")
+        return dx, ds
+
+
+class BandSplitFn(torch.autograd.Function):
+    """(B, T, F) -> (n_bins*B, F/n_bins, T, 1): the (H = mel, W = time) single-channel image the
+    discriminators convolve (discriminators.py:211, 298).  n_bins = 1 is a plain transpose."""
+
+    @staticmethod
+    def forward(ctx, x, n_bins):
+        B, T, Fq = x.shape
+        out = _empty((n_bins * B, Fq // n_bins, T, 1), x)
+        check(L().mq_band_split_fwd(fptr(x), B, T, Fq, n_bins, fptr(out), stream()), "mq_band_split_fwd")
+        ctx.dims = (B, T, Fq, n_bins)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, T, Fq, n_bins = ctx.dims
+        dx = _empty((B, T, Fq), dout)
+        check(L().mq_band_split_bwd(fptr(dout.contiguous()), B, T, Fq, n_bins, fptr(dx), stream()), "mq_band_split_bwd")
+        return dx, None
+
+
+class Concat2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        C1, C2 = a.shape[-1], b.shape[-1]
+        rows = a.numel() // C1
+        y = _empty(tuple(a.shape[:-1]) + (C1 + C2,), a)
+        check(L().mq_concat2(fptr(a), fptr(b), rows, C1, C2, fptr(y), stream()), "mq_concat2")
+        ctx.c = (C1, C2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):  # only used on detached inputs in this model; provided for completeness
+        C1, C2 = ctx.c
+        return dy[..., :C1].contiguous(), dy[..., C1:].contiguous()
+
+
+class AddFn(torch.autograd.Function):
+    """out = alpha*a + beta*b on the device kernel (keeps elementwise arithmetic out of ATen)."""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha, beta):
+        out = torch.empty_like(a)
+        check(L().mq_axpby(fptr(a), fptr(b), alpha, beta, a.numel(), fptr(out), stream()), "mq_axpby")
+        ctx.ab = (alpha, beta)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        alpha, beta = ctx.ab
+        d = d.contiguous()
+        return scale(d, alpha), scale(d, beta), None, None
+
+
+def scale(a, alpha):
+    if alpha == 1.0:
+        return a
+    out = torch.empty_like(a)
+    check(L().mq_axpby(fptr(a), None, float(alpha), 0.0, a.numel(), fptr(out), stream()), "mq_axpby")
+    return out
+
+
+def add(a, b, alpha=1.0, beta=1.0):
+    return AddFn.apply(a, b, float(alpha), float(beta))
+
+
+# ----------------------------------------------------------------------------- small activations on (B, C) tensors
+class ReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = torch.empty_like(x)
+        check(L().mq_relu_fwd(fptr(x), x.numel(), fptr(y), stream()), "mq_relu_fwd")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dx = torch.empty_like(y)
+        check(L().mq_relu_bwd(fptr(dy.contiguous()), fptr(y), y.numel(), fptr(dx), stream()), "mq_relu_bwd")
+        return dx
+
+
+class SigmoidAddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        out = torch.empty_like(a)
+        check(L().mq_sigmoid_add(fptr(a), fptr(b, True), a.numel(), fptr(out), stream()), "mq_sigmoid_add")
+        ctx.save_for_backward(out)
+        ctx.has_b = b is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (out,) = ctx.saved_tensors
+        da = torch.empty_like(out)
+        check(L().mq_sigmoid_add_bwd(fptr(dout.contiguous()), fptr(out), out.numel(), fptr(da), stream()), "mq_sigmoid_add_bwd")
+        return da, (da if ctx.has_b else None)
+
+
+# ----------------------------------------------------------------------------- CBAM
+class CamPoolFn(torch.autograd.Function):
+    """x (B, T, C), mask (B, T) -> (max over ALL t, mean over VALID t), each (B, C)."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        B, T, Cc = x.shape
+        mx, av = _empty((B, Cc), x), _empty((B, Cc), x)
+        am = _empty((B, Cc), x, torch.int32)
+        check(L().mq_cam_pool(fptr(x), ptr(mask, torch.uint8), B, T, Cc, fptr(mx), ptr(am), fptr(av), stream()), "mq_cam_pool")
+        ctx.save_for_backward(am, mask)
+        ctx.dims = (B, T, Cc)
+        ctx.mark_non_differentiable(am)
+        return mx, av
+
+    @staticmethod
+    def backward(ctx, dmx, dav):
+        am, mask = ctx.saved_tensors
+        B, T, Cc = ctx.dims
+        dx = torch.zeros((B, T, Cc), dtype=F32, device=dmx.device)
+        check(L().mq_cam_pool_bwd(fptr(dmx.contiguous()), fptr(dav.contiguous()), ptr(am), ptr(mask, torch.uint8), B, T, Cc,
+                                  fptr(dx), stream()), "mq_cam_pool_bwd")
+        return dx, None
+
+
+class CbamApplyFn(torch.autograd.Function):
+    """out = sigmoid(conv_k(pool_c(gate*x))) * gate * x + x   (attentions.py:310-365, 411)."""
+
+    @staticmethod
+    def forward(ctx, x, gate, w7):
+        B, T, Cc = x.shape
+        ks = w7.shape[-1]
+        feat = _empty((B, T, 2), x)
+        amc = _empty((B, T), x, torch.int32)
+        check(L().mq_sam_pool(fptr(x), fptr(gate), B, T, Cc, fptr(feat), ptr(amc), stream()), "mq_sam_pool")
+        s = _empty((B, T), x)
+        out = torch.empty_like(x)
+        check(L().mq_sam_apply(fptr(x), fptr(gate), fptr(feat), fptr(w7), ks, B, T, Cc, fptr(s), fptr(out), stream()), "mq_sam_apply")
+        ctx.save_for_backward(x, gate, feat, amc, s, w7)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, gate, feat, amc, s, w7 = ctx.saved_tensors
+        B, T, Cc = x.shape
+        ks = w7.shape[-1]
+        dx, dgate, dw7 = torch.empty_like(x), torch.empty_like(gate), torch.empty_like(w7)
+        ws = _ws_bytes(L().mq_cbam_bwd_workspace(B, T, Cc, ks), x)
+        check(L().mq_cbam_bwd(fptr(dout.contiguous()), fptr(x), fptr(gate), fptr(feat), ptr(amc), fptr(s), fptr(w7), ks, B, T, Cc,
+                              fptr(dx), fptr(dgate), fptr(dw7), ptr(ws), stream()), "mq_cbam_bwd")
+        return dx, dgate, dw7
+
+
+# ----------------------------------------------------------------------------- masked SE
+class SeSqueezeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mask):
+        B, H, W, Cc = x.shape
+        sq = _empty((B, Cc), x)
+        check(L().mq_se_squeeze(fptr(x), ptr(mask, torch.uint8), B, H, W, Cc, fptr(sq), stream()), "mq_se_squeeze")
+        ctx.save_for_backward(mask)
+        ctx.dims = (B, H, W, Cc)
+        return sq
+
+    @staticmethod
+    def backward(ctx, dsq):
+        (mask,) = ctx.saved_tensors
+        B, H, W, Cc = ctx.dims
+        dx = torch.zeros(ctx.dims, dtype=F32, device=dsq.device)
+        check(L().mq_se_squeeze_bwd(fptr(dsq.contiguous()), ptr(mask, torch.uint8), B, H, W, Cc, fptr(dx), stream()),
+              "mq_se_squeeze_bwd")
+        return dx, None
+
+
+class SeScaleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, excite):
+        B, H, W, Cc = x.shape
+        y = torch.empty_like(x)
+        check(L().mq_se_scale_fwd(fptr(x), fptr(excite), B, H * W, Cc, fptr(y), stream()), "mq_se_scale_fwd")
+        ctx.save_for_backward(x, excite)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, excite = ctx.saved_tensors
+        B, H, W, Cc = x.shape
+        dx, de = torch.empty_like(x), torch.empty_like(excite)
+        check(L().mq_se_scale_bwd(fptr(dy.contiguous()), fptr(x), fptr(excite), B, H * W, Cc, fptr(dx), fptr(de), stream()),
+              "mq_se_scale_bwd")
+        return dx, de
+
+
+# ----------------------------------------------------------------------------- fused ConvBlock2D
+class ConvBlock2DFn(torch.autograd.Function):
+    """x (B, T, C0) -> y (B, T, C0); effective weights wdw (25), bdw (1), w1 (C0), b1 (C0), w2 (C0), b2 (1)."""
+
+    @staticmethod
+    def forward(ctx, x, mask, wdw, bdw, w1, b1, w2, b2, p_drop, seed):
+        B, T, C0 = x.shape
+        w = Cb2dWeights(wdw=wdw.data_ptr(), bdw=bdw.data_ptr(), w1=w1.data_ptr(), b1=b1.data_ptr(), w2=w2.data_ptr(),
+                        b2=b2.data_ptr())
+        for t in (wdw, bdw, w1, b1, w2, b2):
+            fptr(t)
+        y = torch.empty_like(x)
+        v = torch.empty_like(x)
+        check(L().mq_convblock2d_fwd(C.byref(w), fptr(x), ptr(mask, torch.uint8), B, T, C0, float(p_drop), seed, fptr(y), fptr(v),
+                                     stream()), "mq_convblock2d_fwd")
+        ctx.save_for_backward(x, v, mask, wdw, bdw, w1, b1, w2, b2)
+        ctx.cfg = (float(p_drop), seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, v, mask, wdw, bdw, w1, b1, w2, b2 = ctx.saved_tensors
+        B, T, C0 = x.shape
+        p_drop, seed = ctx.cfg
+        w = Cb2dWeights(wdw=wdw.data_ptr(), bdw=bdw.data_ptr(), w1=w1.data_ptr(), b1=b1.data_ptr(), w2=w2.data_ptr(),
+                        b2=b2.data_ptr())
+        dx = torch.empty_like(x)
+        g = [torch.empty_like(t) for t in (wdw, bdw, w1, b1, w2, b2)]
+        ws = _ws_bytes(L().mq_convblock2d_bwd_workspace(B, T, C0), x)
+        check(L().mq_convblock2d_bwd(C.byref(w), fptr(x), fptr(v), fptr(dy.contiguous()), ptr(mask, torch.uint8), B, T, C0, p_drop,
+                                     seed, fptr(dx), fptr(g[0]), fptr(g[1]), fptr(g[2]), fptr(g[3]), fptr(g[4]), fptr(g[5]), ptr(ws),
+                                     stream()), "mq_convblock2d_bwd")
+        return (dx, None) + tuple(g) + (None, None)
+
+
+# ----------------------------------------------------------------------------- FSQ / VQ
+class FsqFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, desc):
+        d = desc.d
+        n = z.numel() // d
+        codes = torch.empty_like(z)
+        idx = torch.empty(z.shape[:-1], dtype=torch.int32, device=z.device)
+        check(L().mq_fsq_forward(C.byref(desc), fptr(z), n, fptr(codes), ptr(idx), stream()), "mq_fsq_forward")
+        ctx.save_for_backward(z)
+        ctx.desc = desc
+        ctx.mark_non_differentiable(idx)
+        return codes, idx
+
+    @staticmethod
+    def backward(ctx, dcodes, _):
+        (z,) = ctx.saved_tensors
+        dz = torch.empty_like(z)
+        n = z.numel() // ctx.desc.d
+        check(L().mq_fsq_backward(C.byref(ctx.desc), fptr(z), fptr(dcodes.contiguous()), n, fptr(dz), stream()), "mq_fsq_backward")
+        return dz, None
+
+
+def fsq_decode(idx: torch.Tensor, desc) -> torch.Tensor:
+    idx = idx.to(torch.int64).contiguous()
+    codes = torch.empty(tuple(idx.shape) + (desc.d,), dtype=F32, device=idx.device)
+    check(L().mq_fsq_decode(C.byref(desc), ptr(idx, torch.int64), idx.numel(), fptr(codes), stream()), "mq_fsq_decode")
+    return codes
+
+
+def l2_codebook_norms(codebook: torch.Tensor) -> torch.Tensor:
+    k, d = codebook.shape
+    cn = _empty((k,), codebook)
+    check(L().mq_l2_codebook_norms(fptr(codebook), k, d, fptr(cn), stream()), "mq_l2_codebook_norms")
+    return cn
+
+
+def l2_argmin(x: torch.Tensor, codebook: torch.Tensor, cnorm: Optional[torch.Tensor] = None, return_dist=False,
+              workspace: Optional[torch.Tensor] = None):
+    n, d = x.shape
+    k = codebook.shape[0]
+    if cnorm is None:
+        cnorm = l2_codebook_norms(codebook)
+    idx = torch.empty((n,), dtype=torch.int32, device=x.device)
+    dist = _empty((n,), x) if return_dist else None
+    if workspace is None:
+        workspace = _ws_bytes(L().mq_l2_argmin_workspace(n), x)
+    check(L().mq_l2_argmin(fptr(x), fptr(codebook), fptr(cnorm), n, k, d, ptr(idx), fptr(dist, True), ptr(workspace), stream()),
+          "mq_l2_argmin")
+    return (idx, dist) if return_dist else idx
+
+
+def codebook_ema_update(x, idx, cluster_size, embed_sum, codebook, decay=0.99, eps=1e-5):
+    n, d = x.shape
+    k = codebook.shape[0]
+    counts = _empty((k + 4,), x)
+    sums = _empty((k, d), x)
+    check(L().mq_codebook_ema_update(fptr(x), ptr(idx, torch.int32), n, k, d, decay, eps, fptr(cluster_size), fptr(embed_sum),
+                                     fptr(codebook), fptr(counts), fptr(sums), stream()), "mq_codebook_ema_update")
+
+
+# ----------------------------------------------------------------------------- losses
+class MelLossFn(torch.autograd.Function):
+    """MaskedMelLoss('mse') for group sizes g1 and g2 in one pass: returns w1*loss(g1) + w2*loss(g2)."""
+
+    @staticmethod
+    def forward(ctx, x, y, lengths, g1, g2, w1, w2):
+        B, T, Cc = x.shape
+        out2 = _empty((2,), x)
+        ws = _empty((64 * Cc,), x)
+        check(L().mq_mel_loss_fwd(fptr(x), fptr(y), ptr(lengths, torch.int32), B, T, Cc, g1, g2, fptr(out2), fptr(ws), stream()),
+              "mq_mel_loss_fwd")
+        ctx.save_for_backward(x, y, lengths)
+        ctx.cfg = (g1, g2, w1, w2)
+        out = _empty((1,), x)
+        check(L().mq_axpby(fptr(out2[0:1]), fptr(out2[1:2]), float(w1), float(w2), 1, fptr(out), stream()), "mq_axpby")
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, y, lengths = ctx.saved_tensors
+        g1, g2, w1, w2 = ctx.cfg
+        B, T, Cc = x.shape
+        dx = torch.empty_like(x)
+        check(L().mq_mel_loss_bwd(fptr(x), fptr(y), ptr(lengths, torch.int32), B, T, Cc, g1, g2, w1, w2, fptr(gout.contiguous().view(1)),
+                                  fptr(dx), stream()), "mq_mel_loss_bwd")
+        return dx, None, None, None, None, None, None
+
+
+class LsganDFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, real, fake, padded, state, decay):
+        B, H, W = real.shape[0], real.shape[1], real.shape[2]
+        out, saved = _empty((1,), real), _empty((4,), real)
+        check(L().mq_lsgan_d_fwd(fptr(real), fptr(fake), ptr(padded, torch.uint8), B, H, W, decay, fptr(state), fptr(out), fptr(saved),
+                                 stream()), "mq_lsgan_d_fwd")
+        ctx.save_for_backward(real, fake, padded, saved)
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        real, fake, padded, saved = ctx.saved_tensors
+        B, H, W = real.shape[0], real.shape[1], real.shape[2]
+        dr, df = torch.empty_like(real), torch.empty_like(fake)
+        check(L().mq_lsgan_d_bwd(fptr(real), fptr(fake), ptr(padded, torch.uint8), B, H, W, fptr(saved), fptr(gout.contiguous().view(1)),
+                                 fptr(dr), fptr(df), stream()), "mq_lsgan_d_bwd")
+        return dr, df, None, None, None
+
+
+class LsganGFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fake, padded):
+        B, H, W = fake.shape[0], fake.shape[1], fake.shape[2]
+        out, saved = _empty((1,), fake), _empty((4,), fake)
+        check(L().mq_lsgan_g_fwd(fptr(fake), ptr(padded, torch.uint8), B, H, W, fptr(out), fptr(saved), stream()), "mq_lsgan_g_fwd")
+        ctx.save_for_backward(fake, padded, saved)
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        fake, padded, saved = ctx.saved_tensors
+        B, H, W = fake.shape[0], fake.shape[1], fake.shape[2]
+        df = torch.empty_like(fake)
+        check(L().mq_lsgan_g_bwd(fptr(fake), ptr(padded, torch.uint8), B, H, W, fptr(saved), fptr(gout.contiguous().view(1)), fptr(df),
+                                 stream()), "mq_lsgan_g_bwd")
+        return df, None
+
+
+class MaskedMaeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, padded):
+        B, H, W, Cc = pred.shape
+        out2, ws = _empty((2,), pred), _empty((512,), pred)
+        check(L().mq_masked_mae_fwd(fptr(pred), fptr(target), ptr(padded, torch.uint8), B, H, W, Cc, fptr(out2), fptr(ws), stream()),
+              "mq_masked_mae_fwd")
+        ctx.save_for_backward(pred, target, padded, out2)
+        return out2[0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        pred, target, padded, out2 = ctx.saved_tensors
+        B, H, W, Cc = pred.shape
+        dp = torch.empty_like(pred)
+        check(L().mq_masked_mae_bwd(fptr(pred), fptr(target), ptr(padded, torch.uint8), B, H, W, Cc, fptr(out2),
+                                    fptr(gout.contiguous().view(1)), fptr(dp), stream()), "mq_masked_mae_bwd")
+        return dp, None, None
+
+
+# ----------------------------------------------------------------------------- optimiser
+def sumsq(flat: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    out = _empty((1,), flat) if out is None else out
+    ws = _empty((1024,), flat)
+    check(L().mq_sumsq(fptr(flat), flat.numel(), fptr(out), fptr(ws), stream()), "mq_sumsq")
+    return out
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, sumsq_t=None, max_norm=0.0, grad_scale=1.0):
+    check(L().mq_adam_step(fptr(param), fptr(grad), fptr(exp_avg), fptr(exp_avg_sq), param.numel(), float(lr), float(beta1),
+                           float(beta2), float(eps), int(step), fptr(sumsq_t, True), float(max_norm), float(grad_scale),
+                           stream()), "mq_adam_step")

@@ -1,0 +1,418 @@
+"""-m gpu: the HIP kernels, called through the C ABI (mqgan_amd.ops -> libmqgan_hip.so), against the
+oracle (oracle/vq_ref.c, plain torch CPU ops) and the golden fixtures.
+
+Bars: indices / integer outputs bit-exact; fp32 tensors within 1e-4 relative (north star), the
+tolerance being applied to the L2 norm of the error relative to the L2 norm of the reference (and to
+max-abs against the tensor's scale for gradients)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import __graft_entry__ as g
+    g.build()
+    assert torch.cuda.is_available(), "the -m gpu tests need an MI355X"
+    from mqgan_amd import ops
+    return ops
+
+
+from gpu_util import DEV, assert_rel, close, t  # noqa: E402
+
+
+# ----------------------------------------------------------------------------------------- FSQ
+def test_fsq_golden_bit_exact(env):
+    from mqgan_amd.quantizer import FSQ
+    g = load_golden("g1_fsq.npz")
+    q = FSQ(g["levels"].tolist()).to(DEV)
+    z = t(g["z"], requires_grad=True)
+    codes, idx = q(z)
+    assert idx.dtype == torch.int32 and idx.shape == z.shape[:-1]
+    np.testing.assert_array_equal(idx.cpu().numpy(), g["idx"])
+    np.testing.assert_array_equal(codes.detach().cpu().numpy(), g["codes"])
+    (codes * t(g["wgt"])).sum().backward()
+    close(z.grad, g["grad_z"], rtol=1e-4, atol=1e-6)
+    dec = q.indices_to_codes(torch.arange(1000, device=DEV))
+    np.testing.assert_array_equal(dec.cpu().numpy(), g["decode_all"])
+    np.testing.assert_array_equal(q.implicit_codebook.cpu().numpy(), g["implicit_codebook"])
+    g2 = load_golden("g1b_fsq_idx16k.npz")
+    _, idx2 = q(t(g2["z"]))
+    np.testing.assert_array_equal(idx2.cpu().numpy(), g2["idx"].astype(np.int32))
+
+
+@pytest.mark.parametrize("levels", [[8, 5, 5, 5], [8, 8, 5, 5, 5], [7, 3], [2, 9, 4]])
+def test_fsq_large_vs_c_oracle_and_torch(env, levels):
+    from mqgan_amd.quantizer import FSQ
+    from oracle import nn as O
+    from oracle import vq
+    q = FSQ(levels).to(DEV)
+    rng = np.random.default_rng(7)
+    n = 1 << 21
+    z = (rng.standard_normal((n, len(levels))) * 2.0).astype(np.float32)
+    z[:64] = 0.0
+    z[64:128] = np.float32(1e30)
+    z[128:192] = -np.float32(1e30)
+    codes, idx = q(t(z))
+    c_codes, c_idx = vq.fsq_forward(z, levels)
+    np.testing.assert_array_equal(idx.cpu().numpy(), c_idx)            # bit-exact vs the C restatement
+    np.testing.assert_array_equal(codes.cpu().numpy(), c_codes)
+    _, t_idx = O.fsq_forward(torch.from_numpy(z), levels)              # torch CPU (= the reference's arithmetic)
+    flips = int((t_idx.numpy() != c_idx).sum())
+    assert flips <= max(2, n // 500000), f"{flips} index flips vs torch CPU tanh in {n} rows"
+    # round trip: decode(encode) reproduces the codes exactly
+    np.testing.assert_array_equal(q.indices_to_codes(idx.long()).cpu().numpy(), c_codes)
+
+
+def test_fsq_empty_and_odd_shapes(env):
+    from mqgan_amd.quantizer import FSQ
+    q = FSQ([8, 5, 5, 5]).to(DEV)
+    codes, idx = q(torch.zeros((0, 4), device=DEV))
+    assert codes.shape == (0, 4) and idx.shape == (0,)
+    codes, idx = q(torch.zeros((3, 7, 4), device=DEV))
+    assert idx.shape == (3, 7) and int(idx[0, 0]) == 4 + 2 * 8 + 2 * 40 + 2 * 200   # z = 0 -> the centre code
+
+
+# ----------------------------------------------------------------------------------------- L2 argmin
+@pytest.mark.parametrize("n,k,d", [(4096, 1000, 4), (2048, 1024, 256), (1000, 2048, 512), (777, 130, 20), (128, 8192, 64),
+                                   (1, 5, 8)])
+def test_l2_argmin_bit_exact_vs_c_oracle(env, n, k, d):
+    from oracle import vq
+    ops = env
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    cb = rng.standard_normal((k, d)).astype(np.float32)
+    idx, dist = ops.l2_argmin(t(x), t(cb), return_dist=True)
+    want, wdist = vq.l2_argmin(x, cb, threads=8, return_dist=True)
+    np.testing.assert_array_equal(ops.l2_codebook_norms(t(cb)).cpu().numpy(), vq.l2_codebook_norms(cb))
+    np.testing.assert_array_equal(idx.cpu().numpy(), want)
+    np.testing.assert_array_equal(dist.cpu().numpy(), wdist)
+
+
+def test_l2_argmin_ties_and_fsq_bridge(env):
+    ops = env
+    rng = np.random.default_rng(3)
+    cb = rng.standard_normal((300, 32)).astype(np.float32)
+    cb2 = np.concatenate([cb, cb], 0)                                   # every code duplicated: lowest index must win
+    idx = ops.l2_argmin(t(cb), t(cb2))
+    np.testing.assert_array_equal(idx.cpu().numpy(), np.arange(300))
+    g = load_golden("g1_fsq.npz")                                       # SURVEY 8a Q3 pin (i)
+    x = g["bounded_norm"].reshape(-1, 4)
+    idx = ops.l2_argmin(t(x), t(g["implicit_codebook"])).cpu().numpy()
+    safe = g["margin"].reshape(-1, 4).min(axis=1) > 1e-4
+    np.testing.assert_array_equal(idx[safe], g["idx"].reshape(-1)[safe])
+
+
+def test_codebook_ema(env):
+    ops = env
+    rng = np.random.default_rng(5)
+    n, k, d = 5000, 64, 32
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    cb = rng.standard_normal((k, d)).astype(np.float32)
+    idx = ops.l2_argmin(t(x), t(cb))
+    cs, es, cbt = torch.ones(k, device=DEV), t(cb.copy()), t(cb.copy())
+    ops.codebook_ema_update(t(x), idx, cs, es, cbt, decay=0.9, eps=1e-5)
+    ii = idx.cpu().numpy()
+    counts = np.bincount(ii, minlength=k).astype(np.float64)
+    sums = np.zeros((k, d))
+    np.add.at(sums, ii, x.astype(np.float64))
+    cs_w = 0.9 * 1.0 + 0.1 * counts
+    es_w = 0.9 * cb + 0.1 * sums
+    tot = cs_w.sum()
+    sm = (cs_w + 1e-5) / (tot + k * 1e-5) * tot
+    close(cs, cs_w, rtol=1e-5)
+    close(es, es_w, rtol=1e-4, atol=1e-4)
+    close(cbt, es_w / sm[:, None], rtol=1e-4, atol=1e-4)
+
+
+# ----------------------------------------------------------------------------------------- implicit GEMM conv
+CONV_CASES = [
+    # N, H, W, C, K, R, S, stride, pad(top,left), dil, groups, out_hw(None = symmetric formula)
+    dict(N=2, H=1, W=37, C=16, K=24, R=1, S=5, pad=(0, 2)),                                   # conv1d same
+    dict(N=2, H=1, W=37, C=24, K=16, R=1, S=7, pad=(0, 6), out_hw=(1, 37)),                   # causal
+    dict(N=1, H=1, W=300, C=80, K=512, R=1, S=1),                                             # linear, K > 128
+    dict(N=1, H=1, W=64, C=4, K=768, R=1, S=1),                                               # q_out_proj (C = 4)
+    dict(N=1, H=1, W=200, C=768, K=4, R=1, S=1),                                              # q_in_proj  (K = 4)
+    dict(N=2, H=24, W=18, C=8, K=8, R=3, S=3, pad=(1, 1)),                                    # refiner 3x3
+    dict(N=2, H=24, W=18, C=1, K=8, R=3, S=3, pad=(1, 1)),                                    # C = 1 (scalar path)
+    dict(N=2, H=24, W=18, C=64, K=1, R=3, S=3, pad=(1, 1)),                                   # K = 1
+    dict(N=2, H=16, W=40, C=1, K=8, R=5, S=5, stride=(1, 2), pad=(2, 2)),                     # D conv0
+    dict(N=2, H=16, W=20, C=8, K=12, R=5, S=5, stride=(2, 2), pad=(2, 2)),                    # stride (2,2)
+    dict(N=2, H=9, W=21, C=12, K=16, R=3, S=3, stride=(2, 1), pad=(1, 1)),                    # stride (2,1), odd H
+    dict(N=16, H=2, W=40, C=8, K=8, R=3, S=5, stride=(1, 2), pad=(1, 2), groups=8),           # multibin: 8 groups
+    dict(N=2, H=1, W=33, C=132, K=200, R=1, S=3, pad=(0, 1)),                                 # C, K not multiples of 128/16
+    dict(N=1, H=130, W=90, C=64, K=64, R=3, S=3, pad=(1, 1)),                                 # many M tiles, BN = 64
+    dict(N=1, H=5, W=7, C=20, K=36, R=3, S=3, pad=(2, 2), dil=(2, 2)),                        # dilation
+]
+
+
+def _torch_conv(x, w, b, c):
+    """CPU reference in NCHW; x (N,H,W,C) numpy, w (groups*K, C, R, S) torch layout per group."""
+    G = c.get("groups", 1)
+    st, dl = c.get("stride", (1, 1)), c.get("dil", (1, 1))
+    pt, pl = c.get("pad", (0, 0))
+    N, H, W, Cc = x.shape
+    K, R, S = c["K"], c["R"], c["S"]
+    xt = x.permute(0, 3, 1, 2)
+    if "out_hw" in c:        # asymmetric (left-only) padding
+        P, Q = c["out_hw"]
+        need_h = (P - 1) * st[0] + dl[0] * (R - 1) + 1
+        need_w = (Q - 1) * st[1] + dl[1] * (S - 1) + 1
+        xt = F.pad(xt, (pl, need_w - W - pl, pt, need_h - H - pt))
+        pad = (0, 0)
+    else:
+        pad = (pt, pl)
+    outs = []
+    for gi in range(G):
+        xg = xt[gi * (N // G):(gi + 1) * (N // G)]
+        outs.append(F.conv2d(xg, w[gi * K:(gi + 1) * K], b[gi * K:(gi + 1) * K], stride=st, padding=pad, dilation=dl))
+    return torch.cat(outs, 0).permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("c", CONV_CASES, ids=lambda c: "N{N}H{H}W{W}C{C}K{K}R{R}S{S}".format(**c) + f"g{c.get('groups', 1)}")
+def test_conv_fprop_dgrad_wgrad(env, c):
+    ops = env
+    torch.manual_seed(0)
+    G = c.get("groups", 1)
+    x = torch.randn(c["N"], c["H"], c["W"], c["C"], dtype=torch.float64)
+    w = torch.randn(G * c["K"], c["C"], c["R"], c["S"], dtype=torch.float64) * 0.2
+    b = torch.randn(G * c["K"], dtype=torch.float64)
+    x.requires_grad_(True); w.requires_grad_(True); b.requires_grad_(True)
+    y_ref = _torch_conv(x, w, b, c)
+    r = torch.randn_like(y_ref)
+    (y_ref * r).sum().backward()
+
+    xd = x.detach().float().to(DEV).requires_grad_(True)
+    wd = w.detach().float().to(DEV).requires_grad_(True)
+    bd = b.detach().float().to(DEV).requires_grad_(True)
+    w_krsc, w_crsk = [], []
+    for gi in range(G):   # per-group weight prep (plain mode), then stack: exactly what the modules do
+        a, bb = ops.weight_prep(wd[gi * c["K"]:(gi + 1) * c["K"]].contiguous(), None, True)
+        w_krsc.append(a); w_crsk.append(bb)
+    wk, wc = torch.cat(w_krsc, 0), torch.cat(w_crsk, 0)
+    desc = ops.conv_desc(c["N"], c["H"], c["W"], c["C"], c["K"], c["R"], c["S"], stride=c.get("stride", (1, 1)),
+                         pad=c.get("pad", (0, 0)), dil=c.get("dil", (1, 1)), groups=G, out_hw=c.get("out_hw"))
+    y = ops.conv(xd, wk, wc, bd, desc)
+    assert tuple(y.shape) == tuple(y_ref.shape)
+    assert_rel(y, y_ref, 2e-5, "fprop")
+    (y * r.float().to(DEV)).sum().backward()
+    assert_rel(xd.grad, x.grad, 2e-5, "dgrad")
+    assert_rel(wd.grad, w.grad, 2e-5, "wgrad")
+    assert_rel(bd.grad, b.grad, 2e-5, "bias grad")
+
+
+def test_conv_large_split_k_and_tiles(env):
+    """A refiner-sized layer: many M tiles, split-K wgrad with the slab reduction."""
+    ops = env
+    torch.manual_seed(1)
+    N, H, W, Cc, K = 2, 256, 90, 64, 128
+    x = torch.randn(N, H, W, Cc, device=DEV, requires_grad=True)
+    w = (torch.randn(K, Cc, 3, 3, device=DEV) * 0.05).requires_grad_(True)
+    wk, wc = ops.weight_prep(w, None, True)
+    desc = ops.conv_desc(N, H, W, Cc, K, 3, 3, pad=(1, 1))
+    assert ops.L().mq_conv_wgrad_workspace(desc) > 0
+    y = ops.conv(x, wk, wc, None, desc)
+    r = torch.randn_like(y)
+    (y * r).sum().backward()
+    xr = x.detach().cpu().double().requires_grad_(True)
+    wr = w.detach().cpu().double().requires_grad_(True)
+    yr = F.conv2d(xr.permute(0, 3, 1, 2), wr, padding=1).permute(0, 2, 3, 1)
+    (yr * r.cpu().double()).sum().backward()
+    assert_rel(y, yr, 2e-5, "fprop")
+    assert_rel(x.grad, xr.grad, 2e-5, "dgrad")
+    assert_rel(w.grad, wr.grad, 5e-5, "wgrad")
+
+
+def test_conv_rejects_bad_descriptor(env):
+    ops = env
+    from mqgan_amd._lib import MqganHipError
+    x = torch.zeros(3, 1, 8, 4, device=DEV)
+    w = torch.zeros(4, 3, 4, device=DEV)
+    with pytest.raises(MqganHipError):
+        ops.conv(x, w, None, None, ops.conv_desc(3, 1, 8, 4, 4, 1, 3, pad=(0, 1), groups=2))
+
+
+# ----------------------------------------------------------------------------------------- weight prep
+def test_weight_norm_prep_and_backward(env):
+    ops = env
+    torch.manual_seed(2)
+    v = torch.randn(24, 16, 5, dtype=torch.float64, requires_grad=True)
+    gq = (torch.rand(24, 1, 1, dtype=torch.float64) + 0.5).requires_grad_(True)
+    w_ref = v * (gq / v.flatten(1).norm(dim=1).view(-1, 1, 1))
+    r = torch.randn(24, 16, 5, dtype=torch.float64)
+    (w_ref * r).sum().backward()
+    vd = v.detach().float().to(DEV).requires_grad_(True)
+    gd = gq.detach().float().to(DEV).requires_grad_(True)
+    wk, wc = ops.weight_prep(vd, gd, True)
+    assert_rel(wk, w_ref.permute(0, 2, 1), 1e-6, "krsc")
+    assert_rel(wc, w_ref.permute(1, 2, 0), 1e-6, "crsk")
+    (wk * r.permute(0, 2, 1).float().to(DEV)).sum().backward()
+    assert_rel(vd.grad, v.grad, 1e-5, "dv")
+    assert_rel(gd.grad, gq.grad, 1e-5, "dg")
+    # scalar v (ConvBlock2D's point-wise conv): w = g*sign(v), dv == 0 exactly
+    v1 = torch.randn(16, 1, 1, 1, device=DEV, requires_grad=True)
+    g1 = torch.rand(16, 1, 1, 1, device=DEV, requires_grad=True)
+    wk, _ = ops.weight_prep(v1, g1, False)
+    close(wk.view(-1), (g1 * torch.sign(v1)).view(-1), rtol=1e-6)
+    wk.sum().backward()
+    assert float(v1.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("power_iteration", [True, False])
+def test_spectral_norm_prep(env, power_iteration):
+    ops = env
+    from oracle import nn as O
+    torch.manual_seed(3)
+    K, Cc, R, S = 12, 8, 3, 5
+    P = {"weight_orig": (torch.randn(K, Cc, R, S) * 0.02).requires_grad_(True),
+         "weight_u": F.normalize(torch.randn(K), dim=0), "weight_v": F.normalize(torch.randn(Cc * R * S), dim=0)}
+    wd = P["weight_orig"].detach().to(DEV).requires_grad_(True)
+    ud, vd = P["weight_u"].clone().to(DEV), P["weight_v"].clone().to(DEV)
+    w_ref = O.sn_weight(P, "", training=power_iteration)
+    r = torch.randn_like(w_ref)
+    (w_ref * r).sum().backward()
+    wk, wc = ops.spectral_prep(wd, ud, vd, power_iteration, True)
+    assert_rel(wk, w_ref.permute(0, 2, 3, 1).reshape(K, R * S, Cc), 2e-5, "krsc")
+    assert_rel(wc, w_ref.permute(1, 2, 3, 0).reshape(Cc, R * S, K), 2e-5, "crsk")
+    close(ud, P["weight_u"], rtol=1e-4, atol=1e-6)
+    close(vd, P["weight_v"], rtol=1e-4, atol=1e-6)
+    (wk * r.permute(0, 2, 3, 1).reshape(K, R * S, Cc).to(DEV)).sum().backward()
+    assert_rel(wd.grad, P["weight_orig"].grad, 1e-4, "dW")
+
+
+# ----------------------------------------------------------------------------------------- pointwise
+@pytest.mark.parametrize("Cc", [16, 12, 1])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_pointwise_eval(env, Cc, act):
+    ops = env
+    torch.manual_seed(4)
+    B, T = 3, 29
+    h = torch.randn(B, T, Cc, dtype=torch.float64, requires_grad=True)
+    rp = torch.randn(B, T, Cc, dtype=torch.float64, requires_grad=True)
+    ro = torch.randn(B, T, Cc, dtype=torch.float64, requires_grad=True)
+    beta = torch.tensor(1.1, dtype=torch.float64, requires_grad=True)
+    gamma = torch.tensor(0.45, dtype=torch.float64, requires_grad=True)
+    lens = torch.tensor([29, 17, 5])
+    m = (torch.arange(T)[None] >= lens[:, None])
+    tt = (h + rp).masked_fill(m[..., None], 0.0)
+    a = (1 + torch.tanh(beta * tt)) * gamma * tt if act == 1 else (F.leaky_relu(tt, 0.2) if act == 2 else tt)
+    ref = (a + ro).masked_fill(m[..., None], 0.0)
+    r = torch.randn_like(ref)
+    (ref * r).sum().backward()
+    f = lambda v: v.detach().float().to(DEV).requires_grad_(True)
+    hd, rpd, rod, bd, gd = f(h), f(rp), f(ro), f(beta), f(gamma)
+    out = ops.pointwise(hd, act=act, r_pre=rpd, r_post=rod, mask=m.to(torch.uint8).to(DEV), mask_pre=True, mask_post=True,
+                        beta=bd, gamma=gd)
+    assert_rel(out, ref, 1e-5, "fwd")
+    (out * r.float().to(DEV)).sum().backward()
+    assert_rel(hd.grad, h.grad, 1e-5, "dh")
+    assert_rel(rpd.grad, rp.grad, 1e-5, "dr_pre")
+    assert_rel(rod.grad, ro.grad, 1e-5, "dr_post")
+    if act == 1:
+        assert_rel(bd.grad, beta.grad, 1e-4, "dbeta")
+        assert_rel(gd.grad, gamma.grad, 1e-4, "dgamma")
+
+
+def test_pointwise_mask_mappings(env):
+    ops = env
+    torch.manual_seed(5)
+    # refiner layout (N, T, F, C): mask index = row // F
+    N, T, Fq, Cc = 2, 6, 5, 8
+    x = torch.randn(N, T, Fq, Cc, device=DEV)
+    m = (torch.rand(N, T, device=DEV) > 0.5).to(torch.uint8)
+    out = ops.pointwise(x, mask=m, mask_post=True, dmap=(Fq, 1, 1))
+    close(out, x.masked_fill(m.bool()[:, :, None, None], 0.0), rtol=0, atol=0)
+    # discriminator layout (N, H, W, C): mask index = n * W + w
+    N, H, W, Cc = 3, 4, 7, 12
+    x = torch.randn(N, H, W, Cc, device=DEV)
+    m = (torch.rand(N, W, device=DEV) > 0.5).to(torch.uint8)
+    out = ops.pointwise(x, mask=m, mask_post=True, dmap=(H * W, W, W))
+    close(out, x.masked_fill(m.bool()[:, None, :, None], 0.0), rtol=0, atol=0)
+
+
+def test_dropout_statistics_and_backward_consistency(env):
+    ops = env
+    ops.manual_seed(123)
+    x = torch.ones(64, 128, 64, device=DEV, requires_grad=True)
+    y = ops.pointwise(x, p_drop=0.1, training=True)
+    keep = (y != 0).float().mean().item()
+    assert abs(keep - 0.9) < 2e-3, keep
+    vals = torch.unique(y.detach())
+    assert len(vals) == 2 and abs(vals.max().item() - 1 / 0.9) < 1e-4
+    y.sum().backward()
+    np.testing.assert_array_equal((x.grad != 0).cpu().numpy(), (y != 0).detach().cpu().numpy())   # same mask in bwd
+    y2 = ops.pointwise(x.detach(), p_drop=0.1, training=True)
+    assert (y2 != y.detach()).any()                                                      # fresh seed per call
+    y3 = ops.pointwise(x.detach(), p_drop=0.1, training=False)
+    assert bool((y3 == 1).all())                                                         # eval: identity
+    # no visible structure: per-row and per-column keep rates are all close to 0.9
+    k = (y.detach() != 0).float()
+    assert (k.mean(dim=(0, 1)) - 0.9).abs().max().item() < 0.02
+    assert (k.mean(dim=(1, 2)) - 0.9).abs().max().item() < 0.02
+
+
+# ----------------------------------------------------------------------------------------- data movement
+def test_pool_upcat_bandsplit(env):
+    ops = env
+    torch.manual_seed(6)
+    x = torch.randn(2, 8, 5, 12, device=DEV, requires_grad=True)
+    y = ops.AvgPoolT2Fn.apply(x)
+    ref = F.avg_pool2d(x.detach().permute(0, 3, 1, 2), (2, 1)).permute(0, 2, 3, 1)
+    close(y, ref, rtol=1e-6)
+    y.backward(torch.ones_like(y))
+    close(x.grad, torch.full_like(x, 0.5), rtol=0, atol=0)
+    a = torch.randn(2, 4, 5, 6, device=DEV, requires_grad=True)
+    s = torch.randn(2, 8, 5, 3, device=DEV, requires_grad=True)
+    o = ops.UpCatFn.apply(a, s)
+    ref = torch.cat([F.interpolate(a.detach().permute(0, 3, 1, 2), scale_factor=(2, 1), mode="nearest").permute(0, 2, 3, 1),
+                     s.detach()], dim=-1)
+    close(o, ref, rtol=0, atol=0)
+    r = torch.randn_like(o)
+    (o * r).sum().backward()
+    close(a.grad, (r[..., :6].reshape(2, 4, 2, 5, 6)).sum(2), rtol=1e-6)
+    close(s.grad, r[..., 6:], rtol=0, atol=0)
+    xb = torch.randn(3, 37, 16, device=DEV, requires_grad=True)
+    for nb in (1, 8):
+        o = ops.BandSplitFn.apply(xb, nb)
+        bs = 16 // nb
+        ref = torch.stack([xb.detach()[:, :, j * bs:(j + 1) * bs].transpose(1, 2) for j in range(nb)], 0).reshape(nb * 3, bs, 37, 1)
+        close(o, ref, rtol=0, atol=0)
+        r = torch.randn_like(o)
+        xb.grad = None
+        (o * r).sum().backward()
+        want = torch.cat([r[j * 3:(j + 1) * 3, :, :, 0].transpose(1, 2) for j in range(nb)], dim=-1)
+        close(xb.grad, want, rtol=0, atol=0)
+    m = ops.sequence_mask(torch.tensor([5, 0, 9], device=DEV), 9)
+    np.testing.assert_array_equal(m.cpu().numpy(), (np.arange(9)[None] >= np.array([5, 0, 9])[:, None]).astype(np.uint8))
+    np.testing.assert_array_equal(ops.mask_pool(m, 2, True).cpu().numpy(),
+                                  F.max_pool1d(m.float().cpu()[:, None], 2, 2, ceil_mode=True)[:, 0].numpy().astype(np.uint8))
+    np.testing.assert_array_equal(ops.mask_pool(m[:, :8].contiguous(), 2, False).cpu().numpy(),
+                                  F.max_pool1d(m[:, :8].float().cpu()[:, None], 2, 2)[:, 0].numpy().astype(np.uint8))
+    np.testing.assert_array_equal(ops.mask_upsample2(m).cpu().numpy(), np.repeat(m.cpu().numpy(), 2, axis=1))
+
+
+# ----------------------------------------------------------------------------------------- optimiser
+def test_sumsq_and_adam_match_torch(env):
+    ops = env
+    torch.manual_seed(7)
+    n = 100003
+    p0 = torch.randn(n)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-3, betas=(0.5, 0.999))
+    p = p0.clone().to(DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        gq = torch.randn(n) * (3.0 if step == 2 else 0.001)
+        ref.grad = gq.clone()
+        norm = torch.nn.utils.clip_grad_norm_([ref], 1.0)
+        opt.step()
+        gd = gq.to(DEV)
+        ss = ops.sumsq(gd)
+        close(ss.sqrt(), norm, rtol=1e-5)
+        ops.adam_step(p, gd, m, v, 1e-3, 0.5, 0.999, 1e-8, step, ss, 1.0)
+        close(p, ref, rtol=1e-5, atol=1e-7, msg=f"step {step}")

@@ -1,0 +1,113 @@
+"""-m gpu: two full optimisation steps of mqgan_amd.train.Trainer against fixtures G7 / G7b, which
+were produced by the reference's own Trainer._train_discriminator / _train_generator
+(train.py:380-501) on the same weights and batches.  Tolerance: 1e-4 relative (north star)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import DEV, close, npz_state_dict, t  # noqa: E402
+from test_oracle_trainstep import TINY_CFG  # noqa: E402
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    import __graft_entry__ as g
+    g.build()
+    assert torch.cuda.is_available()
+
+
+def make_trainer(g, use_fm):
+    from mqgan_amd.train import Trainer
+    cfg = {"model": TINY_CFG["model"], "training": dict(TINY_CFG["training"], use_fm_loss=use_fm, pretrained=None)}
+    tr = Trainer(cfg, device=DEV, build_data=False)
+    tr.generator.load_state_dict(npz_state_dict(g, "g0/"), strict=True)
+    tr.patch_discriminator.load_state_dict(npz_state_dict(g, "p0/"), strict=True)
+    tr.multibin_discriminator.load_state_dict(npz_state_dict(g, "m0/"), strict=True)
+    tr.arena_g.rebind()
+    tr.arena_d.rebind()
+    return tr
+
+
+@pytest.mark.parametrize("fname,use_fm", [("g7_trainstep.npz", False), ("g7b_trainstep_fm.npz", True)])
+def test_two_train_steps_match_reference(fname, use_fm):
+    g = load_golden(fname)
+    tr = make_trainer(g, use_fm)
+    tr.generator.eval()                       # fixtures were generated with G.eval() (dropout / FSQ noise off)
+    tr.patch_discriminator.train()
+    tr.multibin_discriminator.train()
+    tr.epoch = 1
+    lens = t(g["lens"])
+    for s in range(2):
+        x = t(g[f"s{s}/x"])
+        recon_pre, recon_post = tr.generator(x, lens)
+        close(recon_pre, g[f"s{s}/recon_pre"], rtol=1e-4, atol=2e-5, msg="recon_pre")
+        close(recon_post, g[f"s{s}/recon_post"], rtol=1e-4, atol=2e-5, msg="recon_post")
+        out = tr.train_step(x, lens)
+        for k in ("loss_d", "loss_g_total", "loss_recon_pre", "loss_recon_post", "loss_gan", "loss_fm"):
+            np.testing.assert_allclose(float(out[k]), float(g[f"s{s}/{k}"]), rtol=1e-4, atol=1e-7, err_msg=f"step {s} {k}")
+        np.testing.assert_allclose(out["learning_rate"], float(g[f"s{s}/lr"]), rtol=1e-9)
+        np.testing.assert_allclose(float(tr.optimizer_d.grad_norm()), float(g[f"s{s}/preclip_norm_d"]), rtol=2e-4)
+        np.testing.assert_allclose(float(tr.optimizer_g.grad_norm()), float(g[f"s{s}/preclip_norm_g"]), rtol=2e-4)
+        np.testing.assert_allclose(tr.gan_loss._state[:2].cpu().numpy(), g[f"s{s}/ema"], rtol=1e-4, atol=1e-7)
+        for tag, mod in (("gsum", tr.generator), ("psum", tr.patch_discriminator), ("msum", tr.multibin_discriminator)):
+            for k, v in mod.state_dict().items():
+                want = g[f"s{s}/{tag}/{k}"]
+                v = v.detach().double().cpu()
+                got = np.array([v.sum().item(), v.norm().item()])
+                np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6, err_msg=f"step {s} {tag}/{k}")
+    for k in [f for f in g.files if f.startswith("gfinal/")]:
+        close(tr.generator.state_dict()[k[7:]], g[k], rtol=2e-5, atol=2e-7, msg=k)
+    close(tr.patch_discriminator.state_dict()["convs.1.weight_orig"], g["pfinal/convs.1.weight_orig"], rtol=2e-5, atol=2e-7)
+    close(tr.patch_discriminator.state_dict()["convs.1.weight_u"], g["pfinal/convs.1.weight_u"], rtol=1e-4, atol=1e-6)
+
+
+def test_checkpoint_layout_round_trip(tmp_path):
+    """Checkpoint keys = the reference's (train.py:625-636); the optimiser states load into torch.optim.Adam."""
+    g = load_golden("g7_trainstep.npz")
+    tr = make_trainer(g, False)
+    tr.config["data"] = {"output_dir": str(tmp_path)}
+    tr.generator.eval()
+    tr.train_step(t(g["s0/x"]), t(g["lens"]))
+    path = tr._save_checkpoint(3)
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    for k in ("epoch", "model_state_dict", "optimizer_g_state_dict", "optimizer_d_state_dict", "scaler_g_state_dict",
+              "scaler_d_state_dict", "config"):
+        assert k in ck
+    assert list(ck["model_state_dict"].keys()) == list(npz_state_dict(g, "g0/").keys()) or \
+        set(ck["model_state_dict"]) == set(npz_state_dict(g, "g0/"))
+    # torch's own Adam accepts the optimiser state (same param order / shapes)
+    ref_params = [torch.nn.Parameter(v.clone()) for v in ck["model_state_dict"].values() if v.is_floating_point()]
+    opt = torch.optim.Adam(ref_params, lr=1e-4)
+    opt.load_state_dict(ck["optimizer_g_state_dict"])
+    # resume: a new trainer picks the checkpoint up and continues from epoch 4 with identical weights
+    from mqgan_amd.train import Trainer
+    cfg = dict(tr.config)
+    tr2 = Trainer(cfg, device=DEV, build_data=False)
+    assert tr2.start_epoch == 4
+    for (k, a), (_, b) in zip(tr.generator.state_dict().items(), tr2.generator.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert torch.equal(tr.optimizer_g.exp_avg, tr2.optimizer_g.exp_avg)
+    assert torch.equal(tr.gan_loss._state, tr2.gan_loss._state)
+
+
+def test_train_mode_step_runs_and_is_finite():
+    """Full train-mode step (dropout active everywhere): finite losses, weights move, D u/v normalised."""
+    from mqgan_amd import ops
+    g = load_golden("g7_trainstep.npz")
+    tr = make_trainer(g, False)
+    ops.manual_seed(1)
+    tr.generator.train()
+    before = tr.arena_g.flat_param.clone()
+    out = tr.train_step(t(g["s0/x"]), t(g["lens"]))
+    for k, v in out.items():
+        assert np.isfinite(float(v)), k
+    assert float((tr.arena_g.flat_param - before).abs().max()) > 0
+    # hidden_proj never receives a gradient (its only consumer is detached): weights unchanged
+    sd0 = npz_state_dict(g, "g0/")
+    assert torch.equal(tr.generator.state_dict()["hidden_proj.weight"].cpu(), sd0["hidden_proj.weight"])
+    u = tr.patch_discriminator.state_dict()["convs.0.weight_u"]
+    assert abs(float(u.norm()) - 1.0) < 1e-4
