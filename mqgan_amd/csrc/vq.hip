@@ -272,8 +272,8 @@ extern "C" int mq_fsq_forward(const mqFsqDesc *desc, const float *z, int64_t n, 
 {
     FsqDev p;
     if (to_dev(desc, p, desc ? desc->thresh : nullptr, "mq_fsq_forward")) return 1;
-    MQ_REQUIRE(z && n >= 0 && (codes || idx), "mq_fsq_forward: bad arguments");
     if (n == 0) return 0;
+    MQ_REQUIRE(z && n > 0 && (codes || idx), "mq_fsq_forward: bad arguments");
     const int grid = ew_grid(n, 256);
     if (p.d == 4 && (uintptr_t)z % 16 == 0 && (uintptr_t)codes % 16 == 0)
         hipLaunchKernelGGL((fsq_forward_kernel<4>), dim3(grid), dim3(256), 0, S(stream), z, n, p, codes, idx);
@@ -288,8 +288,8 @@ extern "C" int mq_fsq_backward(const mqFsqDesc *desc, const float *z, const floa
 {
     FsqDev p;
     if (to_dev(desc, p, nullptr, "mq_fsq_backward")) return 1;
-    MQ_REQUIRE(z && dcodes && dz && n >= 0, "mq_fsq_backward: bad arguments");
     if (n == 0) return 0;
+    MQ_REQUIRE(z && dcodes && dz && n > 0, "mq_fsq_backward: bad arguments");
     hipLaunchKernelGGL(fsq_backward_kernel, dim3(ew_grid(n * p.d, 256)), dim3(256), 0, S(stream), z, dcodes, n * p.d, p,
                        dz);
     MQ_LAUNCH_CHECK("mq_fsq_backward");
@@ -300,8 +300,8 @@ extern "C" int mq_fsq_decode(const mqFsqDesc *desc, const int64_t *idx, int64_t 
 {
     FsqDev p;
     if (to_dev(desc, p, nullptr, "mq_fsq_decode")) return 1;
-    MQ_REQUIRE(idx && codes && n >= 0, "mq_fsq_decode: bad arguments");
     if (n == 0) return 0;
+    MQ_REQUIRE(idx && codes && n > 0, "mq_fsq_decode: bad arguments");
     hipLaunchKernelGGL(fsq_decode_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S(stream), idx, n, p, codes);
     MQ_LAUNCH_CHECK("mq_fsq_decode");
     return 0;

@@ -63,7 +63,11 @@ def test_convblock2d_g2():
     close(out, g["out"].transpose(0, 2, 1), rtol=1e-4, atol=1e-5)
     (out * t(g["r"].transpose(0, 2, 1))).sum().backward()
     close(x.grad, g["grad_x"].transpose(0, 2, 1), rtol=1e-4, atol=1e-5)
-    check_param_grads(m, g, "grad/")
+    # pw.original1 is a scalar per channel: w = g * sign(v), so d/dv is exactly 0 here; the reference's
+    # autograd leaves ~1e-7 of rounding noise there (fixture max 6e-7)
+    check_param_grads(m, g, "grad/", skip=("pw.parametrizations.weight.original1",))
+    assert float(m.pw.parametrizations.weight.original1.grad.abs().max()) == 0.0
+    assert np.abs(g["grad/pw.parametrizations.weight.original1"]).max() < 1e-5
 
 
 def test_convblock2d_large_vs_oracle_and_dropout():
@@ -90,7 +94,10 @@ def test_convblock2d_large_vs_oracle_and_dropout():
     assert_rel(xd.grad, xr.grad.permute(0, 2, 1), 1e-4, "dx")
     for name, p in m.named_parameters():
         want = P[name].grad if P[name].grad is not None else torch.zeros_like(P[name])
-        assert_rel(p.grad, want, 2e-4, name) if want.abs().max() > 0 else None
+        if name == "pw.parametrizations.weight.original1":      # exactly 0 here, rounding noise in torch autograd
+            assert float(p.grad.abs().max()) == 0.0 and float(want.abs().max()) < 1e-4
+        elif want.abs().max() > 0:
+            assert_rel(p.grad, want, 2e-4, name)
     # train mode: dropout(0.1) on the hidden (B, C0, C0, T) tensor -> output = eval output in expectation
     m.train()
     ops.manual_seed(9)
