@@ -1,0 +1,120 @@
+"""The N > 1 path on CPU: two processes, gloo backend, 127.0.0.1 rendezvous.  Checks that
+FlatArena + GradReducer (mqgan_amd/ddp.py) produce exactly the sum of the per-rank gradients, with
+several buckets, hooks firing during backward, and a parameter that never gets a gradient
+(`hidden_proj` in the real model) not stalling its bucket."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(13, 37)
+        self.b = torch.nn.Linear(37, 41)
+        self.unused = torch.nn.Linear(5, 3)          # never receives a gradient
+        self.c = torch.nn.Linear(41, 2)
+        self.scale = torch.nn.Parameter(torch.tensor(1.5))   # 0-d parameter, like APTx beta/gamma
+
+    def forward(self, x):
+        return self.c(torch.tanh(self.b(torch.relu(self.a(x))))) * self.scale
+
+
+def _worker(rank, world, port, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mqgan_amd.ddp import FlatArena, GradReducer, broadcast_arena
+        torch.manual_seed(100 + rank)                # different init per rank: broadcast must fix that
+        net = Net()
+        arena = FlatArena([net])
+        broadcast_arena(arena)
+        red = GradReducer(arena, bucket_bytes=1024)  # several buckets
+        assert len(red.buckets) >= 3
+        launched_during_backward = []
+        orig = red._launch
+        red._launch = lambda b: (launched_during_backward.append(b), orig(b))[1]
+        results = []
+        for step in range(2):
+            arena.zero_grad()
+            red.start()
+            torch.manual_seed(7 + 10 * step + rank)
+            x = torch.randn(6, 13)
+            net(x).pow(2).sum().backward()
+            n_hook = len(launched_during_backward)
+            red.finish()
+            results.append((arena.flat_grad.clone(), n_hook))
+        # every parameter still aliases the arena and .grad views were filled in place
+        for p, o in zip(arena.params, arena.offsets):
+            assert p.data_ptr() == arena.flat_param.data_ptr() + 4 * o
+            assert p.grad.data_ptr() == arena.flat_grad.data_ptr() + 4 * o
+        out_q.put((rank, arena.flat_param.clone(), [r[0] for r in results], [r[1] for r in results]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_world2():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=60) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got.sort(key=lambda t: t[0])
+    (_, w0, g0, hooks0), (_, w1, g1, hooks1) = got
+    assert torch.equal(w0, w1), "broadcast_arena must make the replicas identical"
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b), "all ranks must hold the same reduced gradient"
+    assert min(hooks0 + hooks1) >= 1, "at least one bucket must be launched from a hook, i.e. during backward"
+
+    # single-process reference: sum of the two ranks' gradients on the broadcast weights
+    from mqgan_amd.ddp import FlatArena
+    torch.manual_seed(100)
+    net = Net()
+    arena = FlatArena([net])
+    assert torch.equal(arena.flat_param, w0)
+    for step in range(2):
+        total = torch.zeros_like(arena.flat_grad)
+        for rank in range(world):
+            arena.zero_grad()
+            torch.manual_seed(7 + 10 * step + rank)
+            net(torch.randn(6, 13)).pow(2).sum().backward()
+            total += arena.flat_grad
+        torch.testing.assert_close(g0[step], total, rtol=1e-6, atol=1e-6)
+    # the unused layer's slice is all zeros (flushed, not stalled)
+    i = [id(p) for p in arena.params].index(id(net.unused.weight))
+    o = arena.offsets[i]
+    assert float(g0[0][o:o + net.unused.weight.numel()].abs().max()) == 0.0
+
+
+def test_arena_survives_load_state_dict_and_zero_grad():
+    from mqgan_amd.ddp import FlatArena
+    net = Net()
+    arena = FlatArena([net])
+    sd = {k: v.clone() + 1 for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    arena.rebind()
+    for p, o in zip(arena.params, arena.offsets):
+        assert p.data_ptr() == arena.flat_param.data_ptr() + 4 * o
+    assert torch.equal(net.a.weight, sd["a.weight"])
+    net.zero_grad(set_to_none=True)           # something resets .grad: zero_grad() re-attaches the views
+    arena.zero_grad()
+    net(torch.randn(2, 13)).sum().backward()
+    assert float(arena.flat_grad.abs().sum()) > 0
