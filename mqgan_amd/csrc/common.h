@@ -47,6 +47,19 @@ inline int ew_grid(int64_t work_items, int block)
     return (int)g;
 }
 
+// ----------------------------------------------------------------------------- filter-row layout
+// A filter row (all taps x channels of one output channel) is stored channel-BLOCKED:
+//     index(rs, c) = ((c / CB) * RS + rs) * CB + c % CB,   CB = 16 when C % 16 == 0, else CB = C (= plain RSC).
+// The GEMM reduction then walks the R*S taps of one 16-channel slice before moving to the next slice, so the
+// 64-byte-per-pixel slices of the activation tile are re-read from L1/L2 by consecutive K-steps instead of
+// once per tap from the fabric (measured: 51x the tensor size fetched with the plain order).
+__host__ __device__ inline int chan_block(int C) { return (C % 16 == 0) ? 16 : C; }
+__host__ __device__ inline int kidx(int rs, int c, int RS, int CB)
+{
+    const int cb = c / CB;
+    return (cb * RS + rs) * CB + (c - cb * CB);
+}
+
 // ----------------------------------------------------------------------------- wave64 reductions (DPP)
 // sum over the 64 lanes, result valid in lane 63 (row_bcast form, gfx9 family).
 template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf, bool BOUND_CTRL = false>

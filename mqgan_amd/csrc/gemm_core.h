@@ -33,14 +33,37 @@ struct GemmCfg {
     static constexpr int LDS_FLOATS = 2 * (GEMM_BM + BN) * GEMM_LD;
 };
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0xFFFFFFFFu;
+
+// 16-byte loads through a buffer descriptor: an out-of-range offset returns zeros without touching memory
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, size_t bytes)
+{
+    const unsigned n = bytes > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (unsigned)bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), (short)0, (int)n, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
+{
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
+
 __device__ __forceinline__ void lds_store_k4(float *dst, float4 v)
 {
     *reinterpret_cast<float2 *>(dst) = make_float2(v.x, v.z);
     *reinterpret_cast<float2 *>(dst + 2) = make_float2(v.y, v.w);
 }
 
-// ALoad / BLoad: .prepare(k0) once per K-step (k0 = first k of the step), then .load(slot) -> float4 of
-// k = k0 + 4*(tid&3) .. +3 for tile row (tid>>2) + 64*slot.  Out-of-range elements must come back as 0.
+// ALoad / BLoad: .stage(k0) once per K-step, in increasing k0 (0, BK, 2BK, ...): computes and keeps the
+// addresses of the thread's loads for that step; then .fetch(slot) -> float4 of k = k0 + 4*(tid&3) .. +3
+// for tile row (tid>>2) + 64*slot.  Out-of-range elements come back as 0.
+//
+// Per K-step the program order is pinned with sched_barriers into three phases:
+//   1. issue the global loads of tile kt+1 (addresses were computed during the previous step),
+//   2. the 32 MFMAs of tile kt with the LDS fragment reads AND the address arithmetic of tile kt+2
+//      interleaved between them (VALU work rides in the shadow of the matrix pipe),
+//   3. wait for the loads, write them to the other LDS buffer, barrier.
+// Global-load latency is covered by phase 2; there are no branches in the loop (past the end of K the
+// loaders' buffer descriptors return zeros without touching memory).
 template <int BN, class ALoad, class BLoad>
 __device__ __forceinline__ void nt_gemm_mainloop(ALoad &la, BLoad &lb, int nk, float *smem,
                                                  f32x16 (&acc)[GemmCfg<BN>::TM][GemmCfg<BN>::TN])
@@ -56,31 +79,31 @@ __device__ __forceinline__ void nt_gemm_mainloop(ALoad &la, BLoad &lb, int nk, f
     const bool b_active = (BN >= 64) || (tid < BN * 4);
 
     float4 ra[Cfg::A_SLOTS], rb[Cfg::B_SLOTS];
-    la.prepare(0);
-    lb.prepare(0);
+    la.stage(0);
+    lb.stage(0);
 #pragma unroll
-    for (int j = 0; j < Cfg::A_SLOTS; ++j) ra[j] = la.load(j);
+    for (int j = 0; j < Cfg::A_SLOTS; ++j) ra[j] = la.fetch(j);
 #pragma unroll
-    for (int j = 0; j < Cfg::B_SLOTS; ++j) rb[j] = b_active ? lb.load(j) : make_float4(0, 0, 0, 0);
+    for (int j = 0; j < Cfg::B_SLOTS; ++j) rb[j] = b_active ? lb.fetch(j) : make_float4(0, 0, 0, 0);
 #pragma unroll
     for (int j = 0; j < Cfg::A_SLOTS; ++j) lds_store_k4(&As[(ld_row + 64 * j) * GEMM_LD + 4 * ld_kq], ra[j]);
     if (b_active) {
 #pragma unroll
         for (int j = 0; j < Cfg::B_SLOTS; ++j) lds_store_k4(&Bs[(ld_row + 64 * j) * GEMM_LD + 4 * ld_kq], rb[j]);
     }
+    la.stage(GEMM_BK);
+    lb.stage(GEMM_BK);
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        const bool more = (kt + 1 < nk);
-        if (more) {
-            la.prepare((kt + 1) * GEMM_BK);
-            lb.prepare((kt + 1) * GEMM_BK);
+        // phase 1
 #pragma unroll
-            for (int j = 0; j < Cfg::A_SLOTS; ++j) ra[j] = la.load(j);
+        for (int j = 0; j < Cfg::A_SLOTS; ++j) ra[j] = la.fetch(j);
 #pragma unroll
-            for (int j = 0; j < Cfg::B_SLOTS; ++j) rb[j] = b_active ? lb.load(j) : make_float4(0, 0, 0, 0);
-        }
+        for (int j = 0; j < Cfg::B_SLOTS; ++j) rb[j] = b_active ? lb.fetch(j) : make_float4(0, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 2
         const float *Ac = As + cur * GEMM_BM * GEMM_LD + (wm * Cfg::TM * 32 + li) * GEMM_LD + 2 * lh;
         const float *Bc = Bs + cur * BN * GEMM_LD + (wn * Cfg::TN * 32 + li) * GEMM_LD + 2 * lh;
 #pragma unroll
@@ -101,7 +124,11 @@ __device__ __forceinline__ void nt_gemm_mainloop(ALoad &la, BLoad &lb, int nk, f
                 for (int tn = 0; tn < Cfg::TN; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].y, b[tn].y, acc[tm][tn], 0, 0, 0);
         }
-        if (more) {
+        la.stage((kt + 2) * GEMM_BK);
+        lb.stage((kt + 2) * GEMM_BK);
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 3
+        {
             float *An = As + (cur ^ 1) * GEMM_BM * GEMM_LD;
             float *Bn = Bs + (cur ^ 1) * BN * GEMM_LD;
 #pragma unroll
@@ -138,6 +165,18 @@ __device__ __forceinline__ int xcd_remap(int lin, int total)
 {
     const int q = total >> 3, r = total & 7, x = lin & 7;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (lin >> 3);
+}
+
+// Remap that keeps the dispatch order of M tiles (so tiles of unequal cost, listed class by class, are
+// spread evenly over the XCDs) while still putting the nNt column tiles of one M tile on the same XCD:
+// blocks b and b + 8 run on one XCD under round-robin dispatch.
+__device__ __forceinline__ int xcd_pair_remap(int lin, int total, int nNt)
+{
+    const int group = 8 * nNt;
+    const int full = (total / group) * group;
+    if (lin >= full) return lin;
+    const int base = (lin / group) * group, r = lin - base;
+    return base + (r & 7) * nNt + (r >> 3);
 }
 
 }  // namespace mq

@@ -16,25 +16,105 @@ struct ConvGeom {
 };
 
 // ------------------------------------------------------------------------------------------ loaders
-// A operand: gathered activations.  DGRAD = false: ih = oh*sh - ph + r*dh.  DGRAD = true: the gathered
-// tensor is dy (N,P,Q,K) and ih = (oh + ph - r*dh) / sh when divisible.
-template <bool DGRAD, bool VEC>
-struct ConvALoader {
-    const float *__restrict__ src;   // group base of the gathered tensor
+// Vector path (IC % 4 == 0): every 16-byte load goes through a buffer descriptor, so padding taps,
+// ragged tile edges and K tails are "offset = OOB" (zeros, no memory access) - no branches, no
+// selects on data.  The reduction index walks a (chunk, tap row, tap col, channel-in-chunk) grid in
+// the channel-blocked order of common.h; TapWalker keeps that position and the matching element
+// offset incrementally: a K-step costs a handful of adds/compares per thread and no integer division.
+//
+// One walker serves three geometries (see make_walk() on the host):
+//   fprop            : ih = (oh*sh - ph) + jr*dh           taps jr < R,  js < S
+//   dgrad, stride 1  : ih = (oh + ph)    - jr*dh
+//   dgrad, by parity : ih = ((ih' * sh + a + ph) - r0*dh)/sh - jr*(rstep*dh/sh)   taps jr < nr, js < ns
+// i.e. always  ih = bh + jr*step_h,  iw = bw + js*step_w  with per-row (bh, bw) and uniform steps.
+struct WalkGeom {
+    int IH, IW, IC;        // gathered tensor
+    int nR, nS;            // tap grid of this GEMM
+    int step_h, step_w;    // signed coordinate step per tap
+    int CB, nchunks;       // channel blocking of the reduction
+};
+
+template <int WRAPS>       // WRAPS = 1 when CB >= 16 (one carry per K-step), 4 otherwise (CB >= 4)
+struct TapWalker {
+    __amdgpu_buffer_rsrc_t rsrc;
+    WalkGeom w;
+    int rowbase_[2], bh_[2], bw_[2];   // per row slot: element offset of (n, bh, bw, 0) and the base coordinates
+    bool rv_[2];
+    int ci, js, jr, chunk;             // position of the thread's k-quad
+    int hoff, woff, tapoff;            // jr*step_h, js*step_w, (jr*step_h*IW + js*step_w)*IC
+    unsigned off_[2];
+
+    __device__ __forceinline__ void set_row(int j, bool valid, int n, int bh, int bw)
+    {
+        rv_[j] = valid;
+        bh_[j] = bh;
+        bw_[j] = bw;
+        rowbase_[j] = ((n * w.IH + bh) * w.IW + bw) * w.IC;
+    }
+    __device__ __forceinline__ void start(const float *base, size_t elems, const WalkGeom &wg)
+    {
+        w = wg;
+        rsrc = make_rsrc(base, elems * sizeof(float));
+        const int kb = 4 * (threadIdx.x & 3);                 // first k of this thread in step 0
+        const int per = w.nR * w.nS * w.CB;
+        chunk = per > 0 ? kb / per : w.nchunks;
+        const int rem = kb - chunk * (per > 0 ? per : 0);
+        const int tap = rem / w.CB;
+        ci = rem - tap * w.CB;
+        jr = w.nS > 0 ? tap / w.nS : 0;
+        js = tap - jr * w.nS;
+        sync_offsets();
+    }
+    __device__ __forceinline__ void sync_offsets()
+    {
+        hoff = jr * w.step_h;
+        woff = js * w.step_w;
+        tapoff = (hoff * w.IW + woff) * w.IC;
+    }
+    __device__ __forceinline__ void advance()
+    {
+        ci += GEMM_BK;
+#pragma unroll
+        for (int i = 0; i < WRAPS; ++i) {
+            const bool c1 = ci >= w.CB;
+            ci -= c1 ? w.CB : 0;
+            js += c1 ? 1 : 0;
+            const bool c2 = js >= w.nS;
+            js = c2 ? 0 : js;
+            jr += c2 ? 1 : 0;
+            const bool c3 = jr >= w.nR;
+            jr = c3 ? 0 : jr;
+            chunk += c3 ? 1 : 0;
+        }
+        sync_offsets();
+    }
+    __device__ __forceinline__ void stage(int k0)
+    {
+        if (k0 != 0) advance();                               // calls come with k0 = 0, BK, 2BK, ...
+        const bool kv = chunk < w.nchunks;
+        const int cc = chunk * w.CB + ci;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool ok = rv_[j] && kv && (unsigned)(bh_[j] + hoff) < (unsigned)w.IH && (unsigned)(bw_[j] + woff) < (unsigned)w.IW;
+            off_[j] = ok ? (unsigned)(rowbase_[j] + tapoff + cc) * 4u : OOB;
+        }
+    }
+    __device__ __forceinline__ float4 fetch(int j) const { return buf_load4(rsrc, off_[j]); }
+};
+
+// Scalar fallback (IC % 4 != 0: the single-channel first layers, K = 1 logits convs): per-element decode.
+template <bool DGRAD>
+struct ScalarALoader {
+    const float *__restrict__ src;
     ConvGeom g;
     int n_[2], bh_[2], bw_[2];
     bool rv_[2];
-    int kq;
-    // per K-step decode (VEC): one (r, s, c) for the thread's 4 consecutive k
-    int cr, cs, cc;
-    bool kv;
-    int kbase;
-
+    int CB, kbase;
     __device__ __forceinline__ void init(const float *s, const ConvGeom &gg, int m0)
     {
         src = s;
         g = gg;
-        kq = threadIdx.x & 3;
+        CB = chan_block(g.IC);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             int m = m0 + (threadIdx.x >> 2) + 64 * j;
@@ -44,26 +124,11 @@ struct ConvALoader {
             int t = mm / g.OW;
             int oh = t % g.OH;
             n_[j] = t / g.OH;
-            if (DGRAD) {
-                bh_[j] = oh + g.ph;
-                bw_[j] = ow + g.pw;
-            } else {
-                bh_[j] = oh * g.sh - g.ph;
-                bw_[j] = ow * g.sw - g.pw;
-            }
+            bh_[j] = DGRAD ? oh + g.ph : oh * g.sh - g.ph;
+            bw_[j] = DGRAD ? ow + g.pw : ow * g.sw - g.pw;
         }
     }
-    __device__ __forceinline__ void prepare(int k0)
-    {
-        kbase = k0 + 4 * kq;
-        if (VEC) {
-            kv = kbase < g.Kdim;
-            int tap = kbase / g.IC;
-            cc = kbase - tap * g.IC;
-            cr = tap / g.S;
-            cs = tap - cr * g.S;
-        }
-    }
+    __device__ __forceinline__ void stage(int k0) { kbase = k0 + 4 * (threadIdx.x & 3); }
     __device__ __forceinline__ bool coords(int j, int r, int s, int &ih, int &iw) const
     {
         if (DGRAD) {
@@ -73,38 +138,29 @@ struct ConvALoader {
             iw = tw / g.sw;
             if (ih * g.sh != th || iw * g.sw != tw) return false;
             return ih < g.IH && iw < g.IW;
-        } else {
-            ih = bh_[j] + r * g.dh;
-            iw = bw_[j] + s * g.dw;
-            return (unsigned)ih < (unsigned)g.IH && (unsigned)iw < (unsigned)g.IW;
         }
+        ih = bh_[j] + r * g.dh;
+        iw = bw_[j] + s * g.dw;
+        return (unsigned)ih < (unsigned)g.IH && (unsigned)iw < (unsigned)g.IW;
     }
-    __device__ __forceinline__ float4 load(int j) const
+    __device__ __forceinline__ float4 fetch(int j) const
     {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!rv_[j]) return v;
-        if (VEC) {
-            int ih, iw;
-            if (kv && coords(j, cr, cs, ih, iw)) {
-                size_t off = (((size_t)n_[j] * g.IH + ih) * g.IW + iw) * g.IC + cc;
-                v = *reinterpret_cast<const float4 *>(src + off);
-            }
-        } else {
-            float e[4];
+        float e[4] = {0.f, 0.f, 0.f, 0.f};
+        if (rv_[j]) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                e[t] = 0.f;
-                int kk = kbase + t;
+                const int kk = kbase + t;
                 if (kk < g.Kdim) {
-                    int tap = kk / g.IC, c = kk - tap * g.IC;
-                    int r = tap / g.S, s = tap - r * g.S;
+                    const int rscb = g.R * g.S * CB;
+                    const int ch = kk / rscb, rem = kk - ch * rscb;
+                    const int tap = rem / CB;
+                    const int r = tap / g.S, s = tap - r * g.S, c = ch * CB + (rem - tap * CB);
                     int ih, iw;
                     if (coords(j, r, s, ih, iw)) e[t] = src[(((size_t)n_[j] * g.IH + ih) * g.IW + iw) * g.IC + c];
                 }
             }
-            v = make_float4(e[0], e[1], e[2], e[3]);
         }
-        return v;
+        return make_float4(e[0], e[1], e[2], e[3]);
     }
 };
 
@@ -112,38 +168,61 @@ struct ConvALoader {
 template <bool VEC>
 struct DenseBLoader {
     const float *__restrict__ w;
+    __amdgpu_buffer_rsrc_t rsrc;
     int n0, Ncols, Kdim, kbase;
+    unsigned rowoff[2], off_[2];
     __device__ __forceinline__ void init(const float *ww, int n0_, int Ncols_, int Kdim_)
     {
         w = ww;
         n0 = n0_;
         Ncols = Ncols_;
         Kdim = Kdim_;
+        rsrc = make_rsrc(ww, (size_t)Ncols_ * Kdim_ * sizeof(float));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + (threadIdx.x >> 2) + 64 * j;
+            rowoff[j] = n < Ncols ? (unsigned)n * (unsigned)Kdim * 4u : OOB;
+        }
     }
-    __device__ __forceinline__ void prepare(int k0) { kbase = k0 + 4 * (threadIdx.x & 3); }
-    __device__ __forceinline__ float4 load(int j) const
+    __device__ __forceinline__ void stage(int k0)
     {
+        kbase = k0 + 4 * (threadIdx.x & 3);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            off_[j] = (rowoff[j] != OOB && kbase < Kdim) ? rowoff[j] + (unsigned)kbase * 4u : OOB;
+    }
+    __device__ __forceinline__ float4 fetch(int j) const
+    {
+        if (VEC) return buf_load4(rsrc, off_[j]);
         int n = n0 + (threadIdx.x >> 2) + 64 * j;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (n >= Ncols) return v;
         const float *p = w + (size_t)n * Kdim + kbase;
-        if (VEC) {
-            if (kbase < Kdim) v = *reinterpret_cast<const float4 *>(p);
-        } else {
-            if (kbase + 0 < Kdim) v.x = p[0];
-            if (kbase + 1 < Kdim) v.y = p[1];
-            if (kbase + 2 < Kdim) v.z = p[2];
-            if (kbase + 3 < Kdim) v.w = p[3];
-        }
+        if (kbase + 0 < Kdim) v.x = p[0];
+        if (kbase + 1 < Kdim) v.y = p[1];
+        if (kbase + 2 < Kdim) v.z = p[2];
+        if (kbase + 3 < Kdim) v.w = p[3];
         return v;
     }
 };
 
-// ------------------------------------------------------------------------------------------ fprop / dgrad
-template <int BN, bool DGRAD, bool VEC>
+template <int BN>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[GemmCfg<BN>::TM][GemmCfg<BN>::TN])
+{
+#pragma unroll
+    for (int a = 0; a < GemmCfg<BN>::TM; ++a)
+#pragma unroll
+        for (int b = 0; b < GemmCfg<BN>::TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+}
+
+// ------------------------------------------------------------------------------------------ fprop / dgrad (stride 1)
+// MODE 0: scalar loads, 1: vector loads with CB < 16, 2: vector loads with CB >= 16
+template <int BN, bool DGRAD, int MODE>
 __global__ __launch_bounds__(256) void conv_nt_kernel(const float *__restrict__ act, const float *__restrict__ wgt,
                                                       const float *__restrict__ bias, float *__restrict__ out,
-                                                      ConvGeom g, size_t act_group_stride, size_t w_group_stride)
+                                                      ConvGeom g, WalkGeom wg, size_t act_group_stride, size_t w_group_stride)
 {
     using Cfg = GemmCfg<BN>;
     __shared__ __attribute__((aligned(16))) float smem[Cfg::LDS_FLOATS];
@@ -151,21 +230,31 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(const float *__restrict__ 
     const int tile = xcd_remap(blockIdx.x, g.nMt * g.nNt);
     const int mt = tile / g.nNt, nt = tile - mt * g.nNt;   // N tiles of one M tile are neighbours (share A in L2)
     const int m0 = mt * GEMM_BM, n0 = nt * BN;
-
-    ConvALoader<DGRAD, VEC> la;
-    la.init(act + (size_t)grp * act_group_stride, g, m0);
-    DenseBLoader<VEC> lb;
-    lb.init(wgt + (size_t)grp * w_group_stride, n0, g.Ncols, g.Kdim);
+    const float *abase = act + (size_t)grp * act_group_stride;
 
     f32x16 acc[Cfg::TM][Cfg::TN];
+    zero_acc<BN>(acc);
+    DenseBLoader<(MODE > 0)> lb;
+    lb.init(wgt + (size_t)grp * w_group_stride, n0, g.Ncols, g.Kdim);
+    const int nk = (g.Kdim + GEMM_BK - 1) / GEMM_BK;
+    if constexpr (MODE == 0) {
+        ScalarALoader<DGRAD> la;
+        la.init(abase, g, m0);
+        nt_gemm_mainloop<BN>(la, lb, nk, smem, acc);
+    } else {
+        TapWalker<(MODE == 2 ? 1 : 4)> la;
+        la.start(abase, act_group_stride, wg);
 #pragma unroll
-    for (int a = 0; a < Cfg::TM; ++a)
-#pragma unroll
-        for (int b = 0; b < Cfg::TN; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    nt_gemm_mainloop<BN>(la, lb, (g.Kdim + GEMM_BK - 1) / GEMM_BK, smem, acc);
+        for (int j = 0; j < 2; ++j) {
+            const int m = m0 + (threadIdx.x >> 2) + 64 * j;
+            const bool v = m < g.Mtot;
+            const int mm = v ? m : 0;
+            const int ow = mm % g.OW, t = mm / g.OW;
+            const int oh = t % g.OH, n = t / g.OH;
+            la.set_row(j, v, n, DGRAD ? oh + g.ph : oh * g.sh - g.ph, DGRAD ? ow + g.pw : ow * g.sw - g.pw);
+        }
+        nt_gemm_mainloop<BN>(la, lb, nk, smem, acc);
+    }
 
     float *o = out + (size_t)grp * g.Mtot * g.Ncols;
 #pragma unroll
@@ -183,12 +272,141 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(const float *__restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------ dgrad by stride parity
+// For stride > 1 only the taps with (ih + ph - r*dh) % sh == 0 contribute to input pixel ih: 1/sh of
+// the rows of the filter (and 1/sw of its columns).  The input pixels are therefore partitioned into
+// sh*sw parity classes; every M tile lies inside one class and its GEMM runs over that class's taps
+// only, so no MFMA is spent on structural zeros (4x fewer for the (2,2) discriminator layers).
+struct ParityInfo {
+    int ncls;
+    int a[4], b[4];        // class: ih % sh == a, iw % sw == b
+    int Ha[4], Wb[4];      // pixels of the class per image: Ha x Wb
+    int tile0[5];          // prefix sum of M tiles per class
+    int nr[4], ns[4];      // valid taps per class; they form arithmetic progressions r = r0 + j*rstep
+    int r0[4], s0[4], rstep[4], sstep[4];
+};
+
+template <int WRAPS>
+struct ParityBLoader {     // filter bank [Ncols][R*S*IC] (channel-blocked), columns of the class's taps only
+    __amdgpu_buffer_rsrc_t rsrc;
+    int S, RS, CB, nchunks, nr, ns, r0, s0, rstep, sstep;
+    unsigned rowoff[2], off_[2];
+    int ci, js, jr, chunk;
+    __device__ __forceinline__ void init(const float *w, int n0, int Ncols, int IC, int S_, int KdimFull, int nr_, int ns_,
+                                         int r0_, int s0_, int rstep_, int sstep_)
+    {
+        S = S_; CB = chan_block(IC); nchunks = IC / CB; RS = KdimFull / IC;
+        nr = nr_; ns = ns_; r0 = r0_; s0 = s0_; rstep = rstep_; sstep = sstep_;
+        rsrc = make_rsrc(w, (size_t)Ncols * KdimFull * sizeof(float));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + (threadIdx.x >> 2) + 64 * j;
+            rowoff[j] = n < Ncols ? (unsigned)n * (unsigned)KdimFull * 4u : OOB;
+        }
+        const int kb = 4 * (threadIdx.x & 3);
+        const int per = nr * ns * CB;
+        chunk = per > 0 ? kb / per : nchunks;
+        const int rem = kb - chunk * (per > 0 ? per : 0);
+        const int tap = rem / CB;
+        ci = rem - tap * CB;
+        jr = ns > 0 ? tap / ns : 0;
+        js = tap - jr * ns;
+    }
+    __device__ __forceinline__ void stage(int k0)
+    {
+        if (k0 != 0) {
+            ci += GEMM_BK;
+#pragma unroll
+            for (int i = 0; i < WRAPS; ++i) {
+                const bool c1 = ci >= CB;
+                ci -= c1 ? CB : 0;
+                js += c1 ? 1 : 0;
+                const bool c2 = js >= ns;
+                js = c2 ? 0 : js;
+                jr += c2 ? 1 : 0;
+                const bool c3 = jr >= nr;
+                jr = c3 ? 0 : jr;
+                chunk += c3 ? 1 : 0;
+            }
+        }
+        const int col = (chunk * RS + (r0 + jr * rstep) * S + s0 + js * sstep) * CB + ci;
+        const bool kv = chunk < nchunks;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) off_[j] = (kv && rowoff[j] != OOB) ? rowoff[j] + (unsigned)col * 4u : OOB;
+    }
+    __device__ __forceinline__ float4 fetch(int j) const { return buf_load4(rsrc, off_[j]); }
+};
+
+template <int BN, int WRAPS>
+__global__ __launch_bounds__(256) void conv_dgrad_parity_kernel(const float *__restrict__ dy, const float *__restrict__ wgt,
+                                                                float *__restrict__ dx, ConvGeom g, ParityInfo pi,
+                                                                size_t act_group_stride, size_t w_group_stride, int ng)
+{
+    using Cfg = GemmCfg<BN>;
+    __shared__ __attribute__((aligned(16))) float smem[Cfg::LDS_FLOATS];
+    const int grp = blockIdx.y;
+    const int total_mt = pi.tile0[pi.ncls];
+    // classes have different tap counts (= block run times): keep dispatch order so every XCD gets the same mix
+    const int tile = xcd_pair_remap(blockIdx.x, total_mt * g.nNt, g.nNt);
+    const int mtg = tile / g.nNt, nt = tile - mtg * g.nNt;
+    int cls = 0;
+#pragma unroll
+    for (int c = 1; c < 4; ++c)
+        if (c < pi.ncls && mtg >= pi.tile0[c]) cls = c;
+    const int m0 = (mtg - pi.tile0[cls]) * GEMM_BM, n0 = nt * BN;
+    const int Ha = pi.Ha[cls], Wb = pi.Wb[cls], a = pi.a[cls], b = pi.b[cls], nr = pi.nr[cls], ns = pi.ns[cls];
+    const int r0 = pi.r0[cls], s0 = pi.s0[cls], rstep = pi.rstep[cls], sstep = pi.sstep[cls];
+    const int Mc = ng * Ha * Wb;
+    const int Kdim = nr * ns * g.IC;
+    const int shift_h = g.sh == 2 ? 1 : 0, shift_w = g.sw == 2 ? 1 : 0;
+
+    WalkGeom wg;
+    wg.IH = g.IH; wg.IW = g.IW; wg.IC = g.IC; wg.nR = nr; wg.nS = ns;
+    wg.step_h = -((rstep * g.dh) >> shift_h);        // exact: the class's taps keep (ih + ph - r*dh) divisible by sh
+    wg.step_w = -((sstep * g.dw) >> shift_w);
+    wg.CB = chan_block(g.IC); wg.nchunks = g.IC / wg.CB;
+    TapWalker<WRAPS> la;
+    la.start(dy + (size_t)grp * act_group_stride, act_group_stride, wg);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = m0 + (threadIdx.x >> 2) + 64 * j;
+        const bool v = m < Mc;
+        const int mm = v ? m : 0;
+        const int iwq = mm % Wb, t = mm / Wb;
+        const int ihq = t % Ha, n = t / Ha;
+        la.set_row(j, v, n, (ihq * g.sh + a + g.ph - r0 * g.dh) >> shift_h, (iwq * g.sw + b + g.pw - s0 * g.dw) >> shift_w);
+    }
+    ParityBLoader<WRAPS> lb;
+    lb.init(wgt + (size_t)grp * w_group_stride, n0, g.Ncols, g.IC, g.S, g.Kdim, nr, ns, r0, s0, rstep, sstep);
+
+    f32x16 acc[Cfg::TM][Cfg::TN];
+    zero_acc<BN>(acc);
+    nt_gemm_mainloop<BN>(la, lb, (Kdim + GEMM_BK - 1) / GEMM_BK, smem, acc);
+
+    float *o = dx + (size_t)grp * ng * g.OH * g.OW * g.Ncols;
+#pragma unroll
+    for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + acc_row<BN>(tm, r);
+            if (m >= Mc) continue;
+            const int iwq = m % Wb;
+            const int t = m / Wb;
+            const int ihq = t % Ha, n = t / Ha;
+            const size_t base = (((size_t)n * g.OH + ihq * g.sh + a) * g.OW + iwq * g.sw + b) * g.Ncols;
+#pragma unroll
+            for (int tn = 0; tn < Cfg::TN; ++tn) {
+                const int col = n0 + acc_col<BN>(tn);
+                if (col < g.Ncols) o[base + col] = acc[tm][tn][r];
+            }
+        }
+}
+
 // ------------------------------------------------------------------------------------------ wgrad
 // dw[k][kk] = sum_m dy[m][k] * xg[m][kk], kk = (r, s, c), reduction over the pixels m of one group.
 // Both operands are "M/N contiguous" in memory, so the LDS image is [pixel][row] and the MFMA operands
 // are read with ds_read_b64 as (row 2i, row 2i+1): tile t of a wave covers rows {2i + t}.
 constexpr int WG_BK = 16;          // pixels per step
-constexpr int WG_LD = 132;         // 128 + 4 pad (keeps float4 stores aligned, shifts banks per pixel row)
 
 struct WgradGeom {
     int OH, OW;            // P, Q
@@ -197,33 +415,42 @@ struct WgradGeom {
     int Mtot;              // pixels per group
     int K, RSC;
     int nKt, nCt;          // tiles along K (rows) and RSC (cols)
+    int bmk, bnc;          // block tile
     int splits, chunk;     // split-K: pixels per split (multiple of WG_BK)
 };
 
-template <bool VEC>
+// Block tile BMK (output channels k) x BNC (filter columns kk), 4 waves of 64 x 64 each:
+//   <128, 128> general;  <64, 256> when K <= 64 (refiner top level, logits convs) so that rows are not wasted.
+// MODE 0: scalar loads (C or K not a multiple of 4); 1: vector loads, pixel coordinates by division;
+//      2: vector loads, pixel coordinates walked incrementally (OW >= 16: at most one row wrap per step).
+template <int BMK, int BNC, int MODE>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy,
                                                          float *__restrict__ out, WgradGeom g, int groups)
 {
-    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * WG_BK * WG_LD];
-    float *At = smem;                       // [2][WG_BK][WG_LD]  dy tile   (pixel, k)
-    float *Bt = smem + 2 * WG_BK * WG_LD;   // [2][WG_BK][WG_LD]  x gather  (pixel, kk)
+    constexpr int LDA = BMK + 4, LDB = BNC + 4;          // +4 floats: keeps float4 stores aligned, shifts banks per row
+    constexpr int AP = BMK / 64, BP = BNC / 64;          // load passes per thread and step (16 pixels x BMK / BNC floats)
+    constexpr int AQ = BMK / 4, BQ = BNC / 4;            // float4 quads per pixel row
+    constexpr int WNW = BNC / 64;                        // waves along the column axis
+    __shared__ __attribute__((aligned(16))) float smem[2 * WG_BK * (LDA + LDB)];
+    float *At = smem;                                    // [2][WG_BK][LDA]  dy tile   (pixel, k)
+    float *Bt = smem + 2 * WG_BK * LDA;                  // [2][WG_BK][LDB]  x gather  (pixel, kk)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int wm = wave / WNW, wn = wave % WNW, li = lane & 31, lh = lane >> 5;
     const int tile = blockIdx.x;
     const int kt_ = tile / g.nCt, ct = tile - kt_ * g.nCt;
-    const int k0 = kt_ * 128, c0 = ct * 128;
+    const int k0 = kt_ * BMK, c0 = ct * BNC;
     const int grp = blockIdx.y;
     const int split = blockIdx.z;
     const int m_begin = split * g.chunk;
     const int m_end = min(g.Mtot, m_begin + g.chunk);
+    const int ng = g.Mtot / (g.OH * g.OW);
     const float *dyg = dy + (size_t)grp * g.Mtot * g.K;
-    const size_t x_group = (size_t)grp * (g.Mtot / (g.OH * g.OW)) * g.IH * g.IW * g.IC;
-    const float *xg = x + x_group;
+    const float *xg = x + (size_t)grp * ng * g.IH * g.IW * g.IC;
 
-    // loader mapping: pixel = tid/32 + 8*j (j = 0,1), column quad = tid%32
-    const int lp = tid >> 5, lq = tid & 31;
-    // the thread's 4 B columns are fixed for the whole kernel
-    const int kkb = c0 + 4 * lq;
+    // A: pixel = tid / AQ + (256 / AQ) * j, quad = tid % AQ.   B: pixel = tid / BQ + (256 / BQ) * j, quad = tid % BQ.
+    const int apix = tid / AQ, aq = tid % AQ, bpix = tid / BQ, bq = tid % BQ;
+    const int ka = k0 + 4 * aq;
+    const int kkb = c0 + 4 * bq;                         // the thread's 4 filter columns are fixed for the whole kernel
     int br[4], bs[4], bc[4];
     bool bv[4];
 #pragma unroll
@@ -231,12 +458,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
         int kk = kkb + t;
         bv[t] = kk < g.RSC;
         int kc = bv[t] ? kk : 0;
-        int tap = kc / g.IC;
-        bc[t] = kc - tap * g.IC;
+        const int cbw = chan_block(g.IC), rscb = g.R * g.S * cbw;      // channel-blocked filter rows (common.h)
+        const int ch = kc / rscb, rem = kc - ch * rscb;
+        const int tap = rem / cbw;
+        bc[t] = ch * cbw + (rem - tap * cbw);
         br[t] = tap / g.S;
         bs[t] = tap - br[t] * g.S;
     }
-    const int ka = k0 + 4 * lq;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -246,76 +474,135 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    float4 ra[2], rb[2];
-    auto gload = [&](int mstep) {
+    // Three-phase K-step as in gemm_core.h: (1) issue the loads of step st+1 from staged buffer offsets,
+    // (2) MFMAs of step st with the offset arithmetic of step st+2 in their shadow, (3) wait + LDS stores +
+    // barrier.  Out-of-range pixels / taps / channels read zeros through the descriptors.
+    const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(dyg, (size_t)g.Mtot * g.K * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(xg, (size_t)ng * g.IH * g.IW * g.IC * sizeof(float));
+    float4 ra[AP], rb[BP];
+    unsigned oa[AP], ob[BP];
+    int am[AP], bm[BP];                                  // pixel index per slot
+    int bow[BP], boh[BP], bbase[BP];                     // MODE 2: walked coordinates (ow*sw, oh*sh) and element base
+    const int tap_h = br[0] * g.dh - g.ph, tap_w = bs[0] * g.dw - g.pw;
+    const int tap_off = (tap_h * g.IW + tap_w) * g.IC + bc[0];
+
+    auto decode_b = [&](int j) {                         // (re)compute walked state of B slot j from bm[j]
+        const int mm = bm[j] < g.Mtot ? bm[j] : 0;
+        const int ow = mm % g.OW, t2 = mm / g.OW;
+        const int oh = t2 % g.OH, n = t2 / g.OH;
+        bow[j] = ow * g.sw;
+        boh[j] = oh * g.sh;
+        bbase[j] = ((n * g.IH + boh[j]) * g.IW + bow[j]) * g.IC;
+    };
+    auto offsets = [&]() {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int m = mstep + lp + 8 * j;
-            ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < m_end) {
-                const float *pa = dyg + (size_t)m * g.K + ka;
-                if (VEC) {
-                    if (ka < g.K) ra[j] = *reinterpret_cast<const float4 *>(pa);
-                } else {
+        for (int j = 0; j < AP; ++j) oa[j] = (am[j] < m_end && ka < g.K) ? (unsigned)(am[j] * g.K + ka) * 4u : OOB;
+#pragma unroll
+        for (int j = 0; j < BP; ++j) {
+            if (MODE != 2) decode_b(j);
+            const bool ok = bm[j] < m_end && bv[0] && (unsigned)(boh[j] + tap_h) < (unsigned)g.IH &&
+                            (unsigned)(bow[j] + tap_w) < (unsigned)g.IW;
+            ob[j] = ok ? (unsigned)(bbase[j] + tap_off) * 4u : OOB;
+        }
+    };
+    auto advance = [&]() {                               // all slots move on by WG_BK pixels
+#pragma unroll
+        for (int j = 0; j < AP; ++j) am[j] += WG_BK;
+#pragma unroll
+        for (int j = 0; j < BP; ++j) {
+            bm[j] += WG_BK;
+            if (MODE == 2) {                             // OW >= 16: at most one row wrap (and then maybe an image wrap)
+                bow[j] += WG_BK * g.sw;
+                bbase[j] += WG_BK * g.sw * g.IC;
+                const bool w1 = bow[j] >= g.OW * g.sw;
+                bow[j] -= w1 ? g.OW * g.sw : 0;
+                boh[j] += w1 ? g.sh : 0;
+                bbase[j] += w1 ? (g.sh * g.IW - g.OW * g.sw) * g.IC : 0;
+                const bool w2 = boh[j] >= g.OH * g.sh;
+                boh[j] -= w2 ? g.OH * g.sh : 0;
+                bbase[j] += w2 ? (g.IH - g.OH * g.sh) * g.IW * g.IC : 0;
+            }
+        }
+    };
+    auto fetch = [&]() {
+        if (MODE > 0) {
+#pragma unroll
+            for (int j = 0; j < AP; ++j) ra[j] = buf_load4(rs_dy, oa[j]);
+#pragma unroll
+            for (int j = 0; j < BP; ++j) rb[j] = buf_load4(rs_x, ob[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < AP; ++j) {
+                ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (am[j] < m_end) {
+                    const float *pa = dyg + (size_t)am[j] * g.K + ka;
                     if (ka + 0 < g.K) ra[j].x = pa[0];
                     if (ka + 1 < g.K) ra[j].y = pa[1];
                     if (ka + 2 < g.K) ra[j].z = pa[2];
                     if (ka + 3 < g.K) ra[j].w = pa[3];
                 }
-                const int ow = m % g.OW;
-                const int t2 = m / g.OW;
-                const int oh = t2 % g.OH, n = t2 / g.OH;
-                const int bh = oh * g.sh - g.ph, bw = ow * g.sw - g.pw;
-                if (VEC) {
-                    const int ih = bh + br[0] * g.dh, iw = bw + bs[0] * g.dw;
-                    if (bv[0] && (unsigned)ih < (unsigned)g.IH && (unsigned)iw < (unsigned)g.IW)
-                        rb[j] = *reinterpret_cast<const float4 *>(
-                            xg + (((size_t)n * g.IH + ih) * g.IW + iw) * g.IC + bc[0]);
-                } else {
-                    float e[4];
+            }
+#pragma unroll
+            for (int j = 0; j < BP; ++j) {
+                float e[4] = {0.f, 0.f, 0.f, 0.f};
+                const int m = bm[j];
+                if (m < m_end) {
+                    const int ow = m % g.OW, t2 = m / g.OW;
+                    const int oh = t2 % g.OH, n = t2 / g.OH;
+                    const int bh = oh * g.sh - g.ph, bw = ow * g.sw - g.pw;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        e[t] = 0.f;
                         const int ih = bh + br[t] * g.dh, iw = bw + bs[t] * g.dw;
                         if (bv[t] && (unsigned)ih < (unsigned)g.IH && (unsigned)iw < (unsigned)g.IW)
                             e[t] = xg[(((size_t)n * g.IH + ih) * g.IW + iw) * g.IC + bc[t]];
                     }
-                    rb[j] = make_float4(e[0], e[1], e[2], e[3]);
                 }
+                rb[j] = make_float4(e[0], e[1], e[2], e[3]);
             }
         }
     };
     auto sstore = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            *reinterpret_cast<float4 *>(&At[(buf * WG_BK + lp + 8 * j) * WG_LD + 4 * lq]) = ra[j];
-            *reinterpret_cast<float4 *>(&Bt[(buf * WG_BK + lp + 8 * j) * WG_LD + 4 * lq]) = rb[j];
-        }
+        for (int j = 0; j < AP; ++j)
+            *reinterpret_cast<float4 *>(&At[(buf * WG_BK + apix + (256 / AQ) * j) * LDA + 4 * aq]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < BP; ++j)
+            *reinterpret_cast<float4 *>(&Bt[(buf * WG_BK + bpix + (256 / BQ) * j) * LDB + 4 * bq]) = rb[j];
     };
 
-    const int nsteps = (m_end - m_begin + WG_BK - 1) / WG_BK;
-    if (nsteps > 0) {
-        gload(m_begin);
-        sstore(0);
+#pragma unroll
+    for (int j = 0; j < AP; ++j) am[j] = m_begin + apix + (256 / AQ) * j;
+#pragma unroll
+    for (int j = 0; j < BP; ++j) {
+        bm[j] = m_begin + bpix + (256 / BQ) * j;
+        decode_b(j);
     }
+    const int nsteps = (m_end - m_begin + WG_BK - 1) / WG_BK;
+    offsets();
+    fetch();
+    sstore(0);
+    advance();
+    offsets();
     __syncthreads();
     for (int st = 0; st < nsteps; ++st) {
         const int cur = st & 1;
-        const bool more = st + 1 < nsteps;
-        if (more) gload(m_begin + (st + 1) * WG_BK);
-        const float *Ac = At + cur * WG_BK * WG_LD + wm * 64 + 2 * li;
-        const float *Bc = Bt + cur * WG_BK * WG_LD + wn * 64 + 2 * li;
+        fetch();
+        __builtin_amdgcn_sched_barrier(0);
+        const float *Ac = At + cur * WG_BK * LDA + wm * 64 + 2 * li;
+        const float *Bc = Bt + cur * WG_BK * LDB + wn * 64 + 2 * li;
 #pragma unroll
         for (int s = 0; s < WG_BK / 2; ++s) {
-            const float2 a = *reinterpret_cast<const float2 *>(Ac + (2 * s + lh) * WG_LD);
-            const float2 b = *reinterpret_cast<const float2 *>(Bc + (2 * s + lh) * WG_LD);
+            const float2 a = *reinterpret_cast<const float2 *>(Ac + (2 * s + lh) * LDA);
+            const float2 b = *reinterpret_cast<const float2 *>(Bc + (2 * s + lh) * LDB);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.y, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[1][1], 0, 0, 0);
         }
-        if (more) sstore(cur ^ 1);
+        advance();
+        offsets();
+        __builtin_amdgcn_sched_barrier(0);
+        sstore(cur ^ 1);
         __syncthreads();
     }
 
@@ -405,15 +692,69 @@ static int launch_nt(const mqConvDesc *d, const float *act, const float *w, cons
     g.Kdim = d->R * d->S * g.IC;
     const size_t act_gs = (size_t)ng * g.IH * g.IW * g.IC;
     const size_t w_gs = (size_t)g.Ncols * g.Kdim;
-    const bool vec = (g.IC % 4 == 0) && ((uintptr_t)act % 16 == 0) && ((uintptr_t)w % 16 == 0);
+    bool vec = (g.IC % 4 == 0) && ((uintptr_t)act % 16 == 0) && ((uintptr_t)w % 16 == 0) &&
+               act_gs * sizeof(float) < 0x7FFFFFF0ull && w_gs * sizeof(float) < 0xFFFFFFF0ull;
+    const bool strided = g.sh > 1 || g.sw > 1;
+    const bool parity = DGRAD && vec && strided && g.sh <= 2 && g.sw <= 2;
+    if (DGRAD && strided && !parity) vec = false;      // generic strided dgrad only exists on the scalar path
     const int BN = g.Ncols > 64 ? 128 : (g.Ncols > 32 ? 64 : 32);
+    const int cb = chan_block(g.IC);
+    const bool wide = cb >= GEMM_BK;
     g.nMt = (int)cdiv(g.Mtot, GEMM_BM);
     g.nNt = (int)cdiv(g.Ncols, BN);
+    if (parity) {
+        ParityInfo pi;
+        memset(&pi, 0, sizeof(pi));
+        int t0 = 0;
+        for (int a = 0; a < g.sh; ++a)
+            for (int b = 0; b < g.sw; ++b) {
+                const int c = pi.ncls++;
+                pi.a[c] = a; pi.b[c] = b;
+                pi.Ha[c] = g.OH > a ? (g.OH - a + g.sh - 1) / g.sh : 0;
+                pi.Wb[c] = g.OW > b ? (g.OW - b + g.sw - 1) / g.sw : 0;
+                // valid taps of a class form an arithmetic progression (strides <= 2)
+                int first = -1, second = -1;
+                for (int r = 0; r < g.R; ++r)
+                    if ((((a + g.ph - r * g.dh) % g.sh) + g.sh) % g.sh == 0) {
+                        if (first < 0) first = r; else if (second < 0) second = r;
+                        pi.nr[c]++;
+                    }
+                pi.r0[c] = first < 0 ? 0 : first;
+                pi.rstep[c] = second < 0 ? 1 : second - first;
+                first = second = -1;
+                for (int s = 0; s < g.S; ++s)
+                    if ((((b + g.pw - s * g.dw) % g.sw) + g.sw) % g.sw == 0) {
+                        if (first < 0) first = s; else if (second < 0) second = s;
+                        pi.ns[c]++;
+                    }
+                pi.s0[c] = first < 0 ? 0 : first;
+                pi.sstep[c] = second < 0 ? 1 : second - first;
+                pi.tile0[c] = t0;
+                t0 += (int)cdiv((int64_t)ng * pi.Ha[c] * pi.Wb[c], GEMM_BM);
+            }
+        pi.tile0[pi.ncls] = t0;
+        dim3 pgrid(t0 * g.nNt, d->groups);
+#define MQ_PAR(BN_, W_) hipLaunchKernelGGL((conv_dgrad_parity_kernel<BN_, W_>), pgrid, dim3(256), 0, st, act, w, out, g, pi, act_gs, w_gs, ng)
+        if (BN == 128) { if (wide) MQ_PAR(128, 1); else MQ_PAR(128, 4); }
+        else if (BN == 64) { if (wide) MQ_PAR(64, 1); else MQ_PAR(64, 4); }
+        else { if (wide) MQ_PAR(32, 1); else MQ_PAR(32, 4); }
+#undef MQ_PAR
+        MQ_LAUNCH_CHECK("mq_conv_dgrad(parity)");
+        return 0;
+    }
+    WalkGeom wg;
+    wg.IH = g.IH; wg.IW = g.IW; wg.IC = g.IC; wg.nR = g.R; wg.nS = g.S;
+    wg.step_h = DGRAD ? -g.dh : g.dh;
+    wg.step_w = DGRAD ? -g.dw : g.dw;
+    wg.CB = cb; wg.nchunks = g.IC / cb;
+    const int mode = vec ? (wide ? 2 : 1) : 0;
     dim3 grid(g.nMt * g.nNt, d->groups), block(256);
-#define MQ_NT(BN_, V_) hipLaunchKernelGGL((conv_nt_kernel<BN_, DGRAD, V_>), grid, block, 0, st, act, w, bias, out, g, act_gs, w_gs)
-    if (BN == 128) { if (vec) MQ_NT(128, true); else MQ_NT(128, false); }
-    else if (BN == 64) { if (vec) MQ_NT(64, true); else MQ_NT(64, false); }
-    else { if (vec) MQ_NT(32, true); else MQ_NT(32, false); }
+#define MQ_NT(BN_, M_) hipLaunchKernelGGL((conv_nt_kernel<BN_, DGRAD, M_>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs)
+#define MQ_NT3(BN_) do { if (mode == 2) MQ_NT(BN_, 2); else if (mode == 1) MQ_NT(BN_, 1); else MQ_NT(BN_, 0); } while (0)
+    if (BN == 128) MQ_NT3(128);
+    else if (BN == 64) MQ_NT3(64);
+    else MQ_NT3(32);
+#undef MQ_NT3
 #undef MQ_NT
     MQ_LAUNCH_CHECK(DGRAD ? "mq_conv_dgrad" : "mq_conv_fprop");
     return 0;
@@ -428,8 +769,10 @@ static void wgrad_plan(const mqConvDesc *d, WgradGeom &g)
     g.Mtot = ng * d->P * d->Q;
     g.K = d->K;
     g.RSC = d->R * d->S * d->C;
-    g.nKt = (int)cdiv(g.K, 128);
-    g.nCt = (int)cdiv(g.RSC, 128);
+    g.bmk = g.K <= 64 ? 64 : 128;
+    g.bnc = g.K <= 64 ? 256 : 128;
+    g.nKt = (int)cdiv(g.K, g.bmk);
+    g.nCt = (int)cdiv(g.RSC, g.bnc);
     // split the pixel reduction so that ~3 blocks per CU exist, each with >= 32 steps
     const int64_t tiles = (int64_t)g.nKt * g.nCt * d->groups;
     int64_t want = cdiv(256 * 3, tiles);
@@ -482,12 +825,18 @@ extern "C" int mq_conv_wgrad(const mqConvDesc *d, const float *x, const float *d
     MQ_REQUIRE(workspace_bytes >= need && (need == 0 || workspace != nullptr),
                "mq_conv_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
     float *target = g.splits > 1 ? reinterpret_cast<float *>(workspace) : dw;
-    const bool vec = (d->C % 4 == 0) && (d->K % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0);
+    const size_t ng_ = (size_t)(d->N / d->groups);
+    const bool vec = (d->C % 4 == 0) && (d->K % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) &&
+                     (size_t)g.Mtot * g.K * sizeof(float) < 0xFFFFFFF0ull &&
+                     ng_ * d->H * d->W * d->C * sizeof(float) < 0xFFFFFFF0ull;
     dim3 grid(g.nKt * g.nCt, d->groups, g.splits), block(256);
-    if (vec)
-        hipLaunchKernelGGL((conv_wgrad_kernel<true>), grid, block, 0, S(stream), x, dy, target, g, d->groups);
-    else
-        hipLaunchKernelGGL((conv_wgrad_kernel<false>), grid, block, 0, S(stream), x, dy, target, g, d->groups);
+    const int mode = vec ? (d->Q >= WG_BK ? 2 : 1) : 0;
+#define MQ_WG(A_, B_, M_) hipLaunchKernelGGL((conv_wgrad_kernel<A_, B_, M_>), grid, block, 0, S(stream), x, dy, target, g, d->groups)
+#define MQ_WG3(A_, B_) do { if (mode == 2) MQ_WG(A_, B_, 2); else if (mode == 1) MQ_WG(A_, B_, 1); else MQ_WG(A_, B_, 0); } while (0)
+    if (g.bmk == 64) MQ_WG3(64, 256);
+    else MQ_WG3(128, 128);
+#undef MQ_WG3
+#undef MQ_WG
     MQ_LAUNCH_CHECK("mq_conv_wgrad");
     if (g.splits > 1) {
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(ew_grid((int64_t)n, 256)), dim3(256), 0, S(stream), target, dw, n,
@@ -500,7 +849,13 @@ extern "C" int mq_conv_wgrad(const mqConvDesc *d, const float *x, const float *d
 extern "C" int mq_colsum(const float *x, int64_t rows, int cols, float *out, float *workspace, mqStream stream)
 {
     MQ_REQUIRE(x && out && workspace && rows > 0 && cols > 0, "mq_colsum: bad arguments");
-    const int nchunks = (int)(rows < 64 ? 1 : 64);
+    // enough row chunks for ~2048 blocks in total, each with at least 32 rows; at most 1024 (workspace)
+    const int64_t colblocks = cdiv(cols, 64);
+    int64_t want = cdiv(2048, colblocks);
+    if (want > rows / 32) want = rows / 32;
+    if (want > 1024) want = 1024;
+    if (want < 1) want = 1;
+    const int nchunks = (int)want;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)cdiv(cols, 64), nchunks), dim3(64, 4), 0, S(stream), x, rows,
                        cols, workspace, nchunks);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(cols, 256)), dim3(256), 0, S(stream), workspace, cols,

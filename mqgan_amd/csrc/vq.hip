@@ -88,29 +88,29 @@ __global__ void codebook_norms_kernel(const float *__restrict__ c, int k, int d,
     cn[j] = acc;
 }
 
-struct DenseALoader {   // rows of x, K-contiguous; same contract as the conv loaders
-    const float *__restrict__ x;
-    int64_t n;
-    int64_t m0;
-    int d, kbase;
-    __device__ __forceinline__ void prepare(int k0) { kbase = k0 + 4 * (threadIdx.x & 3); }
-    __device__ __forceinline__ float4 load(int j) const
+struct DenseRowLoader {   // rows of a dense [rows][d] matrix, K-contiguous; contract of gemm_core.h
+    __amdgpu_buffer_rsrc_t rsrc;
+    int d;
+    unsigned rowoff[2], off_[2];
+    __device__ __forceinline__ void init(const float *base, int64_t rows_here, int d_)
     {
-        const int64_t m = m0 + (threadIdx.x >> 2) + 64 * j;
-        if (m >= n || kbase >= d) return make_float4(0.f, 0.f, 0.f, 0.f);
-        return *reinterpret_cast<const float4 *>(x + m * d + kbase);
+        // `base` already points at the tile's first row; rows_here = rows available from there
+        d = d_;
+        const int64_t lim = rows_here < 128 ? rows_here : 128;
+        rsrc = make_rsrc(base, (size_t)(lim > 0 ? lim : 0) * d_ * sizeof(float));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = (threadIdx.x >> 2) + 64 * j;
+            rowoff[j] = r < lim ? (unsigned)r * (unsigned)d_ * 4u : OOB;
+        }
     }
-};
-struct DenseCLoader {
-    const float *__restrict__ c;
-    int k, c0, d, kbase;
-    __device__ __forceinline__ void prepare(int k0) { kbase = k0 + 4 * (threadIdx.x & 3); }
-    __device__ __forceinline__ float4 load(int j) const
+    __device__ __forceinline__ void stage(int k0)
     {
-        const int r = c0 + (threadIdx.x >> 2) + 64 * j;
-        if (r >= k || kbase >= d) return make_float4(0.f, 0.f, 0.f, 0.f);
-        return *reinterpret_cast<const float4 *>(c + (size_t)r * d + kbase);
+        const int kbase = k0 + 4 * (threadIdx.x & 3);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) off_[j] = (rowoff[j] != OOB && kbase < d) ? rowoff[j] + (unsigned)kbase * 4u : OOB;
     }
+    __device__ __forceinline__ float4 fetch(int j) const { return buf_load4(rsrc, off_[j]); }
 };
 
 __device__ __forceinline__ unsigned long long pack_dist_idx(float dist, int idx)
@@ -145,8 +145,9 @@ __global__ __launch_bounds__(256) void l2_argmin_kernel(const float *__restrict_
         }
 
     for (int t = t_begin; t < t_end; ++t) {
-        DenseALoader la{x, n, m0, d, 0};
-        DenseCLoader lb{cb, k, t * BN, d, 0};
+        DenseRowLoader la, lb;
+        la.init(x + m0 * d, n - m0, d);
+        lb.init(cb + (size_t)t * BN * d, (int64_t)k - (int64_t)t * BN, d);
         f32x16 acc[Cfg::TM][Cfg::TN];
 #pragma unroll
         for (int a = 0; a < Cfg::TM; ++a)

@@ -21,11 +21,12 @@ __global__ void weight_prep_kernel(int mode, const float *__restrict__ v, const 
         if (threadIdx.x == 0 && inv_norm) inv_norm[k] = inv;
         scale = g[k] * inv;
     }
+    const int cbc = chan_block(C), cbk = chan_block(K);
     for (int i = threadIdx.x; i < fan; i += 256) {
         const int c = i / RS, rs = i - c * RS;
         const float w = vk[i] * scale;
-        if (w_krsc) w_krsc[((size_t)k * RS + rs) * C + c] = w;
-        if (w_crsk) w_crsk[((size_t)c * RS + rs) * K + k] = w;
+        if (w_krsc) w_krsc[(size_t)k * fan + kidx(rs, c, RS, cbc)] = w;
+        if (w_crsk) w_crsk[(size_t)c * RS * K + kidx(rs, k, RS, cbk)] = w;
     }
 }
 
@@ -37,17 +38,19 @@ __global__ void weight_prep_bwd_kernel(int mode, const float *__restrict__ dw_kr
     const int k = blockIdx.x;
     const int fan = C * RS;
     const float *vk = v + (size_t)k * fan;
+    const int cbc = chan_block(C);
+    const float *dwk = dw_krsc + (size_t)k * fan;
     if (mode == 0) {
         for (int i = threadIdx.x; i < fan; i += 256) {
             const int c = i / RS, rs = i - c * RS;
-            dv[(size_t)k * fan + i] = dw_krsc[((size_t)k * RS + rs) * C + c];
+            dv[(size_t)k * fan + i] = dwk[kidx(rs, c, RS, cbc)];
         }
         return;
     }
     float dot = 0.f;
     for (int i = threadIdx.x; i < fan; i += 256) {
         const int c = i / RS, rs = i - c * RS;
-        dot += dw_krsc[((size_t)k * RS + rs) * C + c] * vk[i];
+        dot += dwk[kidx(rs, c, RS, cbc)] * vk[i];
     }
     dot = block_sum<256>(dot, red);
     const float inv = inv_norm[k], gk = g[k];
@@ -59,7 +62,7 @@ __global__ void weight_prep_bwd_kernel(int mode, const float *__restrict__ dw_kr
     const float a = gk * inv, b = gk * dot * inv * inv * inv;
     for (int i = threadIdx.x; i < fan; i += 256) {
         const int c = i / RS, rs = i - c * RS;
-        dv[(size_t)k * fan + i] = a * dw_krsc[((size_t)k * RS + rs) * C + c] - b * vk[i];
+        dv[(size_t)k * fan + i] = a * dwk[kidx(rs, c, RS, cbc)] - b * vk[i];
     }
 }
 
@@ -108,12 +111,13 @@ __global__ void sn_scale_kernel(const float *__restrict__ W, const float *__rest
     const int fan = C * RS;
     const int64_t n = (int64_t)K * fan;
     const float inv = 1.0f / sigma[0];
+    const int cbc = chan_block(C), cbk = chan_block(K);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int k = (int)(i / fan), r = (int)(i - (int64_t)k * fan);
         const int c = r / RS, rs = r - c * RS;
         const float w = W[i] * inv;
-        if (w_krsc) w_krsc[((size_t)k * RS + rs) * C + c] = w;
-        if (w_crsk) w_crsk[((size_t)c * RS + rs) * K + k] = w;
+        if (w_krsc) w_krsc[(size_t)k * fan + kidx(rs, c, RS, cbc)] = w;
+        if (w_crsk) w_crsk[(size_t)c * RS * K + kidx(rs, k, RS, cbk)] = w;
     }
 }
 // partial[b] = sum over a slice of dW (KRSC) * W (KCRS)
@@ -127,7 +131,7 @@ __global__ void sn_bwd_dot_kernel(const float *__restrict__ dw_krsc, const float
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int k = (int)(i / fan), r = (int)(i - (int64_t)k * fan);
         const int c = r / RS, rs = r - c * RS;
-        s += dw_krsc[((size_t)k * RS + rs) * C + c] * W[i];
+        s += dw_krsc[(size_t)k * fan + kidx(rs, c, RS, chan_block(C))] * W[i];
     }
     s = block_sum<256>(s, red);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
@@ -145,7 +149,7 @@ __global__ void sn_bwd_apply_kernel(const float *__restrict__ dw_krsc, const flo
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int k = (int)(i / fan), r = (int)(i - (int64_t)k * fan);
         const int c = r / RS, rs = r - c * RS;
-        dW[i] = dw_krsc[((size_t)k * RS + rs) * C + c] * inv - coef * u[k] * v[r];
+        dW[i] = dw_krsc[(size_t)k * fan + kidx(rs, c, RS, chan_block(C))] * inv - coef * u[k] * v[r];
     }
 }
 

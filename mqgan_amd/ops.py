@@ -70,13 +70,15 @@ class KernelTimer:
 
     def __init__(self):
         self.records = []          # (tag, algorithmic flops, start event, end event)
+        self.details = []
 
-    def run(self, tag, flops, fn):
+    def run(self, tag, flops, fn, detail=None):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         fn()
         e.record()
         self.records.append((tag, flops, s, e))
+        self.details.append(detail)
 
     def summary(self):
         """tag -> dict(launches, flops, ms).  Call after torch.cuda.synchronize()."""
@@ -92,21 +94,28 @@ class KernelTimer:
 TIMER: Optional[KernelTimer] = None
 
 
-def _timed(tag, flops, fn):
+def _timed(tag, flops, fn, detail=None):
     if TIMER is None:
         fn()
     else:
-        TIMER.run(tag, flops, fn)
+        TIMER.run(tag, flops, fn, detail)
 
 
 def _conv_tag(kind, d: ConvDesc):
     """Name of the kernel instantiation the C side picks (igemm.hip: launch_nt / mq_conv_wgrad)."""
     if kind == "wgrad":
         vec = d.C % 4 == 0 and d.K % 4 == 0
-        return f"conv_wgrad_kernel<{str(vec).lower()}>"
+        mode = (2 if d.Q >= 16 else 1) if vec else 0
+        return f"conv_wgrad_kernel<{'64, 256' if d.K <= 64 else '128, 128'}, {mode}>"
     ncols, ic = (d.K, d.C) if kind == "fprop" else (d.C, d.K)
     bn = 128 if ncols > 64 else (64 if ncols > 32 else 32)
-    return f"conv_nt_kernel<{bn}, {str(kind == 'dgrad').lower()}, {str(ic % 4 == 0).lower()}>"
+    strided = d.stride_h > 1 or d.stride_w > 1
+    if kind == "dgrad" and strided:
+        if ic % 4 == 0 and d.stride_h <= 2 and d.stride_w <= 2:
+            return f"conv_dgrad_parity_kernel<{bn}, {1 if ic % 16 == 0 else 4}>"
+        return f"conv_nt_kernel<{bn}, true, 0>"
+    mode = 2 if ic % 16 == 0 else (1 if ic % 4 == 0 else 0)
+    return f"conv_nt_kernel<{bn}, {str(kind == 'dgrad').lower()}, {mode}>"
 
 
 def _conv_flops(d: ConvDesc):
@@ -116,7 +125,7 @@ def _conv_flops(d: ConvDesc):
 def colsum(x2d: torch.Tensor) -> torch.Tensor:
     rows, cols = x2d.shape
     out = _empty((cols,), x2d)
-    ws = _empty((64 * cols,), x2d)
+    ws = _empty((1024 * cols,), x2d)
     check(L().mq_colsum(fptr(x2d), rows, cols, fptr(out), fptr(ws), stream()), "mq_colsum")
     return out
 
@@ -130,7 +139,7 @@ class ConvFn(torch.autograd.Function):
         d = _desc_from_key(key)
         y = _empty((d.N, d.P, d.Q, d.K), x)
         _timed(_conv_tag("fprop", d), _conv_flops(d), lambda: check(
-            L().mq_conv_fprop(C.byref(d), fptr(x), fptr(w_krsc), fptr(bias, True), fptr(y), stream()), "mq_conv_fprop"))
+            L().mq_conv_fprop(C.byref(d), fptr(x), fptr(w_krsc), fptr(bias, True), fptr(y), stream()), "mq_conv_fprop"), key)
         ctx.key = key
         ctx.w_shape = tuple(w_krsc.shape)
         ctx.has_bias = bias is not None
@@ -149,13 +158,13 @@ class ConvFn(torch.autograd.Function):
                 raise _lib.MqganHipError("conv backward wrt the input needs the CRSK weights")
             dx = torch.empty_like(x)
             _timed(_conv_tag("dgrad", d), _conv_flops(d), lambda: check(
-                L().mq_conv_dgrad(C.byref(d), fptr(dy), fptr(w_crsk), fptr(dx), stream()), "mq_conv_dgrad"))
+                L().mq_conv_dgrad(C.byref(d), fptr(dy), fptr(w_crsk), fptr(dx), stream()), "mq_conv_dgrad"), ctx.key)
         if ctx.needs_input_grad[1]:
             dw = _empty(ctx.w_shape, x)      # (groups*K, R*S, C) == KRSC
             nbytes = L().mq_conv_wgrad_workspace(C.byref(d))
             ws = _ws_bytes(nbytes, x)
             _timed(_conv_tag("wgrad", d), _conv_flops(d), lambda: check(
-                L().mq_conv_wgrad(C.byref(d), fptr(x), fptr(dy), fptr(dw), ptr(ws), nbytes, stream()), "mq_conv_wgrad"))
+                L().mq_conv_wgrad(C.byref(d), fptr(x), fptr(dy), fptr(dw), ptr(ws), nbytes, stream()), "mq_conv_wgrad"), ctx.key)
         if ctx.has_bias and ctx.needs_input_grad[3]:
             rows_per_group = (d.N // d.groups) * d.P * d.Q
             if d.groups == 1:

@@ -416,3 +416,24 @@ def test_sumsq_and_adam_match_torch(env):
         close(ss.sqrt(), norm, rtol=1e-5)
         ops.adam_step(p, gd, m, v, 1e-3, 0.5, 0.999, 1e-8, step, ss, 1.0)
         close(p, ref, rtol=1e-5, atol=1e-7, msg=f"step {step}")
+
+
+def test_weight_prep_channel_blocked_layout(env):
+    """Filter rows are channel-blocked when C % 16 == 0 (csrc/common.h: kidx): index(rs, c) =
+    ((c // 16) * RS + rs) * 16 + c % 16; the dgrad layout blocks the K axis the same way."""
+    ops = env
+    K, Cc, R, S = 32, 48, 3, 5
+    RS = R * S
+    w = torch.randn(K, Cc, R, S, device=DEV)
+    wk, wc = ops.weight_prep(w, None, True)
+    wn = w.cpu().numpy().reshape(K, Cc, RS)
+    exp_k = np.zeros((K, RS * Cc), np.float32)
+    exp_c = np.zeros((Cc, RS * K), np.float32)
+    for c in range(Cc):
+        for rs in range(RS):
+            exp_k[:, ((c // 16) * RS + rs) * 16 + c % 16] = wn[:, c, rs]
+    for k in range(K):
+        for rs in range(RS):
+            exp_c[:, ((k // 16) * RS + rs) * 16 + k % 16] = wn[k, :, rs]
+    np.testing.assert_array_equal(wk.cpu().numpy().reshape(K, -1), exp_k)
+    np.testing.assert_array_equal(wc.cpu().numpy().reshape(Cc, -1), exp_c)
