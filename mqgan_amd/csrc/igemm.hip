@@ -454,14 +454,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
     int br[4], bs[4], bc[4];
     bool bv[4];
 #pragma unroll
+    // Columns are enumerated in PLAIN (tap, channel) order so that the 32/64 quads of one pixel row read one
+    // contiguous run of channels (512 B - 1 KB per pixel); the results are scattered into the channel-blocked
+    // filter layout (common.h: kidx) by the epilogue.
     for (int t = 0; t < 4; ++t) {
         int kk = kkb + t;
         bv[t] = kk < g.RSC;
         int kc = bv[t] ? kk : 0;
-        const int cbw = chan_block(g.IC), rscb = g.R * g.S * cbw;      // channel-blocked filter rows (common.h)
-        const int ch = kc / rscb, rem = kc - ch * rscb;
-        const int tap = rem / cbw;
-        bc[t] = ch * cbw + (rem - tap * cbw);
+        const int tap = kc / g.IC;
+        bc[t] = kc - tap * g.IC;
         br[t] = tap / g.S;
         bs[t] = tap - br[t] * g.S;
     }
@@ -612,8 +613,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {
-            const int col = c0 + wn * 64 + 2 * li + tn;
-            if (col >= g.RSC) continue;
+            const int colp = c0 + wn * 64 + 2 * li + tn;          // plain (tap, channel) index
+            if (colp >= g.RSC) continue;
+            const int tap = colp / g.IC;
+            const int col = kidx(tap, colp - tap * g.IC, g.R * g.S, chan_block(g.IC));
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = k0 + wm * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * lh) + tm;
@@ -648,13 +651,22 @@ __global__ void colsum_partial_kernel(const float *__restrict__ x, int64_t rows,
     if (threadIdx.y == 0 && c < cols)
         part[(size_t)blockIdx.y * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
+// grid (ceil(cols/64)), block (64, 16): thread (c, ty) sums chunks ty, ty+16, ...; fixed-order LDS combine
 __global__ void colsum_final_kernel(const float *__restrict__ part, int cols, int nchunks, float *__restrict__ out)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
+    __shared__ float red[16][64];
+    const int c = blockIdx.x * 64 + threadIdx.x;
     float s = 0.f;
-    for (int k = 0; k < nchunks; ++k) s += part[(size_t)k * cols + c];
-    out[c] = s;
+    if (c < cols)
+        for (int k = threadIdx.y; k < nchunks; k += 16) s += part[(size_t)k * cols + c];
+    red[threadIdx.y][threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.y == 0 && c < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+        out[c] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -773,11 +785,13 @@ static void wgrad_plan(const mqConvDesc *d, WgradGeom &g)
     g.bnc = g.K <= 64 ? 256 : 128;
     g.nKt = (int)cdiv(g.K, g.bmk);
     g.nCt = (int)cdiv(g.RSC, g.bnc);
-    // split the pixel reduction so that ~3 blocks per CU exist, each with >= 32 steps
+    // split the pixel reduction so that the grid fills the resident block slots (256 CUs x 4 or 3 blocks)
+    // exactly once when the tile count allows it, each split keeping >= 32 K-steps
     const int64_t tiles = (int64_t)g.nKt * g.nCt * d->groups;
-    int64_t want = cdiv(256 * 3, tiles);
-    int64_t max_splits = cdiv(g.Mtot, WG_BK * 32);
-    int64_t splits = want < max_splits ? want : max_splits;
+    const int64_t slots = 256 * (g.bmk == 64 ? 3 : 4);
+    int64_t splits = tiles >= slots ? 1 : slots / tiles;
+    const int64_t max_splits = cdiv(g.Mtot, WG_BK * 32);
+    if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     if (splits > 512) splits = 512;
     int64_t chunk = cdiv(cdiv(g.Mtot, splits), WG_BK) * WG_BK;
@@ -858,7 +872,7 @@ extern "C" int mq_colsum(const float *x, int64_t rows, int cols, float *out, flo
     const int nchunks = (int)want;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)cdiv(cols, 64), nchunks), dim3(64, 4), 0, S(stream), x, rows,
                        cols, workspace, nchunks);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(cols, 256)), dim3(256), 0, S(stream), workspace, cols,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(cols, 64)), dim3(64, 16), 0, S(stream), workspace, cols,
                        nchunks, out);
     MQ_LAUNCH_CHECK("mq_colsum");
     return 0;
