@@ -45,6 +45,23 @@ def synthetic_batches(B, T, mel, n, device, rank):
     return out
 
 
+def pmc_traffic(kernel_tag):
+    """HBM-side bytes per launch of `kernel_tag` from the last committed PMC pass (tools/pmc_traffic.sh: FETCH_SIZE
+    and WRITE_SIZE in separate rocprofv3 --pmc runs of this same bench, FETCH_SIZE x2 as the gfx950 note in
+    MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside the process, so the figure is taken
+    from profiles/; None when no pass covers this kernel."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        t = json.load(f)
+    e = t.get(kernel_tag)
+    if not e:
+        return None, None
+    return e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+
+
 def time_events(fn, iters):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
@@ -190,8 +207,11 @@ def main():
         total_conv_ms = sum(v["ms"] for v in summ.values())
         dom_tag, dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
         ach = dom["flops"] / (dom["ms"] / 1e3) / 1e12
+        traffic, traffic_src = pmc_traffic(dom_tag)
         roof = {"bound": "mfma", "kernel": dom_tag, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "launches_per_step": dom["launches"] / args.steps,
+                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_flop_per_launch": dom["flops"] / dom["launches"],
+                "launches_per_step": dom["launches"] / args.steps,
                 "avg_launch_ms": dom["ms"] / dom["launches"], "share_of_step_time": dom["ms"] / 1e3 / elapsed,
                 "all_conv_kernels": {k: {"ms_per_step": v["ms"] / args.steps, "TFLOPs": v["flops"] / (v["ms"] / 1e3) / 1e12,
                                          "launches_per_step": v["launches"] / args.steps} for k, v in sorted(summ.items())},

@@ -220,7 +220,7 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[GemmCfg<BN>::TM][GemmCfg<
 // ------------------------------------------------------------------------------------------ fprop / dgrad (stride 1)
 // MODE 0: scalar loads, 1: vector loads with CB < 16, 2: vector loads with CB >= 16
 template <int BN, bool DGRAD, int MODE>
-__global__ __launch_bounds__(256) void conv_nt_kernel(const float *__restrict__ act, const float *__restrict__ wgt,
+__global__ __launch_bounds__(256, 4) void conv_nt_kernel(const float *__restrict__ act, const float *__restrict__ wgt,
                                                       const float *__restrict__ bias, float *__restrict__ out,
                                                       ConvGeom g, WalkGeom wg, size_t act_group_stride, size_t w_group_stride)
 {
@@ -338,7 +338,7 @@ struct ParityBLoader {     // filter bank [Ncols][R*S*IC] (channel-blocked), col
 };
 
 template <int BN, int WRAPS>
-__global__ __launch_bounds__(256) void conv_dgrad_parity_kernel(const float *__restrict__ dy, const float *__restrict__ wgt,
+__global__ __launch_bounds__(256, 4) void conv_dgrad_parity_kernel(const float *__restrict__ dy, const float *__restrict__ wgt,
                                                                 float *__restrict__ dx, ConvGeom g, ParityInfo pi,
                                                                 size_t act_group_stride, size_t w_group_stride, int ng)
 {
@@ -709,7 +709,18 @@ static int launch_nt(const mqConvDesc *d, const float *act, const float *w, cons
     const bool strided = g.sh > 1 || g.sw > 1;
     const bool parity = DGRAD && vec && strided && g.sh <= 2 && g.sw <= 2;
     if (DGRAD && strided && !parity) vec = false;      // generic strided dgrad only exists on the scalar path
-    const int BN = g.Ncols > 64 ? 128 : (g.Ncols > 32 ? 64 : 32);
+    // column tile: the one that wastes the fewest MFMAs on padding, weighted by the measured relative
+    // efficiency of each tile shape (wider tiles reuse the A fragments more)
+    int BN = 128;
+    {
+        const int cand[3] = {128, 64, 32};
+        const double eff[3] = {1.0, 0.9, 0.75};
+        double best = 1e30;
+        for (int i = 0; i < 3; ++i) {
+            const double cost = (double)cdiv(g.Ncols, cand[i]) * cand[i] / eff[i];
+            if (cost < best - 1e-9) { best = cost; BN = cand[i]; }
+        }
+    }
     const int cb = chan_block(g.IC);
     const bool wide = cb >= GEMM_BK;
     g.nMt = (int)cdiv(g.Mtot, GEMM_BM);

@@ -108,7 +108,7 @@ def _conv_tag(kind, d: ConvDesc):
         mode = (2 if d.Q >= 16 else 1) if vec else 0
         return f"conv_wgrad_kernel<{'64, 256' if d.K <= 64 else '128, 128'}, {mode}>"
     ncols, ic = (d.K, d.C) if kind == "fprop" else (d.C, d.K)
-    bn = 128 if ncols > 64 else (64 if ncols > 32 else 32)
+    bn = min((128, 64, 32), key=lambda b: (-(-ncols // b) * b / {128: 1.0, 64: 0.9, 32: 0.75}[b], -b))
     strided = d.stride_h > 1 or d.stride_w > 1
     if kind == "dgrad" and strided:
         if ic % 4 == 0 and d.stride_h <= 2 and d.stride_w <= 2:
