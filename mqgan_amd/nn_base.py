@@ -82,7 +82,21 @@ class ConvParams(nn.Module):
             self.bias = nn.Parameter(b) if bias else None
 
     # effective weights in the kernels' layouts -------------------------------------------------
+    def freeze_(self, frozen: bool = True):
+        """Inference: compute the effective weights once and reuse them (weights no longer change).
+        Never use while training - the optimiser updates parameters in place behind autograd's back."""
+        self._frozen = frozen
+        self._cache = {}
+
     def effective(self, need_crsk: bool = True, power_iteration: bool = False):
+        if getattr(self, "_frozen", False) and not torch.is_grad_enabled():
+            key = (need_crsk,)
+            if key not in self._cache:
+                self._cache[key] = self._effective(need_crsk, False)
+            return self._cache[key]
+        return self._effective(need_crsk, power_iteration)
+
+    def _effective(self, need_crsk: bool = True, power_iteration: bool = False):
         if self.flavour == "plain":
             return ops.weight_prep(self.weight, None, need_crsk)
         if self.flavour == "wn":
