@@ -156,10 +156,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if rank == 0:
         ge.build()
+    # MQGAN_BENCH_SHARE_GPU=1 (rehearsal only): all ranks on device 0 with the gloo backend, to exercise the N > 1
+    # code path on a one-GPU box; RCCL needs one device per rank.
+    share = os.environ.get("MQGAN_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
         dist.barrier()
     from mqgan_amd import _lib, ops
     from mqgan_amd.train import Trainer

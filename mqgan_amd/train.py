@@ -415,13 +415,12 @@ class Trainer:
             self.train_loader.sampler.set_epoch(epoch)
         log_every = self.config.get("logging", {}).get("log_interval", 50)
         frames, t0 = 0, time.time()
-        for i, (real, lens, _) in enumerate(self.train_loader):
-            if real is None or real.size(0) == 0:
+        from .data import PrefetchLoader
+        for i, (real, lens, _) in enumerate(PrefetchLoader(self.train_loader, self.device, depth=2)):
+            if real is None or real.size(0) == 0:      # every file of the batch failed to load (train.py:512-514)
                 continue
-            real = real.to(self.device, non_blocking=True)
-            lens = lens.to(self.device, non_blocking=True)
             out = self.train_step(real, lens)
-            frames += int(lens.sum())
+            frames += real.shape[0] * real.shape[1]    # upper bound (padded frames included); no host sync
             if self.log_fn is not None and (i + 1) % log_every == 0:
                 rec = {k: (float(v) if torch.is_tensor(v) else v) for k, v in out.items()}
                 rec.update(epoch=epoch, step=self.global_step, frames_per_s=frames / (time.time() - t0))

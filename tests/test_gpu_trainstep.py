@@ -1,6 +1,8 @@
 """-m gpu: two full optimisation steps of mqgan_amd.train.Trainer against fixtures G7 / G7b, which
 were produced by the reference's own Trainer._train_discriminator / _train_generator
 (train.py:380-501) on the same weights and batches.  Tolerance: 1e-4 relative (north star)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -111,3 +113,33 @@ def test_train_mode_step_runs_and_is_finite():
     assert torch.equal(tr.generator.state_dict()["hidden_proj.weight"].cpu(), sd0["hidden_proj.weight"])
     u = tr.patch_discriminator.state_dict()["convs.0.weight_u"]
     assert abs(float(u.norm()) - 1.0) < 1e-4
+
+
+def test_trainer_epoch_on_npy_tree_with_bad_files(tmp_path):
+    """Trainer.train() on a small .npy tree: ragged lengths, per-batch crop length from a list, an unreadable
+    file and a wrong-rank file (dropped by the collate, train.py:110-118), prefetching loader, checkpoint
+    written with the reference's name, then auto-resume."""
+    import yaml
+    from mqgan_amd.train import Trainer, synthetic_mel
+    data = tmp_path / "data"
+    (data / "sub").mkdir(parents=True)
+    for i, L in enumerate([64, 40, 96, 33, 70, 128, 50, 48]):
+        np.save(data / ("sub" if i % 3 == 0 else "") / f"u{i}.npy", synthetic_mel(L, 16, i))
+    (data / "broken.npy").write_bytes(b"not an npy file")
+    np.save(data / "rank1.npy", np.zeros(9, np.float32))
+    cfg = {"data": {"data_dir": str(data), "output_dir": str(tmp_path / "out"), "validation_split": 0.0, "crop_len": [32, 48],
+                    "batch_size": 4, "num_workers": 0},
+           "model": TINY_CFG["model"], "training": dict(TINY_CFG["training"], num_epochs=2, pretrained=None),
+           "logging": {"eval_interval": 1, "save_interval": 1, "log_interval": 1, "num_plot_examples": 1}}
+    logs = []
+    tr = Trainer(cfg, device=DEV, log_fn=logs.append)
+    tr.train()
+    assert tr.global_step >= 4 and len(logs) == tr.global_step
+    for rec in logs:
+        for k in ("loss_d", "loss_g_total", "loss_recon_pre", "loss_recon_post", "loss_gan", "loss_fm", "learning_rate"):
+            assert np.isfinite(rec[k]), (k, rec)
+    assert os.path.exists(tmp_path / "out" / "checkpoint_epoch_002.pth")
+    tr2 = Trainer(cfg, device=DEV, log_fn=None)
+    assert tr2.start_epoch == 3
+    assert torch.equal(tr2.arena_g.flat_param, tr.arena_g.flat_param)
+    assert torch.equal(tr2.arena_d.flat_param, tr.arena_d.flat_param)
