@@ -242,15 +242,19 @@ __global__ __launch_bounds__(256, 4) void conv_nt_kernel(const float *__restrict
         la.init(abase, g, m0);
         nt_gemm_mainloop<BN>(la, lb, nk, smem, acc);
     } else {
+        // The buffer descriptor is based at the first image this tile touches, so 32-bit offsets only have to span
+        // the few images of one tile (tensors beyond 4 GB stay on the vector path).
         TapWalker<(MODE == 2 ? 1 : 4)> la;
-        la.start(abase, act_group_stride, wg);
+        const int img0 = m0 / (g.OH * g.OW);
+        const size_t img_elems = (size_t)g.IH * g.IW * g.IC;
+        la.start(abase + img0 * img_elems, act_group_stride - img0 * img_elems, wg);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int m = m0 + (threadIdx.x >> 2) + 64 * j;
             const bool v = m < g.Mtot;
-            const int mm = v ? m : 0;
+            const int mm = v ? m : m0;
             const int ow = mm % g.OW, t = mm / g.OW;
-            const int oh = t % g.OH, n = t / g.OH;
+            const int oh = t % g.OH, n = t / g.OH - img0;
             la.set_row(j, v, n, DGRAD ? oh + g.ph : oh * g.sh - g.ph, DGRAD ? ow + g.pw : ow * g.sw - g.pw);
         }
         nt_gemm_mainloop<BN>(la, lb, nk, smem, acc);
@@ -366,14 +370,16 @@ __global__ __launch_bounds__(256, 4) void conv_dgrad_parity_kernel(const float *
     wg.step_w = -((sstep * g.dw) >> shift_w);
     wg.CB = chan_block(g.IC); wg.nchunks = g.IC / wg.CB;
     TapWalker<WRAPS> la;
-    la.start(dy + (size_t)grp * act_group_stride, act_group_stride, wg);
+    const int img0 = (Ha * Wb) > 0 ? m0 / (Ha * Wb) : 0;
+    const size_t img_elems = (size_t)g.IH * g.IW * g.IC;
+    la.start(dy + (size_t)grp * act_group_stride + img0 * img_elems, act_group_stride - img0 * img_elems, wg);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int m = m0 + (threadIdx.x >> 2) + 64 * j;
         const bool v = m < Mc;
-        const int mm = v ? m : 0;
+        const int mm = v ? m : m0;
         const int iwq = mm % Wb, t = mm / Wb;
-        const int ihq = t % Ha, n = t / Ha;
+        const int ihq = t % Ha, n = t / Ha - img0;
         la.set_row(j, v, n, (ihq * g.sh + a + g.ph - r0 * g.dh) >> shift_h, (iwq * g.sw + b + g.pw - s0 * g.dw) >> shift_w);
     }
     ParityBLoader<WRAPS> lb;
@@ -478,8 +484,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
     // Three-phase K-step as in gemm_core.h: (1) issue the loads of step st+1 from staged buffer offsets,
     // (2) MFMAs of step st with the offset arithmetic of step st+2 in their shadow, (3) wait + LDS stores +
     // barrier.  Out-of-range pixels / taps / channels read zeros through the descriptors.
-    const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(dyg, (size_t)g.Mtot * g.K * sizeof(float));
-    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(xg, (size_t)ng * g.IH * g.IW * g.IC * sizeof(float));
+    // descriptors are based at the first image of this split: 32-bit offsets only span the split's pixel range
+    const int img0 = m_begin / (g.OH * g.OW);
+    const int pix0 = img0 * g.OH * g.OW;
+    const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(dyg + (size_t)pix0 * g.K, (size_t)(g.Mtot - pix0) * g.K * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(xg + (size_t)img0 * g.IH * g.IW * g.IC,
+                                                  (size_t)(ng - img0) * g.IH * g.IW * g.IC * sizeof(float));
     float4 ra[AP], rb[BP];
     unsigned oa[AP], ob[BP];
     int am[AP], bm[BP];                                  // pixel index per slot
@@ -488,16 +498,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
     const int tap_off = (tap_h * g.IW + tap_w) * g.IC + bc[0];
 
     auto decode_b = [&](int j) {                         // (re)compute walked state of B slot j from bm[j]
-        const int mm = bm[j] < g.Mtot ? bm[j] : 0;
+        const int mm = bm[j] < g.Mtot ? bm[j] : pix0;
         const int ow = mm % g.OW, t2 = mm / g.OW;
-        const int oh = t2 % g.OH, n = t2 / g.OH;
+        const int oh = t2 % g.OH, n = t2 / g.OH - img0;
         bow[j] = ow * g.sw;
         boh[j] = oh * g.sh;
         bbase[j] = ((n * g.IH + boh[j]) * g.IW + bow[j]) * g.IC;
     };
     auto offsets = [&]() {
 #pragma unroll
-        for (int j = 0; j < AP; ++j) oa[j] = (am[j] < m_end && ka < g.K) ? (unsigned)(am[j] * g.K + ka) * 4u : OOB;
+        for (int j = 0; j < AP; ++j) oa[j] = (am[j] < m_end && ka < g.K) ? (unsigned)((am[j] - pix0) * g.K + ka) * 4u : OOB;
 #pragma unroll
         for (int j = 0; j < BP; ++j) {
             if (MODE != 2) decode_b(j);
@@ -704,8 +714,11 @@ static int launch_nt(const mqConvDesc *d, const float *act, const float *w, cons
     g.Kdim = d->R * d->S * g.IC;
     const size_t act_gs = (size_t)ng * g.IH * g.IW * g.IC;
     const size_t w_gs = (size_t)g.Ncols * g.Kdim;
+    // 32-bit element offsets inside one tile: the images a 128-row tile can touch must span < 2 GB
+    const size_t img_bytes = (size_t)g.IH * g.IW * g.IC * sizeof(float);
+    const size_t tile_imgs = (size_t)cdiv(GEMM_BM, (int64_t)g.OH * g.OW) + 1;
     bool vec = (g.IC % 4 == 0) && ((uintptr_t)act % 16 == 0) && ((uintptr_t)w % 16 == 0) &&
-               act_gs * sizeof(float) < 0x7FFFFFF0ull && w_gs * sizeof(float) < 0xFFFFFFF0ull;
+               img_bytes * tile_imgs < 0x7FFFFFF0ull && w_gs * sizeof(float) < 0xFFFFFFF0ull;
     const bool strided = g.sh > 1 || g.sw > 1;
     const bool parity = DGRAD && vec && strided && g.sh <= 2 && g.sw <= 2;
     if (DGRAD && strided && !parity) vec = false;      // generic strided dgrad only exists on the scalar path
@@ -850,10 +863,11 @@ extern "C" int mq_conv_wgrad(const mqConvDesc *d, const float *x, const float *d
     MQ_REQUIRE(workspace_bytes >= need && (need == 0 || workspace != nullptr),
                "mq_conv_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
     float *target = g.splits > 1 ? reinterpret_cast<float *>(workspace) : dw;
-    const size_t ng_ = (size_t)(d->N / d->groups);
+    // 32-bit offsets inside one split: its images must span < 2 GB of x and of dy
+    const size_t split_imgs = (size_t)cdiv(g.chunk, (int64_t)d->P * d->Q) + 2;
     const bool vec = (d->C % 4 == 0) && (d->K % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) &&
-                     (size_t)g.Mtot * g.K * sizeof(float) < 0xFFFFFFF0ull &&
-                     ng_ * d->H * d->W * d->C * sizeof(float) < 0xFFFFFFF0ull;
+                     split_imgs * d->P * d->Q * g.K * sizeof(float) < 0x7FFFFFF0ull &&
+                     split_imgs * d->H * d->W * d->C * sizeof(float) < 0x7FFFFFF0ull;
     dim3 grid(g.nKt * g.nCt, d->groups, g.splits), block(256);
     const int mode = vec ? (d->Q >= WG_BK ? 2 : 1) : 0;
 #define MQ_WG(A_, B_, M_) hipLaunchKernelGGL((conv_wgrad_kernel<A_, B_, M_>), grid, block, 0, S(stream), x, dy, target, g, d->groups)
