@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 METRIC = "mel-frames/sec train step (80×512, codebook 1024) at 1/2/4/8 GPU; VQ argmin GB/s"
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32 matrix peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 matrix peak (no sparsity)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
 
 
@@ -143,6 +144,8 @@ def main():
     ap.add_argument("--config", default="hifispeech", choices=["hifispeech", "hifimusic"])
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's)")
     ap.add_argument("--frames", type=int, default=None, help="frames per item (default: the config's crop_len)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="matrix engine of the convs (fp32 = the BASELINE metric's; bf16 = BASELINE config 3, secondary)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vq", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
@@ -177,6 +180,7 @@ def main():
     B = args.batch or cfg["data"]["batch_size"]
     T = args.frames or cfg["data"]["crop_len"]
     mel = cfg["model"]["mel_channels"]
+    cfg["training"]["precision"] = args.precision
     tr = Trainer(cfg, device=device, build_data=False)
     tr.generator.train()
     tr.patch_discriminator.train()
@@ -216,8 +220,9 @@ def main():
         dom_tag, dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
         ach = dom["flops"] / (dom["ms"] / 1e3) / 1e12
         traffic, traffic_src = pmc_traffic(dom_tag)
-        roof = {"bound": "mfma", "kernel": dom_tag, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+        peak = PEAK_BF16_MFMA_TFLOPS if "bf16" in dom_tag else PEAK_F32_MFMA_TFLOPS
+        roof = {"bound": "mfma", "kernel": dom_tag, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_flop_per_launch": dom["flops"] / dom["launches"],
                 "launches_per_step": dom["launches"] / args.steps,
                 "avg_launch_ms": dom["ms"] / dom["launches"], "share_of_step_time": dom["ms"] / 1e3 / elapsed,
@@ -226,7 +231,8 @@ def main():
                 "conv_share_of_step_time": total_conv_ms / 1e3 / elapsed}
         line = {"metric": METRIC, "value": frames / elapsed, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16 convs (f32 accumulate, f32 tensors) / f32 VQ",
+                "data": "synthetic",
                 "config": {"workload": f"{args.config} PreEncoder VQ-GAN train step (G fwd + D step + G step + clip/Adam), "
                                        f"{mel} mels x {T} frames, batch {B}/GPU, FSQ {cfg['model']['generator']['fsq_levels']}, "
                                        "D active, FM off, train-mode dropout", "global_batch": world * B, "frames": T,

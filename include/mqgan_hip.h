@@ -82,7 +82,14 @@ int mq_codebook_ema_update(const float *x, const int32_t *idx, int64_t n, int k,
  * `groups` splits the BATCH (N % groups == 0): images of group g use filter bank g
  * (this is how the eight independent band discriminators run as one launch,
  * discriminators.py:280-311).  pad_h/pad_w are the top/left paddings; P, Q are given
- * explicitly so that causal (left-only) padding is expressible (attentions.py:471-474). */
+ * explicitly so that causal (left-only) padding is expressible (attentions.py:471-474).
+ * `precision` selects the matrix engine.  MQ_PRECISION_F32 (0): exact f32 products, the 1e-4 parity path.
+ * MQ_PRECISION_BF16 (1): the counterpart of the reference's torch.autocast(bfloat16) region (train.py:330-333,
+ * 386,437): operands are rounded to bf16 on their way into LDS (v_mfma_f32_32x32x16_bf16), accumulation,
+ * bias and every tensor in HBM stay f32.  Layers that do not fit the vector path (C or K not a multiple of 4)
+ * run in f32 either way. */
+#define MQ_PRECISION_F32 0
+#define MQ_PRECISION_BF16 1
 typedef struct {
     int N, H, W, C;
     int K, R, S;
@@ -91,6 +98,7 @@ typedef struct {
     int pad_h, pad_w;
     int dil_h, dil_w;
     int groups;
+    int precision;
 } mqConvDesc;
 
 int mq_conv_fprop(const mqConvDesc *desc_host, const float *x, const float *w_krsc, const float *bias, float *y,

@@ -26,7 +26,7 @@ class FsqDesc(C.Structure):
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("N", "H", "W", "C", "K", "R", "S", "P", "Q", "stride_h", "stride_w", "pad_h",
-                                       "pad_w", "dil_h", "dil_w", "groups")]
+                                       "pad_w", "dil_h", "dil_w", "groups", "precision")]
 
 
 class Cb2dWeights(C.Structure):

@@ -21,16 +21,28 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int GEMM_BM = 128;
 constexpr int GEMM_BK = 16;
 constexpr int GEMM_LD = 18;
+constexpr int GEMM_LDH = 40;       // bf16 engine: 32 k's per row + 8 pad (80-byte rows: conflict-free ds_read_b128)
 
-template <int BN>
+// Engine policies.  A tile row of BK k's is loaded as QPR float4 quads, so the 256 threads cover ROWS rows per
+// pass and a 128-row operand tile takes NS passes ("slots").
+struct EngF32 {        // v_mfma_f32_32x32x2_f32: exact f32 products, k-ordered accumulation
+    static constexpr int BK = 16, QPR = 4, ROWS = 64, NS = 2;
+    static constexpr bool BF16 = false;
+};
+struct EngBF16 {       // v_mfma_f32_32x32x16_bf16: operands rounded to bf16 (RNE) on the way into LDS, f32 accumulate
+    static constexpr int BK = 32, QPR = 8, ROWS = 32, NS = 4;
+    static constexpr bool BF16 = true;
+};
+
+template <int BN, class E = EngF32>
 struct GemmCfg {
     static constexpr int WM = (BN == 32) ? 4 : 2;       // waves along M
     static constexpr int WN = 4 / WM;                   // waves along N
     static constexpr int TM = GEMM_BM / WM / 32;        // 32x32 tiles per wave along M
     static constexpr int TN = BN / WN / 32;
-    static constexpr int A_SLOTS = GEMM_BM / 64;        // float4 loads per thread for the A tile
-    static constexpr int B_SLOTS = (BN >= 64) ? BN / 64 : 1;
-    static constexpr int LDS_FLOATS = 2 * (GEMM_BM + BN) * GEMM_LD;
+    static constexpr int A_SLOTS = GEMM_BM / E::ROWS;   // float4 loads per thread for the A tile
+    static constexpr int B_SLOTS = (BN >= E::ROWS) ? BN / E::ROWS : 1;
+    static constexpr int LDS_FLOATS = E::BF16 ? (GEMM_BM + BN) * GEMM_LDH : 2 * (GEMM_BM + BN) * GEMM_LD;   // in 4-byte units
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -141,6 +153,96 @@ __device__ __forceinline__ void nt_gemm_mainloop(ALoad &la, BLoad &lb, int nk, f
         }
         __syncthreads();
     }
+}
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint2 pack_bf16x4(float4 v)
+{
+    const f32x4v f = {v.x, v.y, v.z, v.w};
+    return __builtin_bit_cast(uint2, __builtin_convertvector(f, bf16x4));     // v_cvt_pk_bf16_f32 x2 (RNE, NaN-safe)
+}
+
+// bf16 engine: same loader protocol with EngBF16's mapping (.fetch(slot) -> k = k0 + 4*(tid&7) .. +3 of tile row
+// (tid>>3) + 32*slot), BK = 32.  LDS rows hold 32 bf16 k's in natural order (+8 pad); lane (r, h) reads the 8 k's
+// 16s + 8h .. +7 of row r with one ds_read_b128 per 32x32x16 MFMA operand.
+template <int BN, class ALoad, class BLoad>
+__device__ __forceinline__ void nt_gemm_mainloop_bf16(ALoad &la, BLoad &lb, int nk, float *smem_f,
+                                                      f32x16 (&acc)[GemmCfg<BN, EngBF16>::TM][GemmCfg<BN, EngBF16>::TN])
+{
+    using Cfg = GemmCfg<BN, EngBF16>;
+    constexpr int LD = GEMM_LDH;
+    unsigned short *smem = reinterpret_cast<unsigned short *>(smem_f);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+    const int li = lane & 31, lh = lane >> 5;
+    unsigned short *As = smem;
+    unsigned short *Bs = smem + 2 * GEMM_BM * LD;
+    const int ld_row = tid >> 3, ld_kq = tid & 7;
+
+    float4 ra[Cfg::A_SLOTS], rb[Cfg::B_SLOTS];
+    la.stage(0);
+    lb.stage(0);
+#pragma unroll
+    for (int j = 0; j < Cfg::A_SLOTS; ++j) ra[j] = la.fetch(j);
+#pragma unroll
+    for (int j = 0; j < Cfg::B_SLOTS; ++j) rb[j] = lb.fetch(j);
+#pragma unroll
+    for (int j = 0; j < Cfg::A_SLOTS; ++j) *reinterpret_cast<uint2 *>(&As[(ld_row + 32 * j) * LD + 4 * ld_kq]) = pack_bf16x4(ra[j]);
+#pragma unroll
+    for (int j = 0; j < Cfg::B_SLOTS; ++j) *reinterpret_cast<uint2 *>(&Bs[(ld_row + 32 * j) * LD + 4 * ld_kq]) = pack_bf16x4(rb[j]);
+    la.stage(EngBF16::BK);
+    lb.stage(EngBF16::BK);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+#pragma unroll
+        for (int j = 0; j < Cfg::A_SLOTS; ++j) ra[j] = la.fetch(j);
+#pragma unroll
+        for (int j = 0; j < Cfg::B_SLOTS; ++j) rb[j] = lb.fetch(j);
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned short *Ac = As + cur * GEMM_BM * LD + (wm * Cfg::TM * 32 + li) * LD + 8 * lh;
+        const unsigned short *Bc = Bs + cur * BN * LD + (wn * Cfg::TN * 32 + li) * LD + 8 * lh;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 a[Cfg::TM], b[Cfg::TN];
+#pragma unroll
+            for (int t = 0; t < Cfg::TM; ++t) a[t] = *reinterpret_cast<const bf16x8 *>(Ac + t * 32 * LD + 16 * s);
+#pragma unroll
+            for (int t = 0; t < Cfg::TN; ++t) b[t] = *reinterpret_cast<const bf16x8 *>(Bc + t * 32 * LD + 16 * s);
+#pragma unroll
+            for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < Cfg::TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+        }
+        la.stage((kt + 2) * EngBF16::BK);
+        lb.stage((kt + 2) * EngBF16::BK);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            unsigned short *An = As + (cur ^ 1) * GEMM_BM * LD;
+            unsigned short *Bn = Bs + (cur ^ 1) * BN * LD;
+#pragma unroll
+            for (int j = 0; j < Cfg::A_SLOTS; ++j)
+                *reinterpret_cast<uint2 *>(&An[(ld_row + 32 * j) * LD + 4 * ld_kq]) = pack_bf16x4(ra[j]);
+#pragma unroll
+            for (int j = 0; j < Cfg::B_SLOTS; ++j)
+                *reinterpret_cast<uint2 *>(&Bn[(ld_row + 32 * j) * LD + 4 * ld_kq]) = pack_bf16x4(rb[j]);
+        }
+        __syncthreads();
+    }
+}
+
+template <class E, int BN, class ALoad, class BLoad>
+__device__ __forceinline__ void nt_gemm_run(ALoad &la, BLoad &lb, int nk, float *smem,
+                                            f32x16 (&acc)[GemmCfg<BN, E>::TM][GemmCfg<BN, E>::TN])
+{
+    if constexpr (E::BF16) nt_gemm_mainloop_bf16<BN>(la, lb, nk, smem, acc);
+    else nt_gemm_mainloop<BN>(la, lb, nk, smem, acc);
 }
 
 // row / column of accumulator register r of tile (tm, tn) inside the block tile

@@ -34,15 +34,18 @@ struct WalkGeom {
     int CB, nchunks;       // channel blocking of the reduction
 };
 
-template <int WRAPS>       // WRAPS = 1 when CB >= 16 (one carry per K-step), 4 otherwise (CB >= 4)
+// WRAPS = carries per K-step: ceil(BK / CB) for the smallest CB served (f32: 1 when CB >= 16, else 4;
+// bf16: 2 when CB >= 16, else 8)
+template <int WRAPS, class E = EngF32>
 struct TapWalker {
+    static constexpr int NS = E::NS;
     __amdgpu_buffer_rsrc_t rsrc;
     WalkGeom w;
-    int rowbase_[2], bh_[2], bw_[2];   // per row slot: element offset of (n, bh, bw, 0) and the base coordinates
-    bool rv_[2];
+    int rowbase_[NS], bh_[NS], bw_[NS];   // per row slot: element offset of (n, bh, bw, 0) and the base coordinates
+    bool rv_[NS];
     int ci, js, jr, chunk;             // position of the thread's k-quad
     int hoff, woff, tapoff;            // jr*step_h, js*step_w, (jr*step_h*IW + js*step_w)*IC
-    unsigned off_[2];
+    unsigned off_[NS];
 
     __device__ __forceinline__ void set_row(int j, bool valid, int n, int bh, int bw)
     {
@@ -55,7 +58,7 @@ struct TapWalker {
     {
         w = wg;
         rsrc = make_rsrc(base, elems * sizeof(float));
-        const int kb = 4 * (threadIdx.x & 3);                 // first k of this thread in step 0
+        const int kb = 4 * (threadIdx.x % E::QPR);            // first k of this thread in step 0
         const int per = w.nR * w.nS * w.CB;
         chunk = per > 0 ? kb / per : w.nchunks;
         const int rem = kb - chunk * (per > 0 ? per : 0);
@@ -73,7 +76,7 @@ struct TapWalker {
     }
     __device__ __forceinline__ void advance()
     {
-        ci += GEMM_BK;
+        ci += E::BK;
 #pragma unroll
         for (int i = 0; i < WRAPS; ++i) {
             const bool c1 = ci >= w.CB;
@@ -94,7 +97,7 @@ struct TapWalker {
         const bool kv = chunk < w.nchunks;
         const int cc = chunk * w.CB + ci;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NS; ++j) {
             const bool ok = rv_[j] && kv && (unsigned)(bh_[j] + hoff) < (unsigned)w.IH && (unsigned)(bw_[j] + woff) < (unsigned)w.IW;
             off_[j] = ok ? (unsigned)(rowbase_[j] + tapoff + cc) * 4u : OOB;
         }
@@ -165,12 +168,13 @@ struct ScalarALoader {
 };
 
 // B operand: dense row-major [Ncols][Kdim] filter bank of one group
-template <bool VEC>
+template <bool VEC, class E = EngF32>
 struct DenseBLoader {
+    static constexpr int NS = E::NS;
     const float *__restrict__ w;
     __amdgpu_buffer_rsrc_t rsrc;
     int n0, Ncols, Kdim, kbase;
-    unsigned rowoff[2], off_[2];
+    unsigned rowoff[NS], off_[NS];
     __device__ __forceinline__ void init(const float *ww, int n0_, int Ncols_, int Kdim_)
     {
         w = ww;
@@ -179,22 +183,22 @@ struct DenseBLoader {
         Kdim = Kdim_;
         rsrc = make_rsrc(ww, (size_t)Ncols_ * Kdim_ * sizeof(float));
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + (threadIdx.x >> 2) + 64 * j;
+        for (int j = 0; j < NS; ++j) {
+            const int n = n0 + (threadIdx.x / E::QPR) + E::ROWS * j;
             rowoff[j] = n < Ncols ? (unsigned)n * (unsigned)Kdim * 4u : OOB;
         }
     }
     __device__ __forceinline__ void stage(int k0)
     {
-        kbase = k0 + 4 * (threadIdx.x & 3);
+        kbase = k0 + 4 * (threadIdx.x % E::QPR);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NS; ++j)
             off_[j] = (rowoff[j] != OOB && kbase < Kdim) ? rowoff[j] + (unsigned)kbase * 4u : OOB;
     }
     __device__ __forceinline__ float4 fetch(int j) const
     {
         if (VEC) return buf_load4(rsrc, off_[j]);
-        int n = n0 + (threadIdx.x >> 2) + 64 * j;
+        int n = n0 + (threadIdx.x / E::QPR) + E::ROWS * j;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (n >= Ncols) return v;
         const float *p = w + (size_t)n * Kdim + kbase;
@@ -207,7 +211,7 @@ struct DenseBLoader {
 };
 
 template <int BN>
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[GemmCfg<BN>::TM][GemmCfg<BN>::TN])
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[GemmCfg<BN>::TM][GemmCfg<BN>::TN])   // TM/TN do not depend on the engine
 {
 #pragma unroll
     for (int a = 0; a < GemmCfg<BN>::TM; ++a)
@@ -219,13 +223,12 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[GemmCfg<BN>::TM][GemmCfg<
 
 // ------------------------------------------------------------------------------------------ fprop / dgrad (stride 1)
 // MODE 0: scalar loads, 1: vector loads with CB < 16, 2: vector loads with CB >= 16
-template <int BN, bool DGRAD, int MODE>
-__global__ __launch_bounds__(256, 4) void conv_nt_kernel(const float *__restrict__ act, const float *__restrict__ wgt,
-                                                      const float *__restrict__ bias, float *__restrict__ out,
-                                                      ConvGeom g, WalkGeom wg, size_t act_group_stride, size_t w_group_stride)
+template <class E, int BN, bool DGRAD, int MODE>
+__device__ __forceinline__ void conv_nt_body(const float *__restrict__ act, const float *__restrict__ wgt,
+                                             const float *__restrict__ bias, float *__restrict__ out, const ConvGeom &g,
+                                             const WalkGeom &wg, size_t act_group_stride, size_t w_group_stride, float *smem)
 {
-    using Cfg = GemmCfg<BN>;
-    __shared__ __attribute__((aligned(16))) float smem[Cfg::LDS_FLOATS];
+    using Cfg = GemmCfg<BN, E>;
     const int grp = blockIdx.y;
     const int tile = xcd_remap(blockIdx.x, g.nMt * g.nNt);
     const int mt = tile / g.nNt, nt = tile - mt * g.nNt;   // N tiles of one M tile are neighbours (share A in L2)
@@ -234,30 +237,31 @@ __global__ __launch_bounds__(256, 4) void conv_nt_kernel(const float *__restrict
 
     f32x16 acc[Cfg::TM][Cfg::TN];
     zero_acc<BN>(acc);
-    DenseBLoader<(MODE > 0)> lb;
+    DenseBLoader<(MODE > 0), E> lb;
     lb.init(wgt + (size_t)grp * w_group_stride, n0, g.Ncols, g.Kdim);
-    const int nk = (g.Kdim + GEMM_BK - 1) / GEMM_BK;
+    const int nk = (g.Kdim + E::BK - 1) / E::BK;
     if constexpr (MODE == 0) {
+        static_assert(!E::BF16, "scalar path is f32 only");
         ScalarALoader<DGRAD> la;
         la.init(abase, g, m0);
         nt_gemm_mainloop<BN>(la, lb, nk, smem, acc);
     } else {
         // The buffer descriptor is based at the first image this tile touches, so 32-bit offsets only have to span
         // the few images of one tile (tensors beyond 4 GB stay on the vector path).
-        TapWalker<(MODE == 2 ? 1 : 4)> la;
+        TapWalker<(MODE == 2 ? E::BK / 16 : E::BK / 4), E> la;
         const int img0 = m0 / (g.OH * g.OW);
         const size_t img_elems = (size_t)g.IH * g.IW * g.IC;
         la.start(abase + img0 * img_elems, act_group_stride - img0 * img_elems, wg);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int m = m0 + (threadIdx.x >> 2) + 64 * j;
+        for (int j = 0; j < E::NS; ++j) {
+            const int m = m0 + (threadIdx.x / E::QPR) + E::ROWS * j;
             const bool v = m < g.Mtot;
             const int mm = v ? m : m0;
             const int ow = mm % g.OW, t = mm / g.OW;
             const int oh = t % g.OH, n = t / g.OH - img0;
             la.set_row(j, v, n, DGRAD ? oh + g.ph : oh * g.sh - g.ph, DGRAD ? ow + g.pw : ow * g.sw - g.pw);
         }
-        nt_gemm_mainloop<BN>(la, lb, nk, smem, acc);
+        nt_gemm_run<E, BN>(la, lb, nk, smem, acc);
     }
 
     float *o = out + (size_t)grp * g.Mtot * g.Ncols;
@@ -276,6 +280,25 @@ __global__ __launch_bounds__(256, 4) void conv_nt_kernel(const float *__restrict
     }
 }
 
+template <int BN, bool DGRAD, int MODE>
+__global__ __launch_bounds__(256, 4) void conv_nt_kernel(const float *__restrict__ act, const float *__restrict__ wgt,
+                                                      const float *__restrict__ bias, float *__restrict__ out,
+                                                      ConvGeom g, WalkGeom wg, size_t act_group_stride, size_t w_group_stride)
+{
+    __shared__ __attribute__((aligned(16))) float smem[GemmCfg<BN, EngF32>::LDS_FLOATS];
+    conv_nt_body<EngF32, BN, DGRAD, MODE>(act, wgt, bias, out, g, wg, act_group_stride, w_group_stride, smem);
+}
+// bf16 operands (rounded on the way into LDS), f32 accumulate and f32 tensors in HBM; vector path only
+template <int BN, bool DGRAD, int MODE>
+__global__ __launch_bounds__(256, (BN == 128 ? 3 : 4)) void conv_nt_bf16_kernel(const float *__restrict__ act, const float *__restrict__ wgt,
+                                                           const float *__restrict__ bias, float *__restrict__ out,
+                                                           ConvGeom g, WalkGeom wg, size_t act_group_stride,
+                                                           size_t w_group_stride)
+{
+    __shared__ __attribute__((aligned(16))) float smem[GemmCfg<BN, EngBF16>::LDS_FLOATS];
+    conv_nt_body<EngBF16, BN, DGRAD, MODE>(act, wgt, bias, out, g, wg, act_group_stride, w_group_stride, smem);
+}
+
 // ------------------------------------------------------------------------------------------ dgrad by stride parity
 // For stride > 1 only the taps with (ih + ph - r*dh) % sh == 0 contribute to input pixel ih: 1/sh of
 // the rows of the filter (and 1/sw of its columns).  The input pixels are therefore partitioned into
@@ -290,11 +313,12 @@ struct ParityInfo {
     int r0[4], s0[4], rstep[4], sstep[4];
 };
 
-template <int WRAPS>
+template <int WRAPS, class E = EngF32>
 struct ParityBLoader {     // filter bank [Ncols][R*S*IC] (channel-blocked), columns of the class's taps only
+    static constexpr int NS = E::NS;
     __amdgpu_buffer_rsrc_t rsrc;
     int S, RS, CB, nchunks, nr, ns, r0, s0, rstep, sstep;
-    unsigned rowoff[2], off_[2];
+    unsigned rowoff[NS], off_[NS];
     int ci, js, jr, chunk;
     __device__ __forceinline__ void init(const float *w, int n0, int Ncols, int IC, int S_, int KdimFull, int nr_, int ns_,
                                          int r0_, int s0_, int rstep_, int sstep_)
@@ -303,11 +327,11 @@ struct ParityBLoader {     // filter bank [Ncols][R*S*IC] (channel-blocked), col
         nr = nr_; ns = ns_; r0 = r0_; s0 = s0_; rstep = rstep_; sstep = sstep_;
         rsrc = make_rsrc(w, (size_t)Ncols * KdimFull * sizeof(float));
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + (threadIdx.x >> 2) + 64 * j;
+        for (int j = 0; j < NS; ++j) {
+            const int n = n0 + (threadIdx.x / E::QPR) + E::ROWS * j;
             rowoff[j] = n < Ncols ? (unsigned)n * (unsigned)KdimFull * 4u : OOB;
         }
-        const int kb = 4 * (threadIdx.x & 3);
+        const int kb = 4 * (threadIdx.x % E::QPR);
         const int per = nr * ns * CB;
         chunk = per > 0 ? kb / per : nchunks;
         const int rem = kb - chunk * (per > 0 ? per : 0);
@@ -319,7 +343,7 @@ struct ParityBLoader {     // filter bank [Ncols][R*S*IC] (channel-blocked), col
     __device__ __forceinline__ void stage(int k0)
     {
         if (k0 != 0) {
-            ci += GEMM_BK;
+            ci += E::BK;
 #pragma unroll
             for (int i = 0; i < WRAPS; ++i) {
                 const bool c1 = ci >= CB;
@@ -336,18 +360,17 @@ struct ParityBLoader {     // filter bank [Ncols][R*S*IC] (channel-blocked), col
         const int col = (chunk * RS + (r0 + jr * rstep) * S + s0 + js * sstep) * CB + ci;
         const bool kv = chunk < nchunks;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) off_[j] = (kv && rowoff[j] != OOB) ? rowoff[j] + (unsigned)col * 4u : OOB;
+        for (int j = 0; j < NS; ++j) off_[j] = (kv && rowoff[j] != OOB) ? rowoff[j] + (unsigned)col * 4u : OOB;
     }
     __device__ __forceinline__ float4 fetch(int j) const { return buf_load4(rsrc, off_[j]); }
 };
 
-template <int BN, int WRAPS>
-__global__ __launch_bounds__(256, 4) void conv_dgrad_parity_kernel(const float *__restrict__ dy, const float *__restrict__ wgt,
-                                                                float *__restrict__ dx, ConvGeom g, ParityInfo pi,
-                                                                size_t act_group_stride, size_t w_group_stride, int ng)
+template <class E, int BN, int WRAPS>
+__device__ __forceinline__ void conv_dgrad_parity_body(const float *__restrict__ dy, const float *__restrict__ wgt,
+                                                       float *__restrict__ dx, const ConvGeom &g, const ParityInfo &pi,
+                                                       size_t act_group_stride, size_t w_group_stride, int ng, float *smem)
 {
-    using Cfg = GemmCfg<BN>;
-    __shared__ __attribute__((aligned(16))) float smem[Cfg::LDS_FLOATS];
+    using Cfg = GemmCfg<BN, E>;
     const int grp = blockIdx.y;
     const int total_mt = pi.tile0[pi.ncls];
     // classes have different tap counts (= block run times): keep dispatch order so every XCD gets the same mix
@@ -369,25 +392,25 @@ __global__ __launch_bounds__(256, 4) void conv_dgrad_parity_kernel(const float *
     wg.step_h = -((rstep * g.dh) >> shift_h);        // exact: the class's taps keep (ih + ph - r*dh) divisible by sh
     wg.step_w = -((sstep * g.dw) >> shift_w);
     wg.CB = chan_block(g.IC); wg.nchunks = g.IC / wg.CB;
-    TapWalker<WRAPS> la;
+    TapWalker<WRAPS, E> la;
     const int img0 = (Ha * Wb) > 0 ? m0 / (Ha * Wb) : 0;
     const size_t img_elems = (size_t)g.IH * g.IW * g.IC;
     la.start(dy + (size_t)grp * act_group_stride + img0 * img_elems, act_group_stride - img0 * img_elems, wg);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int m = m0 + (threadIdx.x >> 2) + 64 * j;
+    for (int j = 0; j < E::NS; ++j) {
+        const int m = m0 + (threadIdx.x / E::QPR) + E::ROWS * j;
         const bool v = m < Mc;
         const int mm = v ? m : m0;
         const int iwq = mm % Wb, t = mm / Wb;
         const int ihq = t % Ha, n = t / Ha - img0;
         la.set_row(j, v, n, (ihq * g.sh + a + g.ph - r0 * g.dh) >> shift_h, (iwq * g.sw + b + g.pw - s0 * g.dw) >> shift_w);
     }
-    ParityBLoader<WRAPS> lb;
+    ParityBLoader<WRAPS, E> lb;
     lb.init(wgt + (size_t)grp * w_group_stride, n0, g.Ncols, g.IC, g.S, g.Kdim, nr, ns, r0, s0, rstep, sstep);
 
     f32x16 acc[Cfg::TM][Cfg::TN];
     zero_acc<BN>(acc);
-    nt_gemm_mainloop<BN>(la, lb, (Kdim + GEMM_BK - 1) / GEMM_BK, smem, acc);
+    nt_gemm_run<E, BN>(la, lb, (Kdim + E::BK - 1) / E::BK, smem, acc);
 
     float *o = dx + (size_t)grp * ng * g.OH * g.OW * g.Ncols;
 #pragma unroll
@@ -408,11 +431,29 @@ __global__ __launch_bounds__(256, 4) void conv_dgrad_parity_kernel(const float *
         }
 }
 
+template <int BN, int WRAPS>
+__global__ __launch_bounds__(256, 4) void conv_dgrad_parity_kernel(const float *__restrict__ dy, const float *__restrict__ wgt,
+                                                                float *__restrict__ dx, ConvGeom g, ParityInfo pi,
+                                                                size_t act_group_stride, size_t w_group_stride, int ng)
+{
+    __shared__ __attribute__((aligned(16))) float smem[GemmCfg<BN, EngF32>::LDS_FLOATS];
+    conv_dgrad_parity_body<EngF32, BN, WRAPS>(dy, wgt, dx, g, pi, act_group_stride, w_group_stride, ng, smem);
+}
+template <int BN, int WRAPS>
+__global__ __launch_bounds__(256, (BN == 128 ? 3 : 4)) void conv_dgrad_parity_bf16_kernel(const float *__restrict__ dy,
+                                                                     const float *__restrict__ wgt, float *__restrict__ dx,
+                                                                     ConvGeom g, ParityInfo pi, size_t act_group_stride,
+                                                                     size_t w_group_stride, int ng)
+{
+    __shared__ __attribute__((aligned(16))) float smem[GemmCfg<BN, EngBF16>::LDS_FLOATS];
+    conv_dgrad_parity_body<EngBF16, BN, WRAPS>(dy, wgt, dx, g, pi, act_group_stride, w_group_stride, ng, smem);
+}
+
 // ------------------------------------------------------------------------------------------ wgrad
 // dw[k][kk] = sum_m dy[m][k] * xg[m][kk], kk = (r, s, c), reduction over the pixels m of one group.
 // Both operands are "M/N contiguous" in memory, so the LDS image is [pixel][row] and the MFMA operands
 // are read with ds_read_b64 as (row 2i, row 2i+1): tile t of a wave covers rows {2i + t}.
-constexpr int WG_BK = 16;          // pixels per step
+constexpr int WG_BK = 16;          // pixels per step (f32 engine; the bf16 engine takes 32)
 
 struct WgradGeom {
     int OH, OW;            // P, Q
@@ -429,17 +470,36 @@ struct WgradGeom {
 //   <128, 128> general;  <64, 256> when K <= 64 (refiner top level, logits convs) so that rows are not wasted.
 // MODE 0: scalar loads (C or K not a multiple of 4); 1: vector loads, pixel coordinates by division;
 //      2: vector loads, pixel coordinates walked incrementally (OW >= 16: at most one row wrap per step).
-template <int BMK, int BNC, int MODE>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy,
-                                                         float *__restrict__ out, WgradGeom g, int groups)
+//
+// bf16 engine (BF16 = true): 32 pixels per step; the tiles are rounded to bf16 on their way into LDS and kept
+// [pixel][row] with 2*rows + 64 bytes per pixel (64 mod 256: the four pixel rows of a transposed read fall on
+// disjoint bank quarters).  The MFMA needs 8 consecutive pixels of one row per lane, i.e. the transpose of the
+// image: ds_read_b64_tr_b16 delivers it (lane 4q+p of a 16-lane group addresses pixel p0+q, rows 4p..4p+3 and
+// lane i receives row i of the 4 pixels), two reads per 32x32x16 operand.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+template <int BMK, int BNC, bool BF16>
+struct WgradCfg {
+    static constexpr int BKP = BF16 ? 32 : WG_BK;                    // pixels per step
+    static constexpr int LDA = BF16 ? BMK / 2 + 16 : BMK + 4;        // row pitch in 4-byte units
+    static constexpr int LDB = BF16 ? BNC / 2 + 16 : BNC + 4;        // (f32: +4 keeps float4 stores aligned, shifts banks)
+    static constexpr int LDS_FLOATS = 2 * BKP * (LDA + LDB);
+};
+
+template <int BMK, int BNC, int MODE, bool BF16>
+__device__ __forceinline__ void conv_wgrad_body(const float *__restrict__ x, const float *__restrict__ dy,
+                                                float *__restrict__ out, const WgradGeom &g, int groups, float *smem)
 {
-    constexpr int LDA = BMK + 4, LDB = BNC + 4;          // +4 floats: keeps float4 stores aligned, shifts banks per row
-    constexpr int AP = BMK / 64, BP = BNC / 64;          // load passes per thread and step (16 pixels x BMK / BNC floats)
+    using WC = WgradCfg<BMK, BNC, BF16>;
+    constexpr int BKP = WC::BKP;
+    constexpr int LDA = WC::LDA, LDB = WC::LDB;
+    constexpr int AP = BMK * BKP / 1024, BP = BNC * BKP / 1024;   // load passes per thread and step (BKP pixels x BMK / BNC floats)
     constexpr int AQ = BMK / 4, BQ = BNC / 4;            // float4 quads per pixel row
     constexpr int WNW = BNC / 64;                        // waves along the column axis
-    __shared__ __attribute__((aligned(16))) float smem[2 * WG_BK * (LDA + LDB)];
-    float *At = smem;                                    // [2][WG_BK][LDA]  dy tile   (pixel, k)
-    float *Bt = smem + 2 * WG_BK * LDA;                  // [2][WG_BK][LDB]  x gather  (pixel, kk)
+    float *At = smem;                                    // [2][BKP][LDA]  dy tile   (pixel, k)
+    float *Bt = smem + 2 * BKP * LDA;                    // [2][BKP][LDB]  x gather  (pixel, kk)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WNW, wn = wave % WNW, li = lane & 31, lh = lane >> 5;
     const int tile = blockIdx.x;
@@ -516,22 +576,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
             ob[j] = ok ? (unsigned)(bbase[j] + tap_off) * 4u : OOB;
         }
     };
-    auto advance = [&]() {                               // all slots move on by WG_BK pixels
+    auto advance = [&]() {                               // all slots move on by BKP pixels
 #pragma unroll
-        for (int j = 0; j < AP; ++j) am[j] += WG_BK;
+        for (int j = 0; j < AP; ++j) am[j] += BKP;
 #pragma unroll
         for (int j = 0; j < BP; ++j) {
-            bm[j] += WG_BK;
-            if (MODE == 2) {                             // OW >= 16: at most one row wrap (and then maybe an image wrap)
-                bow[j] += WG_BK * g.sw;
-                bbase[j] += WG_BK * g.sw * g.IC;
-                const bool w1 = bow[j] >= g.OW * g.sw;
-                bow[j] -= w1 ? g.OW * g.sw : 0;
-                boh[j] += w1 ? g.sh : 0;
-                bbase[j] += w1 ? (g.sh * g.IW - g.OW * g.sw) * g.IC : 0;
-                const bool w2 = boh[j] >= g.OH * g.sh;
-                boh[j] -= w2 ? g.OH * g.sh : 0;
-                bbase[j] += w2 ? (g.IH - g.OH * g.sh) * g.IW * g.IC : 0;
+            bm[j] += BKP;
+            if (MODE == 2) {                             // OW >= 16: at most BKP/16 row wraps (each maybe an image wrap)
+                bow[j] += BKP * g.sw;
+                bbase[j] += BKP * g.sw * g.IC;
+#pragma unroll
+                for (int i = 0; i < BKP / 16; ++i) {
+                    const bool w1 = bow[j] >= g.OW * g.sw;
+                    bow[j] -= w1 ? g.OW * g.sw : 0;
+                    boh[j] += w1 ? g.sh : 0;
+                    bbase[j] += w1 ? (g.sh * g.IW - g.OW * g.sw) * g.IC : 0;
+                    const bool w2 = boh[j] >= g.OH * g.sh;
+                    boh[j] -= w2 ? g.OH * g.sh : 0;
+                    bbase[j] += w2 ? (g.IH - g.OH * g.sh) * g.IW * g.IC : 0;
+                }
             }
         }
     };
@@ -573,12 +636,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
         }
     };
     auto sstore = [&](int buf) {
+        if constexpr (BF16) {
 #pragma unroll
-        for (int j = 0; j < AP; ++j)
-            *reinterpret_cast<float4 *>(&At[(buf * WG_BK + apix + (256 / AQ) * j) * LDA + 4 * aq]) = ra[j];
+            for (int j = 0; j < AP; ++j)
+                *reinterpret_cast<uint2 *>(&At[(buf * BKP + apix + (256 / AQ) * j) * LDA + 2 * aq]) = pack_bf16x4(ra[j]);
 #pragma unroll
-        for (int j = 0; j < BP; ++j)
-            *reinterpret_cast<float4 *>(&Bt[(buf * WG_BK + bpix + (256 / BQ) * j) * LDB + 4 * bq]) = rb[j];
+            for (int j = 0; j < BP; ++j)
+                *reinterpret_cast<uint2 *>(&Bt[(buf * BKP + bpix + (256 / BQ) * j) * LDB + 2 * bq]) = pack_bf16x4(rb[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < AP; ++j)
+                *reinterpret_cast<float4 *>(&At[(buf * BKP + apix + (256 / AQ) * j) * LDA + 4 * aq]) = ra[j];
+#pragma unroll
+            for (int j = 0; j < BP; ++j)
+                *reinterpret_cast<float4 *>(&Bt[(buf * BKP + bpix + (256 / BQ) * j) * LDB + 4 * bq]) = rb[j];
+        }
     };
 
 #pragma unroll
@@ -588,7 +660,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
         bm[j] = m_begin + bpix + (256 / BQ) * j;
         decode_b(j);
     }
-    const int nsteps = (m_end - m_begin + WG_BK - 1) / WG_BK;
+    const int nsteps = (m_end - m_begin + BKP - 1) / BKP;
+    // transposed-read lane constants (bf16): 16-lane group G -> rows 16*(G&1).., pixel half h = G>>1
+    const int trq = (lane & 15) >> 2, trp = lane & 3, trg = (lane >> 4) & 1;
     offsets();
     fetch();
     sstore(0);
@@ -599,16 +673,40 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
         const int cur = st & 1;
         fetch();
         __builtin_amdgcn_sched_barrier(0);
-        const float *Ac = At + cur * WG_BK * LDA + wm * 64 + 2 * li;
-        const float *Bc = Bt + cur * WG_BK * LDB + wn * 64 + 2 * li;
+        if constexpr (BF16) {
+            // 4-byte units: pixel (8h + q) of the step, rows wm*64 + 16*trg + 4p  (2 bf16 per unit)
+            const float *Ac = At + (cur * BKP + 8 * lh + trq) * LDA + wm * 32 + 8 * trg + 2 * trp;
+            const float *Bc = Bt + (cur * BKP + 8 * lh + trq) * LDB + wn * 32 + 8 * trg + 2 * trp;
 #pragma unroll
-        for (int s = 0; s < WG_BK / 2; ++s) {
-            const float2 a = *reinterpret_cast<const float2 *>(Ac + (2 * s + lh) * LDA);
-            const float2 b = *reinterpret_cast<const float2 *>(Bc + (2 * s + lh) * LDB);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.y, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[1][1], 0, 0, 0);
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 a[2], b[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(Ac + 16 * s * LDA + 16 * t));
+                    const s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(Ac + (16 * s + 4) * LDA + 16 * t));
+                    a[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    const s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(Bc + 16 * s * LDB + 16 * t));
+                    const s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(Bc + (16 * s + 4) * LDB + 16 * t));
+                    b[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+            }
+        } else {
+            const float *Ac = At + cur * BKP * LDA + wm * 64 + 2 * li;
+            const float *Bc = Bt + cur * BKP * LDB + wn * 64 + 2 * li;
+#pragma unroll
+            for (int s = 0; s < BKP / 2; ++s) {
+                const float2 a = *reinterpret_cast<const float2 *>(Ac + (2 * s + lh) * LDA);
+                const float2 b = *reinterpret_cast<const float2 *>(Bc + (2 * s + lh) * LDB);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.y, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[1][1], 0, 0, 0);
+            }
         }
         advance();
         offsets();
@@ -623,16 +721,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {
-            const int colp = c0 + wn * 64 + 2 * li + tn;          // plain (tap, channel) index
+            const int colp = c0 + wn * 64 + (BF16 ? 32 * tn + li : 2 * li + tn);   // plain (tap, channel) index
             if (colp >= g.RSC) continue;
             const int tap = colp / g.IC;
             const int col = kidx(tap, colp - tap * g.IC, g.R * g.S, chan_block(g.IC));
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = k0 + wm * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * lh) + tm;
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int row = k0 + wm * 64 + (BF16 ? 32 * tm + rr : 2 * rr + tm);
                 if (row < g.K) o[(size_t)row * g.RSC + col] = acc[tm][tn][r];
             }
         }
+}
+
+template <int BMK, int BNC, int MODE>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                         float *__restrict__ out, WgradGeom g, int groups)
+{
+    __shared__ __attribute__((aligned(16))) float smem[WgradCfg<BMK, BNC, false>::LDS_FLOATS];
+    conv_wgrad_body<BMK, BNC, MODE, false>(x, dy, out, g, groups, smem);
+}
+template <int BMK, int BNC, int MODE>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                              float *__restrict__ out, WgradGeom g, int groups)
+{
+    __shared__ __attribute__((aligned(16))) float smem[WgradCfg<BMK, BNC, true>::LDS_FLOATS];
+    conv_wgrad_body<BMK, BNC, MODE, true>(x, dy, out, g, groups, smem);
 }
 
 __global__ void slab_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ out, size_t n, int splits)
@@ -699,6 +813,7 @@ static int check_desc(const mqConvDesc *d, const char *who)
 template <bool DGRAD>
 static int launch_nt(const mqConvDesc *d, const float *act, const float *w, const float *bias, float *out, hipStream_t st)
 {
+    const bool want_bf16 = d->precision == MQ_PRECISION_BF16;
     ConvGeom g;
     const int ng = d->N / d->groups;
     if (!DGRAD) {
@@ -735,7 +850,8 @@ static int launch_nt(const mqConvDesc *d, const float *act, const float *w, cons
         }
     }
     const int cb = chan_block(g.IC);
-    const bool wide = cb >= GEMM_BK;
+    const bool wide = cb >= 16;
+    const bool bf16 = want_bf16 && vec;                // scalar-path layers (C = 1, K = 1 ...) are tiny: they stay f32
     g.nMt = (int)cdiv(g.Mtot, GEMM_BM);
     g.nNt = (int)cdiv(g.Ncols, BN);
     if (parity) {
@@ -771,10 +887,16 @@ static int launch_nt(const mqConvDesc *d, const float *act, const float *w, cons
         pi.tile0[pi.ncls] = t0;
         dim3 pgrid(t0 * g.nNt, d->groups);
 #define MQ_PAR(BN_, W_) hipLaunchKernelGGL((conv_dgrad_parity_kernel<BN_, W_>), pgrid, dim3(256), 0, st, act, w, out, g, pi, act_gs, w_gs, ng)
-        if (BN == 128) { if (wide) MQ_PAR(128, 1); else MQ_PAR(128, 4); }
+#define MQ_PARH(BN_, W_) hipLaunchKernelGGL((conv_dgrad_parity_bf16_kernel<BN_, W_>), pgrid, dim3(256), 0, st, act, w, out, g, pi, act_gs, w_gs, ng)
+        if (bf16) {
+            if (BN == 128) { if (wide) MQ_PARH(128, 2); else MQ_PARH(128, 8); }
+            else if (BN == 64) { if (wide) MQ_PARH(64, 2); else MQ_PARH(64, 8); }
+            else { if (wide) MQ_PARH(32, 2); else MQ_PARH(32, 8); }
+        } else if (BN == 128) { if (wide) MQ_PAR(128, 1); else MQ_PAR(128, 4); }
         else if (BN == 64) { if (wide) MQ_PAR(64, 1); else MQ_PAR(64, 4); }
         else { if (wide) MQ_PAR(32, 1); else MQ_PAR(32, 4); }
 #undef MQ_PAR
+#undef MQ_PARH
         MQ_LAUNCH_CHECK("mq_conv_dgrad(parity)");
         return 0;
     }
@@ -786,18 +908,24 @@ static int launch_nt(const mqConvDesc *d, const float *act, const float *w, cons
     const int mode = vec ? (wide ? 2 : 1) : 0;
     dim3 grid(g.nMt * g.nNt, d->groups), block(256);
 #define MQ_NT(BN_, M_) hipLaunchKernelGGL((conv_nt_kernel<BN_, DGRAD, M_>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs)
-#define MQ_NT3(BN_) do { if (mode == 2) MQ_NT(BN_, 2); else if (mode == 1) MQ_NT(BN_, 1); else MQ_NT(BN_, 0); } while (0)
+#define MQ_NTH(BN_, M_) hipLaunchKernelGGL((conv_nt_bf16_kernel<BN_, DGRAD, M_>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs)
+#define MQ_NT3(BN_) do { if (bf16) { if (mode == 2) MQ_NTH(BN_, 2); else MQ_NTH(BN_, 1); } \
+                         else if (mode == 2) MQ_NT(BN_, 2); else if (mode == 1) MQ_NT(BN_, 1); else MQ_NT(BN_, 0); } while (0)
     if (BN == 128) MQ_NT3(128);
     else if (BN == 64) MQ_NT3(64);
     else MQ_NT3(32);
 #undef MQ_NT3
+#undef MQ_NTH
 #undef MQ_NT
     MQ_LAUNCH_CHECK(DGRAD ? "mq_conv_dgrad" : "mq_conv_fprop");
     return 0;
 }
 
+static bool wgrad_vec_shape(const mqConvDesc *d) { return d->C % 4 == 0 && d->K % 4 == 0; }
+
 static void wgrad_plan(const mqConvDesc *d, WgradGeom &g)
 {
+    const int bk = (d->precision == MQ_PRECISION_BF16 && wgrad_vec_shape(d)) ? 32 : WG_BK;
     const int ng = d->N / d->groups;
     g.OH = d->P; g.OW = d->Q; g.IH = d->H; g.IW = d->W; g.IC = d->C;
     g.R = d->R; g.S = d->S; g.sh = d->stride_h; g.sw = d->stride_w; g.ph = d->pad_h; g.pw = d->pad_w;
@@ -812,13 +940,13 @@ static void wgrad_plan(const mqConvDesc *d, WgradGeom &g)
     // split the pixel reduction so that the grid fills the resident block slots (256 CUs x 4 or 3 blocks)
     // exactly once when the tile count allows it, each split keeping >= 32 K-steps
     const int64_t tiles = (int64_t)g.nKt * g.nCt * d->groups;
-    const int64_t slots = 256 * (g.bmk == 64 ? 3 : 4);
+    const int64_t slots = 256 * ((g.bmk == 64 ? 3 : 4) - (bk == 32 ? 1 : 0));     // resident blocks per CU (registers / LDS)
     int64_t splits = tiles >= slots ? 1 : slots / tiles;
-    const int64_t max_splits = cdiv(g.Mtot, WG_BK * 32);
+    const int64_t max_splits = cdiv(g.Mtot, bk * 32);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     if (splits > 512) splits = 512;
-    int64_t chunk = cdiv(cdiv(g.Mtot, splits), WG_BK) * WG_BK;
+    int64_t chunk = cdiv(cdiv(g.Mtot, splits), bk) * bk;
     g.chunk = (int)chunk;
     g.splits = (int)cdiv(g.Mtot, chunk);
 }
@@ -865,16 +993,21 @@ extern "C" int mq_conv_wgrad(const mqConvDesc *d, const float *x, const float *d
     float *target = g.splits > 1 ? reinterpret_cast<float *>(workspace) : dw;
     // 32-bit offsets inside one split: its images must span < 2 GB of x and of dy
     const size_t split_imgs = (size_t)cdiv(g.chunk, (int64_t)d->P * d->Q) + 2;
-    const bool vec = (d->C % 4 == 0) && (d->K % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) &&
+    const bool vec = wgrad_vec_shape(d) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) &&
                      split_imgs * d->P * d->Q * g.K * sizeof(float) < 0x7FFFFFF0ull &&
                      split_imgs * d->H * d->W * d->C * sizeof(float) < 0x7FFFFFF0ull;
     dim3 grid(g.nKt * g.nCt, d->groups, g.splits), block(256);
     const int mode = vec ? (d->Q >= WG_BK ? 2 : 1) : 0;
+    const bool bf16 = d->precision == MQ_PRECISION_BF16 && wgrad_vec_shape(d);
+    MQ_REQUIRE(!bf16 || vec, "mq_conv_wgrad: bf16 engine needs 16-byte aligned tensors below the 2 GB-per-split span");
 #define MQ_WG(A_, B_, M_) hipLaunchKernelGGL((conv_wgrad_kernel<A_, B_, M_>), grid, block, 0, S(stream), x, dy, target, g, d->groups)
-#define MQ_WG3(A_, B_) do { if (mode == 2) MQ_WG(A_, B_, 2); else if (mode == 1) MQ_WG(A_, B_, 1); else MQ_WG(A_, B_, 0); } while (0)
+#define MQ_WGH(A_, B_, M_) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<A_, B_, M_>), grid, block, 0, S(stream), x, dy, target, g, d->groups)
+#define MQ_WG3(A_, B_) do { if (bf16) { if (mode == 2) MQ_WGH(A_, B_, 2); else MQ_WGH(A_, B_, 1); } \
+                            else if (mode == 2) MQ_WG(A_, B_, 2); else if (mode == 1) MQ_WG(A_, B_, 1); else MQ_WG(A_, B_, 0); } while (0)
     if (g.bmk == 64) MQ_WG3(64, 256);
     else MQ_WG3(128, 128);
 #undef MQ_WG3
+#undef MQ_WGH
 #undef MQ_WG
     MQ_LAUNCH_CHECK("mq_conv_wgrad");
     if (g.splits > 1) {

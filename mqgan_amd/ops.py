@@ -46,14 +46,46 @@ def next_seed() -> int:
 
 
 # ----------------------------------------------------------------------------- convolution
-def conv_desc(N, H, W, Cin, K, R, S, stride=(1, 1), pad=(0, 0), dil=(1, 1), groups=1, out_hw=None) -> ConvDesc:
+PRECISIONS = {"f32": 0, "bf16": 1}
+_conv_precision = 0
+
+
+def set_conv_precision(name: str) -> str:
+    """Matrix engine of every convolution / linear layer created from now on: "f32" (exact products, the parity
+    path) or "bf16" (operands rounded to bf16 inside the kernel, f32 accumulate and f32 tensors - the counterpart
+    of the reference's autocast region, train.py:330-333).  Returns the previous setting."""
+    global _conv_precision
+    prev = [k for k, v in PRECISIONS.items() if v == _conv_precision][0]
+    _conv_precision = PRECISIONS[name]
+    return prev
+
+
+class conv_precision:
+    """``with ops.conv_precision("bf16"): ...`` - scoped set_conv_precision (descriptors capture the setting when they
+    are built, so the backward pass of a layer runs on the engine its forward pass used)."""
+
+    def __init__(self, name: str):
+        self.name = name
+
+    def __enter__(self):
+        self.prev = set_conv_precision(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        set_conv_precision(self.prev)
+        return False
+
+
+def conv_desc(N, H, W, Cin, K, R, S, stride=(1, 1), pad=(0, 0), dil=(1, 1), groups=1, out_hw=None,
+              precision=None) -> ConvDesc:
     if out_hw is None:
         P = (H + 2 * pad[0] - dil[0] * (R - 1) - 1) // stride[0] + 1
         Q = (W + 2 * pad[1] - dil[1] * (S - 1) - 1) // stride[1] + 1
     else:
         P, Q = out_hw
     return ConvDesc(N=N, H=H, W=W, C=Cin, K=K, R=R, S=S, P=P, Q=Q, stride_h=stride[0], stride_w=stride[1], pad_h=pad[0],
-                    pad_w=pad[1], dil_h=dil[0], dil_w=dil[1], groups=groups)
+                    pad_w=pad[1], dil_h=dil[0], dil_w=dil[1], groups=groups,
+                    precision=_conv_precision if precision is None else PRECISIONS.get(precision, precision))
 
 
 def _desc_key(d: ConvDesc):
@@ -103,19 +135,22 @@ def _timed(tag, flops, fn, detail=None):
 
 def _conv_tag(kind, d: ConvDesc):
     """Name of the kernel instantiation the C side picks (igemm.hip: launch_nt / mq_conv_wgrad)."""
+    want_h = d.precision == PRECISIONS["bf16"]
     if kind == "wgrad":
         vec = d.C % 4 == 0 and d.K % 4 == 0
         mode = (2 if d.Q >= 16 else 1) if vec else 0
-        return f"conv_wgrad_kernel<{'64, 256' if d.K <= 64 else '128, 128'}, {mode}>"
+        return f"conv_wgrad_{'bf16_' if want_h and vec else ''}kernel<{'64, 256' if d.K <= 64 else '128, 128'}, {mode}>"
     ncols, ic = (d.K, d.C) if kind == "fprop" else (d.C, d.K)
     bn = min((128, 64, 32), key=lambda b: (-(-ncols // b) * b / {128: 1.0, 64: 0.9, 32: 0.75}[b], -b))
     strided = d.stride_h > 1 or d.stride_w > 1
+    h = want_h and ic % 4 == 0
     if kind == "dgrad" and strided:
         if ic % 4 == 0 and d.stride_h <= 2 and d.stride_w <= 2:
-            return f"conv_dgrad_parity_kernel<{bn}, {1 if ic % 16 == 0 else 4}>"
+            wraps = (2 if ic % 16 == 0 else 8) if h else (1 if ic % 16 == 0 else 4)
+            return f"conv_dgrad_parity_{'bf16_' if h else ''}kernel<{bn}, {wraps}>"
         return f"conv_nt_kernel<{bn}, true, 0>"
     mode = 2 if ic % 16 == 0 else (1 if ic % 4 == 0 else 0)
-    return f"conv_nt_kernel<{bn}, {str(kind == 'dgrad').lower()}, {mode}>"
+    return f"conv_nt_{'bf16_' if h else ''}kernel<{bn}, {str(kind == 'dgrad').lower()}, {mode}>"
 
 
 def _conv_flops(d: ConvDesc):

@@ -185,7 +185,14 @@ class Trainer:
         self.reducer_g = GradReducer(self.arena_g)
         self.reducer_d = GradReducer(self.arena_d)
         self.gan_loss = LSGANLoss().to(self.device)      # ONE instance for all nine discriminators (train.py:216)
-        self.use_bf16 = False                            # fp32 path (BASELINE config 2); bf16 convs are a later round
+        # The reference picks bf16 autocast whenever the GPU supports it (train.py:220, 523); here the engine is an
+        # explicit knob: training.precision = "fp32" (default; the 1e-4 parity path, BASELINE config 2) or "bf16"
+        # (bf16 MFMA operands in every conv / linear, f32 accumulation, f32 tensors; BASELINE config 3).
+        prec = str(config["training"].get("precision", "fp32")).lower()
+        if prec not in ("fp32", "f32", "bf16"):
+            raise ValueError(f"training.precision must be fp32 or bf16, got {prec!r}")
+        self.use_bf16 = prec == "bf16"
+        self.conv_precision = "bf16" if self.use_bf16 else "f32"
         self.log_fn = log_fn
         self.global_step = 0
         self._init_checkpoint_handling()
@@ -397,11 +404,12 @@ class Trainer:
     # -- one optimisation step on a device batch (train.py:516-537) --------------------------------
     def train_step(self, real, lens):
         """real (B, T, mel) fp32 and lens (B,) int32, both on the device -> dict of device scalars."""
-        recon_pre, recon_post = self.generator(real, lens)
-        out = {"loss_d": torch.zeros((), device=self.device)}
-        if self.epoch >= self.config["training"]["discriminator_train_start_epoch"]:
-            out["loss_d"] = self._train_discriminator(real, recon_post, lens)
-        out.update(self._train_generator(real, recon_pre, recon_post, lens))
+        with ops.conv_precision(self.conv_precision):
+            recon_pre, recon_post = self.generator(real, lens)
+            out = {"loss_d": torch.zeros((), device=self.device)}
+            if self.epoch >= self.config["training"]["discriminator_train_start_epoch"]:
+                out["loss_d"] = self._train_discriminator(real, recon_post, lens)
+            out.update(self._train_generator(real, recon_pre, recon_post, lens))
         out["learning_rate"] = self.scheduler_g.get_last_lr()[0]
         self.global_step += 1
         return out

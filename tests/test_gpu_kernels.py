@@ -174,17 +174,21 @@ def _torch_conv(x, w, b, c):
     return torch.cat(outs, 0).permute(0, 2, 3, 1)
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
 @pytest.mark.parametrize("c", CONV_CASES, ids=lambda c: "N{N}H{H}W{W}C{C}K{K}R{R}S{S}".format(**c) + f"g{c.get('groups', 1)}")
-def test_conv_fprop_dgrad_wgrad(env, c):
+def test_conv_fprop_dgrad_wgrad(env, c, precision):
+    """precision="bf16": the operands are drawn bf16-representable, so rounding them inside the kernel is the
+    identity and the bf16 MFMA engine (exact products, f32 accumulation) must meet the same bound as the f32 one."""
     ops = env
     torch.manual_seed(0)
     G = c.get("groups", 1)
-    x = torch.randn(c["N"], c["H"], c["W"], c["C"], dtype=torch.float64)
-    w = torch.randn(G * c["K"], c["C"], c["R"], c["S"], dtype=torch.float64) * 0.2
+    rnd = (lambda v: v.bfloat16().double()) if precision == "bf16" else (lambda v: v)
+    x = rnd(torch.randn(c["N"], c["H"], c["W"], c["C"], dtype=torch.float64))
+    w = rnd(torch.randn(G * c["K"], c["C"], c["R"], c["S"], dtype=torch.float64) * 0.2)
     b = torch.randn(G * c["K"], dtype=torch.float64)
     x.requires_grad_(True); w.requires_grad_(True); b.requires_grad_(True)
     y_ref = _torch_conv(x, w, b, c)
-    r = torch.randn_like(y_ref)
+    r = rnd(torch.randn_like(y_ref))
     (y_ref * r).sum().backward()
 
     xd = x.detach().float().to(DEV).requires_grad_(True)
@@ -196,7 +200,8 @@ def test_conv_fprop_dgrad_wgrad(env, c):
         w_krsc.append(a); w_crsk.append(bb)
     wk, wc = torch.cat(w_krsc, 0), torch.cat(w_crsk, 0)
     desc = ops.conv_desc(c["N"], c["H"], c["W"], c["C"], c["K"], c["R"], c["S"], stride=c.get("stride", (1, 1)),
-                         pad=c.get("pad", (0, 0)), dil=c.get("dil", (1, 1)), groups=G, out_hw=c.get("out_hw"))
+                         pad=c.get("pad", (0, 0)), dil=c.get("dil", (1, 1)), groups=G, out_hw=c.get("out_hw"),
+                         precision=precision)
     y = ops.conv(xd, wk, wc, bd, desc)
     assert tuple(y.shape) == tuple(y_ref.shape)
     assert_rel(y, y_ref, 2e-5, "fprop")
@@ -206,18 +211,20 @@ def test_conv_fprop_dgrad_wgrad(env, c):
     assert_rel(bd.grad, b.grad, 2e-5, "bias grad")
 
 
-def test_conv_large_split_k_and_tiles(env):
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_conv_large_split_k_and_tiles(env, precision):
     """A refiner-sized layer: many M tiles, split-K wgrad with the slab reduction."""
     ops = env
     torch.manual_seed(1)
     N, H, W, Cc, K = 2, 256, 90, 64, 128
-    x = torch.randn(N, H, W, Cc, device=DEV, requires_grad=True)
-    w = (torch.randn(K, Cc, 3, 3, device=DEV) * 0.05).requires_grad_(True)
+    rnd = (lambda v: v.bfloat16().float()) if precision == "bf16" else (lambda v: v)
+    x = rnd(torch.randn(N, H, W, Cc, device=DEV)).requires_grad_(True)
+    w = rnd(torch.randn(K, Cc, 3, 3, device=DEV) * 0.05).requires_grad_(True)
     wk, wc = ops.weight_prep(w, None, True)
-    desc = ops.conv_desc(N, H, W, Cc, K, 3, 3, pad=(1, 1))
+    desc = ops.conv_desc(N, H, W, Cc, K, 3, 3, pad=(1, 1), precision=precision)
     assert ops.L().mq_conv_wgrad_workspace(desc) > 0
     y = ops.conv(x, wk, wc, None, desc)
-    r = torch.randn_like(y)
+    r = rnd(torch.randn_like(y))
     (y * r).sum().backward()
     xr = x.detach().cpu().double().requires_grad_(True)
     wr = w.detach().cpu().double().requires_grad_(True)

@@ -115,6 +115,35 @@ def test_train_mode_step_runs_and_is_finite():
     assert abs(float(u.norm()) - 1.0) < 1e-4
 
 
+def test_bf16_conv_engine_step_tracks_fp32():
+    """training.precision = bf16 (bf16 MFMA operands, f32 accumulate / tensors; BASELINE config 3) is pinned against
+    the build's own fp32 path: same weights and batch, every loss within 2 % and the updated generator within
+    bf16 rounding of the fp32 one.  (Stated tolerance: 2e-2 relative on losses, operands carry 8 mantissa bits.)"""
+    from mqgan_amd.train import Trainer
+    g = load_golden("g7_trainstep.npz")
+    outs, params, norms = {}, {}, {}
+    for prec in ("fp32", "bf16"):
+        cfg = {"model": TINY_CFG["model"], "training": dict(TINY_CFG["training"], use_fm_loss=False, pretrained=None, precision=prec)}
+        tr = Trainer(cfg, device=DEV, build_data=False)
+        tr.generator.load_state_dict(npz_state_dict(g, "g0/"), strict=True)
+        tr.patch_discriminator.load_state_dict(npz_state_dict(g, "p0/"), strict=True)
+        tr.multibin_discriminator.load_state_dict(npz_state_dict(g, "m0/"), strict=True)
+        tr.arena_g.rebind()
+        tr.arena_d.rebind()
+        tr.generator.eval()
+        tr.epoch = 1
+        assert tr.use_bf16 == (prec == "bf16")
+        outs[prec] = {k: float(v) for k, v in tr.train_step(t(g["s0/x"]), t(g["lens"])).items()}
+        norms[prec] = (float(tr.optimizer_g.grad_norm()), float(tr.optimizer_d.grad_norm()))
+        params[prec] = tr.arena_g.flat_param.clone()
+    for k in ("loss_d", "loss_g_total", "loss_recon_pre", "loss_recon_post", "loss_gan"):
+        np.testing.assert_allclose(outs["bf16"][k], outs["fp32"][k], rtol=2e-2, atol=1e-4, err_msg=k)
+        assert outs["bf16"][k] != outs["fp32"][k] or k == "loss_d", f"{k}: bf16 engine did not run"
+    np.testing.assert_allclose(norms["bf16"], norms["fp32"], rtol=5e-2)
+    # one Adam step moves every weight by about lr; the two runs agree to a fraction of that step
+    assert float((params["bf16"] - params["fp32"]).abs().max()) < 5e-4
+
+
 def test_trainer_epoch_on_npy_tree_with_bad_files(tmp_path):
     """Trainer.train() on a small .npy tree: ragged lengths, per-batch crop length from a list, an unreadable
     file and a wrong-rank file (dropped by the collate, train.py:110-118), prefetching loader, checkpoint

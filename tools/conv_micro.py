@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Single-shape conv micro-benchmark (fprop / dgrad / wgrad) for profiling one kernel in isolation.
-usage: conv_micro.py <shape-name> [iters]"""
+usage: conv_micro.py <shape-name> [iters] [fdw] [f32|bf16]"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,6 +16,7 @@ SHAPES = {
 name = sys.argv[1] if len(sys.argv) > 1 else "mid"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 which = sys.argv[3] if len(sys.argv) > 3 else "fdw"
+prec = sys.argv[4] if len(sys.argv) > 4 else "f32"
 c = SHAPES[name]
 dev = "cuda"
 torch.manual_seed(0)
@@ -27,7 +28,8 @@ for g in range(G):
     a, b = ops.weight_prep(w[g * c["K"]:(g + 1) * c["K"]].contiguous(), None, True)
     wk.append(a); wc.append(b)
 wk, wc = torch.cat(wk), torch.cat(wc)
-d = ops.conv_desc(c["N"], c["H"], c["W"], c["C"], c["K"], c["R"], c["S"], stride=c["stride"], pad=c["pad"], groups=G)
+d = ops.conv_desc(c["N"], c["H"], c["W"], c["C"], c["K"], c["R"], c["S"], stride=c["stride"], pad=c["pad"], groups=G,
+                  precision=prec)
 y = ops.conv(x, wk, wc, None, d)
 dy = torch.randn_like(y)
 flops = ops._conv_flops(d)
@@ -47,4 +49,4 @@ for k in which:
         fn()
     e.record(); torch.cuda.synchronize()
     ms = s.elapsed_time(e) / iters
-    print(f"{name} {k}: {ms:.3f} ms  {flops / ms / 1e9:.1f} TFLOP/s")
+    print(f"{name} {prec} {k}: {ms:.3f} ms  {flops / ms / 1e9:.1f} TFLOP/s")
