@@ -110,6 +110,11 @@ int mq_conv_dgrad(const mqConvDesc *desc_host, const float *dy, const float *w_c
 size_t mq_conv_wgrad_workspace(const mqConvDesc *desc_host);
 int mq_conv_wgrad(const mqConvDesc *desc_host, const float *x, const float *dy, float *dw_krsc, void *workspace,
                   size_t workspace_bytes, mqStream stream);
+/* Same, plus dbias (groups, K) = column sums of dy, taken from the dy tiles the weight-gradient GEMM streams anyway
+ * (no second pass over dy).  workspace: mq_conv_wgrad_bias_workspace() bytes, never 0. */
+size_t mq_conv_wgrad_bias_workspace(const mqConvDesc *desc_host);
+int mq_conv_wgrad_bias(const mqConvDesc *desc_host, const float *x, const float *dy, float *dw_krsc, float *dbias,
+                       void *workspace, size_t workspace_bytes, mqStream stream);
 /* out[c] = sum_r x[r][c]  (bias gradients; deterministic two-stage).  workspace: 1024*cols floats. */
 int mq_colsum(const float *x, int64_t rows, int cols, float *out, float *workspace, mqStream stream);
 

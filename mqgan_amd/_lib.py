@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmqgan_hip.so")
+# MQGAN_HIP_LIB: load another build of the same ABI (kernel experiments); the default is the in-tree library
+LIB_PATH = os.environ.get("MQGAN_HIP_LIB") or os.path.join(_HERE, "libmqgan_hip.so")
 _lib = None
 
 
@@ -55,6 +56,8 @@ SIGNATURES = {
     "mq_conv_dgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
     "mq_conv_wgrad_workspace": (_Z, [C.POINTER(ConvDesc)]),
     "mq_conv_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _Z, _P]),
+    "mq_conv_wgrad_bias_workspace": (_Z, [C.POINTER(ConvDesc)]),
+    "mq_conv_wgrad_bias": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _Z, _P]),
     "mq_colsum": (_I, [_P, _L, _I, _P, _P, _P]),
     "mq_weight_prep": (_I, [_I, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "mq_weight_prep_bwd": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),

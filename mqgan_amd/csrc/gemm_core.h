@@ -59,10 +59,19 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned b
     return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
 }
 
+// KORDER: (k0,k2,k1,k3) image = natural accumulation order (the nearest-neighbour search needs it, see the header
+// comment).  Otherwise the quad is stored as loaded - no register shuffles - and every accumulator sums k in the
+// order 4q, 4q+2, 4q+1, 4q+3 (fine for the convolutions, whose parity bound is 1e-4, not bit-exactness).
+template <bool KORDER>
 __device__ __forceinline__ void lds_store_k4(float *dst, float4 v)
 {
-    *reinterpret_cast<float2 *>(dst) = make_float2(v.x, v.z);
-    *reinterpret_cast<float2 *>(dst + 2) = make_float2(v.y, v.w);
+    if (KORDER) {
+        *reinterpret_cast<float2 *>(dst) = make_float2(v.x, v.z);
+        *reinterpret_cast<float2 *>(dst + 2) = make_float2(v.y, v.w);
+    } else {
+        *reinterpret_cast<float2 *>(dst) = make_float2(v.x, v.y);
+        *reinterpret_cast<float2 *>(dst + 2) = make_float2(v.z, v.w);
+    }
 }
 
 // ALoad / BLoad: .stage(k0) once per K-step, in increasing k0 (0, BK, 2BK, ...): computes and keeps the
@@ -76,7 +85,7 @@ __device__ __forceinline__ void lds_store_k4(float *dst, float4 v)
 //   3. wait for the loads, write them to the other LDS buffer, barrier.
 // Global-load latency is covered by phase 2; there are no branches in the loop (past the end of K the
 // loaders' buffer descriptors return zeros without touching memory).
-template <int BN, class ALoad, class BLoad>
+template <int BN, bool KORDER = true, class ALoad, class BLoad>
 __device__ __forceinline__ void nt_gemm_mainloop(ALoad &la, BLoad &lb, int nk, float *smem,
                                                  f32x16 (&acc)[GemmCfg<BN>::TM][GemmCfg<BN>::TN])
 {
@@ -98,10 +107,10 @@ __device__ __forceinline__ void nt_gemm_mainloop(ALoad &la, BLoad &lb, int nk, f
 #pragma unroll
     for (int j = 0; j < Cfg::B_SLOTS; ++j) rb[j] = b_active ? lb.fetch(j) : make_float4(0, 0, 0, 0);
 #pragma unroll
-    for (int j = 0; j < Cfg::A_SLOTS; ++j) lds_store_k4(&As[(ld_row + 64 * j) * GEMM_LD + 4 * ld_kq], ra[j]);
+    for (int j = 0; j < Cfg::A_SLOTS; ++j) lds_store_k4<KORDER>(&As[(ld_row + 64 * j) * GEMM_LD + 4 * ld_kq], ra[j]);
     if (b_active) {
 #pragma unroll
-        for (int j = 0; j < Cfg::B_SLOTS; ++j) lds_store_k4(&Bs[(ld_row + 64 * j) * GEMM_LD + 4 * ld_kq], rb[j]);
+        for (int j = 0; j < Cfg::B_SLOTS; ++j) lds_store_k4<KORDER>(&Bs[(ld_row + 64 * j) * GEMM_LD + 4 * ld_kq], rb[j]);
     }
     la.stage(GEMM_BK);
     lb.stage(GEMM_BK);
@@ -144,11 +153,11 @@ __device__ __forceinline__ void nt_gemm_mainloop(ALoad &la, BLoad &lb, int nk, f
             float *An = As + (cur ^ 1) * GEMM_BM * GEMM_LD;
             float *Bn = Bs + (cur ^ 1) * BN * GEMM_LD;
 #pragma unroll
-            for (int j = 0; j < Cfg::A_SLOTS; ++j) lds_store_k4(&An[(ld_row + 64 * j) * GEMM_LD + 4 * ld_kq], ra[j]);
+            for (int j = 0; j < Cfg::A_SLOTS; ++j) lds_store_k4<KORDER>(&An[(ld_row + 64 * j) * GEMM_LD + 4 * ld_kq], ra[j]);
             if (b_active) {
 #pragma unroll
                 for (int j = 0; j < Cfg::B_SLOTS; ++j)
-                    lds_store_k4(&Bn[(ld_row + 64 * j) * GEMM_LD + 4 * ld_kq], rb[j]);
+                    lds_store_k4<KORDER>(&Bn[(ld_row + 64 * j) * GEMM_LD + 4 * ld_kq], rb[j]);
             }
         }
         __syncthreads();
@@ -242,7 +251,7 @@ __device__ __forceinline__ void nt_gemm_run(ALoad &la, BLoad &lb, int nk, float 
                                             f32x16 (&acc)[GemmCfg<BN, E>::TM][GemmCfg<BN, E>::TN])
 {
     if constexpr (E::BF16) nt_gemm_mainloop_bf16<BN>(la, lb, nk, smem, acc);
-    else nt_gemm_mainloop<BN>(la, lb, nk, smem, acc);
+    else nt_gemm_mainloop<BN, false>(la, lb, nk, smem, acc);
 }
 
 // row / column of accumulator register r of tile (tm, tn) inside the block tile

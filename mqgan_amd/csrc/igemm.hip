@@ -36,7 +36,10 @@ struct WalkGeom {
 
 // WRAPS = carries per K-step: ceil(BK / CB) for the smallest CB served (f32: 1 when CB >= 16, else 4;
 // bf16: 2 when CB >= 16, else 8)
-template <int WRAPS, class E = EngF32>
+// UNIFORM (CB == BK == 16, i.e. C % 16 == 0 on the f32 engine): every K-step is exactly one (chunk, tap) for the
+// whole block and only the channel quad differs per thread, so the position and its offsets are wave-uniform -
+// the compiler keeps them in SGPRs and advances them on the scalar unit; per slot only the bounds test remains.
+template <int WRAPS, class E = EngF32, bool UNIFORM = false>
 struct TapWalker {
     static constexpr int NS = E::NS;
     __amdgpu_buffer_rsrc_t rsrc;
@@ -52,13 +55,20 @@ struct TapWalker {
         rv_[j] = valid;
         bh_[j] = bh;
         bw_[j] = bw;
-        rowbase_[j] = ((n * w.IH + bh) * w.IW + bw) * w.IC;
+        rowbase_[j] = ((n * w.IH + bh) * w.IW + bw) * w.IC + (UNIFORM ? ci : 0);
     }
     __device__ __forceinline__ void start(const float *base, size_t elems, const WalkGeom &wg)
     {
         w = wg;
         rsrc = make_rsrc(base, elems * sizeof(float));
         const int kb = 4 * (threadIdx.x % E::QPR);            // first k of this thread in step 0
+        if (UNIFORM) {
+            ci = kb;
+            chunk = (w.nR > 0 && w.nS > 0) ? 0 : w.nchunks;
+            jr = js = 0;
+            sync_offsets();
+            return;
+        }
         const int per = w.nR * w.nS * w.CB;
         chunk = per > 0 ? kb / per : w.nchunks;
         const int rem = kb - chunk * (per > 0 ? per : 0);
@@ -76,11 +86,11 @@ struct TapWalker {
     }
     __device__ __forceinline__ void advance()
     {
-        ci += E::BK;
+        if (!UNIFORM) ci += E::BK;
 #pragma unroll
         for (int i = 0; i < WRAPS; ++i) {
-            const bool c1 = ci >= w.CB;
-            ci -= c1 ? w.CB : 0;
+            const bool c1 = UNIFORM ? true : ci >= w.CB;
+            if (!UNIFORM) ci -= c1 ? w.CB : 0;
             js += c1 ? 1 : 0;
             const bool c2 = js >= w.nS;
             js = c2 ? 0 : js;
@@ -95,7 +105,7 @@ struct TapWalker {
     {
         if (k0 != 0) advance();                               // calls come with k0 = 0, BK, 2BK, ...
         const bool kv = chunk < w.nchunks;
-        const int cc = chunk * w.CB + ci;
+        const int cc = chunk * w.CB + (UNIFORM ? 0 : ci);
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             const bool ok = rv_[j] && kv && (unsigned)(bh_[j] + hoff) < (unsigned)w.IH && (unsigned)(bw_[j] + woff) < (unsigned)w.IW;
@@ -168,7 +178,7 @@ struct ScalarALoader {
 };
 
 // B operand: dense row-major [Ncols][Kdim] filter bank of one group
-template <bool VEC, class E = EngF32>
+template <bool VEC, class E = EngF32, bool UNIFORM = false>     // UNIFORM: Kdim % BK == 0, so the K-tail test is scalar
 struct DenseBLoader {
     static constexpr int NS = E::NS;
     const float *__restrict__ w;
@@ -186,10 +196,17 @@ struct DenseBLoader {
         for (int j = 0; j < NS; ++j) {
             const int n = n0 + (threadIdx.x / E::QPR) + E::ROWS * j;
             rowoff[j] = n < Ncols ? (unsigned)n * (unsigned)Kdim * 4u : OOB;
+            if (UNIFORM && n < Ncols) rowoff[j] += 16u * (threadIdx.x % E::QPR);
         }
     }
     __device__ __forceinline__ void stage(int k0)
     {
+        if (UNIFORM) {
+            const bool kv = k0 < Kdim;
+#pragma unroll
+            for (int j = 0; j < NS; ++j) off_[j] = (kv && rowoff[j] != OOB) ? rowoff[j] + (unsigned)k0 * 4u : OOB;
+            return;
+        }
         kbase = k0 + 4 * (threadIdx.x % E::QPR);
 #pragma unroll
         for (int j = 0; j < NS; ++j)
@@ -222,7 +239,8 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[GemmCfg<BN>::TM][GemmCfg<
 }
 
 // ------------------------------------------------------------------------------------------ fprop / dgrad (stride 1)
-// MODE 0: scalar loads, 1: vector loads with CB < 16, 2: vector loads with CB >= 16
+// MODE 0: scalar loads, 1: vector loads with CB < 16, 2: vector loads with CB >= 16,
+//      3: vector loads with C % 16 == 0 on the f32 engine (wave-uniform tap walk)
 template <class E, int BN, bool DGRAD, int MODE>
 __device__ __forceinline__ void conv_nt_body(const float *__restrict__ act, const float *__restrict__ wgt,
                                              const float *__restrict__ bias, float *__restrict__ out, const ConvGeom &g,
@@ -237,7 +255,9 @@ __device__ __forceinline__ void conv_nt_body(const float *__restrict__ act, cons
 
     f32x16 acc[Cfg::TM][Cfg::TN];
     zero_acc<BN>(acc);
-    DenseBLoader<(MODE > 0), E> lb;
+    constexpr bool UNI = MODE == 3;
+    static_assert(!UNI || E::BK == 16, "uniform walk needs CB == BK");
+    DenseBLoader<(MODE > 0), E, UNI> lb;
     lb.init(wgt + (size_t)grp * w_group_stride, n0, g.Ncols, g.Kdim);
     const int nk = (g.Kdim + E::BK - 1) / E::BK;
     if constexpr (MODE == 0) {
@@ -248,7 +268,7 @@ __device__ __forceinline__ void conv_nt_body(const float *__restrict__ act, cons
     } else {
         // The buffer descriptor is based at the first image this tile touches, so 32-bit offsets only have to span
         // the few images of one tile (tensors beyond 4 GB stay on the vector path).
-        TapWalker<(MODE == 2 ? E::BK / 16 : E::BK / 4), E> la;
+        TapWalker<(MODE >= 2 ? E::BK / 16 : E::BK / 4), E, UNI> la;
         const int img0 = m0 / (g.OH * g.OW);
         const size_t img_elems = (size_t)g.IH * g.IW * g.IC;
         la.start(abase + img0 * img_elems, act_group_stride - img0 * img_elems, wg);
@@ -313,7 +333,7 @@ struct ParityInfo {
     int r0[4], s0[4], rstep[4], sstep[4];
 };
 
-template <int WRAPS, class E = EngF32>
+template <int WRAPS, class E = EngF32, bool UNIFORM = false>
 struct ParityBLoader {     // filter bank [Ncols][R*S*IC] (channel-blocked), columns of the class's taps only
     static constexpr int NS = E::NS;
     __amdgpu_buffer_rsrc_t rsrc;
@@ -330,8 +350,15 @@ struct ParityBLoader {     // filter bank [Ncols][R*S*IC] (channel-blocked), col
         for (int j = 0; j < NS; ++j) {
             const int n = n0 + (threadIdx.x / E::QPR) + E::ROWS * j;
             rowoff[j] = n < Ncols ? (unsigned)n * (unsigned)KdimFull * 4u : OOB;
+            if (UNIFORM && n < Ncols) rowoff[j] += 16u * (threadIdx.x % E::QPR);
         }
         const int kb = 4 * (threadIdx.x % E::QPR);
+        if (UNIFORM) {
+            ci = 0;                                          // the thread's channel quad is folded into rowoff
+            chunk = (nr > 0 && ns > 0) ? 0 : nchunks;
+            jr = js = 0;
+            return;
+        }
         const int per = nr * ns * CB;
         chunk = per > 0 ? kb / per : nchunks;
         const int rem = kb - chunk * (per > 0 ? per : 0);
@@ -343,11 +370,11 @@ struct ParityBLoader {     // filter bank [Ncols][R*S*IC] (channel-blocked), col
     __device__ __forceinline__ void stage(int k0)
     {
         if (k0 != 0) {
-            ci += E::BK;
+            if (!UNIFORM) ci += E::BK;
 #pragma unroll
             for (int i = 0; i < WRAPS; ++i) {
-                const bool c1 = ci >= CB;
-                ci -= c1 ? CB : 0;
+                const bool c1 = UNIFORM ? true : ci >= CB;
+                if (!UNIFORM) ci -= c1 ? CB : 0;
                 js += c1 ? 1 : 0;
                 const bool c2 = js >= ns;
                 js = c2 ? 0 : js;
@@ -365,12 +392,16 @@ struct ParityBLoader {     // filter bank [Ncols][R*S*IC] (channel-blocked), col
     __device__ __forceinline__ float4 fetch(int j) const { return buf_load4(rsrc, off_[j]); }
 };
 
-template <class E, int BN, int WRAPS>
+// WRAPS_ = 0 selects the wave-uniform walk (C % 16 == 0 on the f32 engine, one carry per K-step)
+template <class E, int BN, int WRAPS_>
 __device__ __forceinline__ void conv_dgrad_parity_body(const float *__restrict__ dy, const float *__restrict__ wgt,
                                                        float *__restrict__ dx, const ConvGeom &g, const ParityInfo &pi,
                                                        size_t act_group_stride, size_t w_group_stride, int ng, float *smem)
 {
     using Cfg = GemmCfg<BN, E>;
+    constexpr bool UNI = WRAPS_ == 0;
+    constexpr int WRAPS = UNI ? 1 : WRAPS_;
+    static_assert(!UNI || E::BK == 16, "uniform walk needs CB == BK");
     const int grp = blockIdx.y;
     const int total_mt = pi.tile0[pi.ncls];
     // classes have different tap counts (= block run times): keep dispatch order so every XCD gets the same mix
@@ -392,7 +423,7 @@ __device__ __forceinline__ void conv_dgrad_parity_body(const float *__restrict__
     wg.step_h = -((rstep * g.dh) >> shift_h);        // exact: the class's taps keep (ih + ph - r*dh) divisible by sh
     wg.step_w = -((sstep * g.dw) >> shift_w);
     wg.CB = chan_block(g.IC); wg.nchunks = g.IC / wg.CB;
-    TapWalker<WRAPS, E> la;
+    TapWalker<WRAPS, E, UNI> la;
     const int img0 = (Ha * Wb) > 0 ? m0 / (Ha * Wb) : 0;
     const size_t img_elems = (size_t)g.IH * g.IW * g.IC;
     la.start(dy + (size_t)grp * act_group_stride + img0 * img_elems, act_group_stride - img0 * img_elems, wg);
@@ -405,7 +436,7 @@ __device__ __forceinline__ void conv_dgrad_parity_body(const float *__restrict__
         const int ihq = t % Ha, n = t / Ha - img0;
         la.set_row(j, v, n, (ihq * g.sh + a + g.ph - r0 * g.dh) >> shift_h, (iwq * g.sw + b + g.pw - s0 * g.dw) >> shift_w);
     }
-    ParityBLoader<WRAPS, E> lb;
+    ParityBLoader<WRAPS, E, UNI> lb;
     lb.init(wgt + (size_t)grp * w_group_stride, n0, g.Ncols, g.IC, g.S, g.Kdim, nr, ns, r0, s0, rstep, sstep);
 
     f32x16 acc[Cfg::TM][Cfg::TN];
@@ -490,7 +521,8 @@ struct WgradCfg {
 
 template <int BMK, int BNC, int MODE, bool BF16>
 __device__ __forceinline__ void conv_wgrad_body(const float *__restrict__ x, const float *__restrict__ dy,
-                                                float *__restrict__ out, const WgradGeom &g, int groups, float *smem)
+                                                float *__restrict__ out, float *__restrict__ bias_out, const WgradGeom &g,
+                                                int groups, float *smem)
 {
     using WC = WgradCfg<BMK, BNC, BF16>;
     constexpr int BKP = WC::BKP;
@@ -507,6 +539,10 @@ __device__ __forceinline__ void conv_wgrad_body(const float *__restrict__ x, con
     const int k0 = kt_ * BMK, c0 = ct * BNC;
     const int grp = blockIdx.y;
     const int split = blockIdx.z;
+    // bias gradient = column sums of dy: the blocks of the first column tile already stream every dy tile of
+    // their rows through registers, so they add them up on the way (bias_out: [split][group][K] partials)
+    const bool do_bias = bias_out != nullptr && ct == 0;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
     const int m_begin = split * g.chunk;
     const int m_end = min(g.Mtot, m_begin + g.chunk);
     const int ng = g.Mtot / (g.OH * g.OW);
@@ -636,6 +672,12 @@ __device__ __forceinline__ void conv_wgrad_body(const float *__restrict__ x, con
         }
     };
     auto sstore = [&](int buf) {
+        if (do_bias) {
+#pragma unroll
+            for (int j = 0; j < AP; ++j) {
+                bsum.x += ra[j].x; bsum.y += ra[j].y; bsum.z += ra[j].z; bsum.w += ra[j].w;
+            }
+        }
         if constexpr (BF16) {
 #pragma unroll
             for (int j = 0; j < AP; ++j)
@@ -715,6 +757,18 @@ __device__ __forceinline__ void conv_wgrad_body(const float *__restrict__ x, con
         __syncthreads();
     }
 
+    if (do_bias) {       // fixed-order reduction over the 256/AQ pixel rows of threads (the last barrier of the loop has passed)
+        float *red = smem;
+        *reinterpret_cast<float4 *>(&red[apix * BMK + 4 * aq]) = bsum;
+        __syncthreads();
+        if (tid < BMK) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 256 / AQ; ++r) t += red[r * BMK + tid];
+            if (k0 + tid < g.K) bias_out[((size_t)split * groups + grp) * g.K + k0 + tid] = t;
+        }
+    }
+
     // slab [split][group][K][RSC]
     float *o = out + ((size_t)split * groups + grp) * (size_t)g.K * g.RSC;
 #pragma unroll
@@ -736,17 +790,19 @@ __device__ __forceinline__ void conv_wgrad_body(const float *__restrict__ x, con
 
 template <int BMK, int BNC, int MODE>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy,
-                                                         float *__restrict__ out, WgradGeom g, int groups)
+                                                         float *__restrict__ out, float *__restrict__ bias_out,
+                                                         WgradGeom g, int groups)
 {
     __shared__ __attribute__((aligned(16))) float smem[WgradCfg<BMK, BNC, false>::LDS_FLOATS];
-    conv_wgrad_body<BMK, BNC, MODE, false>(x, dy, out, g, groups, smem);
+    conv_wgrad_body<BMK, BNC, MODE, false>(x, dy, out, bias_out, g, groups, smem);
 }
 template <int BMK, int BNC, int MODE>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const float *__restrict__ x, const float *__restrict__ dy,
-                                                              float *__restrict__ out, WgradGeom g, int groups)
+                                                              float *__restrict__ out, float *__restrict__ bias_out,
+                                                              WgradGeom g, int groups)
 {
     __shared__ __attribute__((aligned(16))) float smem[WgradCfg<BMK, BNC, true>::LDS_FLOATS];
-    conv_wgrad_body<BMK, BNC, MODE, true>(x, dy, out, g, groups, smem);
+    conv_wgrad_body<BMK, BNC, MODE, true>(x, dy, out, bias_out, g, groups, smem);
 }
 
 __global__ void slab_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ out, size_t n, int splits)
@@ -892,6 +948,8 @@ static int launch_nt(const mqConvDesc *d, const float *act, const float *w, cons
             if (BN == 128) { if (wide) MQ_PARH(128, 2); else MQ_PARH(128, 8); }
             else if (BN == 64) { if (wide) MQ_PARH(64, 2); else MQ_PARH(64, 8); }
             else { if (wide) MQ_PARH(32, 2); else MQ_PARH(32, 8); }
+        } else if (g.IC % 16 == 0) {
+            if (BN == 128) MQ_PAR(128, 0); else if (BN == 64) MQ_PAR(64, 0); else MQ_PAR(32, 0);
         } else if (BN == 128) { if (wide) MQ_PAR(128, 1); else MQ_PAR(128, 4); }
         else if (BN == 64) { if (wide) MQ_PAR(64, 1); else MQ_PAR(64, 4); }
         else { if (wide) MQ_PAR(32, 1); else MQ_PAR(32, 4); }
@@ -905,12 +963,13 @@ static int launch_nt(const mqConvDesc *d, const float *act, const float *w, cons
     wg.step_h = DGRAD ? -g.dh : g.dh;
     wg.step_w = DGRAD ? -g.dw : g.dw;
     wg.CB = cb; wg.nchunks = g.IC / cb;
-    const int mode = vec ? (wide ? 2 : 1) : 0;
+    const int mode = vec ? (wide ? ((g.IC % 16 == 0 && !bf16) ? 3 : 2) : 1) : 0;
     dim3 grid(g.nMt * g.nNt, d->groups), block(256);
 #define MQ_NT(BN_, M_) hipLaunchKernelGGL((conv_nt_kernel<BN_, DGRAD, M_>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs)
 #define MQ_NTH(BN_, M_) hipLaunchKernelGGL((conv_nt_bf16_kernel<BN_, DGRAD, M_>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs)
 #define MQ_NT3(BN_) do { if (bf16) { if (mode == 2) MQ_NTH(BN_, 2); else MQ_NTH(BN_, 1); } \
-                         else if (mode == 2) MQ_NT(BN_, 2); else if (mode == 1) MQ_NT(BN_, 1); else MQ_NT(BN_, 0); } while (0)
+                         else if (mode == 3) MQ_NT(BN_, 3); else if (mode == 2) MQ_NT(BN_, 2); else if (mode == 1) MQ_NT(BN_, 1); \
+                         else MQ_NT(BN_, 0); } while (0)
     if (BN == 128) MQ_NT3(128);
     else if (BN == 64) MQ_NT3(64);
     else MQ_NT3(32);
@@ -970,6 +1029,15 @@ extern "C" int mq_conv_dgrad(const mqConvDesc *d, const float *dy, const float *
     return launch_nt<true>(d, dy, w_crsk, nullptr, dx, S(stream));
 }
 
+static int colsum_launch(const float *x, int64_t rows, int cols, float *out, float *workspace, hipStream_t st);
+
+// bias partials live behind the slabs: [splits][groups][K] (vector path) or the column-sum scratch (scalar path)
+static size_t wgrad_bias_floats(const mqConvDesc *d, const WgradGeom &g)
+{
+    const size_t a = (size_t)g.splits * d->groups * g.K, b = (size_t)1024 * g.K;
+    return a > b ? a : b;
+}
+
 extern "C" size_t mq_conv_wgrad_workspace(const mqConvDesc *d)
 {
     if (check_desc(d, "mq_conv_wgrad_workspace")) return 0;
@@ -979,18 +1047,28 @@ extern "C" size_t mq_conv_wgrad_workspace(const mqConvDesc *d)
     return (size_t)g.splits * d->groups * g.K * g.RSC * sizeof(float);
 }
 
-extern "C" int mq_conv_wgrad(const mqConvDesc *d, const float *x, const float *dy, float *dw, void *workspace,
-                             size_t workspace_bytes, mqStream stream)
+extern "C" size_t mq_conv_wgrad_bias_workspace(const mqConvDesc *d)
 {
-    if (check_desc(d, "mq_conv_wgrad")) return 1;
-    MQ_REQUIRE(x && dy && dw, "mq_conv_wgrad: null pointer");
+    if (check_desc(d, "mq_conv_wgrad_bias_workspace")) return 0;
+    WgradGeom g;
+    wgrad_plan(d, g);
+    return mq_conv_wgrad_workspace(d) + wgrad_bias_floats(d, g) * sizeof(float);
+}
+
+static int wgrad_impl(const mqConvDesc *d, const float *x, const float *dy, float *dw, float *dbias, void *workspace,
+                      size_t workspace_bytes, hipStream_t st, const char *who)
+{
+    if (check_desc(d, who)) return 1;
+    MQ_REQUIRE(x && dy && dw, "%s: null pointer", who);
     WgradGeom g;
     wgrad_plan(d, g);
     const size_t n = (size_t)d->groups * g.K * g.RSC;
-    const size_t need = g.splits > 1 ? (size_t)g.splits * n * sizeof(float) : 0;
-    MQ_REQUIRE(workspace_bytes >= need && (need == 0 || workspace != nullptr),
-               "mq_conv_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
+    const size_t slab_bytes = g.splits > 1 ? (size_t)g.splits * n * sizeof(float) : 0;
+    const size_t need = slab_bytes + (dbias ? wgrad_bias_floats(d, g) * sizeof(float) : 0);
+    MQ_REQUIRE(workspace_bytes >= need && (need == 0 || workspace != nullptr), "%s: workspace too small (%zu < %zu)", who,
+               workspace_bytes, need);
     float *target = g.splits > 1 ? reinterpret_cast<float *>(workspace) : dw;
+    float *bias_ws = dbias ? reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + slab_bytes) : nullptr;
     // 32-bit offsets inside one split: its images must span < 2 GB of x and of dy
     const size_t split_imgs = (size_t)cdiv(g.chunk, (int64_t)d->P * d->Q) + 2;
     const bool vec = wgrad_vec_shape(d) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) &&
@@ -999,9 +1077,11 @@ extern "C" int mq_conv_wgrad(const mqConvDesc *d, const float *x, const float *d
     dim3 grid(g.nKt * g.nCt, d->groups, g.splits), block(256);
     const int mode = vec ? (d->Q >= WG_BK ? 2 : 1) : 0;
     const bool bf16 = d->precision == MQ_PRECISION_BF16 && wgrad_vec_shape(d);
-    MQ_REQUIRE(!bf16 || vec, "mq_conv_wgrad: bf16 engine needs 16-byte aligned tensors below the 2 GB-per-split span");
-#define MQ_WG(A_, B_, M_) hipLaunchKernelGGL((conv_wgrad_kernel<A_, B_, M_>), grid, block, 0, S(stream), x, dy, target, g, d->groups)
-#define MQ_WGH(A_, B_, M_) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<A_, B_, M_>), grid, block, 0, S(stream), x, dy, target, g, d->groups)
+    MQ_REQUIRE(!bf16 || vec, "%s: bf16 engine needs 16-byte aligned tensors below the 2 GB-per-split span", who);
+    // fused bias partials: vector path only; one split writes straight into dbias
+    float *bias_target = (dbias && mode > 0) ? (g.splits > 1 ? bias_ws : dbias) : nullptr;
+#define MQ_WG(A_, B_, M_) hipLaunchKernelGGL((conv_wgrad_kernel<A_, B_, M_>), grid, block, 0, st, x, dy, target, bias_target, g, d->groups)
+#define MQ_WGH(A_, B_, M_) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<A_, B_, M_>), grid, block, 0, st, x, dy, target, bias_target, g, d->groups)
 #define MQ_WG3(A_, B_) do { if (bf16) { if (mode == 2) MQ_WGH(A_, B_, 2); else MQ_WGH(A_, B_, 1); } \
                             else if (mode == 2) MQ_WG(A_, B_, 2); else if (mode == 1) MQ_WG(A_, B_, 1); else MQ_WG(A_, B_, 0); } while (0)
     if (g.bmk == 64) MQ_WG3(64, 256);
@@ -1009,18 +1089,38 @@ extern "C" int mq_conv_wgrad(const mqConvDesc *d, const float *x, const float *d
 #undef MQ_WG3
 #undef MQ_WGH
 #undef MQ_WG
-    MQ_LAUNCH_CHECK("mq_conv_wgrad");
+    MQ_LAUNCH_CHECK(who);
     if (g.splits > 1) {
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(ew_grid((int64_t)n, 256)), dim3(256), 0, S(stream), target, dw, n,
-                           g.splits);
-        MQ_LAUNCH_CHECK("mq_conv_wgrad(reduce)");
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(ew_grid((int64_t)n, 256)), dim3(256), 0, st, target, dw, n, g.splits);
+        if (bias_target) {
+            const size_t nb = (size_t)d->groups * g.K;
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3(ew_grid((int64_t)nb, 256)), dim3(256), 0, st, bias_target, dbias, nb,
+                               g.splits);
+        }
+        MQ_LAUNCH_CHECK(who);
+    }
+    if (dbias && mode == 0) {      // scalar path (K or C not a multiple of 4): stand-alone column sums per group
+        for (int grp = 0; grp < d->groups; ++grp)
+            if (colsum_launch(dy + (size_t)grp * g.Mtot * g.K, g.Mtot, g.K, dbias + (size_t)grp * g.K, bias_ws, st)) return 1;
     }
     return 0;
 }
 
-extern "C" int mq_colsum(const float *x, int64_t rows, int cols, float *out, float *workspace, mqStream stream)
+extern "C" int mq_conv_wgrad(const mqConvDesc *d, const float *x, const float *dy, float *dw, void *workspace,
+                             size_t workspace_bytes, mqStream stream)
 {
-    MQ_REQUIRE(x && out && workspace && rows > 0 && cols > 0, "mq_colsum: bad arguments");
+    return wgrad_impl(d, x, dy, dw, nullptr, workspace, workspace_bytes, S(stream), "mq_conv_wgrad");
+}
+
+extern "C" int mq_conv_wgrad_bias(const mqConvDesc *d, const float *x, const float *dy, float *dw, float *dbias,
+                                  void *workspace, size_t workspace_bytes, mqStream stream)
+{
+    MQ_REQUIRE(dbias != nullptr, "mq_conv_wgrad_bias: null dbias");
+    return wgrad_impl(d, x, dy, dw, dbias, workspace, workspace_bytes, S(stream), "mq_conv_wgrad_bias");
+}
+
+static int colsum_launch(const float *x, int64_t rows, int cols, float *out, float *workspace, hipStream_t st)
+{
     // enough row chunks for ~2048 blocks in total, each with at least 32 rows; at most 1024 (workspace)
     const int64_t colblocks = cdiv(cols, 64);
     int64_t want = cdiv(2048, colblocks);
@@ -1028,10 +1128,15 @@ extern "C" int mq_colsum(const float *x, int64_t rows, int cols, float *out, flo
     if (want > 1024) want = 1024;
     if (want < 1) want = 1;
     const int nchunks = (int)want;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)cdiv(cols, 64), nchunks), dim3(64, 4), 0, S(stream), x, rows,
-                       cols, workspace, nchunks);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(cols, 64)), dim3(64, 16), 0, S(stream), workspace, cols,
-                       nchunks, out);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)cdiv(cols, 64), nchunks), dim3(64, 4), 0, st, x, rows, cols,
+                       workspace, nchunks);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(cols, 64)), dim3(64, 16), 0, st, workspace, cols, nchunks, out);
     MQ_LAUNCH_CHECK("mq_colsum");
     return 0;
+}
+
+extern "C" int mq_colsum(const float *x, int64_t rows, int cols, float *out, float *workspace, mqStream stream)
+{
+    MQ_REQUIRE(x && out && workspace && rows > 0 && cols > 0, "mq_colsum: bad arguments");
+    return colsum_launch(x, rows, cols, out, workspace, S(stream));
 }

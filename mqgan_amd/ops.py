@@ -146,10 +146,10 @@ def _conv_tag(kind, d: ConvDesc):
     h = want_h and ic % 4 == 0
     if kind == "dgrad" and strided:
         if ic % 4 == 0 and d.stride_h <= 2 and d.stride_w <= 2:
-            wraps = (2 if ic % 16 == 0 else 8) if h else (1 if ic % 16 == 0 else 4)
+            wraps = (2 if ic % 16 == 0 else 8) if h else (0 if ic % 16 == 0 else (1 if ic >= 16 else 4))
             return f"conv_dgrad_parity_{'bf16_' if h else ''}kernel<{bn}, {wraps}>"
         return f"conv_nt_kernel<{bn}, true, 0>"
-    mode = 2 if ic % 16 == 0 else (1 if ic % 4 == 0 else 0)
+    mode = (2 if h else 3) if ic % 16 == 0 else ((2 if ic >= 16 else 1) if ic % 4 == 0 else 0)
     return f"conv_nt_{'bf16_' if h else ''}kernel<{bn}, {str(kind == 'dgrad').lower()}, {mode}>"
 
 
@@ -194,13 +194,23 @@ class ConvFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             _timed(_conv_tag("dgrad", d), _conv_flops(d), lambda: check(
                 L().mq_conv_dgrad(C.byref(d), fptr(dy), fptr(w_crsk), fptr(dx), stream()), "mq_conv_dgrad"), ctx.key)
+        want_db = ctx.has_bias and ctx.needs_input_grad[3]
         if ctx.needs_input_grad[1]:
             dw = _empty(ctx.w_shape, x)      # (groups*K, R*S, C) == KRSC
-            nbytes = L().mq_conv_wgrad_workspace(C.byref(d))
-            ws = _ws_bytes(nbytes, x)
-            _timed(_conv_tag("wgrad", d), _conv_flops(d), lambda: check(
-                L().mq_conv_wgrad(C.byref(d), fptr(x), fptr(dy), fptr(dw), ptr(ws), nbytes, stream()), "mq_conv_wgrad"), ctx.key)
-        if ctx.has_bias and ctx.needs_input_grad[3]:
+            if want_db:                      # bias gradient rides on the dy tiles of the weight-gradient GEMM
+                db = _empty((d.groups * d.K,), x)
+                nbytes = L().mq_conv_wgrad_bias_workspace(C.byref(d))
+                ws = _ws_bytes(nbytes, x)
+                _timed(_conv_tag("wgrad", d), _conv_flops(d), lambda: check(
+                    L().mq_conv_wgrad_bias(C.byref(d), fptr(x), fptr(dy), fptr(dw), fptr(db), ptr(ws), nbytes, stream()),
+                    "mq_conv_wgrad_bias"), ctx.key)
+            else:
+                nbytes = L().mq_conv_wgrad_workspace(C.byref(d))
+                ws = _ws_bytes(nbytes, x)
+                _timed(_conv_tag("wgrad", d), _conv_flops(d), lambda: check(
+                    L().mq_conv_wgrad(C.byref(d), fptr(x), fptr(dy), fptr(dw), ptr(ws), nbytes, stream()), "mq_conv_wgrad"),
+                    ctx.key)
+        elif want_db:
             rows_per_group = (d.N // d.groups) * d.P * d.Q
             if d.groups == 1:
                 db = colsum(dy.view(-1, d.K))

@@ -11,6 +11,9 @@ SHAPES = {
     "up2":   dict(N=32, H=512, W=90, C=192, K=64, R=3, S=3, stride=(1, 1), pad=(1, 1), groups=1),
     "d1c1":  dict(N=32, H=80, W=256, C=256, K=256, R=5, S=5, stride=(2, 2), pad=(2, 2), groups=1),
     "d2c1":  dict(N=256, H=10, W=512, C=128, K=128, R=3, S=5, stride=(1, 1), pad=(1, 2), groups=8),
+    "midsq": dict(N=32, H=64, W=64, C=512, K=512, R=3, S=3, stride=(1, 1), pad=(1, 1), groups=1),     # 4096 tiles = 4 full rounds
+    "mid1":  dict(N=32, H=64, W=64, C=4608, K=512, R=1, S=1, stride=(1, 1), pad=(0, 0), groups=1),    # same GEMM, no taps
+    "mid8":  dict(N=64, H=64, W=64, C=512, K=512, R=3, S=3, stride=(1, 1), pad=(1, 1), groups=1),     # 8 full rounds
     "enc":   dict(N=32, H=1, W=512, C=512, K=512, R=1, S=3, stride=(1, 1), pad=(0, 1), groups=1),
 }
 name = sys.argv[1] if len(sys.argv) > 1 else "mid"
