@@ -115,6 +115,18 @@ int mq_conv_wgrad(const mqConvDesc *desc_host, const float *x, const float *dy, 
 size_t mq_conv_wgrad_bias_workspace(const mqConvDesc *desc_host);
 int mq_conv_wgrad_bias(const mqConvDesc *desc_host, const float *x, const float *dy, float *dw_krsc, float *dbias,
                        void *workspace, size_t workspace_bytes, mqStream stream);
+/* Thin convolutions (single input or output channel: the first conv of each discriminator and of the refiner,
+ * discriminators.py:139-150, preencoder.py:148; the logits convs, discriminators.py:162-167, and the refiner's
+ * last conv, preencoder.py:165).  They run as a tap gather / fold around a 1x1 GEMM so that the wide tensor is
+ * read once.  T = R*S rounded up to a multiple of 4; `desc` is the descriptor of the thin conv itself.
+ *   gather : img (N,H,W)   -> cols (N,P,Q,T)   cols[.,t] = img at tap t of the output pixel (0 outside / t >= R*S)
+ *   scatter: cols (N,P,Q,T)-> img (N,H,W)      transpose of gather (gradient wrt the image)
+ *   reduce : u (N,H,W,T)   -> y (N,P,Q)        y = bias[group] + sum_t u[input pixel of tap t][t]
+ *   expand : dy (N,P,Q)    -> du (N,H,W,T)     transpose of reduce */
+int mq_taps_gather(const mqConvDesc *desc_host, int T, const float *img, float *cols, mqStream stream);
+int mq_taps_scatter(const mqConvDesc *desc_host, int T, const float *cols, float *img, mqStream stream);
+int mq_taps_reduce(const mqConvDesc *desc_host, int T, const float *u, const float *bias, float *y, mqStream stream);
+int mq_taps_expand(const mqConvDesc *desc_host, int T, const float *dy, float *du, mqStream stream);
 /* out[c] = sum_r x[r][c]  (bias gradients; deterministic two-stage).  workspace: 1024*cols floats. */
 int mq_colsum(const float *x, int64_t rows, int cols, float *out, float *workspace, mqStream stream);
 

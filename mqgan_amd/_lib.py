@@ -59,6 +59,10 @@ SIGNATURES = {
     "mq_conv_wgrad_bias_workspace": (_Z, [C.POINTER(ConvDesc)]),
     "mq_conv_wgrad_bias": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _Z, _P]),
     "mq_colsum": (_I, [_P, _L, _I, _P, _P, _P]),
+    "mq_taps_gather": (_I, [C.POINTER(ConvDesc), _I, _P, _P, _P]),
+    "mq_taps_scatter": (_I, [C.POINTER(ConvDesc), _I, _P, _P, _P]),
+    "mq_taps_reduce": (_I, [C.POINTER(ConvDesc), _I, _P, _P, _P, _P]),
+    "mq_taps_expand": (_I, [C.POINTER(ConvDesc), _I, _P, _P, _P]),
     "mq_weight_prep": (_I, [_I, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "mq_weight_prep_bwd": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "mq_spectral_prep": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P]),

@@ -219,7 +219,73 @@ class ConvFn(torch.autograd.Function):
         return dx, dw, None, db, None
 
 
+class TapsGatherFn(torch.autograd.Function):
+    """img (N,H,W) -> cols (N,P,Q,T): the taps of every output pixel of a single-input-channel conv."""
+
+    @staticmethod
+    def forward(ctx, img, key, T):
+        d = _desc_from_key(key)
+        cols = _empty((d.N, d.P, d.Q, T), img)
+        check(L().mq_taps_gather(C.byref(d), T, fptr(img), fptr(cols), stream()), "mq_taps_gather")
+        ctx.key, ctx.T = key, T
+        return cols
+
+    @staticmethod
+    def backward(ctx, dcols):
+        d = _desc_from_key(ctx.key)
+        dimg = _empty((d.N, d.H, d.W), dcols)
+        check(L().mq_taps_scatter(C.byref(d), ctx.T, fptr(dcols.contiguous()), fptr(dimg), stream()), "mq_taps_scatter")
+        return dimg, None, None
+
+
+class TapsReduceFn(torch.autograd.Function):
+    """u (N,H,W,T) -> y (N,P,Q): folds the per-tap partial products of a single-output-channel conv, adds the bias."""
+
+    @staticmethod
+    def forward(ctx, u, bias, key, T):
+        d = _desc_from_key(key)
+        y = _empty((d.N, d.P, d.Q), u)
+        check(L().mq_taps_reduce(C.byref(d), T, fptr(u), fptr(bias, True), fptr(y), stream()), "mq_taps_reduce")
+        ctx.key, ctx.T, ctx.has_bias = key, T, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        d = _desc_from_key(ctx.key)
+        dy = dy.contiguous()
+        du = _empty((d.N, d.H, d.W, ctx.T), dy)
+        check(L().mq_taps_expand(C.byref(d), ctx.T, fptr(dy), fptr(du), stream()), "mq_taps_expand")
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[1]:
+            db = torch.cat([colsum(dy.view(d.groups, -1, 1)[g]) for g in range(d.groups)]) if d.groups > 1 else colsum(dy.view(-1, 1))
+        return du, db, None, None
+
+
+def _thin_conv(x, w_krsc, w_crsk, bias, desc: ConvDesc):
+    """C = 1 or K = 1 with more than one tap (csrc/taps.hip): tap gather / fold around a 1x1 GEMM."""
+    G, K, Cin, RS = desc.groups, desc.K, desc.C, desc.R * desc.S
+    T = (RS + 3) // 4 * 4
+    key = _desc_key(desc)
+    need_dx = x.requires_grad
+    if Cin == 1:
+        cols = TapsGatherFn.apply(x.view(desc.N, desc.H, desc.W), key, T)
+        wk = torch.nn.functional.pad(w_krsc.view(G * K, RS), (0, T - RS)).contiguous().view(G * K, 1, T)         # KRSC of the 1x1 conv
+        wc = wk.view(G, K, T).transpose(1, 2).contiguous().view(G * T, 1, K) if need_dx else None              # its CRSK
+        d1 = conv_desc(desc.N, desc.P, desc.Q, T, K, 1, 1, groups=G, precision=desc.precision)
+        return ConvFn.apply(cols, wk, wc, bias, _desc_key(d1))
+    # K = 1: w_krsc is (G, RS, C) in the channel-blocked order [C/CB][RS][CB] -> rows = taps, plain channels
+    CB = 16 if Cin % 16 == 0 else Cin
+    wt = w_krsc.view(G, Cin // CB, RS, CB).permute(0, 2, 1, 3).contiguous().view(G, RS, Cin)
+    wk = torch.nn.functional.pad(wt, (0, 0, 0, T - RS)).contiguous().view(G * T, 1, Cin)                        # KRSC: T "output channels"
+    wc = wk.view(G, T, Cin).transpose(1, 2).contiguous().view(G * Cin, 1, T) if need_dx else None
+    d1 = conv_desc(desc.N, desc.H, desc.W, Cin, T, 1, 1, groups=G, precision=desc.precision)
+    u = ConvFn.apply(x, wk, wc, None, _desc_key(d1))
+    return TapsReduceFn.apply(u, bias, key, T).view(desc.N, desc.P, desc.Q, 1)
+
+
 def conv(x, w_krsc, w_crsk, bias, desc: ConvDesc):
+    if desc.R * desc.S > 1 and ((desc.C == 1) != (desc.K == 1)) and (desc.C % 4 == 0 or desc.K % 4 == 0):
+        return _thin_conv(x, w_krsc, w_crsk, bias, desc)
     return ConvFn.apply(x, w_krsc, w_crsk, bias, _desc_key(desc))
 
 
