@@ -996,15 +996,26 @@ static void wgrad_plan(const mqConvDesc *d, WgradGeom &g)
     g.bnc = g.K <= 64 ? 256 : 128;
     g.nKt = (int)cdiv(g.K, g.bmk);
     g.nCt = (int)cdiv(g.RSC, g.bnc);
-    // split the pixel reduction so that the grid fills the resident block slots (256 CUs x 4 or 3 blocks)
-    // exactly once when the tile count allows it, each split keeping >= 32 K-steps
+    // Split the pixel reduction so that the grid fills whole rounds of the resident block slots (256 CUs x the
+    // blocks a CU holds): among the split counts that keep >= 32 K-steps per split, take the one with the best
+    // fill  tiles*s / (rounds * slots), charging a little for every extra round of slabs (write + re-read).
     const int64_t tiles = (int64_t)g.nKt * g.nCt * d->groups;
     const int64_t slots = 256 * ((g.bmk == 64 ? 3 : 4) - (bk == 32 ? 1 : 0));     // resident blocks per CU (registers / LDS)
-    int64_t splits = tiles >= slots ? 1 : slots / tiles;
-    const int64_t max_splits = cdiv(g.Mtot, bk * 32);
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    if (splits > 512) splits = 512;
+    int64_t max_splits = cdiv(g.Mtot, bk * 32);
+    if (max_splits > 512) max_splits = 512;
+    if (max_splits < 1) max_splits = 1;
+    int64_t lo = slots / tiles, hi = 4 * slots / tiles + 1;      // from "one round" up to about four rounds
+    if (lo < 1) lo = 1;
+    if (lo > max_splits) lo = max_splits;
+    if (hi > max_splits) hi = max_splits;
+    int64_t splits = lo;
+    double best = -1.0;
+    for (int64_t sp = lo; sp <= hi; ++sp) {
+        const int64_t blocks = tiles * sp;
+        const double rounds = (double)cdiv(blocks, slots);
+        const double score = (double)blocks / (rounds * (double)slots) - 0.004 * rounds;
+        if (score > best + 1e-12) { best = score; splits = sp; }
+    }
     int64_t chunk = cdiv(cdiv(g.Mtot, splits), bk) * bk;
     g.chunk = (int)chunk;
     g.splits = (int)cdiv(g.Mtot, chunk);
