@@ -2,6 +2,10 @@
 // See include/mqgan_hip.h (mq_conv_*) for the interface and gemm_core.h for the tile engine.
 #include "gemm_core.h"
 
+#ifndef MQ_NT_OCC
+#define MQ_NT_OCC 4        // resident blocks per CU of the f32 fprop / dgrad kernels
+#endif
+
 namespace mq {
 
 struct ConvGeom {
@@ -301,7 +305,7 @@ __device__ __forceinline__ void conv_nt_body(const float *__restrict__ act, cons
 }
 
 template <int BN, bool DGRAD, int MODE>
-__global__ __launch_bounds__(256, 4) void conv_nt_kernel(const float *__restrict__ act, const float *__restrict__ wgt,
+__global__ __launch_bounds__(256, MQ_NT_OCC) void conv_nt_kernel(const float *__restrict__ act, const float *__restrict__ wgt,
                                                       const float *__restrict__ bias, float *__restrict__ out,
                                                       ConvGeom g, WalkGeom wg, size_t act_group_stride, size_t w_group_stride)
 {
@@ -463,7 +467,7 @@ __device__ __forceinline__ void conv_dgrad_parity_body(const float *__restrict__
 }
 
 template <int BN, int WRAPS>
-__global__ __launch_bounds__(256, 4) void conv_dgrad_parity_kernel(const float *__restrict__ dy, const float *__restrict__ wgt,
+__global__ __launch_bounds__(256, MQ_NT_OCC) void conv_dgrad_parity_kernel(const float *__restrict__ dy, const float *__restrict__ wgt,
                                                                 float *__restrict__ dx, ConvGeom g, ParityInfo pi,
                                                                 size_t act_group_stride, size_t w_group_stride, int ng)
 {
