@@ -144,7 +144,7 @@ def main():
     ap.add_argument("--config", default="hifispeech", choices=["hifispeech", "hifimusic"])
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's)")
     ap.add_argument("--frames", type=int, default=None, help="frames per item (default: the config's crop_len)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp32x3"],
                     help="matrix engine of the convs (fp32 = the BASELINE metric's; bf16 = BASELINE config 3, secondary)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vq", action="store_true")
@@ -220,7 +220,8 @@ def main():
         dom_tag, dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
         ach = dom["flops"] / (dom["ms"] / 1e3) / 1e12
         traffic, traffic_src = pmc_traffic(dom_tag)
-        peak = PEAK_BF16_MFMA_TFLOPS if "bf16" in dom_tag else PEAK_F32_MFMA_TFLOPS
+        # the split engine spends 6 bf16 MFMAs per f32 product block: its ceiling is a sixth of the bf16 peak
+        peak = PEAK_BF16_MFMA_TFLOPS if "bf16" in dom_tag else (PEAK_BF16_MFMA_TFLOPS / 6 if "_x3_" in dom_tag else PEAK_F32_MFMA_TFLOPS)
         roof = {"bound": "mfma", "kernel": dom_tag, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                 "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_flop_per_launch": dom["flops"] / dom["launches"],
@@ -231,7 +232,8 @@ def main():
                 "conv_share_of_step_time": total_conv_ms / 1e3 / elapsed}
         line = {"metric": METRIC, "value": frames / elapsed, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16 convs (f32 accumulate, f32 tensors) / f32 VQ",
+                "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16 convs (f32 accumulate, f32 tensors) / f32 VQ",
+                                              "fp32x3": "f32 via 3-term bf16 split (6 products, f32 accumulate) / f32 VQ"}[args.precision],
                 "data": "synthetic",
                 "config": {"workload": f"{args.config} PreEncoder VQ-GAN train step (G fwd + D step + G step + clip/Adam), "
                                        f"{mel} mels x {T} frames, batch {B}/GPU, FSQ {cfg['model']['generator']['fsq_levels']}, "

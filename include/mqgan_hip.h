@@ -90,6 +90,11 @@ int mq_codebook_ema_update(const float *x, const int32_t *idx, int64_t n, int k,
  * run in f32 either way. */
 #define MQ_PRECISION_F32 0
 #define MQ_PRECISION_BF16 1
+/* MQ_PRECISION_F32X3 (2): f32 results from the bf16 matrix pipe.  Every operand is split exactly into three bf16
+ * terms (8+8+8 significant bits) inside the kernel and 6 of the 9 cross products (all terms down to 2^-24
+ * relative) are accumulated in f32: the error of an f32 FMA chain (measured: same rms error against f64 as
+ * MQ_PRECISION_F32), not bit-identical to it.  Opt-in; the default engine is MQ_PRECISION_F32. */
+#define MQ_PRECISION_F32X3 2
 typedef struct {
     int N, H, W, C;
     int K, R, S;

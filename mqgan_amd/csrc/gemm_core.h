@@ -27,12 +27,21 @@ constexpr int GEMM_LDH = 40;       // bf16 engine: 32 k's per row + 8 pad (80-by
 // pass and a 128-row operand tile takes NS passes ("slots").
 struct EngF32 {        // v_mfma_f32_32x32x2_f32: exact f32 products, k-ordered accumulation
     static constexpr int BK = 16, QPR = 4, ROWS = 64, NS = 2;
-    static constexpr bool BF16 = false;
+    static constexpr bool BF16 = false, SPLIT = false;
 };
 struct EngBF16 {       // v_mfma_f32_32x32x16_bf16: operands rounded to bf16 (RNE) on the way into LDS, f32 accumulate
     static constexpr int BK = 32, QPR = 8, ROWS = 32, NS = 4;
-    static constexpr bool BF16 = true;
+    static constexpr bool BF16 = true, SPLIT = false;
 };
+// f32 on the bf16 matrix pipe: every operand x is decomposed exactly into three bf16 terms x = h + m + l (8 + 8 + 8
+// significant bits) on its way into LDS and the product is formed from 6 of the 9 cross terms (everything down to
+// 2^-24 relative: hh, hm, mh, hl, lh, mm), each exact in the f32 accumulator - the accuracy of an f32 FMA chain
+// at 6 x 32 cycles per 32x32x16 block instead of 8 x 64.
+struct EngSplit {
+    static constexpr int BK = 16, QPR = 4, ROWS = 64, NS = 2;
+    static constexpr bool BF16 = false, SPLIT = true;
+};
+constexpr int GEMM_LDS3 = 24;      // split engine: 16 bf16 k's per row + 8 pad (48-byte rows: conflict-free ds_read_b128)
 
 template <int BN, class E = EngF32>
 struct GemmCfg {
@@ -42,7 +51,8 @@ struct GemmCfg {
     static constexpr int TN = BN / WN / 32;
     static constexpr int A_SLOTS = GEMM_BM / E::ROWS;   // float4 loads per thread for the A tile
     static constexpr int B_SLOTS = (BN >= E::ROWS) ? BN / E::ROWS : 1;
-    static constexpr int LDS_FLOATS = E::BF16 ? (GEMM_BM + BN) * GEMM_LDH : 2 * (GEMM_BM + BN) * GEMM_LD;   // in 4-byte units
+    static constexpr int LDS_FLOATS = E::SPLIT ? 3 * (GEMM_BM + BN) * GEMM_LDS3                       // in 4-byte units
+                                      : E::BF16 ? (GEMM_BM + BN) * GEMM_LDH : 2 * (GEMM_BM + BN) * GEMM_LD;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -246,11 +256,117 @@ __device__ __forceinline__ void nt_gemm_mainloop_bf16(ALoad &la, BLoad &lb, int 
     }
 }
 
+// x = h + m + l exactly, each term a bf16 (truncation splits: the remainders x - h and (x - h) - m are exact in f32)
+__device__ __forceinline__ void split3_bf16x4(float4 v, uint2 &h, uint2 &m, uint2 &l)
+{
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    unsigned hb[4], mb[4], lb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned xi = __builtin_bit_cast(unsigned, x[i]);
+        hb[i] = xi;                                                    // its upper half is h
+        const float r1 = x[i] - __builtin_bit_cast(float, xi & 0xFFFF0000u);
+        const unsigned ri = __builtin_bit_cast(unsigned, r1);
+        mb[i] = ri;
+        lb[i] = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, ri & 0xFFFF0000u));
+    }
+    // v_perm_b32: bytes 3,2 of the second element over bytes 3,2 of the first = two bf16 in k order
+    h = make_uint2(__builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u), __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u));
+    m = make_uint2(__builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u), __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u));
+    l = make_uint2(__builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u), __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u));
+}
+
+// Split engine main loop: EngF32's loader mapping (BK = 16), three bf16 LDS images per operand, double buffered.
+template <int BN, class ALoad, class BLoad>
+__device__ __forceinline__ void nt_gemm_mainloop_split(ALoad &la, BLoad &lb, int nk, float *smem_f,
+                                                       f32x16 (&acc)[GemmCfg<BN, EngSplit>::TM][GemmCfg<BN, EngSplit>::TN])
+{
+    using Cfg = GemmCfg<BN, EngSplit>;
+    constexpr int LD = GEMM_LDS3;
+    constexpr int A_IMG = 2 * GEMM_BM * LD, B_IMG = 2 * BN * LD;        // one image, both buffers (in bf16 elements)
+    unsigned short *As = reinterpret_cast<unsigned short *>(smem_f);     // [3][2][128][LD]
+    unsigned short *Bs = As + 3 * A_IMG;                                 // [3][2][BN][LD]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int ld_row = tid >> 2, ld_kq = tid & 3;
+    const bool b_active = (BN >= 64) || (tid < BN * 4);
+
+    float4 ra[Cfg::A_SLOTS], rb[Cfg::B_SLOTS];
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < Cfg::A_SLOTS; ++j) {
+            uint2 h, m, l;
+            split3_bf16x4(ra[j], h, m, l);
+            unsigned short *d = As + (buf * GEMM_BM + ld_row + 64 * j) * LD + 4 * ld_kq;
+            *reinterpret_cast<uint2 *>(d) = h;
+            *reinterpret_cast<uint2 *>(d + A_IMG) = m;
+            *reinterpret_cast<uint2 *>(d + 2 * A_IMG) = l;
+        }
+        if (b_active) {
+#pragma unroll
+            for (int j = 0; j < Cfg::B_SLOTS; ++j) {
+                uint2 h, m, l;
+                split3_bf16x4(rb[j], h, m, l);
+                unsigned short *d = Bs + (buf * BN + ld_row + 64 * j) * LD + 4 * ld_kq;
+                *reinterpret_cast<uint2 *>(d) = h;
+                *reinterpret_cast<uint2 *>(d + B_IMG) = m;
+                *reinterpret_cast<uint2 *>(d + 2 * B_IMG) = l;
+            }
+        }
+    };
+    la.stage(0);
+    lb.stage(0);
+#pragma unroll
+    for (int j = 0; j < Cfg::A_SLOTS; ++j) ra[j] = la.fetch(j);
+#pragma unroll
+    for (int j = 0; j < Cfg::B_SLOTS; ++j) rb[j] = b_active ? lb.fetch(j) : make_float4(0, 0, 0, 0);
+    store_tile(0);
+    la.stage(EngSplit::BK);
+    lb.stage(EngSplit::BK);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+#pragma unroll
+        for (int j = 0; j < Cfg::A_SLOTS; ++j) ra[j] = la.fetch(j);
+#pragma unroll
+        for (int j = 0; j < Cfg::B_SLOTS; ++j) rb[j] = b_active ? lb.fetch(j) : make_float4(0, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned short *Ac = As + (cur * GEMM_BM + wm * Cfg::TM * 32 + li) * LD + 8 * lh;
+        const unsigned short *Bc = Bs + (cur * BN + wn * Cfg::TN * 32 + li) * LD + 8 * lh;
+        bf16x8 a[3][Cfg::TM], b[3][Cfg::TN];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+#pragma unroll
+            for (int t = 0; t < Cfg::TM; ++t) a[g][t] = *reinterpret_cast<const bf16x8 *>(Ac + g * A_IMG + t * 32 * LD);
+#pragma unroll
+            for (int t = 0; t < Cfg::TN; ++t) b[g][t] = *reinterpret_cast<const bf16x8 *>(Bc + g * B_IMG + t * 32 * LD);
+        }
+        // smallest terms first: l*h, h*l, m*m, then h*m, m*h, then h*h
+        constexpr int PA[6] = {2, 0, 1, 0, 1, 0}, PB[6] = {0, 2, 1, 1, 0, 0};
+#pragma unroll
+        for (int p = 0; p < 6; ++p)
+#pragma unroll
+            for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < Cfg::TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[p]][tm], b[PB[p]][tn], acc[tm][tn], 0, 0, 0);
+        la.stage((kt + 2) * EngSplit::BK);
+        lb.stage((kt + 2) * EngSplit::BK);
+        __builtin_amdgcn_sched_barrier(0);
+        store_tile(cur ^ 1);
+        __syncthreads();
+    }
+}
+
 template <class E, int BN, class ALoad, class BLoad>
 __device__ __forceinline__ void nt_gemm_run(ALoad &la, BLoad &lb, int nk, float *smem,
                                             f32x16 (&acc)[GemmCfg<BN, E>::TM][GemmCfg<BN, E>::TN])
 {
-    if constexpr (E::BF16) nt_gemm_mainloop_bf16<BN>(la, lb, nk, smem, acc);
+    if constexpr (E::SPLIT) nt_gemm_mainloop_split<BN>(la, lb, nk, smem, acc);
+    else if constexpr (E::BF16) nt_gemm_mainloop_bf16<BN>(la, lb, nk, smem, acc);
     else nt_gemm_mainloop<BN, false>(la, lb, nk, smem, acc);
 }
 

@@ -265,7 +265,7 @@ __device__ __forceinline__ void conv_nt_body(const float *__restrict__ act, cons
     lb.init(wgt + (size_t)grp * w_group_stride, n0, g.Ncols, g.Kdim);
     const int nk = (g.Kdim + E::BK - 1) / E::BK;
     if constexpr (MODE == 0) {
-        static_assert(!E::BF16, "scalar path is f32 only");
+        static_assert(!E::BF16 && !E::SPLIT, "scalar path is f32 only");
         ScalarALoader<DGRAD> la;
         la.init(abase, g, m0);
         nt_gemm_mainloop<BN>(la, lb, nk, smem, acc);
@@ -311,6 +311,16 @@ __global__ __launch_bounds__(256, MQ_NT_OCC) void conv_nt_kernel(const float *__
 {
     __shared__ __attribute__((aligned(16))) float smem[GemmCfg<BN, EngF32>::LDS_FLOATS];
     conv_nt_body<EngF32, BN, DGRAD, MODE>(act, wgt, bias, out, g, wg, act_group_stride, w_group_stride, smem);
+}
+// f32 via three-term bf16 split (gemm_core.h: EngSplit); vector path only
+template <int BN, bool DGRAD, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_nt_x3_kernel(const float *__restrict__ act, const float *__restrict__ wgt,
+                                                         const float *__restrict__ bias, float *__restrict__ out,
+                                                         ConvGeom g, WalkGeom wg, size_t act_group_stride,
+                                                         size_t w_group_stride)
+{
+    __shared__ __attribute__((aligned(16))) float smem[GemmCfg<BN, EngSplit>::LDS_FLOATS];
+    conv_nt_body<EngSplit, BN, DGRAD, MODE>(act, wgt, bias, out, g, wg, act_group_stride, w_group_stride, smem);
 }
 // bf16 operands (rounded on the way into LDS), f32 accumulate and f32 tensors in HBM; vector path only
 template <int BN, bool DGRAD, int MODE>
@@ -475,6 +485,14 @@ __global__ __launch_bounds__(256, MQ_NT_OCC) void conv_dgrad_parity_kernel(const
     conv_dgrad_parity_body<EngF32, BN, WRAPS>(dy, wgt, dx, g, pi, act_group_stride, w_group_stride, ng, smem);
 }
 template <int BN, int WRAPS>
+__global__ __launch_bounds__(256, 2) void conv_dgrad_parity_x3_kernel(const float *__restrict__ dy, const float *__restrict__ wgt,
+                                                                   float *__restrict__ dx, ConvGeom g, ParityInfo pi,
+                                                                   size_t act_group_stride, size_t w_group_stride, int ng)
+{
+    __shared__ __attribute__((aligned(16))) float smem[GemmCfg<BN, EngSplit>::LDS_FLOATS];
+    conv_dgrad_parity_body<EngSplit, BN, WRAPS>(dy, wgt, dx, g, pi, act_group_stride, w_group_stride, ng, smem);
+}
+template <int BN, int WRAPS>
 __global__ __launch_bounds__(256, (BN == 128 ? 3 : 4)) void conv_dgrad_parity_bf16_kernel(const float *__restrict__ dy,
                                                                      const float *__restrict__ wgt, float *__restrict__ dx,
                                                                      ConvGeom g, ParityInfo pi, size_t act_group_stride,
@@ -515,27 +533,32 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-template <int BMK, int BNC, bool BF16>
+// ENG: 0 = f32 MFMA, 1 = bf16 operands, 2 = f32 by three-term bf16 split (three LDS images per operand, 16 pixels/step)
+template <int BMK, int BNC, int ENG>
 struct WgradCfg {
-    static constexpr int BKP = BF16 ? 32 : WG_BK;                    // pixels per step
+    static constexpr bool BF16 = ENG != 0;                           // bf16 LDS images, transposed reads
+    static constexpr int NIMG = ENG == 2 ? 3 : 1;
+    static constexpr int BKP = ENG == 1 ? 32 : WG_BK;                // pixels per step
     static constexpr int LDA = BF16 ? BMK / 2 + 16 : BMK + 4;        // row pitch in 4-byte units
     static constexpr int LDB = BF16 ? BNC / 2 + 16 : BNC + 4;        // (f32: +4 keeps float4 stores aligned, shifts banks)
-    static constexpr int LDS_FLOATS = 2 * BKP * (LDA + LDB);
+    static constexpr int LDS_FLOATS = NIMG * 2 * BKP * (LDA + LDB);
 };
 
-template <int BMK, int BNC, int MODE, bool BF16>
+template <int BMK, int BNC, int MODE, int ENG>
 __device__ __forceinline__ void conv_wgrad_body(const float *__restrict__ x, const float *__restrict__ dy,
                                                 float *__restrict__ out, float *__restrict__ bias_out, const WgradGeom &g,
                                                 int groups, float *smem)
 {
-    using WC = WgradCfg<BMK, BNC, BF16>;
+    using WC = WgradCfg<BMK, BNC, ENG>;
+    constexpr bool BF16 = WC::BF16, X3 = ENG == 2;
+    constexpr int IMG_A = 2 * WC::BKP * WC::LDA, IMG_B = 2 * WC::BKP * WC::LDB;     // one image, both buffers
     constexpr int BKP = WC::BKP;
     constexpr int LDA = WC::LDA, LDB = WC::LDB;
     constexpr int AP = BMK * BKP / 1024, BP = BNC * BKP / 1024;   // load passes per thread and step (BKP pixels x BMK / BNC floats)
     constexpr int AQ = BMK / 4, BQ = BNC / 4;            // float4 quads per pixel row
     constexpr int WNW = BNC / 64;                        // waves along the column axis
     float *At = smem;                                    // [2][BKP][LDA]  dy tile   (pixel, k)
-    float *Bt = smem + 2 * BKP * LDA;                    // [2][BKP][LDB]  x gather  (pixel, kk)
+    float *Bt = smem + WC::NIMG * 2 * BKP * LDA;         // [2][BKP][LDB]  x gather  (pixel, kk)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WNW, wn = wave % WNW, li = lane & 31, lh = lane >> 5;
     const int tile = blockIdx.x;
@@ -682,7 +705,26 @@ __device__ __forceinline__ void conv_wgrad_body(const float *__restrict__ x, con
                 bsum.x += ra[j].x; bsum.y += ra[j].y; bsum.z += ra[j].z; bsum.w += ra[j].w;
             }
         }
-        if constexpr (BF16) {
+        if constexpr (X3) {
+#pragma unroll
+            for (int j = 0; j < AP; ++j) {
+                uint2 h, m, l;
+                split3_bf16x4(ra[j], h, m, l);
+                float *d = &At[(buf * BKP + apix + (256 / AQ) * j) * LDA + 2 * aq];
+                *reinterpret_cast<uint2 *>(d) = h;
+                *reinterpret_cast<uint2 *>(d + IMG_A) = m;
+                *reinterpret_cast<uint2 *>(d + 2 * IMG_A) = l;
+            }
+#pragma unroll
+            for (int j = 0; j < BP; ++j) {
+                uint2 h, m, l;
+                split3_bf16x4(rb[j], h, m, l);
+                float *d = &Bt[(buf * BKP + bpix + (256 / BQ) * j) * LDB + 2 * bq];
+                *reinterpret_cast<uint2 *>(d) = h;
+                *reinterpret_cast<uint2 *>(d + IMG_B) = m;
+                *reinterpret_cast<uint2 *>(d + 2 * IMG_B) = l;
+            }
+        } else if constexpr (BF16) {
 #pragma unroll
             for (int j = 0; j < AP; ++j)
                 *reinterpret_cast<uint2 *>(&At[(buf * BKP + apix + (256 / AQ) * j) * LDA + 2 * aq]) = pack_bf16x4(ra[j]);
@@ -719,7 +761,30 @@ __device__ __forceinline__ void conv_wgrad_body(const float *__restrict__ x, con
         const int cur = st & 1;
         fetch();
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (BF16) {
+        if constexpr (X3) {
+            const float *Ac = At + (cur * BKP + 8 * lh + trq) * LDA + wm * 32 + 8 * trg + 2 * trp;
+            const float *Bc = Bt + (cur * BKP + 8 * lh + trq) * LDB + wn * 32 + 8 * trg + 2 * trp;
+            bf16x8 a[3][2], b[3][2];
+#pragma unroll
+            for (int gi = 0; gi < 3; ++gi)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(Ac + gi * IMG_A + 16 * t));
+                    const s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(Ac + gi * IMG_A + 4 * LDA + 16 * t));
+                    a[gi][t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    const s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(Bc + gi * IMG_B + 16 * t));
+                    const s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(Bc + gi * IMG_B + 4 * LDB + 16 * t));
+                    b[gi][t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+            constexpr int PA[6] = {2, 0, 1, 0, 1, 0}, PB[6] = {0, 2, 1, 1, 0, 0};      // smallest terms first
+#pragma unroll
+            for (int p = 0; p < 6; ++p)
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[p]][tm], b[PB[p]][tn], acc[tm][tn], 0, 0, 0);
+        } else if constexpr (BF16) {
             // 4-byte units: pixel (8h + q) of the step, rows wm*64 + 16*trg + 4p  (2 bf16 per unit)
             const float *Ac = At + (cur * BKP + 8 * lh + trq) * LDA + wm * 32 + 8 * trg + 2 * trp;
             const float *Bc = Bt + (cur * BKP + 8 * lh + trq) * LDB + wn * 32 + 8 * trg + 2 * trp;
@@ -797,16 +862,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
                                                          float *__restrict__ out, float *__restrict__ bias_out,
                                                          WgradGeom g, int groups)
 {
-    __shared__ __attribute__((aligned(16))) float smem[WgradCfg<BMK, BNC, false>::LDS_FLOATS];
-    conv_wgrad_body<BMK, BNC, MODE, false>(x, dy, out, bias_out, g, groups, smem);
+    __shared__ __attribute__((aligned(16))) float smem[WgradCfg<BMK, BNC, 0>::LDS_FLOATS];
+    conv_wgrad_body<BMK, BNC, MODE, 0>(x, dy, out, bias_out, g, groups, smem);
 }
 template <int BMK, int BNC, int MODE>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const float *__restrict__ x, const float *__restrict__ dy,
                                                               float *__restrict__ out, float *__restrict__ bias_out,
                                                               WgradGeom g, int groups)
 {
-    __shared__ __attribute__((aligned(16))) float smem[WgradCfg<BMK, BNC, true>::LDS_FLOATS];
-    conv_wgrad_body<BMK, BNC, MODE, true>(x, dy, out, bias_out, g, groups, smem);
+    __shared__ __attribute__((aligned(16))) float smem[WgradCfg<BMK, BNC, 1>::LDS_FLOATS];
+    conv_wgrad_body<BMK, BNC, MODE, 1>(x, dy, out, bias_out, g, groups, smem);
+}
+template <int BMK, int BNC, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                               float *__restrict__ out, float *__restrict__ bias_out,
+                                                               WgradGeom g, int groups)
+{
+    __shared__ __attribute__((aligned(16))) float smem[WgradCfg<BMK, BNC, 2>::LDS_FLOATS];
+    conv_wgrad_body<BMK, BNC, MODE, 2>(x, dy, out, bias_out, g, groups, smem);
 }
 
 __global__ void slab_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ out, size_t n, int splits)
@@ -874,6 +947,7 @@ template <bool DGRAD>
 static int launch_nt(const mqConvDesc *d, const float *act, const float *w, const float *bias, float *out, hipStream_t st)
 {
     const bool want_bf16 = d->precision == MQ_PRECISION_BF16;
+    const bool want_x3 = d->precision == MQ_PRECISION_F32X3;
     ConvGeom g;
     const int ng = d->N / d->groups;
     if (!DGRAD) {
@@ -912,6 +986,7 @@ static int launch_nt(const mqConvDesc *d, const float *act, const float *w, cons
     const int cb = chan_block(g.IC);
     const bool wide = cb >= 16;
     const bool bf16 = want_bf16 && vec;                // scalar-path layers (C = 1, K = 1 ...) are tiny: they stay f32
+    const bool x3 = want_x3 && vec;
     g.nMt = (int)cdiv(g.Mtot, GEMM_BM);
     g.nNt = (int)cdiv(g.Ncols, BN);
     if (parity) {
@@ -948,7 +1023,14 @@ static int launch_nt(const mqConvDesc *d, const float *act, const float *w, cons
         dim3 pgrid(t0 * g.nNt, d->groups);
 #define MQ_PAR(BN_, W_) hipLaunchKernelGGL((conv_dgrad_parity_kernel<BN_, W_>), pgrid, dim3(256), 0, st, act, w, out, g, pi, act_gs, w_gs, ng)
 #define MQ_PARH(BN_, W_) hipLaunchKernelGGL((conv_dgrad_parity_bf16_kernel<BN_, W_>), pgrid, dim3(256), 0, st, act, w, out, g, pi, act_gs, w_gs, ng)
-        if (bf16) {
+        if (x3) {
+#define MQ_PARX(BN_, W_) hipLaunchKernelGGL((conv_dgrad_parity_x3_kernel<BN_, W_>), pgrid, dim3(256), 0, st, act, w, out, g, pi, act_gs, w_gs, ng)
+            const int wr = g.IC % 16 == 0 ? 0 : (wide ? 1 : 4);
+            if (BN == 128) { if (wr == 0) MQ_PARX(128, 0); else if (wr == 1) MQ_PARX(128, 1); else MQ_PARX(128, 4); }
+            else if (BN == 64) { if (wr == 0) MQ_PARX(64, 0); else if (wr == 1) MQ_PARX(64, 1); else MQ_PARX(64, 4); }
+            else { if (wr == 0) MQ_PARX(32, 0); else if (wr == 1) MQ_PARX(32, 1); else MQ_PARX(32, 4); }
+#undef MQ_PARX
+        } else if (bf16) {
             if (BN == 128) { if (wide) MQ_PARH(128, 2); else MQ_PARH(128, 8); }
             else if (BN == 64) { if (wide) MQ_PARH(64, 2); else MQ_PARH(64, 8); }
             else { if (wide) MQ_PARH(32, 2); else MQ_PARH(32, 8); }
@@ -971,13 +1053,16 @@ static int launch_nt(const mqConvDesc *d, const float *act, const float *w, cons
     dim3 grid(g.nMt * g.nNt, d->groups), block(256);
 #define MQ_NT(BN_, M_) hipLaunchKernelGGL((conv_nt_kernel<BN_, DGRAD, M_>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs)
 #define MQ_NTH(BN_, M_) hipLaunchKernelGGL((conv_nt_bf16_kernel<BN_, DGRAD, M_>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs)
-#define MQ_NT3(BN_) do { if (bf16) { if (mode == 2) MQ_NTH(BN_, 2); else MQ_NTH(BN_, 1); } \
+#define MQ_NTX(BN_, M_) hipLaunchKernelGGL((conv_nt_x3_kernel<BN_, DGRAD, M_>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs)
+#define MQ_NT3(BN_) do { if (x3) { if (mode == 3) MQ_NTX(BN_, 3); else if (mode == 2) MQ_NTX(BN_, 2); else MQ_NTX(BN_, 1); } \
+                         else if (bf16) { if (mode == 2) MQ_NTH(BN_, 2); else MQ_NTH(BN_, 1); } \
                          else if (mode == 3) MQ_NT(BN_, 3); else if (mode == 2) MQ_NT(BN_, 2); else if (mode == 1) MQ_NT(BN_, 1); \
                          else MQ_NT(BN_, 0); } while (0)
     if (BN == 128) MQ_NT3(128);
     else if (BN == 64) MQ_NT3(64);
     else MQ_NT3(32);
 #undef MQ_NT3
+#undef MQ_NTX
 #undef MQ_NTH
 #undef MQ_NT
     MQ_LAUNCH_CHECK(DGRAD ? "mq_conv_dgrad" : "mq_conv_fprop");
@@ -1004,7 +1089,8 @@ static void wgrad_plan(const mqConvDesc *d, WgradGeom &g)
     // blocks a CU holds): among the split counts that keep >= 32 K-steps per split, take the one with the best
     // fill  tiles*s / (rounds * slots), charging a little for every extra round of slabs (write + re-read).
     const int64_t tiles = (int64_t)g.nKt * g.nCt * d->groups;
-    const int64_t slots = 256 * ((g.bmk == 64 ? 3 : 4) - (bk == 32 ? 1 : 0));     // resident blocks per CU (registers / LDS)
+    const bool x3 = d->precision == MQ_PRECISION_F32X3 && wgrad_vec_shape(d);
+    const int64_t slots = x3 ? 512 : 256 * ((g.bmk == 64 ? 3 : 4) - (bk == 32 ? 1 : 0));   // resident blocks per CU (registers / LDS)
     int64_t max_splits = cdiv(g.Mtot, bk * 32);
     if (max_splits > 512) max_splits = 512;
     if (max_splits < 1) max_splits = 1;
@@ -1092,16 +1178,20 @@ static int wgrad_impl(const mqConvDesc *d, const float *x, const float *dy, floa
     dim3 grid(g.nKt * g.nCt, d->groups, g.splits), block(256);
     const int mode = vec ? (d->Q >= WG_BK ? 2 : 1) : 0;
     const bool bf16 = d->precision == MQ_PRECISION_BF16 && wgrad_vec_shape(d);
-    MQ_REQUIRE(!bf16 || vec, "%s: bf16 engine needs 16-byte aligned tensors below the 2 GB-per-split span", who);
+    const bool x3 = d->precision == MQ_PRECISION_F32X3 && wgrad_vec_shape(d);
+    MQ_REQUIRE(!(bf16 || x3) || vec, "%s: bf16 engines need 16-byte aligned tensors below the 2 GB-per-split span", who);
     // fused bias partials: vector path only; one split writes straight into dbias
     float *bias_target = (dbias && mode > 0) ? (g.splits > 1 ? bias_ws : dbias) : nullptr;
 #define MQ_WG(A_, B_, M_) hipLaunchKernelGGL((conv_wgrad_kernel<A_, B_, M_>), grid, block, 0, st, x, dy, target, bias_target, g, d->groups)
 #define MQ_WGH(A_, B_, M_) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<A_, B_, M_>), grid, block, 0, st, x, dy, target, bias_target, g, d->groups)
-#define MQ_WG3(A_, B_) do { if (bf16) { if (mode == 2) MQ_WGH(A_, B_, 2); else MQ_WGH(A_, B_, 1); } \
+#define MQ_WGX(A_, B_, M_) hipLaunchKernelGGL((conv_wgrad_x3_kernel<A_, B_, M_>), grid, block, 0, st, x, dy, target, bias_target, g, d->groups)
+#define MQ_WG3(A_, B_) do { if (x3) { if (mode == 2) MQ_WGX(A_, B_, 2); else MQ_WGX(A_, B_, 1); } \
+                            else if (bf16) { if (mode == 2) MQ_WGH(A_, B_, 2); else MQ_WGH(A_, B_, 1); } \
                             else if (mode == 2) MQ_WG(A_, B_, 2); else if (mode == 1) MQ_WG(A_, B_, 1); else MQ_WG(A_, B_, 0); } while (0)
     if (g.bmk == 64) MQ_WG3(64, 256);
     else MQ_WG3(128, 128);
 #undef MQ_WG3
+#undef MQ_WGX
 #undef MQ_WGH
 #undef MQ_WG
     MQ_LAUNCH_CHECK(who);

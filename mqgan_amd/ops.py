@@ -46,7 +46,7 @@ def next_seed() -> int:
 
 
 # ----------------------------------------------------------------------------- convolution
-PRECISIONS = {"f32": 0, "bf16": 1}
+PRECISIONS = {"f32": 0, "bf16": 1, "f32x3": 2}
 _conv_precision = 0
 
 
@@ -135,22 +135,23 @@ def _timed(tag, flops, fn, detail=None):
 
 def _conv_tag(kind, d: ConvDesc):
     """Name of the kernel instantiation the C side picks (igemm.hip: launch_nt / mq_conv_wgrad)."""
-    want_h = d.precision == PRECISIONS["bf16"]
+    eng = {0: "", 1: "bf16_", 2: "x3_"}[d.precision]
     if kind == "wgrad":
         vec = d.C % 4 == 0 and d.K % 4 == 0
         mode = (2 if d.Q >= 16 else 1) if vec else 0
-        return f"conv_wgrad_{'bf16_' if want_h and vec else ''}kernel<{'64, 256' if d.K <= 64 else '128, 128'}, {mode}>"
+        return f"conv_wgrad_{eng if vec else ''}kernel<{'64, 256' if d.K <= 64 else '128, 128'}, {mode}>"
     ncols, ic = (d.K, d.C) if kind == "fprop" else (d.C, d.K)
     bn = min((128, 64, 32), key=lambda b: (-(-ncols // b) * b / {128: 1.0, 64: 0.9, 32: 0.75}[b], -b))
     strided = d.stride_h > 1 or d.stride_w > 1
-    h = want_h and ic % 4 == 0
+    e = eng if ic % 4 == 0 else ""
+    bf = e == "bf16_"
     if kind == "dgrad" and strided:
         if ic % 4 == 0 and d.stride_h <= 2 and d.stride_w <= 2:
-            wraps = (2 if ic % 16 == 0 else 8) if h else (0 if ic % 16 == 0 else (1 if ic >= 16 else 4))
-            return f"conv_dgrad_parity_{'bf16_' if h else ''}kernel<{bn}, {wraps}>"
+            wraps = (2 if ic % 16 == 0 else 8) if bf else (0 if ic % 16 == 0 else (1 if ic >= 16 else 4))
+            return f"conv_dgrad_parity_{e}kernel<{bn}, {wraps}>"
         return f"conv_nt_kernel<{bn}, true, 0>"
-    mode = (2 if h else 3) if ic % 16 == 0 else ((2 if ic >= 16 else 1) if ic % 4 == 0 else 0)
-    return f"conv_nt_{'bf16_' if h else ''}kernel<{bn}, {str(kind == 'dgrad').lower()}, {mode}>"
+    mode = (2 if bf else 3) if ic % 16 == 0 else ((2 if ic >= 16 else 1) if ic % 4 == 0 else 0)
+    return f"conv_nt_{e}kernel<{bn}, {str(kind == 'dgrad').lower()}, {mode}>"
 
 
 def _conv_flops(d: ConvDesc):

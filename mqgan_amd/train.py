@@ -186,13 +186,15 @@ class Trainer:
         self.reducer_d = GradReducer(self.arena_d)
         self.gan_loss = LSGANLoss().to(self.device)      # ONE instance for all nine discriminators (train.py:216)
         # The reference picks bf16 autocast whenever the GPU supports it (train.py:220, 523); here the engine is an
-        # explicit knob: training.precision = "fp32" (default; the 1e-4 parity path, BASELINE config 2) or "bf16"
+        # explicit knob: training.precision = "fp32" (default; the 1e-4 parity path, BASELINE config 2), "fp32x3" or "bf16"
         # (bf16 MFMA operands in every conv / linear, f32 accumulation, f32 tensors; BASELINE config 3).
         prec = str(config["training"].get("precision", "fp32")).lower()
-        if prec not in ("fp32", "f32", "bf16"):
-            raise ValueError(f"training.precision must be fp32 or bf16, got {prec!r}")
+        if prec not in ("fp32", "f32", "bf16", "f32x3", "fp32x3"):
+            raise ValueError(f"training.precision must be fp32, fp32x3 or bf16, got {prec!r}")
         self.use_bf16 = prec == "bf16"
-        self.conv_precision = "bf16" if self.use_bf16 else "f32"
+        # "fp32x3": f32 results from the bf16 matrix pipe (exact three-term split of every operand, 6 cross products);
+        # opt-in - it has the error of an f32 FMA chain but is not bit-identical to the default engine
+        self.conv_precision = "bf16" if self.use_bf16 else ("f32x3" if prec.endswith("x3") else "f32")
         self.log_fn = log_fn
         self.global_step = 0
         self._init_checkpoint_handling()

@@ -174,11 +174,12 @@ def _torch_conv(x, w, b, c):
     return torch.cat(outs, 0).permute(0, 2, 3, 1)
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("precision", ["f32", "bf16", "f32x3"])
 @pytest.mark.parametrize("c", CONV_CASES, ids=lambda c: "N{N}H{H}W{W}C{C}K{K}R{R}S{S}".format(**c) + f"g{c.get('groups', 1)}")
 def test_conv_fprop_dgrad_wgrad(env, c, precision):
     """precision="bf16": the operands are drawn bf16-representable, so rounding them inside the kernel is the
-    identity and the bf16 MFMA engine (exact products, f32 accumulation) must meet the same bound as the f32 one."""
+    identity and the bf16 MFMA engine (exact products, f32 accumulation) must meet the same bound as the f32 one.
+    precision="f32x3" (three-term bf16 split of f32 operands) takes arbitrary f32 inputs and the f32 bound."""
     ops = env
     torch.manual_seed(0)
     G = c.get("groups", 1)
@@ -211,7 +212,7 @@ def test_conv_fprop_dgrad_wgrad(env, c, precision):
     assert_rel(bd.grad, b.grad, 2e-5, "bias grad")
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("precision", ["f32", "bf16", "f32x3"])
 def test_conv_large_split_k_and_tiles(env, precision):
     """A refiner-sized layer: many M tiles, split-K wgrad with the slab reduction."""
     ops = env

@@ -22,9 +22,9 @@ def built():
     assert torch.cuda.is_available()
 
 
-def make_trainer(g, use_fm):
+def make_trainer(g, use_fm, precision="fp32"):
     from mqgan_amd.train import Trainer
-    cfg = {"model": TINY_CFG["model"], "training": dict(TINY_CFG["training"], use_fm_loss=use_fm, pretrained=None)}
+    cfg = {"model": TINY_CFG["model"], "training": dict(TINY_CFG["training"], use_fm_loss=use_fm, pretrained=None, precision=precision)}
     tr = Trainer(cfg, device=DEV, build_data=False)
     tr.generator.load_state_dict(npz_state_dict(g, "g0/"), strict=True)
     tr.patch_discriminator.load_state_dict(npz_state_dict(g, "p0/"), strict=True)
@@ -34,10 +34,13 @@ def make_trainer(g, use_fm):
     return tr
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3"])
 @pytest.mark.parametrize("fname,use_fm", [("g7_trainstep.npz", False), ("g7b_trainstep_fm.npz", True)])
-def test_two_train_steps_match_reference(fname, use_fm):
+def test_two_train_steps_match_reference(fname, use_fm, precision):
+    """fp32x3 (f32 from the bf16 matrix pipe by exact operand splitting) is held to the same fixtures and the
+    same tolerances as the default f32 MFMA engine."""
     g = load_golden(fname)
-    tr = make_trainer(g, use_fm)
+    tr = make_trainer(g, use_fm, precision)
     tr.generator.eval()                       # fixtures were generated with G.eval() (dropout / FSQ noise off)
     tr.patch_discriminator.train()
     tr.multibin_discriminator.train()
