@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256, MQ_NT_OCC) void conv_nt_kernel(const float *__
 }
 // f32 via three-term bf16 split (gemm_core.h: EngSplit); vector path only
 template <int BN, bool DGRAD, int MODE>
-__global__ __launch_bounds__(256, 2) void conv_nt_x3_kernel(const float *__restrict__ act, const float *__restrict__ wgt,
+__global__ __launch_bounds__(256, 3) void conv_nt_x3_kernel(const float *__restrict__ act, const float *__restrict__ wgt,
                                                          const float *__restrict__ bias, float *__restrict__ out,
                                                          ConvGeom g, WalkGeom wg, size_t act_group_stride,
                                                          size_t w_group_stride)
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256, MQ_NT_OCC) void conv_dgrad_parity_kernel(const
     conv_dgrad_parity_body<EngF32, BN, WRAPS>(dy, wgt, dx, g, pi, act_group_stride, w_group_stride, ng, smem);
 }
 template <int BN, int WRAPS>
-__global__ __launch_bounds__(256, 2) void conv_dgrad_parity_x3_kernel(const float *__restrict__ dy, const float *__restrict__ wgt,
+__global__ __launch_bounds__(256, 3) void conv_dgrad_parity_x3_kernel(const float *__restrict__ dy, const float *__restrict__ wgt,
                                                                    float *__restrict__ dx, ConvGeom g, ParityInfo pi,
                                                                    size_t act_group_stride, size_t w_group_stride, int ng)
 {
@@ -776,7 +776,7 @@ __device__ __forceinline__ void conv_wgrad_body(const float *__restrict__ x, con
                     const s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(Bc + gi * IMG_B + 4 * LDB + 16 * t));
                     b[gi][t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7));
                 }
-            constexpr int PA[6] = {2, 0, 1, 0, 1, 0}, PB[6] = {0, 2, 1, 1, 0, 0};      // smallest terms first
+            constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};      // h*h first (see gemm_core.h)
 #pragma unroll
             for (int p = 0; p < 6; ++p)
 #pragma unroll
