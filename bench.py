@@ -136,6 +136,33 @@ def cpu_baseline(seconds_budget=30.0):
                       f"{el:.1f} s on {threads} threads ({os.cpu_count()} logical CPUs visible)"}
 
 
+def quick_engine(cfg, precision, device, batches, lens, B, T, steps=4, warmup=1):
+    """Step time of the same workload on another conv engine (training.precision)."""
+    import copy
+    from mqgan_amd.train import Trainer
+    c = copy.deepcopy(cfg)
+    c["training"]["precision"] = precision
+    tr = Trainer(c, device=device, build_data=False)
+    tr.generator.train(); tr.patch_discriminator.train(); tr.multibin_discriminator.train()
+    tr.epoch = 1
+    for i in range(warmup):
+        tr.train_step(batches[i % len(batches)], lens)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        last = tr.train_step(batches[i % len(batches)], lens)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"value": B * T * steps / dt, "unit": "mel-frames/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+           "losses_finite": all(np.isfinite(float(v)) for v in last.values()),
+           "arithmetic": {"fp32x3": "f32 operands split exactly into 3 bf16 terms in-kernel, 6 cross products on the bf16 MFMA, "
+                                    "f32 accumulate; passes the reference fixtures at the f32 tolerances",
+                          "bf16": "operands rounded to bf16 in-kernel, f32 accumulate, f32 tensors (reference autocast mode)"}[precision]}
+    del tr
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,6 +175,7 @@ def main():
                     help="matrix engine of the convs (fp32 = the BASELINE metric's; bf16 = BASELINE config 3, secondary)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vq", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the secondary fp32x3 / bf16 engine timings")
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     args = ap.parse_args()
 
@@ -240,6 +268,11 @@ def main():
                                        "D active, FM off, train-mode dropout", "global_batch": world * B, "frames": T,
                            "parallelism": f"dp{world}"},
                 "losses_finite": bool(finite), "roofline": roof}
+        if world == 1 and not args.no_alt and args.precision == "fp32":
+            # secondary figures, same workload, opt-in engines (never `value`): see DESIGN.md section 3
+            del tr
+            torch.cuda.empty_cache()
+            line["other_engines"] = {p: quick_engine(cfg, p, device, batches, lens, B, T) for p in ("fp32x3", "bf16")}
         if not args.no_vq:
             line["vq"] = bench_vq(device)
         if world == 1 and not args.no_cpu_baseline:
