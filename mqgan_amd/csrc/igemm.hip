@@ -1,5 +1,7 @@
 // Implicit-GEMM convolution (fprop / dgrad / wgrad) on f32 MFMA for gfx950, NHWC.
 // See include/mqgan_hip.h (mq_conv_*) for the interface and gemm_core.h for the tile engine.
+#include <type_traits>
+
 #include "gemm_core.h"
 
 #ifndef MQ_NT_OCC
@@ -522,7 +524,9 @@ struct WgradGeom {
 // Block tile BMK (output channels k) x BNC (filter columns kk), 4 waves of 64 x 64 each:
 //   <128, 128> general;  <64, 256> when K <= 64 (refiner top level, logits convs) so that rows are not wasted.
 // MODE 0: scalar loads (C or K not a multiple of 4); 1: vector loads, pixel coordinates by division;
-//      2: vector loads, pixel coordinates walked incrementally (OW >= 16: at most one row wrap per step).
+//      2: vector loads, pixel coordinates walked incrementally per thread (OW >= 16: at most BKP/16 row wraps per step);
+//      3: OW >= BKP - the first pixel of the step is walked on the scalar unit and every thread adds its constant
+//         pixel delta (at most one row wrap inside a step): half the vector work of mode 2.
 //
 // bf16 engine (BF16 = true): 32 pixels per step; the tiles are rounded to bf16 on their way into LDS and kept
 // [pixel][row] with 2*rows + 64 bytes per pixel (64 mod 256: the four pixel rows of a transposed read fall on
@@ -561,11 +565,18 @@ __device__ __forceinline__ void conv_wgrad_body(const float *__restrict__ x, con
     float *Bt = smem + WC::NIMG * 2 * BKP * LDA;         // [2][BKP][LDB]  x gather  (pixel, kk)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WNW, wn = wave % WNW, li = lane & 31, lh = lane >> 5;
-    const int tile = blockIdx.x;
+    // All tiles of one (split, group) read the same pixel range of x and dy.  Blocks are dispatched round-robin
+    // over the 8 XCDs, so the linear block id is remapped such that each XCD works through whole (split, group)
+    // sets one after the other: the pixel range is fetched into ONE L2 instead of all eight.
+    const int ntile = gridDim.x;
+    const int lin = blockIdx.x + ntile * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int virt = xcd_remap(lin, ntile * gridDim.y * gridDim.z);
+    const int tile = virt % ntile;
+    const int sg = virt / ntile;
+    const int grp = sg % gridDim.y;
+    const int split = sg / gridDim.y;
     const int kt_ = tile / g.nCt, ct = tile - kt_ * g.nCt;
     const int k0 = kt_ * BMK, c0 = ct * BNC;
-    const int grp = blockIdx.y;
-    const int split = blockIdx.z;
     // bias gradient = column sums of dy: the blocks of the first column tile already stream every dy tile of
     // their rows through registers, so they add them up on the way (bias_out: [split][group][K] partials)
     const bool do_bias = bias_out != nullptr && ct == 0;
@@ -628,7 +639,47 @@ __device__ __forceinline__ void conv_wgrad_body(const float *__restrict__ x, con
         boh[j] = oh * g.sh;
         bbase[j] = ((n * g.IH + boh[j]) * g.IW + bow[j]) * g.IC;
     };
+    // MODE 3 state: wave-uniform position of the staged step's first pixel + per-thread constants
+    int s_p = m_begin, s_ow, s_oh, s_base4;
+    int dA[AP], vA[AP], dB[BP], vB[BP], tw[BP];
+    {
+        const int ow = s_p % g.OW, t2 = s_p / g.OW;
+        s_ow = ow;
+        s_oh = t2 % g.OH;
+        s_base4 = (((t2 / g.OH - img0) * g.IH + s_oh * g.sh) * g.IW + ow * g.sw) * g.IC * 4;
+#pragma unroll
+        for (int j = 0; j < AP; ++j) {
+            dA[j] = apix + (256 / AQ) * j;
+            vA[j] = (dA[j] * g.K + ka) * 4;
+        }
+#pragma unroll
+        for (int j = 0; j < BP; ++j) {
+            dB[j] = bpix + (256 / BQ) * j;
+            vB[j] = (dB[j] * g.sw * g.IC + tap_off) * 4;
+            tw[j] = dB[j] * g.sw + tap_w;
+        }
+    }
     auto offsets = [&]() {
+        if constexpr (MODE == 3) {
+            const int left = m_end - s_p;                    // pixels of this split from the step's first one on
+            const int s_a = (s_p - pix0) * g.K * 4;
+#pragma unroll
+            for (int j = 0; j < AP; ++j) oa[j] = ((dA[j] < left) & (ka < g.K)) ? (unsigned)(vA[j] + s_a) : OOB;
+            const int wrapd = g.OW - s_ow;                   // deltas >= wrapd fall on the next output row
+            const bool last_row = s_oh + 1 == g.OH;          // ... which is row 0 of the next image
+            const int rowjump = ((g.sh * g.IW - g.OW * g.sw) + (last_row ? (g.IH - g.OH * g.sh) * g.IW : 0)) * g.IC * 4;
+            const bool okA = (unsigned)(s_oh * g.sh + tap_h) < (unsigned)g.IH;
+            const bool okB = (unsigned)((last_row ? 0 : (s_oh + 1) * g.sh) + tap_h) < (unsigned)g.IH;
+            const int s_iw = s_ow * g.sw;
+#pragma unroll
+            for (int j = 0; j < BP; ++j) {
+                const bool c = dB[j] >= wrapd;
+                const int iw = s_iw + tw[j] - (c ? g.OW * g.sw : 0);
+                const bool ok = (dB[j] < left) & bv[0] & (c ? okB : okA) & ((unsigned)iw < (unsigned)g.IW);
+                ob[j] = ok ? (unsigned)(vB[j] + s_base4 + (c ? rowjump : 0)) : OOB;
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < AP; ++j) oa[j] = (am[j] < m_end && ka < g.K) ? (unsigned)((am[j] - pix0) * g.K + ka) * 4u : OOB;
 #pragma unroll
@@ -640,6 +691,19 @@ __device__ __forceinline__ void conv_wgrad_body(const float *__restrict__ x, con
         }
     };
     auto advance = [&]() {                               // all slots move on by BKP pixels
+        if constexpr (MODE == 3) {                           // scalar unit only
+            s_p += BKP;
+            s_ow += BKP;
+            s_base4 += BKP * g.sw * g.IC * 4;
+            const bool w1 = s_ow >= g.OW;
+            s_ow -= w1 ? g.OW : 0;
+            s_oh += w1 ? 1 : 0;
+            s_base4 += w1 ? (g.sh * g.IW - g.OW * g.sw) * g.IC * 4 : 0;
+            const bool w2 = s_oh >= g.OH;
+            s_oh = w2 ? 0 : s_oh;
+            s_base4 += w2 ? (g.IH - g.OH * g.sh) * g.IW * g.IC * 4 : 0;
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < AP; ++j) am[j] += BKP;
 #pragma unroll
@@ -698,8 +762,8 @@ __device__ __forceinline__ void conv_wgrad_body(const float *__restrict__ x, con
             }
         }
     };
-    auto sstore = [&](int buf) {
-        if (do_bias) {
+    auto sstore = [&](int buf, auto bias_tag) {
+        if constexpr (decltype(bias_tag)::value) {
 #pragma unroll
             for (int j = 0; j < AP; ++j) {
                 bsum.x += ra[j].x; bsum.y += ra[j].y; bsum.z += ra[j].z; bsum.w += ra[j].w;
@@ -751,9 +815,11 @@ __device__ __forceinline__ void conv_wgrad_body(const float *__restrict__ x, con
     const int nsteps = (m_end - m_begin + BKP - 1) / BKP;
     // transposed-read lane constants (bf16): 16-lane group G -> rows 16*(G&1).., pixel half h = G>>1
     const int trq = (lane & 15) >> 2, trp = lane & 3, trg = (lane >> 4) & 1;
+    // the K loop exists twice: the blocks that also sum the bias gradient pay for those adds, the others do not
+    auto run = [&](auto bias_tag) {
     offsets();
     fetch();
-    sstore(0);
+    sstore(0, bias_tag);
     advance();
     offsets();
     __syncthreads();
@@ -822,9 +888,12 @@ __device__ __forceinline__ void conv_wgrad_body(const float *__restrict__ x, con
         advance();
         offsets();
         __builtin_amdgcn_sched_barrier(0);
-        sstore(cur ^ 1);
+        sstore(cur ^ 1, bias_tag);
         __syncthreads();
     }
+    };
+    if (do_bias) run(std::true_type{});
+    else run(std::false_type{});
 
     if (do_bias) {       // fixed-order reduction over the 256/AQ pixel rows of threads (the last barrier of the loop has passed)
         float *red = smem;
@@ -1176,8 +1245,8 @@ static int wgrad_impl(const mqConvDesc *d, const float *x, const float *dy, floa
                      split_imgs * d->P * d->Q * g.K * sizeof(float) < 0x7FFFFFF0ull &&
                      split_imgs * d->H * d->W * d->C * sizeof(float) < 0x7FFFFFF0ull;
     dim3 grid(g.nKt * g.nCt, d->groups, g.splits), block(256);
-    const int mode = vec ? (d->Q >= WG_BK ? 2 : 1) : 0;
     const bool bf16 = d->precision == MQ_PRECISION_BF16 && wgrad_vec_shape(d);
+    const int mode = vec ? (d->Q >= (bf16 ? 32 : WG_BK) ? 3 : (d->Q >= WG_BK ? 2 : 1)) : 0;
     const bool x3 = d->precision == MQ_PRECISION_F32X3 && wgrad_vec_shape(d);
     MQ_REQUIRE(!(bf16 || x3) || vec, "%s: bf16 engines need 16-byte aligned tensors below the 2 GB-per-split span", who);
     // fused bias partials: vector path only; one split writes straight into dbias
@@ -1185,9 +1254,9 @@ static int wgrad_impl(const mqConvDesc *d, const float *x, const float *dy, floa
 #define MQ_WG(A_, B_, M_) hipLaunchKernelGGL((conv_wgrad_kernel<A_, B_, M_>), grid, block, 0, st, x, dy, target, bias_target, g, d->groups)
 #define MQ_WGH(A_, B_, M_) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<A_, B_, M_>), grid, block, 0, st, x, dy, target, bias_target, g, d->groups)
 #define MQ_WGX(A_, B_, M_) hipLaunchKernelGGL((conv_wgrad_x3_kernel<A_, B_, M_>), grid, block, 0, st, x, dy, target, bias_target, g, d->groups)
-#define MQ_WG3(A_, B_) do { if (x3) { if (mode == 2) MQ_WGX(A_, B_, 2); else MQ_WGX(A_, B_, 1); } \
-                            else if (bf16) { if (mode == 2) MQ_WGH(A_, B_, 2); else MQ_WGH(A_, B_, 1); } \
-                            else if (mode == 2) MQ_WG(A_, B_, 2); else if (mode == 1) MQ_WG(A_, B_, 1); else MQ_WG(A_, B_, 0); } while (0)
+#define MQ_WG3(A_, B_) do { if (x3) { if (mode == 3) MQ_WGX(A_, B_, 3); else MQ_WGX(A_, B_, 1); } \
+                            else if (bf16) { if (mode == 3) MQ_WGH(A_, B_, 3); else if (mode == 2) MQ_WGH(A_, B_, 2); else MQ_WGH(A_, B_, 1); } \
+                            else if (mode == 3) MQ_WG(A_, B_, 3); else if (mode == 1) MQ_WG(A_, B_, 1); else MQ_WG(A_, B_, 0); } while (0)
     if (g.bmk == 64) MQ_WG3(64, 256);
     else MQ_WG3(128, 128);
 #undef MQ_WG3

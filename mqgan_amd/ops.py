@@ -138,7 +138,7 @@ def _conv_tag(kind, d: ConvDesc):
     eng = {0: "", 1: "bf16_", 2: "x3_"}[d.precision]
     if kind == "wgrad":
         vec = d.C % 4 == 0 and d.K % 4 == 0
-        mode = (2 if d.Q >= 16 else 1) if vec else 0
+        mode = (3 if d.Q >= (32 if eng == "bf16_" else 16) else (2 if d.Q >= 16 else 1)) if vec else 0
         return f"conv_wgrad_{eng if vec else ''}kernel<{'64, 256' if d.K <= 64 else '128, 128'}, {mode}>"
     ncols, ic = (d.K, d.C) if kind == "fprop" else (d.C, d.K)
     bn = min((128, 64, 32), key=lambda b: (-(-ncols // b) * b / {128: 1.0, 64: 0.9, 32: 0.75}[b], -b))
