@@ -951,8 +951,30 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const float *__re
     conv_wgrad_body<BMK, BNC, MODE, 2>(x, dy, out, bias_out, g, groups, smem);
 }
 
+// out[i] = sum_k slabs[k][i] in the fixed order k = 0, 1, ... (deterministic).  float4 per thread, four slabs in
+// flight per accumulation step so that the loads overlap (the sums are still formed in slab order).
+template <bool VEC>      // VEC: n % 4 == 0 and 16-byte aligned pointers
 __global__ void slab_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ out, size_t n, int splits)
 {
+    const size_t n4 = VEC ? n >> 2 : 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 *p = reinterpret_cast<const float4 *>(slabs) + i;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        int k = 0;
+        for (; k + 4 <= splits; k += 4) {
+            const float4 a = p[(size_t)k * n4], b = p[(size_t)(k + 1) * n4], c = p[(size_t)(k + 2) * n4], d = p[(size_t)(k + 3) * n4];
+            s.x = (((s.x + a.x) + b.x) + c.x) + d.x;
+            s.y = (((s.y + a.y) + b.y) + c.y) + d.y;
+            s.z = (((s.z + a.z) + b.z) + c.z) + d.z;
+            s.w = (((s.w + a.w) + b.w) + c.w) + d.w;
+        }
+        for (; k < splits; ++k) {
+            const float4 a = p[(size_t)k * n4];
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
+        reinterpret_cast<float4 *>(out)[i] = s;
+    }
+    if (VEC) return;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         float s = 0.f;
         for (int k = 0; k < splits; ++k) s += slabs[(size_t)k * n + i];
@@ -1265,11 +1287,13 @@ static int wgrad_impl(const mqConvDesc *d, const float *x, const float *dy, floa
 #undef MQ_WG
     MQ_LAUNCH_CHECK(who);
     if (g.splits > 1) {
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(ew_grid((int64_t)n, 256)), dim3(256), 0, st, target, dw, n, g.splits);
+        const bool v4 = n % 4 == 0 && (uintptr_t)target % 16 == 0 && (uintptr_t)dw % 16 == 0;
+        if (v4) hipLaunchKernelGGL(slab_reduce_kernel<true>, dim3(ew_grid((int64_t)n / 4, 256)), dim3(256), 0, st, target, dw, n, g.splits);
+        else hipLaunchKernelGGL(slab_reduce_kernel<false>, dim3(ew_grid((int64_t)n, 256)), dim3(256), 0, st, target, dw, n, g.splits);
         if (bias_target) {
             const size_t nb = (size_t)d->groups * g.K;
-            hipLaunchKernelGGL(slab_reduce_kernel, dim3(ew_grid((int64_t)nb, 256)), dim3(256), 0, st, bias_target, dbias, nb,
-                               g.splits);
+            hipLaunchKernelGGL(slab_reduce_kernel<false>, dim3(ew_grid((int64_t)nb, 256)), dim3(256), 0, st, bias_target, dbias,
+                               nb, g.splits);
         }
         MQ_LAUNCH_CHECK(who);
     }
