@@ -140,29 +140,27 @@ __device__ __forceinline__ void nt_gemm_mainloop(ALoad &la, BLoad &lb, int nk, f
         // phase 2
         const float *Ac = As + cur * GEMM_BM * GEMM_LD + (wm * Cfg::TM * 32 + li) * GEMM_LD + 2 * lh;
         const float *Bc = Bs + cur * BN * GEMM_LD + (wn * Cfg::TN * 32 + li) * GEMM_LD + 2 * lh;
+        auto mfma_quads = [&](int q0, int q1) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float2 a[Cfg::TM], b[Cfg::TN];
+            for (int q = q0; q < q1; ++q) {
+                float2 a[Cfg::TM], b[Cfg::TN];
 #pragma unroll
-            for (int t = 0; t < Cfg::TM; ++t) a[t] = *reinterpret_cast<const float2 *>(Ac + t * 32 * GEMM_LD + 4 * q);
+                for (int t = 0; t < Cfg::TM; ++t) a[t] = *reinterpret_cast<const float2 *>(Ac + t * 32 * GEMM_LD + 4 * q);
 #pragma unroll
-            for (int t = 0; t < Cfg::TN; ++t) b[t] = *reinterpret_cast<const float2 *>(Bc + t * 32 * GEMM_LD + 4 * q);
+                for (int t = 0; t < Cfg::TN; ++t) b[t] = *reinterpret_cast<const float2 *>(Bc + t * 32 * GEMM_LD + 4 * q);
 #pragma unroll
-            for (int tm = 0; tm < Cfg::TM; ++tm)
+                for (int tm = 0; tm < Cfg::TM; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < Cfg::TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].x, b[tn].x, acc[tm][tn], 0, 0, 0);
+                    for (int tn = 0; tn < Cfg::TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].x, b[tn].x, acc[tm][tn], 0, 0, 0);
 #pragma unroll
-            for (int tm = 0; tm < Cfg::TM; ++tm)
+                for (int tm = 0; tm < Cfg::TM; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < Cfg::TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].y, b[tn].y, acc[tm][tn], 0, 0, 0);
-        }
-        la.stage((kt + 2) * GEMM_BK);
-        lb.stage((kt + 2) * GEMM_BK);
-        __builtin_amdgcn_sched_barrier(0);
-        // phase 3
-        {
+                    for (int tn = 0; tn < Cfg::TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].y, b[tn].y, acc[tm][tn], 0, 0, 0);
+            }
+        };
+        auto store_next = [&]() {
             float *An = As + (cur ^ 1) * GEMM_BM * GEMM_LD;
             float *Bn = Bs + (cur ^ 1) * BN * GEMM_LD;
 #pragma unroll
@@ -172,7 +170,13 @@ __device__ __forceinline__ void nt_gemm_mainloop(ALoad &la, BLoad &lb, int nk, f
                 for (int j = 0; j < Cfg::B_SLOTS; ++j)
                     lds_store_k4<KORDER>(&Bn[(ld_row + 64 * j) * GEMM_LD + 4 * ld_kq], rb[j]);
             }
-        }
+        };
+        mfma_quads(0, 4);
+        la.stage((kt + 2) * GEMM_BK);
+        lb.stage((kt + 2) * GEMM_BK);
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 3  (writing the tile in the middle of the MFMA phase instead was measured: no difference)
+        store_next();
         __syncthreads();
     }
 }
