@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .nn_base import ConvParams
+from .nn_base import ConvParams, share_effective_weights
 
 
 class ChannelSELayerMasked(nn.Module):
@@ -95,6 +95,17 @@ class MultiBinDiscriminator(nn.Module):
 
 def _stacked(bands, get, need_crsk=True, power_iteration=False, detach=False):
     """Effective weights of the same layer of every band, stacked along the group axis."""
+    shared = share_effective_weights.active
+    key = ("stacked", id(get(bands[0])), len(bands), need_crsk, detach)
+    if shared is not None and not power_iteration and key in shared:
+        return shared[key]
+    out = _stack_now(bands, get, need_crsk, power_iteration, detach)
+    if shared is not None and not power_iteration:
+        shared[key] = out
+    return out
+
+
+def _stack_now(bands, get, need_crsk, power_iteration, detach):
     ws = [get(b).effective(need_crsk=need_crsk, power_iteration=power_iteration) for b in bands]
     if len(ws) == 1:
         w_krsc, w_crsk = ws[0]

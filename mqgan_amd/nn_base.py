@@ -48,6 +48,24 @@ class _Parametrizations(nn.Module):
         self.weight = _WNOriginals(g, v)
 
 
+class share_effective_weights:
+    """``with share_effective_weights(): D(real); D(fake)`` - inside the block every layer's effective weights are
+    computed once and reused by later forward passes, as long as the pass does not change them (i.e. no spectral-norm
+    power iteration: discriminators in eval mode, which is their state from the first generator step of an epoch
+    on, train.py:415-416).  The weight gradient then flows through the normalisation once, with the output
+    gradients of all passes already summed - the same derivative the reference accumulates pass by pass."""
+    active = None
+
+    def __enter__(self):
+        self.prev = share_effective_weights.active
+        share_effective_weights.active = {}
+        return self
+
+    def __exit__(self, *exc):
+        share_effective_weights.active = self.prev
+        return False
+
+
 class ConvParams(nn.Module):
     """Weights of one conv / linear layer.  ``flavour`` in {"plain", "wn", "wn_legacy", "sn"}."""
 
@@ -94,6 +112,13 @@ class ConvParams(nn.Module):
             if key not in self._cache:
                 self._cache[key] = self._effective(need_crsk, False)
             return self._cache[key]
+        shared = share_effective_weights.active
+        if shared is not None and not power_iteration:
+            key = (id(self), need_crsk)
+            if key not in shared:
+                hit = shared.get((id(self), True)) if not need_crsk else None     # a CRSK-bearing entry serves both
+                shared[key] = hit if hit is not None else self._effective(need_crsk, False)
+            return shared[key]
         return self._effective(need_crsk, power_iteration)
 
     def _effective(self, need_crsk: bool = True, power_iteration: bool = False):

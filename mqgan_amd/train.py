@@ -28,6 +28,7 @@ from . import ops
 from .ddp import FlatArena, GradReducer, broadcast_arena
 from .discriminators import MelSpectrogramPatchDiscriminator2D, MultiBinDiscriminator, run_discriminators
 from .losses import LSGANLoss, masked_mae, recon_loss
+from .nn_base import share_effective_weights
 from .preencoder import PreEncoder
 
 
@@ -324,11 +325,12 @@ class Trainer:
         self.optimizer_d.zero_grad()
         self.reducer_d.start()
         fake = recon.detach()
-        rl, rmask, _ = self._d1(real, lens)
-        fl, _, _ = self._d1(fake, lens)
-        loss = self.gan_loss.discriminator_loss(rl, fl, rmask, rmask)
-        rl2, rmask2, _ = self._d2(real, lens)
-        fl2, _, _ = self._d2(fake, lens)
+        with share_effective_weights():                  # real and fake passes share one weight preparation when
+            rl, rmask, _ = self._d1(real, lens)          # the discriminators are in eval mode (no power iteration)
+            fl, _, _ = self._d1(fake, lens)
+            loss = self.gan_loss.discriminator_loss(rl, fl, rmask, rmask)
+            rl2, rmask2, _ = self._d2(real, lens)
+            fl2, _, _ = self._d2(fake, lens)
         B = real.shape[0]
         m0 = rmask2[:B].contiguous()                     # the reference uses the mask of bin 0 for every bin (:392-393)
         G = self.multibin_discriminator.n_bins
