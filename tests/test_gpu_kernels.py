@@ -236,6 +236,28 @@ def test_conv_large_split_k_and_tiles(env, precision):
     assert_rel(w.grad, wr.grad, 5e-5, "wgrad")
 
 
+def test_f32x3_engine_has_the_error_of_the_f32_engine(env):
+    """K-dim 4608 (the deepest reduction on the path): rms and max error against float64 of the split engine
+    (three bf16 terms, six products) vs the exact-product f32 MFMA engine - same order, well inside 2e-5."""
+    ops = env
+    torch.manual_seed(5)
+    N, H, W, Cc, K = 1, 16, 24, 512, 128
+    x = torch.randn(N, H, W, Cc, dtype=torch.float64)
+    w = torch.randn(K, Cc, 3, 3, dtype=torch.float64) * 0.05
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1)
+    scale = ref.pow(2).mean().sqrt()
+    wk, wc = ops.weight_prep(w.float().to(DEV), None, True)
+    errs = {}
+    for prec in ("f32", "f32x3"):
+        d = ops.conv_desc(N, H, W, Cc, K, 3, 3, pad=(1, 1), precision=prec)
+        y = ops.conv(x.float().to(DEV), wk, wc, None, d).double().cpu()
+        e = (y - ref) / scale
+        errs[prec] = (float(e.pow(2).mean().sqrt()), float(e.abs().max()))
+    assert errs["f32"][0] < 2e-6 and errs["f32x3"][0] < 2e-6, errs
+    assert errs["f32x3"][0] < 1.5 * errs["f32"][0] + 1e-8, errs
+    assert errs["f32x3"][1] < 2.0 * errs["f32"][1] + 1e-7, errs
+
+
 def test_conv_rejects_bad_descriptor(env):
     ops = env
     from mqgan_amd._lib import MqganHipError
