@@ -325,17 +325,30 @@ class Trainer:
         self.optimizer_d.zero_grad()
         self.reducer_d.start()
         fake = recon.detach()
-        with share_effective_weights():                  # real and fake passes share one weight preparation when
-            rl, rmask, _ = self._d1(real, lens)          # the discriminators are in eval mode (no power iteration)
+        B = real.shape[0]
+        G = self.multibin_discriminator.n_bins
+        if not (self.patch_discriminator.training or self.multibin_discriminator.training):
+            # Eval-mode discriminators (their state from the first generator step of an epoch on, train.py:415-416) are
+            # per-sample functions with fixed weights: real and fake go through as ONE batch of 2B - half the launches,
+            # fuller tiles, and every weight gradient is formed by one GEMM instead of two plus an add.
+            both, lens2 = torch.cat([real, fake], 0), torch.cat([lens, lens], 0)
+            al, amask, _ = self._d1(both, lens2)
+            rmask = amask[:B]
+            loss = self.gan_loss.discriminator_loss(al[:B], al[B:], rmask, rmask)
+            al2, amask2, _ = self._d2(both, lens2)       # band j owns rows [2jB, 2(j+1)B): real first, then fake
+            m0 = amask2[:B].contiguous()                 # the reference uses the mask of bin 0 for every bin (:392-393)
+            pairs = [(al2[2 * j * B:(2 * j + 1) * B], al2[(2 * j + 1) * B:(2 * j + 2) * B]) for j in range(G)]
+        else:
+            # train mode: every forward runs one power iteration (u, v change between passes), so the passes stay separate
+            rl, rmask, _ = self._d1(real, lens)
             fl, _, _ = self._d1(fake, lens)
             loss = self.gan_loss.discriminator_loss(rl, fl, rmask, rmask)
             rl2, rmask2, _ = self._d2(real, lens)
             fl2, _, _ = self._d2(fake, lens)
-        B = real.shape[0]
-        m0 = rmask2[:B].contiguous()                     # the reference uses the mask of bin 0 for every bin (:392-393)
-        G = self.multibin_discriminator.n_bins
+            m0 = rmask2[:B].contiguous()
+            pairs = list(zip(self._bands(rl2), self._bands(fl2)))
         mbd = None
-        for r, f in zip(self._bands(rl2), self._bands(fl2)):
+        for r, f in pairs:
             l = self.gan_loss.discriminator_loss(r, f, m0, m0)
             mbd = l if mbd is None else ops.add(mbd, l)
         loss_d = ops.add(loss, mbd, 1.0, 1.0 / G)
@@ -360,8 +373,13 @@ class Trainer:
         lam_g = lam_fm = 0.0
         if d_active:
             use_fm = bool(t["use_fm_loss"])
-            gl, gmask, gf = self._d1(recon_post, lens, feats=use_fm, detach_params=True)
-            gl2, gmask2, gf2 = self._d2(recon_post, lens, feats=use_fm, detach_params=True)
+            with share_effective_weights():              # the FM passes over `real` reuse the weight preparations
+                gl, gmask, gf = self._d1(recon_post, lens, feats=use_fm, detach_params=True)
+                gl2, gmask2, gf2 = self._d2(recon_post, lens, feats=use_fm, detach_params=True)
+                if use_fm:
+                    with torch.no_grad():
+                        _, _, rf = self._d1(real, lens, feats=True, detach_params=True)
+                        _, _, rf2 = self._d2(real, lens, feats=True, detach_params=True)
             B = real.shape[0]
             G = self.multibin_discriminator.n_bins
             m0 = gmask2[:B].contiguous()
@@ -373,9 +391,6 @@ class Trainer:
             loss_gan = ops.add(l1, l2, 0.5, 0.5 / G)
             lam_g, lam_fm = t["loss_weights"]["Gloss_lambda"], t["loss_weights"]["fm_lambda"]
             if use_fm:
-                with torch.no_grad():
-                    _, _, rf = self._d1(real, lens, feats=True, detach_params=True)
-                    _, _, rf2 = self._d2(real, lens, feats=True, detach_params=True)
                 f1 = None
                 for (r, m), (f, _) in zip(rf, gf):
                     l = masked_mae(f, r, m)
