@@ -69,6 +69,13 @@ struct TapWalker {
         rsrc = make_rsrc(base, elems * sizeof(float));
         const int kb = 4 * (threadIdx.x % E::QPR);            // first k of this thread in step 0
         if (UNIFORM) {
+            // the geometry is the same for the whole block; say so, so that the walk stays in SGPRs even when it was
+            // selected per block (parity classes)
+            w.nR = __builtin_amdgcn_readfirstlane(w.nR);
+            w.nS = __builtin_amdgcn_readfirstlane(w.nS);
+            w.step_h = __builtin_amdgcn_readfirstlane(w.step_h);
+            w.step_w = __builtin_amdgcn_readfirstlane(w.step_w);
+            w.nchunks = __builtin_amdgcn_readfirstlane(w.nchunks);
             ci = kb;
             chunk = (w.nR > 0 && w.nS > 0) ? 0 : w.nchunks;
             jr = js = 0;
@@ -370,6 +377,9 @@ struct ParityBLoader {     // filter bank [Ncols][R*S*IC] (channel-blocked), col
         }
         const int kb = 4 * (threadIdx.x % E::QPR);
         if (UNIFORM) {
+            nr = __builtin_amdgcn_readfirstlane(nr); ns = __builtin_amdgcn_readfirstlane(ns);
+            r0 = __builtin_amdgcn_readfirstlane(r0); s0 = __builtin_amdgcn_readfirstlane(s0);
+            rstep = __builtin_amdgcn_readfirstlane(rstep); sstep = __builtin_amdgcn_readfirstlane(sstep);
             ci = 0;                                          // the thread's channel quad is folded into rowoff
             chunk = (nr > 0 && ns > 0) ? 0 : nchunks;
             jr = js = 0;
