@@ -12,6 +12,8 @@
 // operands of MFMA steps 2q and 2q+1.  Every accumulator therefore sums k in natural order, which
 // the nearest-neighbour search relies on for bit-exactness against oracle/vq_ref.c.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace mq {
@@ -129,8 +131,10 @@ __device__ __forceinline__ void nt_gemm_mainloop(ALoad &la, BLoad &lb, int nk, f
     lb.stage(GEMM_BK);
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+    // One K-step; `cur` (the LDS buffer being read) is a compile-time constant, the loop below is unrolled by two:
+    // all LDS addresses are loop-invariant registers + immediates instead of per-step vector adds.
+    auto k_step = [&](int kt, auto cur_tag) {
+        constexpr int cur = decltype(cur_tag)::value;
         // phase 1
 #pragma unroll
         for (int j = 0; j < Cfg::A_SLOTS; ++j) ra[j] = la.fetch(j);
@@ -178,7 +182,13 @@ __device__ __forceinline__ void nt_gemm_mainloop(ALoad &la, BLoad &lb, int nk, f
         // phase 3  (writing the tile in the middle of the MFMA phase instead was measured: no difference)
         store_next();
         __syncthreads();
+    };
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        k_step(kt, std::integral_constant<int, 0>{});
+        k_step(kt + 1, std::integral_constant<int, 1>{});
     }
+    if (kt < nk) k_step(kt, std::integral_constant<int, 0>{});
 }
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
