@@ -833,8 +833,9 @@ __device__ __forceinline__ void conv_wgrad_body(const float *__restrict__ x, con
     advance();
     offsets();
     __syncthreads();
-    for (int st = 0; st < nsteps; ++st) {
-        const int cur = st & 1;
+    // one K-step with the LDS buffer index as a compile-time constant (loop unrolled by two below)
+    auto w_step = [&](auto cur_tag) {
+        constexpr int cur = decltype(cur_tag)::value;
         fetch();
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (X3) {
@@ -900,7 +901,13 @@ __device__ __forceinline__ void conv_wgrad_body(const float *__restrict__ x, con
         __builtin_amdgcn_sched_barrier(0);
         sstore(cur ^ 1, bias_tag);
         __syncthreads();
+    };
+    int st = 0;
+    for (; st + 1 < nsteps; st += 2) {
+        w_step(std::integral_constant<int, 0>{});
+        w_step(std::integral_constant<int, 1>{});
     }
+    if (st < nsteps) w_step(std::integral_constant<int, 0>{});
     };
     if (do_bias) run(std::true_type{});
     else run(std::false_type{});
@@ -937,7 +944,7 @@ __device__ __forceinline__ void conv_wgrad_body(const float *__restrict__ x, con
 }
 
 template <int BMK, int BNC, int MODE>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+__global__ __launch_bounds__(256, (BMK == 128 && MODE > 0) ? 4 : 3) void conv_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy,
                                                          float *__restrict__ out, float *__restrict__ bias_out,
                                                          WgradGeom g, int groups)
 {
@@ -945,7 +952,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
     conv_wgrad_body<BMK, BNC, MODE, 0>(x, dy, out, bias_out, g, groups, smem);
 }
 template <int BMK, int BNC, int MODE>
-__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+__global__ __launch_bounds__(256, BMK == 128 ? 3 : 2) void conv_wgrad_bf16_kernel(const float *__restrict__ x, const float *__restrict__ dy,
                                                               float *__restrict__ out, float *__restrict__ bias_out,
                                                               WgradGeom g, int groups)
 {
