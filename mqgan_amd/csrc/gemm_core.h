@@ -347,8 +347,8 @@ __device__ __forceinline__ void nt_gemm_mainloop_split(ALoad &la, BLoad &lb, int
     lb.stage(EngSplit::BK);
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+    auto k_step = [&](int kt, auto cur_tag) {                  // LDS buffer index as a constant, loop unrolled by two
+        constexpr int cur = decltype(cur_tag)::value;
 #pragma unroll
         for (int j = 0; j < Cfg::A_SLOTS; ++j) ra[j] = la.fetch(j);
 #pragma unroll
@@ -378,7 +378,13 @@ __device__ __forceinline__ void nt_gemm_mainloop_split(ALoad &la, BLoad &lb, int
         lb.stage((kt + 2) * EngSplit::BK);
         store_tile(cur ^ 1);      // no scheduling fence here: the splitting VALU work may overlap the MFMA tail
         __syncthreads();
+    };
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        k_step(kt, std::integral_constant<int, 0>{});
+        k_step(kt + 1, std::integral_constant<int, 1>{});
     }
+    if (kt < nk) k_step(kt, std::integral_constant<int, 0>{});
 }
 
 template <class E, int BN, class ALoad, class BLoad>
