@@ -21,35 +21,61 @@ struct FsqDev {
 };
 
 template <int D>
+__device__ __forceinline__ int fsq_quantise(const FsqDev &p, const float (&zv)[D], float (&cv)[D])
+{
+    int id = 0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        if (D != 4 && j >= p.d) break;
+        int lvl = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < p.nthr[j]) lvl += (zv[j] >= p.thresh[j][k]) ? 1 : 0;
+        const int q = lvl - p.half_width[j];
+        cv[j] = (float)q / (float)p.half_width[j];
+        id += lvl * p.basis[j];
+    }
+    return id;
+}
+
+// Streaming kernel: D == 4 takes four vectors per thread and iteration - the four 16-byte loads are issued before
+// any arithmetic so that enough bytes are in flight to cover HBM latency; inputs and outputs are touched once, so
+// they bypass the caches' allocation (non-temporal).
+template <int D>
 __global__ void fsq_forward_kernel(const float *__restrict__ z, int64_t n, FsqDev p, float *__restrict__ codes,
                                    int32_t *__restrict__ idx)
 {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (D == 4) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 *zin = reinterpret_cast<const f4 *>(z);
+        f4 *cout = reinterpret_cast<f4 *>(codes);
+        for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * stride) {
+            f4 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = i0 + u * stride;
+                t[u] = i < n ? __builtin_nontemporal_load(zin + i) : f4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = i0 + u * stride;
+                if (i >= n) break;
+                const float zv[D] = {t[u].x, t[u].y, t[u].z, t[u].w};
+                float cv[D];
+                const int id = fsq_quantise<D>(p, zv, cv);
+                if (codes) __builtin_nontemporal_store(f4{cv[0], cv[1], cv[2], cv[3]}, cout + i);
+                if (idx) __builtin_nontemporal_store(id, idx + i);
+            }
+        }
+        return;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         float zv[D], cv[D];
-        if (D == 4) {
-            const float4 t = reinterpret_cast<const float4 *>(z)[i];
-            zv[0] = t.x; zv[1] = t.y; zv[2] = t.z; zv[3] = t.w;
-        } else {
-            for (int j = 0; j < p.d; ++j) zv[j] = z[i * p.d + j];
-        }
-        int id = 0;
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-            if (D != 4 && j >= p.d) break;
-            int lvl = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (k < p.nthr[j]) lvl += (zv[j] >= p.thresh[j][k]) ? 1 : 0;
-            const int q = lvl - p.half_width[j];
-            cv[j] = (float)q / (float)p.half_width[j];
-            id += lvl * p.basis[j];
-        }
-        if (codes) {
-            if (D == 4)
-                reinterpret_cast<float4 *>(codes)[i] = make_float4(cv[0], cv[1], cv[2], cv[3]);
-            else
-                for (int j = 0; j < p.d; ++j) codes[i * p.d + j] = cv[j];
-        }
+        for (int j = 0; j < D; ++j) zv[j] = j < p.d ? z[i * p.d + j] : 0.f;
+        const int id = fsq_quantise<D>(p, zv, cv);
+        if (codes)
+            for (int j = 0; j < p.d; ++j) codes[i * p.d + j] = cv[j];
         if (idx) idx[i] = id;
     }
 }
@@ -275,11 +301,12 @@ extern "C" int mq_fsq_forward(const mqFsqDesc *desc, const float *z, int64_t n, 
     if (to_dev(desc, p, desc ? desc->thresh : nullptr, "mq_fsq_forward")) return 1;
     if (n == 0) return 0;
     MQ_REQUIRE(z && n > 0 && (codes || idx), "mq_fsq_forward: bad arguments");
-    const int grid = ew_grid(n, 256);
-    if (p.d == 4 && (uintptr_t)z % 16 == 0 && (uintptr_t)codes % 16 == 0)
-        hipLaunchKernelGGL((fsq_forward_kernel<4>), dim3(grid), dim3(256), 0, S(stream), z, n, p, codes, idx);
-    else
-        hipLaunchKernelGGL((fsq_forward_kernel<8>), dim3(grid), dim3(256), 0, S(stream), z, n, p, codes, idx);
+    if (p.d == 4 && (uintptr_t)z % 16 == 0 && (uintptr_t)codes % 16 == 0) {
+        hipLaunchKernelGGL((fsq_forward_kernel<4>), dim3(ew_grid(cdiv(n, 4), 256)), dim3(256), 0, S(stream), z, n, p, codes, idx);
+        MQ_LAUNCH_CHECK("mq_fsq_forward");
+        return 0;
+    }
+    hipLaunchKernelGGL((fsq_forward_kernel<8>), dim3(ew_grid(n, 256)), dim3(256), 0, S(stream), z, n, p, codes, idx);
     MQ_LAUNCH_CHECK("mq_fsq_forward");
     return 0;
 }
