@@ -258,6 +258,36 @@ def test_f32x3_engine_has_the_error_of_the_f32_engine(env):
     assert errs["f32x3"][1] < 2.0 * errs["f32"][1] + 1e-7, errs
 
 
+def test_full_size_conv_beyond_4gb_engines_agree(env):
+    """BASELINE config 3 refiner shape (16 x 1024 x 144 pixels, 384 channels: x and y are 3.6 GB each, past the 32-bit
+    offset range): the f32 MFMA engine and the fp32x3 engine are independent code paths over the same loaders with
+    image-relative descriptors; fprop, dgrad and wgrad must agree to f32 accuracy, and a translated copy of one image
+    placed last in the batch must reproduce the first image's output exactly (addressing check at the far end)."""
+    ops = env
+    torch.manual_seed(11)
+    N, H, W, Cc, K = 16, 1024, 144, 384, 384
+    x = torch.randn(N, H, W, Cc, device=DEV)
+    x[N - 1] = x[0]
+    w = torch.randn(K, Cc, 3, 3, device=DEV) * 0.02
+    wk, wc = ops.weight_prep(w, None, True)
+    r = torch.randn(N, H, W, K, device=DEV)
+    outs = {}
+    for prec in ("f32", "f32x3"):
+        xd = x.clone().requires_grad_(True)
+        wkd = wk.clone().requires_grad_(True)
+        d = ops.conv_desc(N, H, W, Cc, K, 3, 3, pad=(1, 1), precision=prec)
+        y = ops.conv(xd, wkd, wc, None, d)
+        assert torch.equal(y[N - 1], y[0]), "last image differs from its copy: addressing past 4 GB"
+        (y * r).sum().backward()
+        outs[prec] = (y.detach(), xd.grad, wkd.grad)
+        del y, xd
+    for name, a, b in zip(("fprop", "dgrad", "wgrad"), outs["f32"], outs["f32x3"]):
+        scale = float(a.pow(2).mean().sqrt())
+        err = float((a - b).abs().max()) / scale
+        # wgrad adds 2.4 M pixel terms per weight in f32 (different split counts per engine): sqrt(n) * 2^-24 ~ 1e-4
+        assert err < (3e-4 if name == "wgrad" else 5e-5), f"{name}: engines differ by {err:.2e} of the rms"
+
+
 def test_conv_rejects_bad_descriptor(env):
     ops = env
     from mqgan_amd._lib import MqganHipError
