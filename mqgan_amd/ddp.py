@@ -14,7 +14,7 @@ Design (MI355X-first, not a port of torch DDP):
     reference preencoder.py:413-415) do not block a bucket: whatever is still pending is flushed by
     ``finish()``.
 """
-from typing import Iterable, List, Optional
+from typing import Iterable, List
 
 import torch
 import torch.distributed as dist

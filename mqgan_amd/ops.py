@@ -7,7 +7,7 @@ frame masks are uint8 (B, T) with 1 = padded.
 """
 import ctypes as C
 import itertools
-from typing import Optional, Tuple
+from typing import Optional
 
 import torch
 

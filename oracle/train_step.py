@@ -6,7 +6,7 @@ Follows train.py:380-410 (_train_discriminator), :412-501 (_train_generator),
 forward shared by both steps).  Adam / clip_grad_norm_ / LambdaLR are torch's
 own, as in the reference.
 """
-from typing import Dict, List
+from typing import Dict
 
 import torch
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Single-shape conv micro-benchmark (fprop / dgrad / wgrad) for profiling one kernel in isolation.
 usage: conv_micro.py <shape-name> [iters] [fdw] [f32|bf16]"""
-import os, sys, time
+import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mqgan_amd import ops
