@@ -108,6 +108,14 @@ typedef struct {
 
 int mq_conv_fprop(const mqConvDesc *desc_host, const float *x, const float *w_krsc, const float *bias, float *y,
                   mqStream stream);
+/* bf16-storage variants for MQ_PRECISION_BF16: the operands are bf16 COPIES (mq_cast_bf16) of the f32 tensors - half
+ * the bytes and half the loads of the variant that rounds inside the kernel, bit-identical results.  Requires the
+ * reduction channel count (C for fprop, K for dgrad) to be a multiple of 16; outputs stay f32. */
+int mq_cast_bf16(const float *in, uint16_t *out_bf16, int64_t n, mqStream stream);
+int mq_conv_fprop_h(const mqConvDesc *desc_host, const uint16_t *x_bf16, const uint16_t *w_krsc_bf16, const float *bias,
+                    float *y, mqStream stream);
+int mq_conv_dgrad_h(const mqConvDesc *desc_host, const uint16_t *dy_bf16, const uint16_t *w_crsk_bf16, float *dx,
+                    mqStream stream);
 /* dx (N,H,W,C) = conv_transpose(dy (N,P,Q,K)); weights given as (groups, C, R, S, K) */
 int mq_conv_dgrad(const mqConvDesc *desc_host, const float *dy, const float *w_crsk, float *dx, mqStream stream);
 /* dw (groups, K, R, S, C); split-K over pixels with a deterministic slab reduction.

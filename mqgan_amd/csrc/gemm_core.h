@@ -29,11 +29,18 @@ constexpr int GEMM_LDH = 40;       // bf16 engine: 32 k's per row + 8 pad (80-by
 // pass and a 128-row operand tile takes NS passes ("slots").
 struct EngF32 {        // v_mfma_f32_32x32x2_f32: exact f32 products, k-ordered accumulation
     static constexpr int BK = 16, QPR = 4, ROWS = 64, NS = 2;
-    static constexpr bool BF16 = false, SPLIT = false;
+    static constexpr int ESZ = 4, EPL = 4;              // operand element size in HBM, elements per 16-byte load
+    static constexpr bool BF16 = false, SPLIT = false, RAW = false;
 };
 struct EngBF16 {       // v_mfma_f32_32x32x16_bf16: operands rounded to bf16 (RNE) on the way into LDS, f32 accumulate
     static constexpr int BK = 32, QPR = 8, ROWS = 32, NS = 4;
-    static constexpr bool BF16 = true, SPLIT = false;
+    static constexpr int ESZ = 4, EPL = 4;
+    static constexpr bool BF16 = true, SPLIT = false, RAW = false;
+};
+struct EngBF16H {      // same MFMA and LDS image, but the operands are ALREADY bf16 in HBM (mq_cast_bf16 copies):
+    static constexpr int BK = 32, QPR = 4, ROWS = 64, NS = 2;      // half the bytes, half the loads, no conversion
+    static constexpr int ESZ = 2, EPL = 8;
+    static constexpr bool BF16 = true, SPLIT = false, RAW = true;
 };
 // f32 on the bf16 matrix pipe: every operand x is decomposed exactly into three bf16 terms x = h + m + l (8 + 8 + 8
 // significant bits) on its way into LDS and the product is formed from 6 of the 9 cross terms (everything down to
@@ -41,7 +48,8 @@ struct EngBF16 {       // v_mfma_f32_32x32x16_bf16: operands rounded to bf16 (RN
 // at 6 x 32 cycles per 32x32x16 block instead of 8 x 64.
 struct EngSplit {
     static constexpr int BK = 16, QPR = 4, ROWS = 64, NS = 2;
-    static constexpr bool BF16 = false, SPLIT = true;
+    static constexpr int ESZ = 4, EPL = 4;
+    static constexpr bool BF16 = false, SPLIT = true, RAW = false;
 };
 // split engine: 16 bf16 k's per row, no padding (three images must fit three blocks per CU); the two 16-byte halves
 // of a row are swapped in rows with bit 3 set, so the 16 rows a ds_read_b128 lane group touches (distinct mod 16)
@@ -204,11 +212,11 @@ __device__ __forceinline__ uint2 pack_bf16x4(float4 v)
 // bf16 engine: same loader protocol with EngBF16's mapping (.fetch(slot) -> k = k0 + 4*(tid&7) .. +3 of tile row
 // (tid>>3) + 32*slot), BK = 32.  LDS rows hold 32 bf16 k's in natural order (+8 pad); lane (r, h) reads the 8 k's
 // 16s + 8h .. +7 of row r with one ds_read_b128 per 32x32x16 MFMA operand.
-template <int BN, class ALoad, class BLoad>
+template <int BN, class E, class ALoad, class BLoad>
 __device__ __forceinline__ void nt_gemm_mainloop_bf16(ALoad &la, BLoad &lb, int nk, float *smem_f,
-                                                      f32x16 (&acc)[GemmCfg<BN, EngBF16>::TM][GemmCfg<BN, EngBF16>::TN])
+                                                      f32x16 (&acc)[GemmCfg<BN, E>::TM][GemmCfg<BN, E>::TN])
 {
-    using Cfg = GemmCfg<BN, EngBF16>;
+    using Cfg = GemmCfg<BN, E>;
     constexpr int LD = GEMM_LDH;
     unsigned short *smem = reinterpret_cast<unsigned short *>(smem_f);
     const int tid = threadIdx.x;
@@ -217,7 +225,13 @@ __device__ __forceinline__ void nt_gemm_mainloop_bf16(ALoad &la, BLoad &lb, int 
     const int li = lane & 31, lh = lane >> 5;
     unsigned short *As = smem;
     unsigned short *Bs = smem + 2 * GEMM_BM * LD;
-    const int ld_row = tid >> 3, ld_kq = tid & 7;
+    const int ld_row = tid / E::QPR, ld_kq = tid % E::QPR;
+    const bool b_active = (BN >= E::ROWS) || (tid < BN * E::QPR);
+    // RAW: the 16 bytes loaded are 8 bf16 - stored as they are; otherwise 4 floats are rounded and packed into 8 bytes
+    auto put = [&](unsigned short *row, float4 v) {
+        if constexpr (E::RAW) *reinterpret_cast<float4 *>(row + 8 * ld_kq) = v;
+        else *reinterpret_cast<uint2 *>(row + 4 * ld_kq) = pack_bf16x4(v);
+    };
 
     float4 ra[Cfg::A_SLOTS], rb[Cfg::B_SLOTS];
     la.stage(0);
@@ -225,13 +239,15 @@ __device__ __forceinline__ void nt_gemm_mainloop_bf16(ALoad &la, BLoad &lb, int 
 #pragma unroll
     for (int j = 0; j < Cfg::A_SLOTS; ++j) ra[j] = la.fetch(j);
 #pragma unroll
-    for (int j = 0; j < Cfg::B_SLOTS; ++j) rb[j] = lb.fetch(j);
+    for (int j = 0; j < Cfg::B_SLOTS; ++j) rb[j] = b_active ? lb.fetch(j) : make_float4(0, 0, 0, 0);
 #pragma unroll
-    for (int j = 0; j < Cfg::A_SLOTS; ++j) *reinterpret_cast<uint2 *>(&As[(ld_row + 32 * j) * LD + 4 * ld_kq]) = pack_bf16x4(ra[j]);
+    for (int j = 0; j < Cfg::A_SLOTS; ++j) put(&As[(ld_row + E::ROWS * j) * LD], ra[j]);
+    if (b_active) {
 #pragma unroll
-    for (int j = 0; j < Cfg::B_SLOTS; ++j) *reinterpret_cast<uint2 *>(&Bs[(ld_row + 32 * j) * LD + 4 * ld_kq]) = pack_bf16x4(rb[j]);
-    la.stage(EngBF16::BK);
-    lb.stage(EngBF16::BK);
+        for (int j = 0; j < Cfg::B_SLOTS; ++j) put(&Bs[(ld_row + E::ROWS * j) * LD], rb[j]);
+    }
+    la.stage(E::BK);
+    lb.stage(E::BK);
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
@@ -239,7 +255,7 @@ __device__ __forceinline__ void nt_gemm_mainloop_bf16(ALoad &la, BLoad &lb, int 
 #pragma unroll
         for (int j = 0; j < Cfg::A_SLOTS; ++j) ra[j] = la.fetch(j);
 #pragma unroll
-        for (int j = 0; j < Cfg::B_SLOTS; ++j) rb[j] = lb.fetch(j);
+        for (int j = 0; j < Cfg::B_SLOTS; ++j) rb[j] = b_active ? lb.fetch(j) : make_float4(0, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         const unsigned short *Ac = As + cur * GEMM_BM * LD + (wm * Cfg::TM * 32 + li) * LD + 8 * lh;
         const unsigned short *Bc = Bs + cur * BN * LD + (wn * Cfg::TN * 32 + li) * LD + 8 * lh;
@@ -256,18 +272,18 @@ __device__ __forceinline__ void nt_gemm_mainloop_bf16(ALoad &la, BLoad &lb, int 
                 for (int tn = 0; tn < Cfg::TN; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
         }
-        la.stage((kt + 2) * EngBF16::BK);
-        lb.stage((kt + 2) * EngBF16::BK);
+        la.stage((kt + 2) * E::BK);
+        lb.stage((kt + 2) * E::BK);
         __builtin_amdgcn_sched_barrier(0);
         {
             unsigned short *An = As + (cur ^ 1) * GEMM_BM * LD;
             unsigned short *Bn = Bs + (cur ^ 1) * BN * LD;
 #pragma unroll
-            for (int j = 0; j < Cfg::A_SLOTS; ++j)
-                *reinterpret_cast<uint2 *>(&An[(ld_row + 32 * j) * LD + 4 * ld_kq]) = pack_bf16x4(ra[j]);
+            for (int j = 0; j < Cfg::A_SLOTS; ++j) put(&An[(ld_row + E::ROWS * j) * LD], ra[j]);
+            if (b_active) {
 #pragma unroll
-            for (int j = 0; j < Cfg::B_SLOTS; ++j)
-                *reinterpret_cast<uint2 *>(&Bn[(ld_row + 32 * j) * LD + 4 * ld_kq]) = pack_bf16x4(rb[j]);
+                for (int j = 0; j < Cfg::B_SLOTS; ++j) put(&Bn[(ld_row + E::ROWS * j) * LD], rb[j]);
+            }
         }
         __syncthreads();
     }
@@ -392,7 +408,7 @@ __device__ __forceinline__ void nt_gemm_run(ALoad &la, BLoad &lb, int nk, float 
                                             f32x16 (&acc)[GemmCfg<BN, E>::TM][GemmCfg<BN, E>::TN])
 {
     if constexpr (E::SPLIT) nt_gemm_mainloop_split<BN>(la, lb, nk, smem, acc);
-    else if constexpr (E::BF16) nt_gemm_mainloop_bf16<BN>(la, lb, nk, smem, acc);
+    else if constexpr (E::BF16) nt_gemm_mainloop_bf16<BN, E>(la, lb, nk, smem, acc);
     else nt_gemm_mainloop<BN, false>(la, lb, nk, smem, acc);
 }
 

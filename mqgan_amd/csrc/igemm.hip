@@ -66,8 +66,8 @@ struct TapWalker {
     __device__ __forceinline__ void start(const float *base, size_t elems, const WalkGeom &wg)
     {
         w = wg;
-        rsrc = make_rsrc(base, elems * sizeof(float));
-        const int kb = 4 * (threadIdx.x % E::QPR);            // first k of this thread in step 0
+        rsrc = make_rsrc(base, elems * E::ESZ);               // (for 2-byte operands `base` is a bf16 array in disguise)
+        const int kb = E::EPL * (threadIdx.x % E::QPR);       // first k of this thread in step 0
         if (UNIFORM) {
             // the geometry is the same for the whole block; say so, so that the walk stays in SGPRs even when it was
             // selected per block (parity classes)
@@ -122,7 +122,7 @@ struct TapWalker {
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             const bool ok = rv_[j] && kv && (unsigned)(bh_[j] + hoff) < (unsigned)w.IH && (unsigned)(bw_[j] + woff) < (unsigned)w.IW;
-            off_[j] = ok ? (unsigned)(rowbase_[j] + tapoff + cc) * 4u : OOB;
+            off_[j] = ok ? (unsigned)(rowbase_[j] + tapoff + cc) * (unsigned)E::ESZ : OOB;
         }
     }
     __device__ __forceinline__ float4 fetch(int j) const { return buf_load4(rsrc, off_[j]); }
@@ -204,11 +204,11 @@ struct DenseBLoader {
         n0 = n0_;
         Ncols = Ncols_;
         Kdim = Kdim_;
-        rsrc = make_rsrc(ww, (size_t)Ncols_ * Kdim_ * sizeof(float));
+        rsrc = make_rsrc(ww, (size_t)Ncols_ * Kdim_ * E::ESZ);
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             const int n = n0 + (threadIdx.x / E::QPR) + E::ROWS * j;
-            rowoff[j] = n < Ncols ? (unsigned)n * (unsigned)Kdim * 4u : OOB;
+            rowoff[j] = n < Ncols ? (unsigned)n * (unsigned)Kdim * (unsigned)E::ESZ : OOB;
             if (UNIFORM && n < Ncols) rowoff[j] += 16u * (threadIdx.x % E::QPR);
         }
     }
@@ -220,10 +220,10 @@ struct DenseBLoader {
             for (int j = 0; j < NS; ++j) off_[j] = (kv && rowoff[j] != OOB) ? rowoff[j] + (unsigned)k0 * 4u : OOB;
             return;
         }
-        kbase = k0 + 4 * (threadIdx.x % E::QPR);
+        kbase = k0 + E::EPL * (threadIdx.x % E::QPR);
 #pragma unroll
         for (int j = 0; j < NS; ++j)
-            off_[j] = (rowoff[j] != OOB && kbase < Kdim) ? rowoff[j] + (unsigned)kbase * 4u : OOB;
+            off_[j] = (rowoff[j] != OOB && kbase < Kdim) ? rowoff[j] + (unsigned)kbase * (unsigned)E::ESZ : OOB;
     }
     __device__ __forceinline__ float4 fetch(int j) const
     {
@@ -264,14 +264,16 @@ __device__ __forceinline__ void conv_nt_body(const float *__restrict__ act, cons
     const int tile = xcd_remap(blockIdx.x, g.nMt * g.nNt);
     const int mt = tile / g.nNt, nt = tile - mt * g.nNt;   // N tiles of one M tile are neighbours (share A in L2)
     const int m0 = mt * GEMM_BM, n0 = nt * BN;
-    const float *abase = act + (size_t)grp * act_group_stride;
+    // operand pointers advance in elements of E::ESZ bytes (bf16 operands travel as float* in disguise)
+    auto at = [](const float *p, size_t elems) { return reinterpret_cast<const float *>(reinterpret_cast<const char *>(p) + elems * E::ESZ); };
+    const float *abase = at(act, (size_t)grp * act_group_stride);
 
     f32x16 acc[Cfg::TM][Cfg::TN];
     zero_acc<BN>(acc);
     constexpr bool UNI = MODE == 3;
     static_assert(!UNI || E::BK == 16, "uniform walk needs CB == BK");
     DenseBLoader<(MODE > 0), E, UNI> lb;
-    lb.init(wgt + (size_t)grp * w_group_stride, n0, g.Ncols, g.Kdim);
+    lb.init(at(wgt, (size_t)grp * w_group_stride), n0, g.Ncols, g.Kdim);
     const int nk = (g.Kdim + E::BK - 1) / E::BK;
     if constexpr (MODE == 0) {
         static_assert(!E::BF16 && !E::SPLIT, "scalar path is f32 only");
@@ -284,7 +286,7 @@ __device__ __forceinline__ void conv_nt_body(const float *__restrict__ act, cons
         TapWalker<(MODE >= 2 ? E::BK / 16 : E::BK / 4), E, UNI> la;
         const int img0 = m0 / (g.OH * g.OW);
         const size_t img_elems = (size_t)g.IH * g.IW * g.IC;
-        la.start(abase + img0 * img_elems, act_group_stride - img0 * img_elems, wg);
+        la.start(at(abase, img0 * img_elems), act_group_stride - img0 * img_elems, wg);
 #pragma unroll
         for (int j = 0; j < E::NS; ++j) {
             const int m = m0 + (threadIdx.x / E::QPR) + E::ROWS * j;
@@ -331,6 +333,15 @@ __global__ __launch_bounds__(256, 3) void conv_nt_x3_kernel(const float *__restr
     __shared__ __attribute__((aligned(16))) float smem[GemmCfg<BN, EngSplit>::LDS_FLOATS];
     conv_nt_body<EngSplit, BN, DGRAD, MODE>(act, wgt, bias, out, g, wg, act_group_stride, w_group_stride, smem);
 }
+// bf16 operands already in HBM (x_h, w_h from mq_cast_bf16), f32 accumulate, f32 output; C % 16 == 0 only
+template <int BN, bool DGRAD>
+__global__ __launch_bounds__(256, (BN == 128 ? 3 : 4)) void conv_nt_h_kernel(const float *__restrict__ act, const float *__restrict__ wgt,
+                                                        const float *__restrict__ bias, float *__restrict__ out, ConvGeom g,
+                                                        WalkGeom wg, size_t act_group_stride, size_t w_group_stride)
+{
+    __shared__ __attribute__((aligned(16))) float smem[GemmCfg<BN, EngBF16H>::LDS_FLOATS];
+    conv_nt_body<EngBF16H, BN, DGRAD, 2>(act, wgt, bias, out, g, wg, act_group_stride, w_group_stride, smem);
+}
 // bf16 operands (rounded on the way into LDS), f32 accumulate and f32 tensors in HBM; vector path only
 template <int BN, bool DGRAD, int MODE>
 __global__ __launch_bounds__(256, (BN == 128 ? 3 : 4)) void conv_nt_bf16_kernel(const float *__restrict__ act, const float *__restrict__ wgt,
@@ -368,14 +379,14 @@ struct ParityBLoader {     // filter bank [Ncols][R*S*IC] (channel-blocked), col
     {
         S = S_; CB = chan_block(IC); nchunks = IC / CB; RS = KdimFull / IC;
         nr = nr_; ns = ns_; r0 = r0_; s0 = s0_; rstep = rstep_; sstep = sstep_;
-        rsrc = make_rsrc(w, (size_t)Ncols * KdimFull * sizeof(float));
+        rsrc = make_rsrc(w, (size_t)Ncols * KdimFull * E::ESZ);
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             const int n = n0 + (threadIdx.x / E::QPR) + E::ROWS * j;
-            rowoff[j] = n < Ncols ? (unsigned)n * (unsigned)KdimFull * 4u : OOB;
+            rowoff[j] = n < Ncols ? (unsigned)n * (unsigned)KdimFull * (unsigned)E::ESZ : OOB;
             if (UNIFORM && n < Ncols) rowoff[j] += 16u * (threadIdx.x % E::QPR);
         }
-        const int kb = 4 * (threadIdx.x % E::QPR);
+        const int kb = E::EPL * (threadIdx.x % E::QPR);
         if (UNIFORM) {
             nr = __builtin_amdgcn_readfirstlane(nr); ns = __builtin_amdgcn_readfirstlane(ns);
             r0 = __builtin_amdgcn_readfirstlane(r0); s0 = __builtin_amdgcn_readfirstlane(s0);
@@ -413,7 +424,7 @@ struct ParityBLoader {     // filter bank [Ncols][R*S*IC] (channel-blocked), col
         const int col = (chunk * RS + (r0 + jr * rstep) * S + s0 + js * sstep) * CB + ci;
         const bool kv = chunk < nchunks;
 #pragma unroll
-        for (int j = 0; j < NS; ++j) off_[j] = (kv && rowoff[j] != OOB) ? rowoff[j] + (unsigned)col * 4u : OOB;
+        for (int j = 0; j < NS; ++j) off_[j] = (kv && rowoff[j] != OOB) ? rowoff[j] + (unsigned)col * (unsigned)E::ESZ : OOB;
     }
     __device__ __forceinline__ float4 fetch(int j) const { return buf_load4(rsrc, off_[j]); }
 };
@@ -452,7 +463,8 @@ __device__ __forceinline__ void conv_dgrad_parity_body(const float *__restrict__
     TapWalker<WRAPS, E, UNI> la;
     const int img0 = (Ha * Wb) > 0 ? m0 / (Ha * Wb) : 0;
     const size_t img_elems = (size_t)g.IH * g.IW * g.IC;
-    la.start(dy + (size_t)grp * act_group_stride + img0 * img_elems, act_group_stride - img0 * img_elems, wg);
+    auto at = [](const float *p, size_t elems) { return reinterpret_cast<const float *>(reinterpret_cast<const char *>(p) + elems * E::ESZ); };
+    la.start(at(dy, (size_t)grp * act_group_stride + img0 * img_elems), act_group_stride - img0 * img_elems, wg);
 #pragma unroll
     for (int j = 0; j < E::NS; ++j) {
         const int m = m0 + (threadIdx.x / E::QPR) + E::ROWS * j;
@@ -463,7 +475,7 @@ __device__ __forceinline__ void conv_dgrad_parity_body(const float *__restrict__
         la.set_row(j, v, n, (ihq * g.sh + a + g.ph - r0 * g.dh) >> shift_h, (iwq * g.sw + b + g.pw - s0 * g.dw) >> shift_w);
     }
     ParityBLoader<WRAPS, E, UNI> lb;
-    lb.init(wgt + (size_t)grp * w_group_stride, n0, g.Ncols, g.IC, g.S, g.Kdim, nr, ns, r0, s0, rstep, sstep);
+    lb.init(at(wgt, (size_t)grp * w_group_stride), n0, g.Ncols, g.IC, g.S, g.Kdim, nr, ns, r0, s0, rstep, sstep);
 
     f32x16 acc[Cfg::TM][Cfg::TN];
     zero_acc<BN>(acc);
@@ -503,6 +515,15 @@ __global__ __launch_bounds__(256, 3) void conv_dgrad_parity_x3_kernel(const floa
 {
     __shared__ __attribute__((aligned(16))) float smem[GemmCfg<BN, EngSplit>::LDS_FLOATS];
     conv_dgrad_parity_body<EngSplit, BN, WRAPS>(dy, wgt, dx, g, pi, act_group_stride, w_group_stride, ng, smem);
+}
+template <int BN>
+__global__ __launch_bounds__(256, (BN == 128 ? 3 : 4)) void conv_dgrad_parity_h_kernel(const float *__restrict__ dy,
+                                                                  const float *__restrict__ wgt, float *__restrict__ dx,
+                                                                  ConvGeom g, ParityInfo pi, size_t act_group_stride,
+                                                                  size_t w_group_stride, int ng)
+{
+    __shared__ __attribute__((aligned(16))) float smem[GemmCfg<BN, EngBF16H>::LDS_FLOATS];
+    conv_dgrad_parity_body<EngBF16H, BN, 2>(dy, wgt, dx, g, pi, act_group_stride, w_group_stride, ng, smem);
 }
 template <int BN, int WRAPS>
 __global__ __launch_bounds__(256, (BN == 128 ? 3 : 4)) void conv_dgrad_parity_bf16_kernel(const float *__restrict__ dy,
@@ -1051,10 +1072,12 @@ static int check_desc(const mqConvDesc *d, const char *who)
     return 0;
 }
 
+// hmode: act and w are bf16 arrays (mq_cast_bf16 copies of the f32 tensors), passed as float* in disguise
 template <bool DGRAD>
-static int launch_nt(const mqConvDesc *d, const float *act, const float *w, const float *bias, float *out, hipStream_t st)
+static int launch_nt(const mqConvDesc *d, const float *act, const float *w, const float *bias, float *out, hipStream_t st,
+                     bool hmode = false)
 {
-    const bool want_bf16 = d->precision == MQ_PRECISION_BF16;
+    const bool want_bf16 = d->precision == MQ_PRECISION_BF16 && !hmode;
     const bool want_x3 = d->precision == MQ_PRECISION_F32X3;
     ConvGeom g;
     const int ng = d->N / d->groups;
@@ -1072,11 +1095,15 @@ static int launch_nt(const mqConvDesc *d, const float *act, const float *w, cons
     const size_t act_gs = (size_t)ng * g.IH * g.IW * g.IC;
     const size_t w_gs = (size_t)g.Ncols * g.Kdim;
     // 32-bit element offsets inside one tile: the images a 128-row tile can touch must span < 2 GB
-    const size_t img_bytes = (size_t)g.IH * g.IW * g.IC * sizeof(float);
+    const size_t img_bytes = (size_t)g.IH * g.IW * g.IC * (hmode ? 2 : sizeof(float));
     const size_t tile_imgs = (size_t)cdiv(GEMM_BM, (int64_t)g.OH * g.OW) + 1;
     bool vec = (g.IC % 4 == 0) && ((uintptr_t)act % 16 == 0) && ((uintptr_t)w % 16 == 0) &&
                img_bytes * tile_imgs < 0x7FFFFFF0ull && w_gs * sizeof(float) < 0xFFFFFFF0ull;
     const bool strided = g.sh > 1 || g.sw > 1;
+    if (hmode)
+        MQ_REQUIRE(vec && g.IC % 16 == 0 && (!strided || !DGRAD || (g.sh <= 2 && g.sw <= 2)),
+                   "bf16-operand conv needs 16-byte aligned tensors, a reduction channel count that is a multiple of 16 "
+                   "and strides <= 2 (got C=%d)", g.IC);
     const bool parity = DGRAD && vec && strided && g.sh <= 2 && g.sw <= 2;
     if (DGRAD && strided && !parity) vec = false;      // generic strided dgrad only exists on the scalar path
     // column tile: the one that wastes the fewest MFMAs on padding, weighted by the measured relative
@@ -1131,7 +1158,11 @@ static int launch_nt(const mqConvDesc *d, const float *act, const float *w, cons
         dim3 pgrid(t0 * g.nNt, d->groups);
 #define MQ_PAR(BN_, W_) hipLaunchKernelGGL((conv_dgrad_parity_kernel<BN_, W_>), pgrid, dim3(256), 0, st, act, w, out, g, pi, act_gs, w_gs, ng)
 #define MQ_PARH(BN_, W_) hipLaunchKernelGGL((conv_dgrad_parity_bf16_kernel<BN_, W_>), pgrid, dim3(256), 0, st, act, w, out, g, pi, act_gs, w_gs, ng)
-        if (x3) {
+        if (hmode) {
+#define MQ_PARHH(BN_) hipLaunchKernelGGL((conv_dgrad_parity_h_kernel<BN_>), pgrid, dim3(256), 0, st, act, w, out, g, pi, act_gs, w_gs, ng)
+            if (BN == 128) MQ_PARHH(128); else if (BN == 64) MQ_PARHH(64); else MQ_PARHH(32);
+#undef MQ_PARHH
+        } else if (x3) {
 #define MQ_PARX(BN_, W_) hipLaunchKernelGGL((conv_dgrad_parity_x3_kernel<BN_, W_>), pgrid, dim3(256), 0, st, act, w, out, g, pi, act_gs, w_gs, ng)
             const int wr = g.IC % 16 == 0 ? 0 : (wide ? 1 : 4);
             if (BN == 128) { if (wr == 0) MQ_PARX(128, 0); else if (wr == 1) MQ_PARX(128, 1); else MQ_PARX(128, 4); }
@@ -1162,7 +1193,8 @@ static int launch_nt(const mqConvDesc *d, const float *act, const float *w, cons
 #define MQ_NT(BN_, M_) hipLaunchKernelGGL((conv_nt_kernel<BN_, DGRAD, M_>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs)
 #define MQ_NTH(BN_, M_) hipLaunchKernelGGL((conv_nt_bf16_kernel<BN_, DGRAD, M_>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs)
 #define MQ_NTX(BN_, M_) hipLaunchKernelGGL((conv_nt_x3_kernel<BN_, DGRAD, M_>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs)
-#define MQ_NT3(BN_) do { if (x3) { if (mode == 3) MQ_NTX(BN_, 3); else if (mode == 2) MQ_NTX(BN_, 2); else MQ_NTX(BN_, 1); } \
+#define MQ_NTHH(BN_) hipLaunchKernelGGL((conv_nt_h_kernel<BN_, DGRAD>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs)
+#define MQ_NT3(BN_) do { if (hmode) MQ_NTHH(BN_); else if (x3) { if (mode == 3) MQ_NTX(BN_, 3); else if (mode == 2) MQ_NTX(BN_, 2); else MQ_NTX(BN_, 1); } \
                          else if (bf16) { if (mode == 2) MQ_NTH(BN_, 2); else MQ_NTH(BN_, 1); } \
                          else if (mode == 3) MQ_NT(BN_, 3); else if (mode == 2) MQ_NT(BN_, 2); else if (mode == 1) MQ_NT(BN_, 1); \
                          else MQ_NT(BN_, 0); } while (0)
@@ -1170,6 +1202,7 @@ static int launch_nt(const mqConvDesc *d, const float *act, const float *w, cons
     else if (BN == 64) MQ_NT3(64);
     else MQ_NT3(32);
 #undef MQ_NT3
+#undef MQ_NTHH
 #undef MQ_NTX
 #undef MQ_NTH
 #undef MQ_NT
@@ -1229,6 +1262,22 @@ extern "C" int mq_conv_fprop(const mqConvDesc *d, const float *x, const float *w
     if (check_desc(d, "mq_conv_fprop")) return 1;
     MQ_REQUIRE(x && w && y, "mq_conv_fprop: null pointer");
     return launch_nt<false>(d, x, w, bias, y, S(stream));
+}
+
+extern "C" int mq_conv_fprop_h(const mqConvDesc *d, const uint16_t *x_h, const uint16_t *w_h, const float *bias, float *y,
+                               mqStream stream)
+{
+    if (check_desc(d, "mq_conv_fprop_h")) return 1;
+    MQ_REQUIRE(x_h && w_h && y, "mq_conv_fprop_h: null pointer");
+    return launch_nt<false>(d, reinterpret_cast<const float *>(x_h), reinterpret_cast<const float *>(w_h), bias, y, S(stream), true);
+}
+
+extern "C" int mq_conv_dgrad_h(const mqConvDesc *d, const uint16_t *dy_h, const uint16_t *w_crsk_h, float *dx, mqStream stream)
+{
+    if (check_desc(d, "mq_conv_dgrad_h")) return 1;
+    MQ_REQUIRE(dy_h && w_crsk_h && dx, "mq_conv_dgrad_h: null pointer");
+    return launch_nt<true>(d, reinterpret_cast<const float *>(dy_h), reinterpret_cast<const float *>(w_crsk_h), nullptr, dx,
+                           S(stream), true);
 }
 
 extern "C" int mq_conv_dgrad(const mqConvDesc *d, const float *dy, const float *w_crsk, float *dx, mqStream stream)

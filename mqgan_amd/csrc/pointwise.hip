@@ -399,6 +399,24 @@ static int make_pw(const mqPointwiseDesc *d, PwParams &p, const char *who)
 }
 static bool al16(const void *q) { return q == nullptr || ((uintptr_t)q % 16) == 0; }
 
+
+// f32 -> bf16 (round to nearest even, NaN stays NaN): the operand copies the bf16-storage conv kernels read
+__global__ void cast_bf16_kernel(const float *__restrict__ in, unsigned short *__restrict__ out, int64_t n8, int64_t n)
+{
+    typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+    typedef float f32x8v __attribute__((ext_vector_type(8)));
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 a = reinterpret_cast<const float4 *>(in)[2 * i], b = reinterpret_cast<const float4 *>(in)[2 * i + 1];
+        const f32x8v f = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        reinterpret_cast<bf16x8v *>(out)[i] = __builtin_convertvector(f, bf16x8v);
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = n8 * 8 + threadIdx.x; i < n; i += blockDim.x) {
+            const __bf16 h = (__bf16)in[i];
+            out[i] = __builtin_bit_cast(unsigned short, h);
+        }
+}
+
 }  // namespace mq
 
 using namespace mq;
@@ -568,5 +586,16 @@ extern "C" int mq_relu_bwd(const float *dy, const float *y, int64_t n, float *dx
     MQ_REQUIRE(dy && y && dx && n > 0, "mq_relu_bwd: bad arguments");
     hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S(stream), dy, y, n, dx);
     MQ_LAUNCH_CHECK("mq_relu_bwd");
+    return 0;
+}
+
+extern "C" int mq_cast_bf16(const float *in, uint16_t *out, int64_t n, mqStream stream)
+{
+    if (n == 0) return 0;
+    MQ_REQUIRE(in && out && n > 0, "mq_cast_bf16: bad arguments");
+    MQ_REQUIRE((uintptr_t)in % 16 == 0 && (uintptr_t)out % 16 == 0, "mq_cast_bf16: pointers must be 16-byte aligned");
+    const int64_t n8 = n / 8;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(ew_grid(n8 > 0 ? n8 : 1, 256)), dim3(256), 0, S(stream), in, out, n8, n);
+    MQ_LAUNCH_CHECK("mq_cast_bf16");
     return 0;
 }

@@ -288,6 +288,38 @@ def test_full_size_conv_beyond_4gb_engines_agree(env):
         assert err < (3e-4 if name == "wgrad" else 5e-5), f"{name}: engines differ by {err:.2e} of the rms"
 
 
+@pytest.mark.parametrize("c", [dict(N=2, H=24, W=18, C=32, K=48, R=3, S=3, pad=(1, 1)),
+                               dict(N=2, H=16, W=20, C=16, K=32, R=5, S=5, stride=(2, 2), pad=(2, 2)),
+                               dict(N=16, H=2, W=40, C=16, K=16, R=3, S=5, stride=(1, 2), pad=(1, 2), groups=8),
+                               dict(N=1, H=1, W=300, C=80, K=512, R=1, S=1)],
+                         ids=lambda c: "N{N}H{H}W{W}C{C}K{K}R{R}S{S}".format(**c))
+def test_bf16_storage_kernels_bit_identical(env, c):
+    """mq_conv_fprop_h / mq_conv_dgrad_h read bf16 copies made by mq_cast_bf16; the bf16 engine rounds the same f32
+    values inside the kernel (same rounding, same K order): outputs must be bit-identical."""
+    ops = env
+    torch.manual_seed(3)
+    G = c.get("groups", 1)
+    x = torch.randn(c["N"], c["H"], c["W"], c["C"], device=DEV)
+    w = torch.randn(G * c["K"], c["C"], c["R"], c["S"], device=DEV) * 0.2
+    b = torch.randn(G * c["K"], device=DEV)
+    ws = [ops.weight_prep(w[g * c["K"]:(g + 1) * c["K"]].contiguous(), None, True) for g in range(G)]
+    wk, wc = torch.cat([a for a, _ in ws]), torch.cat([bb for _, bb in ws])
+    d = ops.conv_desc(c["N"], c["H"], c["W"], c["C"], c["K"], c["R"], c["S"], stride=c.get("stride", (1, 1)),
+                      pad=c.get("pad", (0, 0)), groups=G, precision="bf16")
+    outs = []
+    for storage in (False, True):
+        ops.BF16_STORAGE = storage
+        try:
+            xd = x.clone().requires_grad_(True)
+            y = ops.conv(xd, wk, wc, b, d)
+            y.backward(torch.ones_like(y) * 0.37)
+            outs.append((y.detach(), xd.grad))
+        finally:
+            ops.BF16_STORAGE = False
+    assert torch.equal(outs[0][0], outs[1][0]), "fprop differs"
+    assert torch.equal(outs[0][1], outs[1][1]), "dgrad differs"
+
+
 def test_conv_rejects_bad_descriptor(env):
     ops = env
     from mqgan_amd._lib import MqganHipError

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Single-shape conv micro-benchmark (fprop / dgrad / wgrad) for profiling one kernel in isolation.
-usage: conv_micro.py <shape-name> [iters] [fdw] [f32|bf16]"""
+usage: conv_micro.py <shape-name> [iters] [fdw] [f32|f32x3|bf16|bf16h]   (bf16h: bf16 operand copies, cast outside the timing)"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -32,7 +32,7 @@ for g in range(G):
     wk.append(a); wc.append(b)
 wk, wc = torch.cat(wk), torch.cat(wc)
 d = ops.conv_desc(c["N"], c["H"], c["W"], c["C"], c["K"], c["R"], c["S"], stride=c["stride"], pad=c["pad"], groups=G,
-                  precision=prec)
+                  precision="bf16" if prec == "bf16h" else prec)
 y = ops.conv(x, wk, wc, None, d)
 dy = torch.randn_like(y)
 flops = ops._conv_flops(d)
@@ -43,6 +43,12 @@ nb = L.mq_conv_wgrad_workspace(C.byref(d)); ws = ops._ws_bytes(nb, x)
 fns = {"f": lambda: L.mq_conv_fprop(C.byref(d), ops.fptr(x), ops.fptr(wk), None, ops.fptr(y), ops.stream()),
        "d": lambda: L.mq_conv_dgrad(C.byref(d), ops.fptr(dy), ops.fptr(wc), ops.fptr(dx), ops.stream()),
        "w": lambda: L.mq_conv_wgrad(C.byref(d), ops.fptr(x), ops.fptr(dy), ops.fptr(dw), ops.ptr(ws), nb, ops.stream())}
+if prec == "bf16h":
+    BF = torch.bfloat16
+    x_h, wk_h, dy_h, wc_h = ops.cast_bf16(x.detach()), ops.cast_bf16(wk.detach()), ops.cast_bf16(dy), ops.cast_bf16(wc.detach())
+    fns["f"] = lambda: L.mq_conv_fprop_h(C.byref(d), ops.ptr(x_h, BF), ops.ptr(wk_h, BF), None, ops.fptr(y), ops.stream())
+    fns["d"] = lambda: L.mq_conv_dgrad_h(C.byref(d), ops.ptr(dy_h, BF), ops.ptr(wc_h, BF), ops.fptr(dx), ops.stream())
+    fns["c"] = lambda: ops.cast_bf16(x.detach())
 for k in which:
     fn = fns[k]
     fn(); torch.cuda.synchronize()
