@@ -1,5 +1,6 @@
 // Implicit-GEMM convolution (fprop / dgrad / wgrad) on f32 MFMA for gfx950, NHWC.
 // See include/mqgan_hip.h (mq_conv_*) for the interface and gemm_core.h for the tile engine.
+#include <algorithm>
 #include <type_traits>
 
 #include "gemm_core.h"
@@ -1246,6 +1247,12 @@ static void wgrad_plan(const mqConvDesc *d, WgradGeom &g)
         const double rounds = (double)cdiv(blocks, slots);
         const double score = (double)blocks / (rounds * (double)slots) - 0.004 * rounds;
         if (score > best + 1e-12) { best = score; splits = sp; }
+    }
+    // 32-bit offsets inside one split: the images a split touches (plus two of slack) must span < 2 GB of x and of dy
+    {
+        const int64_t pq = (int64_t)d->P * d->Q;
+        const int64_t img = 4 * std::max((int64_t)d->H * d->W * d->C, pq * (int64_t)d->K);
+        while (splits < max_splits && (cdiv(cdiv(g.Mtot, splits), pq) + 2) * img >= 0x7FFFFFF0ll) ++splits;
     }
     int64_t chunk = cdiv(cdiv(g.Mtot, splits), bk) * bk;
     g.chunk = (int)chunk;
