@@ -175,3 +175,32 @@ def test_trainer_epoch_on_npy_tree_with_bad_files(tmp_path):
     assert tr2.start_epoch == 3
     assert torch.equal(tr2.arena_g.flat_param, tr.arena_g.flat_param)
     assert torch.equal(tr2.arena_d.flat_param, tr.arena_d.flat_param)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3", "bf16"])
+def test_full_size_hifimusic_step_runs_on_every_engine(precision):
+    """BASELINE config 3 at full size (16 x 1024 frames x 128 mels; activations up to 9.7 GB, past 32-bit offsets):
+    one optimisation step per engine - finite losses, finite gradient norms, weights move."""
+    import yaml
+    from mqgan_amd import ops
+    from mqgan_amd.train import Trainer, synthetic_mel
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "configs", "model_config_hifimusic.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    cfg["training"]["precision"] = precision
+    B, T, mel = cfg["data"]["batch_size"], cfg["data"]["crop_len"], cfg["model"]["mel_channels"]
+    tr = Trainer(cfg, device=DEV, build_data=False)
+    ops.manual_seed(2)
+    tr.generator.train(); tr.patch_discriminator.train(); tr.multibin_discriminator.train()
+    tr.epoch = 1
+    x = torch.from_numpy(np.stack([synthetic_mel(T, mel, b) for b in range(B)])).to(DEV)
+    lens = torch.full((B,), T, dtype=torch.int32, device=DEV)
+    before = tr.arena_g.flat_param[:4096].clone()
+    for _ in range(2):                       # second step: discriminators in eval mode (real and fake as one batch)
+        out = tr.train_step(x, lens)
+    for k, v in out.items():
+        assert np.isfinite(float(v)), (precision, k)
+    assert np.isfinite(float(tr.optimizer_g.grad_norm())) and np.isfinite(float(tr.optimizer_d.grad_norm()))
+    assert float((tr.arena_g.flat_param[:4096] - before).abs().max()) > 0
+    del tr
+    torch.cuda.empty_cache()
