@@ -376,8 +376,8 @@ extern "C" int mq_codebook_ema_update(const float *x, const int32_t *idx, int64_
 {
     MQ_REQUIRE(x && idx && cluster_size && embed_sum && codebook && counts_ws && sums_ws, "mq_codebook_ema_update: null pointer");
     MQ_REQUIRE(n > 0 && k > 0 && d > 0, "mq_codebook_ema_update: bad sizes");
-    hipMemsetAsync(counts_ws, 0, ((size_t)k + 4) * sizeof(float), S(stream));   // +4: slot k holds the total
-    hipMemsetAsync(sums_ws, 0, (size_t)k * d * sizeof(float), S(stream));
+    (void)hipMemsetAsync(counts_ws, 0, ((size_t)k + 4) * sizeof(float), S(stream));   // +4: slot k holds the total
+    (void)hipMemsetAsync(sums_ws, 0, (size_t)k * d * sizeof(float), S(stream));
     hipLaunchKernelGGL(ema_accumulate_kernel, dim3(ew_grid(n * 64, 256)), dim3(256), 0, S(stream), x, idx, n, d, counts_ws,
                        sums_ws);
     hipLaunchKernelGGL(ema_sizes_kernel, dim3(1), dim3(1024), 0, S(stream), counts_ws, k, decay, cluster_size, counts_ws + k);
