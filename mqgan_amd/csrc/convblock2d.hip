@@ -13,6 +13,7 @@
 namespace mq {
 
 constexpr int CB_TT = 4;     // time steps per block tile
+constexpr int CB_TM = 8;     // time steps per thread in the MLP backward (amortises the per-channel wave reductions)
 constexpr int CB_TC = 64;    // channels per block tile (fwd)
 
 __device__ __forceinline__ uint64_t cb_group(int64_t pixel, int k, int groups_per_pixel)
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void cb2d_fwd_kernel(const float *__restrict__
     y[pixel] = acc;
 }
 
-// Backward pass 1: per-pixel MLP backward.  Thread = channel c, CB_TT consecutive time steps.
+// Backward pass 1: per-pixel MLP backward.  Thread = channel c, CB_TM consecutive time steps.
 // Produces dv (masked) and per-block partials of dw1, db1, dw2 (3*C0) and db2.
 __global__ __launch_bounds__(256) void cb2d_bwd_mlp_kernel(const float *__restrict__ v_save, const float *__restrict__ dy,
                                                            const uint8_t *__restrict__ mask, const float *__restrict__ w1,
@@ -111,12 +112,12 @@ __global__ __launch_bounds__(256) void cb2d_bwd_mlp_kernel(const float *__restri
         const int64_t r = tile / ntiles_c;
         const int tt_ = (int)(r % ntiles_t), b = (int)(r / ntiles_t);
         const int c = ct * 256 + tid;
-        const int t0 = tt_ * CB_TT;
-        float v[CB_TT], g[CB_TT], dva[CB_TT];
-        bool on[CB_TT];
-        int64_t pix[CB_TT];
+        const int t0 = tt_ * CB_TM;
+        float v[CB_TM], g[CB_TM], dva[CB_TM];
+        bool on[CB_TM];
+        int64_t pix[CB_TM];
 #pragma unroll
-        for (int p = 0; p < CB_TT; ++p) {
+        for (int p = 0; p < CB_TM; ++p) {
             const int t = t0 + p;
             const bool inb = (c < C0) && (t < T);
             pix[p] = inb ? ((int64_t)b * T + t) * C0 + c : 0;
@@ -127,10 +128,10 @@ __global__ __launch_bounds__(256) void cb2d_bwd_mlp_kernel(const float *__restri
             dva[p] = 0.f;
         }
         for (int k0 = 0; k0 < C0; k0 += 8) {
-            Drop8 rng[CB_TT];
+            Drop8 rng[CB_TM];
             if (thresh16) {
 #pragma unroll
-                for (int p = 0; p < CB_TT; ++p) rng[p] = Drop8(seed, cb_group(pix[p], k0, gpp));
+                for (int p = 0; p < CB_TM; ++p) rng[p] = Drop8(seed, cb_group(pix[p], k0, gpp));
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256) void cb2d_bwd_mlp_kernel(const float *__restri
                 const float wk1 = sw1[k], bk1 = sb1[k], wk2 = sw2[k];
                 float s_w2 = 0.f, s_w1 = 0.f, s_b1 = 0.f;
 #pragma unroll
-                for (int p = 0; p < CB_TT; ++p) {
+                for (int p = 0; p < CB_TM; ++p) {
                     const float h = fmaf(wk1, v[p], bk1);
                     const float s = aptx_s(h);
                     float keep = 1.0f;
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void cb2d_bwd_mlp_kernel(const float *__restri
             }
         }
 #pragma unroll
-        for (int p = 0; p < CB_TT; ++p)
+        for (int p = 0; p < CB_TM; ++p)
             if (c < C0 && t0 + p < T) dv[pix[p]] = dva[p];
     }
     db2 = block_sum<256>(db2, red);
@@ -239,7 +240,7 @@ __global__ void cb2d_reduce_kernel(const float *__restrict__ part, int nparts, i
 }
 
 struct CbPlan {
-    int ntc_mlp, ntt, grid_mlp, ntc_st, grid_st;
+    int ntc_mlp, ntt, ntt_mlp, grid_mlp, ntc_st, grid_st;
     size_t off_dv, off_p1, off_p2, off_r1, off_r2, total;
 };
 static CbPlan cb_plan(int B, int T, int C0)
@@ -247,8 +248,9 @@ static CbPlan cb_plan(int B, int T, int C0)
     CbPlan p;
     p.ntc_mlp = (int)cdiv(C0, 256);
     p.ntt = (int)cdiv(T, CB_TT);
+    p.ntt_mlp = (int)cdiv(T, CB_TM);
     p.ntc_st = (int)cdiv(C0, CB_TC);
-    int64_t t1 = (int64_t)B * p.ntt * p.ntc_mlp, t2 = (int64_t)B * p.ntt * p.ntc_st;
+    int64_t t1 = (int64_t)B * p.ntt_mlp * p.ntc_mlp, t2 = (int64_t)B * p.ntt * p.ntc_st;
     p.grid_mlp = (int)(t1 < 1024 ? t1 : 1024);
     p.grid_st = (int)(t2 < 1024 ? t2 : 1024);
     size_t o = 0;
@@ -324,7 +326,7 @@ extern "C" int mq_convblock2d_bwd(const mqCb2dWeights *w, const float *x, const 
     hipStream_t st = S(stream);
     const size_t shm = (size_t)(15 * C0) * sizeof(float);
     hipLaunchKernelGGL(cb2d_bwd_mlp_kernel, dim3(p.grid_mlp), dim3(256), shm, st, v_save, dy, mask, w->w1, w->b1, w->w2, B, T, C0, th,
-                       sc, seed, dv, p1, p.ntc_mlp, p.ntt);
+                       sc, seed, dv, p1, p.ntc_mlp, p.ntt_mlp);
     hipLaunchKernelGGL(cb2d_bwd_stencil_kernel, dim3(p.grid_st), dim3(256), 0, st, x, dv, w->wdw, B, T, C0, dx, p2, p.ntc_st, p.ntt);
     hipLaunchKernelGGL(cb2d_reduce_kernel, dim3((unsigned)cdiv(3 * C0 + 1, 256)), dim3(256), 0, st, p1, p.grid_mlp, 3 * C0 + 1, r1);
     hipLaunchKernelGGL(cb2d_reduce_kernel, dim3(1), dim3(256), 0, st, p2, p.grid_st, 26, r2);
