@@ -14,6 +14,10 @@ SHAPES = {
     "midsq": dict(N=32, H=64, W=64, C=512, K=512, R=3, S=3, stride=(1, 1), pad=(1, 1), groups=1),     # 4096 tiles = 4 full rounds
     "mid1":  dict(N=32, H=64, W=64, C=4608, K=512, R=1, S=1, stride=(1, 1), pad=(0, 0), groups=1),    # same GEMM, no taps
     "mid8":  dict(N=64, H=64, W=64, C=512, K=512, R=3, S=3, stride=(1, 1), pad=(1, 1), groups=1),     # 8 full rounds
+    "c3r1":  dict(N=16, H=1024, W=144, C=96, K=96, R=3, S=3, stride=(1, 1), pad=(1, 1), groups=1),     # hifimusic refiner levels
+    "c3r2":  dict(N=16, H=512, W=144, C=192, K=192, R=3, S=3, stride=(1, 1), pad=(1, 1), groups=1),
+    "c3mid": dict(N=16, H=128, W=144, C=768, K=768, R=3, S=3, stride=(1, 1), pad=(1, 1), groups=1),
+    "c3d2":  dict(N=256, H=16, W=1024, C=128, K=128, R=3, S=5, stride=(1, 1), pad=(1, 2), groups=8),
     "enc":   dict(N=32, H=1, W=512, C=512, K=512, R=1, S=3, stride=(1, 1), pad=(0, 1), groups=1),
 }
 name = sys.argv[1] if len(sys.argv) > 1 else "mid"
