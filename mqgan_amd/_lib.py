@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MQGAN_HIP_LIB: load another build of the same ABI (kernel experiments); the default is the in-tree library
 LIB_PATH = os.environ.get("MQGAN_HIP_LIB") or os.path.join(_HERE, "libmqgan_hip.so")
 _lib = None
+ABI_VERSION = 2
 
 
 class MqganHipError(RuntimeError):
@@ -128,6 +129,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if lib.mq_abi_version() != ABI_VERSION:       # a stale build would misread mqConvDesc (struct layout changed)
+        raise MqganHipError(f"{LIB_PATH} has ABI version {lib.mq_abi_version()}, this package needs {ABI_VERSION}: rebuild "
+                            "(`make -C mqgan_amd/csrc`)")
     _lib = lib
     return lib
 

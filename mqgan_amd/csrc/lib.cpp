@@ -5,5 +5,6 @@ namespace mq {
 thread_local char g_err[512] = "";
 }
 
-extern "C" int mq_abi_version(void) { return 1; }
+// 2: mqConvDesc gained `precision`; mq_conv_wgrad_bias, mq_taps_*, mq_cast_bf16, mq_conv_*_h added
+extern "C" int mq_abi_version(void) { return 2; }
 extern "C" const char *mq_last_error(void) { return mq::g_err; }
