@@ -353,6 +353,12 @@ class Trainer:
             mbd = l if mbd is None else ops.add(mbd, l)
         loss_d = ops.add(loss, mbd, 1.0, 1.0 / G)
         loss_d.backward()
+        if self.world > 1:
+            # The LeCam EMAs are linear in the batch means they are fed: averaging the two scalars over the ranks after
+            # the nine updates of this step leaves every replica with the EMA of the GLOBAL means (equal shard sizes).
+            ema = self.gan_loss._state[:2]
+            dist.all_reduce(ema)
+            ema.mul_(1.0 / self.world)
         self.reducer_d.finish()
         clip = self.config["training"].get("clip_grad_norm", 1.0)
         self.optimizer_d.step(max_norm=clip or 0.0, grad_scale=1.0 / self.world)
