@@ -108,6 +108,12 @@ typedef struct {
 
 int mq_conv_fprop(const mqConvDesc *desc_host, const float *x, const float *w_krsc, const float *bias, float *y,
                   mqStream stream);
+/* fprop with the discriminators' activation fused into the store (discriminators.py:219,232):
+ *   y = padded(row) ? 0 : LeakyReLU_slope(conv(x) + bias);  padded(row m) = mask[(m / d1) * d2 + m % d3] != 0  (mask may be NULL)
+ * Any engine (desc->precision); C % 4 == 0.  The pre-activation is not stored: LeakyReLU's derivative is read off the
+ * sign of y (mq_pointwise_bwd with h = y). */
+int mq_conv_fprop_leaky(const mqConvDesc *desc_host, const float *x, const float *w_krsc, const float *bias, const uint8_t *mask,
+                        int64_t d1, int64_t d2, int64_t d3, float slope, float *y, mqStream stream);
 /* bf16-storage variants for MQ_PRECISION_BF16: the operands are bf16 COPIES (mq_cast_bf16) of the f32 tensors - half
  * the bytes and half the loads of the variant that rounds inside the kernel, bit-identical results.  Requires the
  * reduction channel count (C for fprop, K for dgrad) to be a multiple of 16; outputs stay f32. */

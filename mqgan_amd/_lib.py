@@ -55,6 +55,7 @@ SIGNATURES = {
     "mq_codebook_ema_update": (_I, [_P, _P, _L, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P]),
     "mq_conv_fprop": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "mq_conv_dgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
+    "mq_conv_fprop_leaky": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _L, _L, _L, _F, _P, _P]),
     "mq_cast_bf16": (_I, [_P, _P, _L, _P]),
     "mq_conv_fprop_h": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "mq_conv_dgrad_h": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P]),

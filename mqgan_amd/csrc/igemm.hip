@@ -22,6 +22,16 @@ struct ConvGeom {
     int nMt, nNt;
 };
 
+// Optional fused epilogue of the fprop kernels: y = padded(row) ? 0 : leaky(conv + bias), i.e. the discriminators'
+// conv -> LeakyReLU -> masked_fill (discriminators.py:219,232) without a second pass over the output.  The frame mask
+// index of output row m is (m / d1) * d2 + (m % d3), as in the pointwise kernels.
+struct NtEpi {
+    const uint8_t *mask;       // nullptr: no masking
+    int d1, d2, d3;
+    float slope;
+    int act;                   // 0: plain store, 2: LeakyReLU(slope) (+ mask)
+};
+
 // ------------------------------------------------------------------------------------------ loaders
 // Vector path (IC % 4 == 0): every 16-byte load goes through a buffer descriptor, so padding taps,
 // ragged tile edges and K tails are "offset = OOB" (zeros, no memory access) - no branches, no
@@ -258,7 +268,8 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[GemmCfg<BN>::TM][GemmCfg<
 template <class E, int BN, bool DGRAD, int MODE>
 __device__ __forceinline__ void conv_nt_body(const float *__restrict__ act, const float *__restrict__ wgt,
                                              const float *__restrict__ bias, float *__restrict__ out, const ConvGeom &g,
-                                             const WalkGeom &wg, size_t act_group_stride, size_t w_group_stride, float *smem)
+                                             const WalkGeom &wg, size_t act_group_stride, size_t w_group_stride, float *smem,
+                                             const NtEpi &epi)
 {
     using Cfg = GemmCfg<BN, E>;
     const int grp = blockIdx.y;
@@ -301,6 +312,22 @@ __device__ __forceinline__ void conv_nt_body(const float *__restrict__ act, cons
     }
 
     float *o = out + (size_t)grp * g.Mtot * g.Ncols;
+    // fused activation: the padded flag of each of the tile's 128 rows is looked up once (LDS is free after the main
+    // loop's last barrier)
+    unsigned char *padf = reinterpret_cast<unsigned char *>(smem);
+    const bool fused = !DGRAD && epi.act != 0;
+    if (fused) {
+        if (threadIdx.x < GEMM_BM) {
+            const int m = m0 + threadIdx.x;
+            unsigned char pd = 0;
+            if (epi.mask != nullptr && m < g.Mtot) {
+                const int64_t mg = (int64_t)grp * g.Mtot + m;
+                pd = epi.mask[(mg / epi.d1) * epi.d2 + (mg % epi.d3)] != 0;
+            }
+            padf[threadIdx.x] = pd;
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int tn = 0; tn < Cfg::TN; ++tn) {
         const int n = n0 + acc_col<BN>(tn);
@@ -310,8 +337,14 @@ __device__ __forceinline__ void conv_nt_body(const float *__restrict__ act, cons
         for (int tm = 0; tm < Cfg::TM; ++tm)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + acc_row<BN>(tm, r);
-                if (m < g.Mtot) o[(size_t)m * g.Ncols + n] = acc[tm][tn][r] + bv;
+                const int row = acc_row<BN>(tm, r);
+                const int m = m0 + row;
+                float v = acc[tm][tn][r] + bv;
+                if (fused) {
+                    v = v > 0.f ? v : epi.slope * v;
+                    v = padf[row] ? 0.f : v;
+                }
+                if (m < g.Mtot) o[(size_t)m * g.Ncols + n] = v;
             }
     }
 }
@@ -319,39 +352,39 @@ __device__ __forceinline__ void conv_nt_body(const float *__restrict__ act, cons
 template <int BN, bool DGRAD, int MODE>
 __global__ __launch_bounds__(256, MQ_NT_OCC) void conv_nt_kernel(const float *__restrict__ act, const float *__restrict__ wgt,
                                                       const float *__restrict__ bias, float *__restrict__ out,
-                                                      ConvGeom g, WalkGeom wg, size_t act_group_stride, size_t w_group_stride)
+                                                      ConvGeom g, WalkGeom wg, size_t act_group_stride, size_t w_group_stride, NtEpi epi)
 {
     __shared__ __attribute__((aligned(16))) float smem[GemmCfg<BN, EngF32>::LDS_FLOATS];
-    conv_nt_body<EngF32, BN, DGRAD, MODE>(act, wgt, bias, out, g, wg, act_group_stride, w_group_stride, smem);
+    conv_nt_body<EngF32, BN, DGRAD, MODE>(act, wgt, bias, out, g, wg, act_group_stride, w_group_stride, smem, epi);
 }
 // f32 via three-term bf16 split (gemm_core.h: EngSplit); vector path only
 template <int BN, bool DGRAD, int MODE>
 __global__ __launch_bounds__(256, 3) void conv_nt_x3_kernel(const float *__restrict__ act, const float *__restrict__ wgt,
                                                          const float *__restrict__ bias, float *__restrict__ out,
                                                          ConvGeom g, WalkGeom wg, size_t act_group_stride,
-                                                         size_t w_group_stride)
+                                                         size_t w_group_stride, NtEpi epi)
 {
     __shared__ __attribute__((aligned(16))) float smem[GemmCfg<BN, EngSplit>::LDS_FLOATS];
-    conv_nt_body<EngSplit, BN, DGRAD, MODE>(act, wgt, bias, out, g, wg, act_group_stride, w_group_stride, smem);
+    conv_nt_body<EngSplit, BN, DGRAD, MODE>(act, wgt, bias, out, g, wg, act_group_stride, w_group_stride, smem, epi);
 }
 // bf16 operands already in HBM (x_h, w_h from mq_cast_bf16), f32 accumulate, f32 output; C % 16 == 0 only
 template <int BN, bool DGRAD>
 __global__ __launch_bounds__(256, (BN == 128 ? 3 : 4)) void conv_nt_h_kernel(const float *__restrict__ act, const float *__restrict__ wgt,
                                                         const float *__restrict__ bias, float *__restrict__ out, ConvGeom g,
-                                                        WalkGeom wg, size_t act_group_stride, size_t w_group_stride)
+                                                        WalkGeom wg, size_t act_group_stride, size_t w_group_stride, NtEpi epi)
 {
     __shared__ __attribute__((aligned(16))) float smem[GemmCfg<BN, EngBF16H>::LDS_FLOATS];
-    conv_nt_body<EngBF16H, BN, DGRAD, 2>(act, wgt, bias, out, g, wg, act_group_stride, w_group_stride, smem);
+    conv_nt_body<EngBF16H, BN, DGRAD, 2>(act, wgt, bias, out, g, wg, act_group_stride, w_group_stride, smem, epi);
 }
 // bf16 operands (rounded on the way into LDS), f32 accumulate and f32 tensors in HBM; vector path only
 template <int BN, bool DGRAD, int MODE>
 __global__ __launch_bounds__(256, (BN == 128 ? 3 : 4)) void conv_nt_bf16_kernel(const float *__restrict__ act, const float *__restrict__ wgt,
                                                            const float *__restrict__ bias, float *__restrict__ out,
                                                            ConvGeom g, WalkGeom wg, size_t act_group_stride,
-                                                           size_t w_group_stride)
+                                                           size_t w_group_stride, NtEpi epi)
 {
     __shared__ __attribute__((aligned(16))) float smem[GemmCfg<BN, EngBF16>::LDS_FLOATS];
-    conv_nt_body<EngBF16, BN, DGRAD, MODE>(act, wgt, bias, out, g, wg, act_group_stride, w_group_stride, smem);
+    conv_nt_body<EngBF16, BN, DGRAD, MODE>(act, wgt, bias, out, g, wg, act_group_stride, w_group_stride, smem, epi);
 }
 
 // ------------------------------------------------------------------------------------------ dgrad by stride parity
@@ -1076,7 +1109,7 @@ static int check_desc(const mqConvDesc *d, const char *who)
 // hmode: act and w are bf16 arrays (mq_cast_bf16 copies of the f32 tensors), passed as float* in disguise
 template <bool DGRAD>
 static int launch_nt(const mqConvDesc *d, const float *act, const float *w, const float *bias, float *out, hipStream_t st,
-                     bool hmode = false)
+                     bool hmode = false, NtEpi epi = NtEpi{nullptr, 1, 0, 1, 0.f, 0})
 {
     const bool want_bf16 = d->precision == MQ_PRECISION_BF16 && !hmode;
     const bool want_x3 = d->precision == MQ_PRECISION_F32X3;
@@ -1191,10 +1224,10 @@ static int launch_nt(const mqConvDesc *d, const float *act, const float *w, cons
     wg.CB = cb; wg.nchunks = g.IC / cb;
     const int mode = vec ? (wide ? ((g.IC % 16 == 0 && !bf16) ? 3 : 2) : 1) : 0;
     dim3 grid(g.nMt * g.nNt, d->groups), block(256);
-#define MQ_NT(BN_, M_) hipLaunchKernelGGL((conv_nt_kernel<BN_, DGRAD, M_>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs)
-#define MQ_NTH(BN_, M_) hipLaunchKernelGGL((conv_nt_bf16_kernel<BN_, DGRAD, M_>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs)
-#define MQ_NTX(BN_, M_) hipLaunchKernelGGL((conv_nt_x3_kernel<BN_, DGRAD, M_>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs)
-#define MQ_NTHH(BN_) hipLaunchKernelGGL((conv_nt_h_kernel<BN_, DGRAD>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs)
+#define MQ_NT(BN_, M_) hipLaunchKernelGGL((conv_nt_kernel<BN_, DGRAD, M_>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs, epi)
+#define MQ_NTH(BN_, M_) hipLaunchKernelGGL((conv_nt_bf16_kernel<BN_, DGRAD, M_>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs, epi)
+#define MQ_NTX(BN_, M_) hipLaunchKernelGGL((conv_nt_x3_kernel<BN_, DGRAD, M_>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs, epi)
+#define MQ_NTHH(BN_) hipLaunchKernelGGL((conv_nt_h_kernel<BN_, DGRAD>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs, epi)
 #define MQ_NT3(BN_) do { if (hmode) MQ_NTHH(BN_); else if (x3) { if (mode == 3) MQ_NTX(BN_, 3); else if (mode == 2) MQ_NTX(BN_, 2); else MQ_NTX(BN_, 1); } \
                          else if (bf16) { if (mode == 2) MQ_NTH(BN_, 2); else MQ_NTH(BN_, 1); } \
                          else if (mode == 3) MQ_NT(BN_, 3); else if (mode == 2) MQ_NT(BN_, 2); else if (mode == 1) MQ_NT(BN_, 1); \
@@ -1269,6 +1302,18 @@ extern "C" int mq_conv_fprop(const mqConvDesc *d, const float *x, const float *w
     if (check_desc(d, "mq_conv_fprop")) return 1;
     MQ_REQUIRE(x && w && y, "mq_conv_fprop: null pointer");
     return launch_nt<false>(d, x, w, bias, y, S(stream));
+}
+
+extern "C" int mq_conv_fprop_leaky(const mqConvDesc *d, const float *x, const float *w, const float *bias, const uint8_t *mask,
+                                   int64_t d1, int64_t d2, int64_t d3, float slope, float *y, mqStream stream)
+{
+    if (check_desc(d, "mq_conv_fprop_leaky")) return 1;
+    MQ_REQUIRE(x && w && y, "mq_conv_fprop_leaky: null pointer");
+    MQ_REQUIRE(d->C % 4 == 0, "mq_conv_fprop_leaky: the fused epilogue exists on the vector path only (C %% 4 == 0, got %d)", d->C);
+    MQ_REQUIRE(mask == nullptr || (d1 > 0 && d3 > 0 && d2 >= 0 && d1 < INT32_MAX && d2 < INT32_MAX && d3 < INT32_MAX),
+               "mq_conv_fprop_leaky: bad mask map");
+    NtEpi epi{mask, (int)(mask ? d1 : 1), (int)(mask ? d2 : 0), (int)(mask ? d3 : 1), slope, 2};
+    return launch_nt<false>(d, x, w, bias, y, S(stream), false, epi);
 }
 
 extern "C" int mq_conv_fprop_h(const mqConvDesc *d, const uint16_t *x_h, const uint16_t *w_h, const float *bias, float *y,

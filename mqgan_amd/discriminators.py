@@ -154,12 +154,10 @@ def run_discriminators(bands: List[MelSpectrogramPatchDiscriminator2D], x, x_len
         wk, wc, bias = _stacked(bands, lambda d: d.convs[i], need_crsk=(need_dx or not first), power_iteration=training,
                                 detach=detach_params)
         desc = ops.conv_desc(N, H, W, Cin, conv_i.cout, kh, kw, stride=(sh, sw), pad=((kh - 1) // 2, (kw - 1) // 2), groups=G)
-        out = ops.conv(out, wk, wc, bias, desc)
-        if sh > 1 or sw > 1:                                                  # ceil-mode max-pool of the mask (:223-229)
-            if sw > 1:
-                mask = ops.mask_pool(mask, sw, ceil_mode=True)
-        P, Q = out.shape[1], out.shape[2]
-        out = ops.pointwise(out, act=ops.ACT_LEAKY, mask=mask, mask_post=True, dmap=(P * Q, Q, Q))   # (:219, :232)
+        if sw > 1:                                                            # ceil-mode max-pool of the mask (:223-229)
+            mask = ops.mask_pool(mask, sw, ceil_mode=True)
+        # conv -> LeakyReLU(0.2) -> masked_fill (:219, :232), fused into the conv's store where the kernel allows it
+        out = ops.conv_leaky(out, wk, wc, bias, desc, mask, (desc.P * desc.Q, desc.Q, desc.Q))
         if return_features and d0.ret_features_map[i]:
             feats.append((out, mask))
     return out, mask, feats

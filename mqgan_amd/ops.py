@@ -218,45 +218,85 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        d = _desc_from_key(ctx.key)
         x, w_crsk = ctx.saved_tensors
-        dy = dy.contiguous()
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            if not ctx.have_crsk:
-                raise _lib.MqganHipError("conv backward wrt the input needs the CRSK weights")
-            dx = torch.empty_like(x)
-            if _h_ok(d, d.K):
-                dy_h, wc_h = cast_bf16(dy), cast_bf16(w_crsk)
-                _timed(_conv_tag("dgrad", d), _conv_flops(d), lambda: check(
-                    L().mq_conv_dgrad_h(C.byref(d), ptr(dy_h, BF16), ptr(wc_h, BF16), fptr(dx), stream()), "mq_conv_dgrad_h"),
-                    ctx.key)
-            else:
-                _timed(_conv_tag("dgrad", d), _conv_flops(d), lambda: check(
-                    L().mq_conv_dgrad(C.byref(d), fptr(dy), fptr(w_crsk), fptr(dx), stream()), "mq_conv_dgrad"), ctx.key)
-        want_db = ctx.has_bias and ctx.needs_input_grad[3]
-        if ctx.needs_input_grad[1]:
-            dw = _empty(ctx.w_shape, x)      # (groups*K, R*S, C) == KRSC
-            if want_db:                      # bias gradient rides on the dy tiles of the weight-gradient GEMM
-                db = _empty((d.groups * d.K,), x)
-                nbytes = L().mq_conv_wgrad_bias_workspace(C.byref(d))
-                ws = _ws_bytes(nbytes, x)
-                _timed(_conv_tag("wgrad", d), _conv_flops(d), lambda: check(
-                    L().mq_conv_wgrad_bias(C.byref(d), fptr(x), fptr(dy), fptr(dw), fptr(db), ptr(ws), nbytes, stream()),
-                    "mq_conv_wgrad_bias"), ctx.key)
-            else:
-                nbytes = L().mq_conv_wgrad_workspace(C.byref(d))
-                ws = _ws_bytes(nbytes, x)
-                _timed(_conv_tag("wgrad", d), _conv_flops(d), lambda: check(
-                    L().mq_conv_wgrad(C.byref(d), fptr(x), fptr(dy), fptr(dw), ptr(ws), nbytes, stream()), "mq_conv_wgrad"),
-                    ctx.key)
-        elif want_db:
-            rows_per_group = (d.N // d.groups) * d.P * d.Q
-            if d.groups == 1:
-                db = colsum(dy.view(-1, d.K))
-            else:
-                db = torch.cat([colsum(dy.view(d.groups, rows_per_group, d.K)[g]) for g in range(d.groups)])
+        dx, dw, db = _conv_backward(ctx, x, w_crsk, dy.contiguous())
         return dx, dw, None, db, None
+
+
+def _conv_backward(ctx, x, w_crsk, dy):
+    """dgrad / wgrad (+ fused bias gradient) of a conv whose forward stored key, w_shape, has_bias, have_crsk on ctx;
+    inputs 0, 1, 3 of the Function are x, w_krsc, bias."""
+    d = _desc_from_key(ctx.key)
+    dx = dw = db = None
+    if ctx.needs_input_grad[0]:
+        if not ctx.have_crsk:
+            raise _lib.MqganHipError("conv backward wrt the input needs the CRSK weights")
+        dx = torch.empty_like(x)
+        if _h_ok(d, d.K):
+            dy_h, wc_h = cast_bf16(dy), cast_bf16(w_crsk)
+            _timed(_conv_tag("dgrad", d), _conv_flops(d), lambda: check(
+                L().mq_conv_dgrad_h(C.byref(d), ptr(dy_h, BF16), ptr(wc_h, BF16), fptr(dx), stream()), "mq_conv_dgrad_h"),
+                ctx.key)
+        else:
+            _timed(_conv_tag("dgrad", d), _conv_flops(d), lambda: check(
+                L().mq_conv_dgrad(C.byref(d), fptr(dy), fptr(w_crsk), fptr(dx), stream()), "mq_conv_dgrad"), ctx.key)
+    want_db = ctx.has_bias and ctx.needs_input_grad[3]
+    if ctx.needs_input_grad[1]:
+        dw = _empty(ctx.w_shape, x)      # (groups*K, R*S, C) == KRSC
+        if want_db:                      # bias gradient rides on the dy tiles of the weight-gradient GEMM
+            db = _empty((d.groups * d.K,), x)
+            nbytes = L().mq_conv_wgrad_bias_workspace(C.byref(d))
+            ws = _ws_bytes(nbytes, x)
+            _timed(_conv_tag("wgrad", d), _conv_flops(d), lambda: check(
+                L().mq_conv_wgrad_bias(C.byref(d), fptr(x), fptr(dy), fptr(dw), fptr(db), ptr(ws), nbytes, stream()),
+                "mq_conv_wgrad_bias"), ctx.key)
+        else:
+            nbytes = L().mq_conv_wgrad_workspace(C.byref(d))
+            ws = _ws_bytes(nbytes, x)
+            _timed(_conv_tag("wgrad", d), _conv_flops(d), lambda: check(
+                L().mq_conv_wgrad(C.byref(d), fptr(x), fptr(dy), fptr(dw), ptr(ws), nbytes, stream()), "mq_conv_wgrad"),
+                ctx.key)
+    elif want_db:
+        rows_per_group = (d.N // d.groups) * d.P * d.Q
+        if d.groups == 1:
+            db = colsum(dy.view(-1, d.K))
+        else:
+            db = torch.cat([colsum(dy.view(d.groups, rows_per_group, d.K)[g]) for g in range(d.groups)])
+    return dx, dw, db
+
+
+class ConvLeakyFn(torch.autograd.Function):
+    """y = padded ? 0 : LeakyReLU(conv(x, w) + bias), activation and mask fused into the conv's store
+    (mq_conv_fprop_leaky).  The pre-activation is never written: the backward pass reads LeakyReLU's derivative off
+    the sign of y."""
+
+    @staticmethod
+    def forward(ctx, x, w_krsc, w_crsk, bias, mask, key, dmap, slope):
+        d = _desc_from_key(key)
+        y = _empty((d.N, d.P, d.Q, d.K), x)
+        _timed(_conv_tag("fprop", d), _conv_flops(d), lambda: check(
+            L().mq_conv_fprop_leaky(C.byref(d), fptr(x), fptr(w_krsc), fptr(bias, True), ptr(mask, torch.uint8, True), dmap[0],
+                                    dmap[1], dmap[2], float(slope), fptr(y), stream()), "mq_conv_fprop_leaky"), key)
+        ctx.key, ctx.dmap, ctx.slope = key, dmap, slope
+        ctx.w_shape = tuple(w_krsc.shape)
+        ctx.has_bias = bias is not None
+        ctx.have_crsk = w_crsk is not None
+        ctx.save_for_backward(x, w_crsk if w_crsk is not None else w_krsc, y, mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w_crsk, y, mask = ctx.saved_tensors
+        if ctx.slope != 0.2:
+            raise _lib.MqganHipError("the pointwise backward kernel implements LeakyReLU(0.2) only")
+        Cc = y.shape[-1]
+        pd = PointwiseDesc(rows=y.numel() // Cc, C=Cc, act=ACT_LEAKY, mask_pre=0, mask_post=int(mask is not None),
+                           d1=ctx.dmap[0], d2=ctx.dmap[1], d3=ctx.dmap[2], p_drop=0.0, seed=0)
+        dy = torch.empty_like(y)
+        check(L().mq_pointwise_bwd(C.byref(pd), fptr(dout.contiguous()), fptr(y), None, ptr(mask, torch.uint8, True), None,
+                                   None, fptr(dy), None, None, None, None, stream()), "mq_pointwise_bwd")
+        dx, dw, db = _conv_backward(ctx, x, w_crsk, dy)
+        return dx, dw, None, db, None, None, None, None
 
 
 class TapsGatherFn(torch.autograd.Function):
@@ -301,7 +341,7 @@ class TapsReduceFn(torch.autograd.Function):
         return du, db, None, None
 
 
-def _thin_conv(x, w_krsc, w_crsk, bias, desc: ConvDesc):
+def _thin_conv(x, w_krsc, w_crsk, bias, desc: ConvDesc, leaky=None):
     """C = 1 or K = 1 with more than one tap (csrc/taps.hip): tap gather / fold around a 1x1 GEMM."""
     G, K, Cin, RS = desc.groups, desc.K, desc.C, desc.R * desc.S
     T = (RS + 3) // 4 * 4
@@ -312,6 +352,8 @@ def _thin_conv(x, w_krsc, w_crsk, bias, desc: ConvDesc):
         wk = torch.nn.functional.pad(w_krsc.view(G * K, RS), (0, T - RS)).contiguous().view(G * K, 1, T)         # KRSC of the 1x1 conv
         wc = wk.view(G, K, T).transpose(1, 2).contiguous().view(G * T, 1, K) if need_dx else None              # its CRSK
         d1 = conv_desc(desc.N, desc.P, desc.Q, T, K, 1, 1, groups=G, precision=desc.precision)
+        if leaky is not None and not _h_ok(d1, T):          # same output rows (n, p, q): the fused activation applies
+            return ConvLeakyFn.apply(cols, wk, wc, bias, leaky[0], _desc_key(d1), leaky[1], leaky[2])
         return ConvFn.apply(cols, wk, wc, bias, _desc_key(d1))
     # K = 1: w_krsc is (G, RS, C) in the channel-blocked order [C/CB][RS][CB] -> rows = taps, plain channels
     CB = 16 if Cin % 16 == 0 else Cin
@@ -321,6 +363,16 @@ def _thin_conv(x, w_krsc, w_crsk, bias, desc: ConvDesc):
     d1 = conv_desc(desc.N, desc.H, desc.W, Cin, T, 1, 1, groups=G, precision=desc.precision)
     u = ConvFn.apply(x, wk, wc, None, _desc_key(d1))
     return TapsReduceFn.apply(u, bias, key, T).view(desc.N, desc.P, desc.Q, 1)
+
+
+def conv_leaky(x, w_krsc, w_crsk, bias, desc: ConvDesc, mask, dmap, slope: float = 0.2):
+    """LeakyReLU(conv) with padded frames zeroed - one kernel where the fused epilogue applies, conv + pointwise otherwise."""
+    thin = desc.R * desc.S > 1 and ((desc.C == 1) != (desc.K == 1)) and (desc.C % 4 == 0 or desc.K % 4 == 0)
+    if thin and desc.C == 1:
+        return _thin_conv(x, w_krsc, w_crsk, bias, desc, leaky=(mask, tuple(dmap), slope))
+    if thin or desc.C % 4 != 0 or _h_ok(desc, desc.C):
+        return pointwise(conv(x, w_krsc, w_crsk, bias, desc), act=ACT_LEAKY, mask=mask, mask_post=mask is not None, dmap=dmap)
+    return ConvLeakyFn.apply(x, w_krsc, w_crsk, bias, mask, _desc_key(desc), tuple(dmap), slope)
 
 
 def conv(x, w_krsc, w_crsk, bias, desc: ConvDesc):
