@@ -59,17 +59,21 @@ int mq_fsq_decode(const mqFsqDesc *desc_host, const int64_t *idx, int64_t n, flo
 
 /* Generic L2 nearest neighbour (no reference code, arithmetic
  * defined in oracle/vq_ref.c): cnorm[k] = fma-chain_d c[k][d]^2; idx[n] = argmin_k
- * fma(-2, fma-chain_d x[n][d]*c[k][d], cnorm[k]), ties to the lowest k.
+ * fma(-2, fma-chain_d x[n][d]*c[k][d], cnorm[k]), ties to the lowest k, NaN distances count as -inf.
  * Requires d % 4 == 0.  best_dist nullable. */
 int mq_l2_codebook_norms(const float *codebook, int k, int d, float *cnorm, mqStream stream);
 size_t mq_l2_argmin_workspace(int64_t n);
 int mq_l2_argmin(const float *x, const float *codebook, const float *cnorm, int64_t n, int k, int d, int32_t *idx,
                  float *best_dist, void *workspace, mqStream stream);
-/* codebook EMA update (row Q3, parity unpinned): cluster_size = decay*cluster_size + (1-decay)*count_k;
- * embed_sum = decay*embed_sum + (1-decay)*sum_{n: idx[n]==k} x[n]; codebook = embed_sum / smoothed(cluster_size).
- * counts_ws (k + 4) and sums_ws (k*d) are scratch (zeroed by the call). */
+/* codebook EMA update (row Q3; no reference code - arithmetic AND summation order are defined in oracle/vq_ref.c
+ * section 3, and the kernels are bit-exact against it, deterministic, no float atomics):
+ *   cluster_size = decay*cluster_size + (1-decay)*count_k;  embed_sum = decay*embed_sum + (1-decay)*sum_{n: idx[n]==k} x[n];
+ *   codebook = embed_sum / smoothed(cluster_size)  (Laplace smoothing with eps; dead codes keep embed_sum / smoothed).
+ * Rows whose idx lies outside [0, k) are ignored.  idx out of a NaN row: mq_l2_argmin counts a NaN distance as -inf,
+ * so it always returns a valid index. */
+size_t mq_codebook_ema_workspace(int64_t n, int k, int d);
 int mq_codebook_ema_update(const float *x, const int32_t *idx, int64_t n, int k, int d, float decay, float eps,
-                           float *cluster_size, float *embed_sum, float *codebook, float *counts_ws, float *sums_ws,
+                           float *cluster_size, float *embed_sum, float *codebook, void *workspace, size_t workspace_bytes,
                            mqStream stream);
 
 /* ------------------------------------------------------------------ convolutions

@@ -52,7 +52,8 @@ SIGNATURES = {
     "mq_l2_codebook_norms": (_I, [_P, _I, _I, _P, _P]),
     "mq_l2_argmin_workspace": (_Z, [_L]),
     "mq_l2_argmin": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _P]),
-    "mq_codebook_ema_update": (_I, [_P, _P, _L, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P]),
+    "mq_codebook_ema_workspace": (_Z, [_L, _I, _I]),
+    "mq_codebook_ema_update": (_I, [_P, _P, _L, _I, _I, _F, _F, _P, _P, _P, _P, _Z, _P]),
     "mq_conv_fprop": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "mq_conv_dgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
     "mq_conv_fprop_leaky": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _L, _L, _L, _F, _P, _P]),
@@ -144,6 +145,8 @@ def check(rc, what=""):
 
 
 def stream():
+    """HIP stream every kernel of this call is launched on: the current stream of the CURRENT device.  ptr() refuses
+    tensors that live on another device, so a launch can never pair device-N pointers with device-0's stream."""
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -155,6 +158,9 @@ def ptr(t, dtype=None, allow_none=False):
         raise MqganHipError("required tensor is None")
     if not t.is_cuda:
         raise MqganHipError("mqgan_amd ops need HIP device tensors (got a CPU tensor); there is no CPU path")
+    if t.device.index != torch.cuda.current_device():
+        raise MqganHipError(f"tensor lives on {t.device} but the current HIP device is cuda:{torch.cuda.current_device()}: "
+                            "call torch.cuda.set_device(...) (Trainer / ScriptedPreEncoder do) before launching kernels")
     if not t.is_contiguous():
         raise MqganHipError(f"tensor of shape {tuple(t.shape)} is not contiguous")
     if dtype is not None and t.dtype != dtype:

@@ -191,7 +191,8 @@ __global__ __launch_bounds__(256) void l2_argmin_kernel(const float *__restrict_
                 for (int tm = 0; tm < Cfg::TM; ++tm)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float dist = fmaf(-2.0f, acc[tm][tn][r], cnv);
+                        float dist = fmaf(-2.0f, acc[tm][tn][r], cnv);
+                        dist = dist != dist ? -INFINITY : dist;      // NaN counts as -inf: the first NaN column wins
                         if (dist < best[tm][r]) {       // strict: lowest index wins ties inside a lane
                             best[tm][r] = dist;
                             bidx[tm][r] = col;
@@ -232,44 +233,83 @@ __global__ void l2_unpack_kernel(const unsigned long long *__restrict__ packed, 
 }
 
 // ------------------------------------------------------------------------------------------ codebook EMA
-__global__ void ema_accumulate_kernel(const float *__restrict__ x, const int32_t *__restrict__ idx, int64_t n, int d,
-                                      float *__restrict__ counts, float *__restrict__ sums)
+// Arithmetic and summation order are DEFINED in oracle/vq_ref.c (section 3 of its header); every step below is one
+// correctly rounded f32 operation (the _rn intrinsics keep the compiler from contracting them), so the result is
+// bit-exact against that definition and identical from run to run (no float atomics).
+constexpr int EMA_SEG = 2048;         // rows per segment
+constexpr int EMA_DCH = 1024;         // feature columns per pass of a wave (16 registers per lane)
+
+// grid (k, segments), one wave per (code, segment): part[s][c][:] = sum of the segment's rows with idx == c, in row order
+__global__ __launch_bounds__(64) void ema_partial_kernel(const float *__restrict__ x, const int32_t *__restrict__ idx, int64_t n,
+                                                         int k, int d, float *__restrict__ part, int *__restrict__ counts)
 {
-    // one wave per row: lanes stride the feature dim
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t i = wave; i < n; i += nwaves) {
-        const int c = idx[i];
-        if (lane == 0) atomicAdd(&counts[c], 1.0f);
-        for (int t = lane; t < d; t += 64) atomicAdd(&sums[(size_t)c * d + t], x[i * d + t]);
+    const int c = blockIdx.x, s = blockIdx.y, lane = threadIdx.x;
+    const int64_t i0 = (int64_t)s * EMA_SEG, i1 = min(n, i0 + EMA_SEG);
+    float *o = part + ((size_t)s * k + c) * d;
+    int cnt = 0;
+    for (int t0 = 0; t0 < d; t0 += EMA_DCH) {
+        float acc[EMA_DCH / 64];
+#pragma unroll
+        for (int j = 0; j < EMA_DCH / 64; ++j) acc[j] = 0.f;
+        for (int64_t i = i0; i < i1; i += 64) {
+            const bool hit = (i + lane < i1) && idx[i + lane] == c;
+            unsigned long long m = __ballot(hit);
+            if (t0 == 0) cnt += __popcll(m);
+            while (m) {
+                const int b = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const float *row = x + (size_t)(i + b) * d + t0;
+#pragma unroll
+                for (int j = 0; j < EMA_DCH / 64; ++j) {
+                    const int t = lane + 64 * j;
+                    if (t0 + t < d) acc[j] = __fadd_rn(acc[j], row[t]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < EMA_DCH / 64; ++j) {
+            const int t = lane + 64 * j;
+            if (t0 + t < d) o[t0 + t] = acc[j];
+        }
     }
+    if (lane == 0 && cnt) atomicAdd(&counts[c], cnt);       // integer: exact and order-independent
 }
-__global__ void ema_sizes_kernel(const float *__restrict__ counts, int k, float decay, float *__restrict__ cluster_size,
-                                 float *__restrict__ total)
+// one block of 1024: cluster sizes, then their total in the fixed order of the definition
+__global__ __launch_bounds__(1024) void ema_sizes_kernel(const int *__restrict__ counts, int k, float decay,
+                                                         float *__restrict__ cluster_size, float *__restrict__ total)
 {
-    __shared__ float red[16];
+    __shared__ float lanes[1024];
+    const float omd = __fsub_rn(1.0f, decay);
     float s = 0.f;
-    for (int j = threadIdx.x; j < k; j += blockDim.x) {
-        const float v = cluster_size[j] * decay + (1.0f - decay) * counts[j];
-        cluster_size[j] = v;
-        s += v;
+    for (int c = threadIdx.x; c < k; c += 1024) {
+        const float v = __fmaf_rn(omd, (float)counts[c], __fmul_rn(cluster_size[c], decay));
+        cluster_size[c] = v;
+        s = __fadd_rn(s, v);
     }
-    s = block_sum<1024>(s, red);
-    if (threadIdx.x == 0) total[0] = s;
+    lanes[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int l = 0; l < 1024; ++l) t = __fadd_rn(t, lanes[l]);
+        total[0] = t;
+    }
 }
-__global__ void ema_codebook_kernel(const float *__restrict__ sums, const float *__restrict__ cluster_size,
+__global__ void ema_codebook_kernel(const float *__restrict__ part, int nseg, const float *__restrict__ cluster_size,
                                     const float *__restrict__ total, int k, int d, float decay, float eps,
                                     float *__restrict__ embed_sum, float *__restrict__ codebook)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)k * d) return;
-    const int j = (int)(i / d);
-    const float es = embed_sum[i] * decay + (1.0f - decay) * sums[i];
+    const int64_t kd = (int64_t)k * d;
+    if (i >= kd) return;
+    const int c = (int)(i / d);
+    float sum = 0.f;
+    for (int s = 0; s < nseg; ++s) sum = __fadd_rn(sum, part[(size_t)s * kd + i]);
+    const float es = __fmaf_rn(__fsub_rn(1.0f, decay), sum, __fmul_rn(embed_sum[i], decay));
     embed_sum[i] = es;
-    const float ntot = total[0];
-    const float smoothed = (cluster_size[j] + eps) / (ntot + (float)k * eps) * ntot;   // Laplace smoothing
-    codebook[i] = es / smoothed;
+    const float tot = total[0];
+    const float den = __fadd_rn(tot, __fmul_rn((float)k, eps));
+    const float sm = __fmul_rn(__fdiv_rn(__fadd_rn(cluster_size[c], eps), den), tot);      // Laplace smoothing
+    codebook[i] = __fdiv_rn(es, sm);
 }
 
 static int to_dev(const mqFsqDesc *h, FsqDev &p, const float (*thresh)[8], const char *who)
@@ -370,19 +410,32 @@ extern "C" int mq_l2_argmin(const float *x, const float *codebook, const float *
     return 0;
 }
 
-extern "C" int mq_codebook_ema_update(const float *x, const int32_t *idx, int64_t n, int k, int d, float decay, float eps,
-                                      float *cluster_size, float *embed_sum, float *codebook, float *counts_ws,
-                                      float *sums_ws, mqStream stream)
+static int ema_segments(int64_t n) { return (int)cdiv(n, EMA_SEG); }
+
+extern "C" size_t mq_codebook_ema_workspace(int64_t n, int k, int d)
 {
-    MQ_REQUIRE(x && idx && cluster_size && embed_sum && codebook && counts_ws && sums_ws, "mq_codebook_ema_update: null pointer");
-    MQ_REQUIRE(n > 0 && k > 0 && d > 0, "mq_codebook_ema_update: bad sizes");
-    (void)hipMemsetAsync(counts_ws, 0, ((size_t)k + 4) * sizeof(float), S(stream));   // +4: slot k holds the total
-    (void)hipMemsetAsync(sums_ws, 0, (size_t)k * d * sizeof(float), S(stream));
-    hipLaunchKernelGGL(ema_accumulate_kernel, dim3(ew_grid(n * 64, 256)), dim3(256), 0, S(stream), x, idx, n, d, counts_ws,
-                       sums_ws);
-    hipLaunchKernelGGL(ema_sizes_kernel, dim3(1), dim3(1024), 0, S(stream), counts_ws, k, decay, cluster_size, counts_ws + k);
-    hipLaunchKernelGGL(ema_codebook_kernel, dim3((unsigned)cdiv((int64_t)k * d, 256)), dim3(256), 0, S(stream), sums_ws,
-                       cluster_size, counts_ws + k, k, d, decay, eps, embed_sum, codebook);
+    if (n <= 0 || k <= 0 || d <= 0) return 0;
+    return ((size_t)ema_segments(n) * k * d + 4) * sizeof(float) + (size_t)k * sizeof(int);
+}
+
+extern "C" int mq_codebook_ema_update(const float *x, const int32_t *idx, int64_t n, int k, int d, float decay, float eps,
+                                      float *cluster_size, float *embed_sum, float *codebook, void *workspace,
+                                      size_t workspace_bytes, mqStream stream)
+{
+    MQ_REQUIRE(x && idx && cluster_size && embed_sum && codebook && workspace, "mq_codebook_ema_update: null pointer");
+    MQ_REQUIRE(n > 0 && k > 0 && d > 0 && k <= 65535, "mq_codebook_ema_update: need n > 0, 0 < k <= 65535, d > 0");
+    MQ_REQUIRE(workspace_bytes >= mq_codebook_ema_workspace(n, k, d), "mq_codebook_ema_update: workspace too small");
+    const int nseg = ema_segments(n);
+    MQ_REQUIRE(nseg <= 65535, "mq_codebook_ema_update: n too large");
+    float *part = reinterpret_cast<float *>(workspace);
+    float *total = part + (size_t)nseg * k * d;
+    int *counts = reinterpret_cast<int *>(total + 4);
+    hipError_t e = hipMemsetAsync(counts, 0, (size_t)k * sizeof(int), S(stream));
+    MQ_REQUIRE(e == hipSuccess, "mq_codebook_ema_update: memset failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(ema_partial_kernel, dim3(k, nseg), dim3(64), 0, S(stream), x, idx, n, k, d, part, counts);
+    hipLaunchKernelGGL(ema_sizes_kernel, dim3(1), dim3(1024), 0, S(stream), counts, k, decay, cluster_size, total);
+    hipLaunchKernelGGL(ema_codebook_kernel, dim3((unsigned)cdiv((int64_t)k * d, 256)), dim3(256), 0, S(stream), part, nseg,
+                       cluster_size, total, k, d, decay, eps, embed_sum, codebook);
     MQ_LAUNCH_CHECK("mq_codebook_ema_update");
     return 0;
 }

@@ -846,12 +846,13 @@ def l2_argmin(x: torch.Tensor, codebook: torch.Tensor, cnorm: Optional[torch.Ten
 
 
 def codebook_ema_update(x, idx, cluster_size, embed_sum, codebook, decay=0.99, eps=1e-5):
+    """In-place EMA update of (cluster_size, embed_sum, codebook); deterministic, bit-exact against oracle/vq_ref.c."""
     n, d = x.shape
     k = codebook.shape[0]
-    counts = _empty((k + 4,), x)
-    sums = _empty((k, d), x)
+    nbytes = L().mq_codebook_ema_workspace(n, k, d)
+    ws = _ws_bytes(nbytes, x)
     check(L().mq_codebook_ema_update(fptr(x), ptr(idx, torch.int32), n, k, d, decay, eps, fptr(cluster_size), fptr(embed_sum),
-                                     fptr(codebook), fptr(counts), fptr(sums), stream()), "mq_codebook_ema_update")
+                                     fptr(codebook), ptr(ws), nbytes, stream()), "mq_codebook_ema_update")
 
 
 # ----------------------------------------------------------------------------- losses

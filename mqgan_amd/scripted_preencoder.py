@@ -41,6 +41,9 @@ class ScriptedPreEncoder:
         if self.device.type != "cuda":
             raise RuntimeError("mqgan_amd.ScriptedPreEncoder runs on the HIP device only (device='cuda'); "
                                "there is no CPU path")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        torch.cuda.set_device(self.device)               # kernels launch on the current device's stream
         config_path = os.path.join(model_dir, "model_config.yaml")
         if not os.path.exists(config_path):
             raise FileNotFoundError(f"model_config.yaml not found in: {model_dir}")

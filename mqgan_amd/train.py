@@ -170,6 +170,10 @@ class Trainer:
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.device = torch.device(device) if device is not None else self._get_device()
+        if self.device.type == "cuda":
+            if self.device.index is None:
+                self.device = torch.device("cuda", torch.cuda.current_device())
+            torch.cuda.set_device(self.device)           # kernels launch on the current device's stream (_lib.stream)
         self.start_epoch = 1
         self.epoch = 1
         self._setup_seeds()
@@ -226,8 +230,10 @@ class Trainer:
         if self.world > 1:
             sampler = torch.utils.data.distributed.DistributedSampler(train_ds, self.world, self.rank, shuffle=True,
                                                                       seed=self.config["training"]["seed"])
+        # data parallel: every rank must take the same number of equally sized steps (the collectives are matched one
+        # to one), so the ragged last batch is dropped there; a single process keeps it like the reference does
         loader = torch.utils.data.DataLoader(train_ds, batch_size=cfg["batch_size"], shuffle=sampler is None, sampler=sampler,
-                                             num_workers=cfg.get("num_workers", 0), pin_memory=True,
+                                             num_workers=cfg.get("num_workers", 0), pin_memory=True, drop_last=self.world > 1,
                                              collate_fn=partial(pad_collate_fn, crop_lens=cfg["crop_len"]))
         return loader, eval_ds
 
@@ -447,16 +453,22 @@ class Trainer:
         if self.world > 1 and hasattr(self.train_loader.sampler, "set_epoch"):
             self.train_loader.sampler.set_epoch(epoch)
         log_every = self.config.get("logging", {}).get("log_interval", 50)
-        frames, t0 = 0, time.time()
+        frames, t0 = torch.zeros((), dtype=torch.int64, device=self.device), time.time()
         from .data import PrefetchLoader
         for i, (real, lens, _) in enumerate(PrefetchLoader(self.train_loader, self.device, depth=2)):
-            if real is None or real.size(0) == 0:      # every file of the batch failed to load (train.py:512-514)
+            empty = real is None or real.size(0) == 0   # every file of the batch failed to load (train.py:512-514)
+            if self.world > 1:
+                # the step is full of collectives: either every rank takes it or none does
+                flag = torch.tensor([0.0 if empty else 1.0], device=self.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                empty = float(flag.item()) == 0.0
+            if empty:
                 continue
             out = self.train_step(real, lens)
-            frames += real.shape[0] * real.shape[1]    # upper bound (padded frames included); no host sync
+            frames += lens.sum()                        # the metric counts VALID frames (sum of lengths); no host sync
             if self.log_fn is not None and (i + 1) % log_every == 0:
                 rec = {k: (float(v) if torch.is_tensor(v) else v) for k, v in out.items()}
-                rec.update(epoch=epoch, step=self.global_step, frames_per_s=frames / (time.time() - t0))
+                rec.update(epoch=epoch, step=self.global_step, frames_per_s=int(frames.item()) / (time.time() - t0))
                 self.log_fn(rec)
 
     def train(self):

@@ -104,3 +104,20 @@ def l2_argmin(x: np.ndarray, cb: np.ndarray, threads: int = 1, return_dist=False
         with ThreadPoolExecutor(threads) as ex:   # ctypes releases the GIL
             list(ex.map(run, ranges))
     return (idx, dist) if return_dist else idx
+
+
+def codebook_ema(x: np.ndarray, idx: np.ndarray, cluster_size: np.ndarray, embed_sum: np.ndarray, decay=0.99, eps=1e-5):
+    """One EMA codebook update under the arithmetic and summation order defined in vq_ref.c (section 3 of its
+    header).  Returns new (cluster_size, embed_sum, codebook); inputs are not modified."""
+    x = np.ascontiguousarray(x, np.float32)
+    idx = np.ascontiguousarray(idx, np.int32)
+    n, d = x.shape
+    k = cluster_size.shape[0]
+    cs = np.array(cluster_size, np.float32, copy=True)
+    es = np.array(embed_sum, np.float32, copy=True).reshape(k, d)
+    cb = np.empty((k, d), np.float32)
+    ws = np.empty((k, d), np.float32)
+    lib().codebook_ema_ref(_p(x, ctypes.c_float), _p(idx, ctypes.c_int32), ctypes.c_int64(n), ctypes.c_int(k), ctypes.c_int(d),
+                           ctypes.c_float(decay), ctypes.c_float(eps), _p(cs, ctypes.c_float), _p(es, ctypes.c_float),
+                           _p(cb, ctypes.c_float), _p(ws, ctypes.c_float))
+    return cs, es, cb

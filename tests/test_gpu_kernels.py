@@ -64,9 +64,40 @@ def test_fsq_large_vs_c_oracle_and_torch(env, levels):
     np.testing.assert_array_equal(codes.cpu().numpy(), c_codes)
     _, t_idx = O.fsq_forward(torch.from_numpy(z), levels)              # torch CPU (= the reference's arithmetic)
     flips = int((t_idx.numpy() != c_idx).sum())
-    assert flips <= max(2, n // 500000), f"{flips} index flips vs torch CPU tanh in {n} rows"
+    assert flips == 0, f"{flips} index flips vs torch CPU tanh in {n} rows"
     # round trip: decode(encode) reproduces the codes exactly
     np.testing.assert_array_equal(q.indices_to_codes(idx.long()).cpu().numpy(), c_codes)
+
+
+@pytest.mark.parametrize("levels", [[8, 5, 5, 5], [8, 8, 5, 5, 5], [7, 3], [2, 9, 4]])
+def test_fsq_at_the_thresholds(env, levels):
+    """Inputs exactly at every level threshold theta, at nextafter(theta, -inf) and nextafter(theta, +inf), for every
+    dimension and level: the kernel (which counts z >= theta) must agree with the C restatement of the reference
+    arithmetic on all of them, and the level must step by exactly one across theta."""
+    from mqgan_amd.quantizer import FSQ
+    from oracle import vq
+    q = FSQ(levels).to(DEV)
+    th = np.array([[q._desc.thresh[j][k] for k in range(8)] for j in range(8)], np.float32)
+    rows = []
+    for j, L in enumerate(levels):
+        for k in range(L - 1):
+            for v in (th[j, k], np.nextafter(th[j, k], np.float32(-np.inf)), np.nextafter(th[j, k], np.float32(np.inf))):
+                z = np.zeros(len(levels), np.float32)
+                z[j] = v
+                rows.append(z)
+    z = np.stack(rows)
+    codes, idx = q(t(z))
+    c_codes, c_idx = vq.fsq_forward(z, levels)
+    np.testing.assert_array_equal(idx.cpu().numpy(), c_idx)
+    np.testing.assert_array_equal(codes.cpu().numpy(), c_codes)
+    basis = np.cumprod([1] + list(levels[:-1]))
+    r = 0
+    for j, L in enumerate(levels):
+        for k in range(L - 1):
+            at, below = int(c_idx[r]), int(c_idx[r + 1])
+            assert at - below == basis[j], (levels, j, k, at, below)       # theta is the first z of level k + 1
+            assert int(c_idx[r + 2]) == at
+            r += 3
 
 
 def test_fsq_empty_and_odd_shapes(env):
@@ -80,7 +111,7 @@ def test_fsq_empty_and_odd_shapes(env):
 
 # ----------------------------------------------------------------------------------------- L2 argmin
 @pytest.mark.parametrize("n,k,d", [(4096, 1000, 4), (2048, 1024, 256), (1000, 2048, 512), (777, 130, 20), (128, 8192, 64),
-                                   (1, 5, 8)])
+                                   (1, 5, 8), (16384, 1024, 256), (2048, 8192, 512), (16384, 2048, 512)])
 def test_l2_argmin_bit_exact_vs_c_oracle(env, n, k, d):
     from oracle import vq
     ops = env
@@ -106,6 +137,68 @@ def test_l2_argmin_ties_and_fsq_bridge(env):
     idx = ops.l2_argmin(t(x), t(g["implicit_codebook"])).cpu().numpy()
     safe = g["margin"].reshape(-1, 4).min(axis=1) > 1e-4
     np.testing.assert_array_equal(idx[safe], g["idx"].reshape(-1)[safe])
+
+
+def test_l2_argmin_nan_rows_give_a_valid_index(env):
+    """A NaN distance counts as -inf (vq_ref.c): rows with a NaN feature return index 0 like torch.argmin, never an
+    out-of-range sentinel; other rows are unaffected."""
+    from oracle import vq
+    ops = env
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((300, 64)).astype(np.float32)
+    cb = rng.standard_normal((257, 64)).astype(np.float32)
+    x[7, 3] = np.nan
+    x[131, :] = np.nan
+    cb2 = cb.copy()
+    idx, dist = ops.l2_argmin(t(x), t(cb2), return_dist=True)
+    want, wdist = vq.l2_argmin(x, cb2, threads=4, return_dist=True)
+    got = idx.cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    assert got[7] == 0 and got[131] == 0 and got.min() >= 0 and got.max() < 257
+    np.testing.assert_array_equal(dist.cpu().numpy(), wdist)
+    x[7, 3] = 0.0
+    cb2[200, 5] = np.nan                                    # one NaN code: it wins every row (first NaN column)
+    idx = ops.l2_argmin(t(x[:100]), t(cb2))
+    np.testing.assert_array_equal(idx.cpu().numpy(), vq.l2_argmin(x[:100], cb2))
+    assert int(idx[0]) == 200
+
+
+@pytest.mark.parametrize("n,k,d", [(5000, 64, 32), (16384, 1024, 256), (16384, 8192, 512), (100, 7, 1100)])
+def test_codebook_ema_bit_exact_vs_c_oracle(env, n, k, d):
+    """EMA update against its definition in oracle/vq_ref.c (fixed summation order): cluster sizes, embedding sums and
+    the new codebook bit for bit, twice in a row (state carried), with dead codes, and identical when repeated."""
+    from oracle import vq
+    ops = env
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    cb = rng.standard_normal((k, d)).astype(np.float32)
+    if d % 4 == 0:
+        idx = ops.l2_argmin(t(x), t(cb)).cpu().numpy()
+    else:
+        idx = rng.integers(0, k, n).astype(np.int32)
+    idx[idx == 3] = 4                                        # code 3 is dead in every update
+    cs, es = np.ones(k, np.float32), cb.copy()
+    cs_d, es_d, cb_d = t(cs.copy()), t(es.copy()), t(cb.copy())
+    for it in range(2):
+        cs, es, cbn = vq.codebook_ema(x, idx, cs, es, decay=0.9, eps=1e-5)
+        ops.codebook_ema_update(t(x), t(idx), cs_d, es_d, cb_d, decay=0.9, eps=1e-5)
+        np.testing.assert_array_equal(cs_d.cpu().numpy(), cs)
+        np.testing.assert_array_equal(es_d.cpu().numpy(), es)
+        np.testing.assert_array_equal(cb_d.cpu().numpy(), cbn)
+    assert cs[3] == np.float32(np.float32(1.0 * np.float32(0.9)) * np.float32(0.9))
+    # determinism + rows with out-of-range indices are ignored
+    a = [t(np.ones(k, np.float32)), t(cb.copy()), t(cb.copy())]
+    b = [t(np.ones(k, np.float32)), t(cb.copy()), t(cb.copy())]
+    bad = idx.copy()
+    bad[::97] = k + 5
+    bad[1::97] = -1
+    ops.codebook_ema_update(t(x), t(bad), *a, decay=0.99, eps=1e-5)
+    ops.codebook_ema_update(t(x), t(bad), *b, decay=0.99, eps=1e-5)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    w = vq.codebook_ema(x, bad, np.ones(k, np.float32), cb, decay=0.99, eps=1e-5)
+    for u, v in zip(a, w):
+        np.testing.assert_array_equal(u.cpu().numpy(), v)
 
 
 def test_codebook_ema(env):
@@ -148,6 +241,9 @@ CONV_CASES = [
     dict(N=2, H=1, W=33, C=132, K=200, R=1, S=3, pad=(0, 1)),                                 # C, K not multiples of 128/16
     dict(N=1, H=130, W=90, C=64, K=64, R=3, S=3, pad=(1, 1)),                                 # many M tiles, BN = 64
     dict(N=1, H=5, W=7, C=20, K=36, R=3, S=3, pad=(2, 2), dil=(2, 2)),                        # dilation
+    dict(N=2, H=40, W=64, C=256, K=256, R=5, S=5, stride=(2, 2), pad=(2, 2)),                 # patch-D convs.1 width (C2)
+    dict(N=1, H=16, W=48, C=384, K=384, R=7, S=7, stride=(2, 2), pad=(3, 3)),                 # patch-D convs.1 width (C3)
+    dict(N=1, H=64, W=90, C=192, K=64, R=3, S=3, pad=(1, 1)),                                 # refiner ups.2.conv1 (C2)
 ]
 
 

@@ -204,3 +204,109 @@ def test_full_size_hifimusic_step_runs_on_every_engine(precision):
     assert float((tr.arena_g.flat_param[:4096] - before).abs().max()) > 0
     del tr
     torch.cuda.empty_cache()
+
+
+def _hifispeech_cfg(precision="fp32"):
+    import yaml
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "configs", "model_config_hifispeech.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    cfg["training"]["precision"] = precision
+    return cfg
+
+
+def test_hifispeech_architecture_step_matches_oracle():
+    """BASELINE config 2's ARCHITECTURE (channels [512,512,512,768], refiner 64, the shipped discriminators, 80 mels)
+    on a small ragged batch: one optimisation step of the HIP path against oracle.train_step.OracleTrainer with the
+    same weights (G.eval(), D in train mode).  This is module-level parity at the widths the benchmark times:
+    C % 16 == 0 wave-uniform tap walks, BN = 128 tiles, split-K weight gradients, stride-parity dgrad at 256-512
+    channels.  Tolerance 1e-4 relative (north star) on losses / reconstructions, 2e-4 on gradient norms,
+    post-Adam tensors within 2e-5 of the oracle's (one Adam step moves a weight by ~lr = 1e-7..1e-4)."""
+    from oracle import train_step as TS
+    from mqgan_amd.train import Trainer, synthetic_mel
+    cfg = _hifispeech_cfg()
+    m = cfg["model"]
+    pc, mc = m["discriminator_patch"], m["discriminator_multibin"]
+    Pg = TS.init_generator_params(cfg, seed=42)
+    Pp = TS.init_patch_params(80, pc["hidden_channels"], pc["kernel_sizes"], seed=1)
+    Pm = TS.init_multibin_params(80, mc["n_bins"], mc["hidden_channels"], mc["kernel_sizes"], seed=2)
+    # spread the latents so that the FSQ indices are not all the centre code (random-init encoders collapse, SURVEY 8c)
+    Pg["q_in_proj.weight"] = Pg["q_in_proj.weight"] * 40.0
+    B, T = 2, 64
+    x = torch.from_numpy(np.stack([synthetic_mel(T, 80, 700 + b) for b in range(B)]))
+    lens = torch.tensor([T, 41], dtype=torch.int32)
+    x[1, 41:] = 0.0
+
+    tr = Trainer(cfg, device=DEV, build_data=False)
+    tr.generator.load_state_dict(Pg, strict=True)
+    tr.patch_discriminator.load_state_dict(Pp, strict=True)
+    tr.multibin_discriminator.load_state_dict(Pm, strict=True)
+    tr.arena_g.rebind()
+    tr.arena_d.rebind()
+    tr.generator.eval()
+    tr.patch_discriminator.train()
+    tr.multibin_discriminator.train()
+    tr.epoch = 1
+
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    otr = TS.OracleTrainer(TS.make_leaves(Pg), TS.make_leaves(Pp), TS.make_leaves(Pm), cfg, gen_training=False)
+    want = otr.step(x, lens)
+
+    xd, ld = x.to(DEV), lens.to(DEV)
+    recon_pre, recon_post = tr.generator(xd, ld)
+    close(recon_pre, want["recon_pre"], rtol=1e-4, atol=5e-5, msg="recon_pre")
+    close(recon_post, want["recon_post"], rtol=1e-4, atol=5e-5, msg="recon_post")
+    idx = tr.generator.encode(xd, (torch.arange(T, device=DEV)[None, :] >= ld[:, None])[:, None, :])
+    assert len(torch.unique(idx)) > 8, "degenerate latent: the FSQ path is not exercised"
+    out = tr.train_step(xd, ld)
+    for k in ("loss_d", "loss_g_total", "loss_recon_pre", "loss_recon_post", "loss_gan"):
+        np.testing.assert_allclose(float(out[k]), float(want[k]), rtol=1e-4, atol=1e-6, err_msg=k)
+    np.testing.assert_allclose(float(tr.optimizer_d.grad_norm()), otr.last_norm_d, rtol=2e-4)
+    np.testing.assert_allclose(float(tr.optimizer_g.grad_norm()), otr.last_norm_g, rtol=2e-4)
+    np.testing.assert_allclose(tr.gan_loss._state[:2].cpu().numpy(), [otr.gan.ema_real.item(), otr.gan.ema_fake.item()],
+                               rtol=1e-4, atol=1e-7)
+    sd = tr.generator.state_dict()
+    for k in ("refiner.ups.0.conv.conv1.parametrizations.weight.original1", "refiner.mid.conv2.parametrizations.weight.original1",
+              "refiner.pre.conv2.bias", "encoder_blocks.2.conv1.parametrizations.weight.original1", "decoder_blocks.0.conv2.weight_v",
+              "post.conv_out.weight", "out_proj.weight", "refiner.reproj.weight"):
+        close(sd[k], otr.Pg[k], rtol=2e-5, atol=2e-7, msg=k)
+    pd, md = tr.patch_discriminator.state_dict(), tr.multibin_discriminator.state_dict()
+    for k in ("convs.1.weight_orig", "convs.3.weight_orig", "convs.5.weight_orig", "se_block.fc1.weight", "convs.2.bias"):
+        close(pd[k], otr.Pp[k], rtol=2e-5, atol=2e-7, msg="patch " + k)
+    for k in ("discriminators.0.convs.2.weight_orig", "discriminators.7.convs.4.weight_orig", "discriminators.3.convs.1.weight_u"):
+        close(md[k], otr.Pm[k], rtol=1e-4, atol=1e-6, msg="multibin " + k)
+    del tr
+    torch.cuda.empty_cache()
+
+
+def test_full_size_config2_step_engines_agree():
+    """BASELINE config 2 at full size (hifispeech, 32 x 512 frames x 80 mels, fp32): one optimisation step on the
+    default f32 MFMA engine and on the fp32x3 engine - two independent matrix engines over the same loaders - from
+    the same weights and batch, G.eval() so the step is deterministic: every loss and both gradient norms agree to
+    1e-4 relative, finite, and the weights move."""
+    from mqgan_amd.train import Trainer, synthetic_mel
+    res = {}
+    for prec in ("fp32", "fp32x3"):
+        cfg = _hifispeech_cfg(prec)
+        B, T, mel = cfg["data"]["batch_size"], cfg["data"]["crop_len"], cfg["model"]["mel_channels"]
+        assert (B, T, mel) == (32, 512, 80)
+        torch.manual_seed(42)
+        tr = Trainer(cfg, device=DEV, build_data=False)
+        tr.generator.eval()
+        tr.patch_discriminator.train()
+        tr.multibin_discriminator.train()
+        tr.epoch = 1
+        x = torch.from_numpy(np.stack([synthetic_mel(T, mel, b) for b in range(B)])).to(DEV)
+        lens = torch.full((B,), T, dtype=torch.int32, device=DEV)
+        lens[3], lens[17] = 300, 411                      # two ragged items: masks are live at full size
+        before = tr.arena_g.flat_param[:4096].clone()
+        out = tr.train_step(x, lens)
+        res[prec] = {k: float(v) for k, v in out.items()}
+        res[prec]["norm_g"] = float(tr.optimizer_g.grad_norm())
+        res[prec]["norm_d"] = float(tr.optimizer_d.grad_norm())
+        assert all(np.isfinite(v) for v in res[prec].values()), res[prec]
+        assert float((tr.arena_g.flat_param[:4096] - before).abs().max()) > 0
+        del tr
+        torch.cuda.empty_cache()
+    for k in ("loss_d", "loss_g_total", "loss_recon_pre", "loss_recon_post", "loss_gan", "norm_g", "norm_d"):
+        np.testing.assert_allclose(res["fp32x3"][k], res["fp32"][k], rtol=1e-4, atol=1e-7, err_msg=k)
