@@ -269,12 +269,14 @@ def test_hifispeech_architecture_step_matches_oracle():
     for k in ("refiner.ups.0.conv.conv1.parametrizations.weight.original1", "refiner.mid.conv2.parametrizations.weight.original1",
               "refiner.pre.conv2.bias", "encoder_blocks.2.conv1.parametrizations.weight.original1", "decoder_blocks.0.conv2.weight_v",
               "post.conv_out.weight", "out_proj.weight", "refiner.reproj.weight"):
-        close(sd[k], otr.Pg[k], rtol=2e-5, atol=2e-7, msg=k)
+        close(sd[k], otr.Pg[k], rtol=2e-5, atol=2e-7, msg=k)       # lr_g = 1e-7 at the first warm-up step
     pd, md = tr.patch_discriminator.state_dict(), tr.multibin_discriminator.state_dict()
     for k in ("convs.1.weight_orig", "convs.3.weight_orig", "convs.5.weight_orig", "se_block.fc1.weight", "convs.2.bias"):
-        close(pd[k], otr.Pp[k], rtol=2e-5, atol=2e-7, msg="patch " + k)
+        # the first Adam step moves every weight by lr * g / (|g| + 1e-8) = +-lr_d (1.15e-4) except where |g| ~ 1e-8: there
+        # the step size itself is rounding-sensitive, so the bound is a fraction (5 %) of one step
+        close(pd[k], otr.Pp[k], rtol=2e-5, atol=6e-6, msg="patch " + k)
     for k in ("discriminators.0.convs.2.weight_orig", "discriminators.7.convs.4.weight_orig", "discriminators.3.convs.1.weight_u"):
-        close(md[k], otr.Pm[k], rtol=1e-4, atol=1e-6, msg="multibin " + k)
+        close(md[k], otr.Pm[k], rtol=1e-4, atol=6e-6, msg="multibin " + k)
     del tr
     torch.cuda.empty_cache()
 
