@@ -126,6 +126,32 @@ int mq_conv_fprop_h(const mqConvDesc *desc_host, const uint16_t *x_bf16, const u
                     float *y, mqStream stream);
 int mq_conv_dgrad_h(const mqConvDesc *desc_host, const uint16_t *dy_bf16, const uint16_t *w_crsk_bf16, float *dx,
                     mqStream stream);
+/* ---- bf16-STORAGE convolutions ("H2" kernels, csrc/igemm_h2.hip): MQ_PRECISION_BF16 with activations, output
+ * gradients and effective weights held as bf16 tensors in HBM - what the reference's autocast region stores
+ * (train.py:220,523: conv outputs are bf16 tensors there).  Block tile 256 x {64..256} x 64, both operands staged by
+ * LDS-DMA, f32 accumulation.  Shapes: C % 32 == 0, K % 32 == 0, strides <= 2 (mq_h2_supported; the weight gradient
+ * additionally needs Q >= 16: mq_h2_wgrad_supported); every other layer stays on the kernels above.
+ *   mq_h2_weight_image: f32 effective weights (KRSC for fprop, CRSK for dgrad, as mq_weight_prep writes them) ->
+ *                       bf16 image [groups * rows][Kp], Kp = R*S*Cin rounded up to 64, reduction order
+ *                       (chunk of 64 or 32 channels, tap, channel); mq_h2_weight_elems gives its size.
+ *   mq_conv_fprop_h2  : y = epilogue(conv(x) + bias);  act 0: none;  act 2: LeakyReLU(slope) then zero on padded
+ *                       rows (mask index of row m: (m / d1) * d2 + m % d3), as mq_conv_fprop_leaky.  y is bf16
+ *                       (out_f32 = 0) or f32 (out_f32 = 1).
+ *   mq_conv_dgrad_h2  : dx = conv_transpose(dy), dx bf16 or f32; strided layers run by stride parity.
+ *   mq_conv_wgrad_h2  : dw_krsc (f32, the layout mq_weight_prep_bwd reads) and, if dbias != NULL, dbias (f32) from
+ *                       bf16 x and dy; split-K over pixels with a deterministic slab reduction. */
+int mq_h2_supported(const mqConvDesc *desc_host);
+int mq_h2_wgrad_supported(const mqConvDesc *desc_host);
+size_t mq_h2_weight_elems(const mqConvDesc *desc_host, int dgrad);
+int mq_h2_weight_image(const mqConvDesc *desc_host, int dgrad, const float *w, uint16_t *w_h2, mqStream stream);
+int mq_conv_fprop_h2(const mqConvDesc *desc_host, const uint16_t *x, const uint16_t *w_h2, const float *bias,
+                     const uint8_t *mask, int64_t d1, int64_t d2, int64_t d3, int act, float slope, int out_f32, void *y,
+                     mqStream stream);
+int mq_conv_dgrad_h2(const mqConvDesc *desc_host, const uint16_t *dy, const uint16_t *wt_h2, int out_f32, void *dx,
+                     mqStream stream);
+size_t mq_conv_wgrad_h2_workspace(const mqConvDesc *desc_host);
+int mq_conv_wgrad_h2(const mqConvDesc *desc_host, const uint16_t *x, const uint16_t *dy, float *dw_krsc, float *dbias,
+                     void *workspace, size_t workspace_bytes, mqStream stream);
 /* dx (N,H,W,C) = conv_transpose(dy (N,P,Q,K)); weights given as (groups, C, R, S, K) */
 int mq_conv_dgrad(const mqConvDesc *desc_host, const float *dy, const float *w_crsk, float *dx, mqStream stream);
 /* dw (groups, K, R, S, C); split-K over pixels with a deterministic slab reduction.
@@ -220,6 +246,19 @@ int mq_pointwise_fwd(const mqPointwiseDesc *desc_host, const float *h, const flo
 int mq_pointwise_bwd(const mqPointwiseDesc *desc_host, const float *dout, const float *h, const float *r_pre,
                      const uint8_t *mask, const float *beta, const float *gamma, float *dt, float *dpost,
                      float *dbeta, float *dgamma, float *workspace, mqStream stream);
+
+/* bf16-storage variants (activations held as bf16 tensors, see the H2 convolutions): same semantics, arithmetic in
+ * f32, results rounded to bf16 on the store; C % 8 == 0 and 16-byte aligned tensors. */
+int mq_pointwise_fwd_h(const mqPointwiseDesc *desc_host, const uint16_t *h, const uint16_t *r_pre, const uint16_t *r_post,
+                       const uint8_t *mask, const float *beta, const float *gamma, uint16_t *out, mqStream stream);
+int mq_pointwise_bwd_h(const mqPointwiseDesc *desc_host, const uint16_t *dout, const uint16_t *h, const uint16_t *r_pre,
+                       const uint8_t *mask, const float *beta, const float *gamma, uint16_t *dt, uint16_t *dpost,
+                       float *dbeta, float *dgamma, float *workspace, mqStream stream);
+int mq_cast_f32(const uint16_t *in_bf16, float *out, int64_t n, mqStream stream);
+int mq_avgpool_t2_fwd_h(const uint16_t *x, int N, int T, int F, int C, uint16_t *y, mqStream stream);
+int mq_avgpool_t2_bwd_h(const uint16_t *dy, int N, int T, int F, int C, uint16_t *dx, mqStream stream);
+int mq_upcat_fwd_h(const uint16_t *x, const uint16_t *skip, int N, int T, int F, int C1, int C2, uint16_t *out, mqStream stream);
+int mq_upcat_bwd_h(const uint16_t *dout, int N, int T, int F, int C1, int C2, uint16_t *dx, uint16_t *dskip, mqStream stream);
 
 /* frame masks */
 int mq_sequence_mask(const int32_t *lengths, int B, int T, uint8_t *mask, mqStream stream);           /* preencoder.py:15-24 */

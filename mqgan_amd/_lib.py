@@ -60,6 +60,14 @@ SIGNATURES = {
     "mq_cast_bf16": (_I, [_P, _P, _L, _P]),
     "mq_conv_fprop_h": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "mq_conv_dgrad_h": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
+    "mq_h2_supported": (_I, [C.POINTER(ConvDesc)]),
+    "mq_h2_wgrad_supported": (_I, [C.POINTER(ConvDesc)]),
+    "mq_h2_weight_elems": (_Z, [C.POINTER(ConvDesc), _I]),
+    "mq_h2_weight_image": (_I, [C.POINTER(ConvDesc), _I, _P, _P, _P]),
+    "mq_conv_fprop_h2": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _L, _L, _L, _I, _F, _I, _P, _P]),
+    "mq_conv_dgrad_h2": (_I, [C.POINTER(ConvDesc), _P, _P, _I, _P, _P]),
+    "mq_conv_wgrad_h2_workspace": (_Z, [C.POINTER(ConvDesc)]),
+    "mq_conv_wgrad_h2": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _Z, _P]),
     "mq_conv_wgrad_workspace": (_Z, [C.POINTER(ConvDesc)]),
     "mq_conv_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _Z, _P]),
     "mq_conv_wgrad_bias_workspace": (_Z, [C.POINTER(ConvDesc)]),
@@ -79,6 +87,13 @@ SIGNATURES = {
                                 _P, _P]),
     "mq_pointwise_fwd": (_I, [C.POINTER(PointwiseDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "mq_pointwise_bwd": (_I, [C.POINTER(PointwiseDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mq_pointwise_fwd_h": (_I, [C.POINTER(PointwiseDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mq_pointwise_bwd_h": (_I, [C.POINTER(PointwiseDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mq_cast_f32": (_I, [_P, _P, _L, _P]),
+    "mq_avgpool_t2_fwd_h": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "mq_avgpool_t2_bwd_h": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "mq_upcat_fwd_h": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "mq_upcat_bwd_h": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "mq_sequence_mask": (_I, [_P, _I, _I, _P, _P]),
     "mq_mask_pool": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "mq_mask_upsample2": (_I, [_P, _I, _I, _P, _P]),

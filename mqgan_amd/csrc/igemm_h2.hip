@@ -1,0 +1,881 @@
+// bf16-STORAGE implicit-GEMM convolution for gfx950 ("H2" kernels, MQ_PRECISION_BF16 with bf16 activations).
+// Interface: include/mqgan_hip.h (mq_h2_*, mq_conv_*_h2).
+//
+// What differs from igemm.hip's bf16 engine (f32 tensors, operands rounded on their way into LDS):
+//   * activations, output gradients and the effective weights are bf16 IN HBM (what the reference's autocast region
+//     stores, train.py:220,523): half the bytes from L2 / HBM, no conversion in the kernel;
+//   * block = 512 threads = 8 waves (4 along M x 2 along N), tile 256 x (64*TN) x 64: at 128 x 128 a bf16 MFMA tile
+//     needs 64 B/clk/CU from L2 at full matrix rate, more than an XCD's L2 delivers - 256 x 256 needs 32;
+//   * both operand tiles are staged by LDS-DMA (buffer_load_dwordx4 ... lds): no VGPR staging, no v_cvt_pk, no
+//     ds_write, no LDS address arithmetic in the loop.  Padding taps, ragged tile edges and K tails are
+//     "offset beyond the descriptor" - the DMA then writes zeros;
+//   * LDS rows are 128 bytes (64 bf16 k's); the 16-byte chunk index is XOR-swizzled with (row >> 1) & 7 so that the
+//     16 rows a ds_read_b128 lane group touches fall on 16 distinct bank quads.  The DMA writes lane-linear, so the
+//     swizzle is applied to the per-lane SOURCE address and again on the fragment reads;
+//   * a ring of NSTAGE tiles (3 where LDS allows, else 2), one barrier per K-step, counted vmcnt.
+// Reduction order: (channel chunk of CB, tap row, tap col, channel in chunk) with CB = 64 (C % 64 == 0: one tap per
+// K-step, the whole walk on the scalar unit) or CB = 32 (two consecutive taps per K-step).  Every DMA instruction
+// moves 8 pixels x 128 contiguous bytes (CB = 64) - whole cache lines.
+#include <algorithm>
+
+#include "gemm_core.h"
+
+namespace mq {
+
+typedef __attribute__((address_space(3))) void lds_void;
+// generic pointer into a __shared__ array -> LDS (address space 3) pointer: the low 32 bits are the LDS offset
+__device__ __forceinline__ lds_void *lds_ptr(const void *p) { return reinterpret_cast<lds_void *>(reinterpret_cast<uintptr_t>(p)); }
+
+constexpr int H2_BM = 256, H2_BK = 64, H2_ROWB = 128;
+
+struct H2Parity {              // dgrad by stride parity (see igemm.hip): per class geometry
+    int ncls;
+    int a[4], b[4], Ha[4], Wb[4], tile0[5];
+    int nr[4], ns[4], r0[4], s0[4], rstep[4], sstep[4];
+};
+
+struct H2Geom {
+    int OH, OW;                // rows m of the GEMM enumerate (n, oh, ow)
+    int IH, IW, IC;            // gathered tensor (bf16, NHWC)
+    int Mtot, Ncols;
+    int nMt, nNt;
+    int R, S;                  // full filter (weight image layout)
+    int nR, nS;                // tap grid walked (= R, S except for parity classes)
+    int step_h, step_w;        // signed coordinate step per tap
+    int mul_h, mul_w, add_h, add_w;   // base coordinate of a row: bh = oh * mul_h + add_h
+    int CB, nchunks;           // channel block of the reduction, IC / CB
+    int Kp;                    // weight row pitch in elements (multiple of 64)
+    int sh, sw, ph, pw, dh, dw;
+    int ng;                    // images per group
+};
+
+struct H2Epi {
+    const float *bias;         // [groups * Ncols] or null
+    const uint8_t *mask;       // frame mask (1 = padded) or null; index of output row m: (m / d1) * d2 + m % d3
+    int d1, d2, d3;
+    int act;                   // 0: none, 2: LeakyReLU(slope) then masked_fill
+    float slope;
+    int out_f32;               // 1: f32 output, 0: bf16
+};
+
+__device__ __forceinline__ unsigned short f2bf(float v)
+{
+    return __builtin_bit_cast(unsigned short, (__bf16)v);          // v_cvt_pk_bf16_f32 (RNE, NaN-safe)
+}
+
+// TN: 32-column MFMA tiles per wave along N (block tile N = 64 * TN); CBK: channel block (64 or 32);
+// PARITY: dgrad by stride parity (tap subset and output scatter per class)
+template <int TN, int NSTAGE, int CBK, bool PARITY>
+__device__ __forceinline__ void conv_h2_body(const unsigned short *__restrict__ act, const unsigned short *__restrict__ wgt,
+                                             void *__restrict__ out, const H2Geom &g, const H2Parity &pi, const H2Epi &epi,
+                                             size_t act_group_stride, char *smem)
+{
+    constexpr int BN = 64 * TN;
+    constexpr int STAGE = (H2_BM + BN) * H2_ROWB;
+    constexpr int NSUB = 64 / CBK;                 // (chunk, tap) positions per K-step
+    constexpr int CPB = CBK / 8;                   // 16-byte chunks per position
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int grp = blockIdx.y;
+
+    // ---- tile of this block
+    int m0, n0, Mc, OWc, OHc, nR, nS, step_h, step_w, tap_r0 = 0, tap_s0 = 0, tap_rstep = 1, tap_sstep = 1;
+    int cls_a = 0, cls_b = 0;
+    if constexpr (PARITY) {
+        const int total_mt = pi.tile0[pi.ncls];
+        const int tile = xcd_pair_remap(blockIdx.x, total_mt * g.nNt, g.nNt);
+        const int mtg = tile / g.nNt, nt = tile - mtg * g.nNt;
+        int cls = 0;
+#pragma unroll
+        for (int c = 1; c < 4; ++c)
+            if (c < pi.ncls && mtg >= pi.tile0[c]) cls = c;
+        m0 = (mtg - pi.tile0[cls]) * H2_BM;
+        n0 = nt * BN;
+        OHc = pi.Ha[cls]; OWc = pi.Wb[cls];
+        Mc = g.ng * OHc * OWc;
+        nR = pi.nr[cls]; nS = pi.ns[cls];
+        tap_r0 = pi.r0[cls]; tap_s0 = pi.s0[cls]; tap_rstep = pi.rstep[cls]; tap_sstep = pi.sstep[cls];
+        cls_a = pi.a[cls]; cls_b = pi.b[cls];
+        const int shift_h = g.sh == 2 ? 1 : 0, shift_w = g.sw == 2 ? 1 : 0;
+        step_h = -((tap_rstep * g.dh) >> shift_h);      // exact: the class's taps keep (ih + ph - r*dh) divisible by sh
+        step_w = -((tap_sstep * g.dw) >> shift_w);
+    } else {
+        const int tile = xcd_remap(blockIdx.x, g.nMt * g.nNt);
+        const int mt = tile / g.nNt, nt = tile - mt * g.nNt;
+        m0 = mt * H2_BM;
+        n0 = nt * BN;
+        OHc = g.OH; OWc = g.OW; Mc = g.Mtot;
+        nR = g.nR; nS = g.nS; step_h = g.step_h; step_w = g.step_w;
+    }
+    nR = __builtin_amdgcn_readfirstlane(nR); nS = __builtin_amdgcn_readfirstlane(nS);
+    step_h = __builtin_amdgcn_readfirstlane(step_h); step_w = __builtin_amdgcn_readfirstlane(step_w);
+
+    // ---- DMA slots.  Piece p = wave + 8 j covers tile rows 8p .. 8p+7; lane -> row 8p + (lane >> 3), physical
+    // chunk lane & 7; the logical chunk it must fetch undoes the read-side swizzle ((row >> 1) & 7 = (4*wave + (lane >> 4)) & 7).
+    const int lrow = lane >> 3;
+    const int lc = (lane & 7) ^ ((((wave & 1) << 2) | (lane >> 4)) & 7);
+    const int sub = lc / CPB;                                  // which of the step's positions this lane loads
+    const int cin_b = (lc % CPB) * 16;                         // byte offset inside the position's channel run
+    const int img0 = (OHc * OWc) > 0 ? m0 / (OHc * OWc) : 0;
+    const size_t img_elems = (size_t)g.IH * g.IW * g.IC;
+    const unsigned short *abase = act + (size_t)grp * act_group_stride + (size_t)img0 * img_elems;
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(abase, (act_group_stride - (size_t)img0 * img_elems) * 2);
+    const unsigned short *wbase = wgt + ((size_t)grp * g.Ncols + n0) * g.Kp;
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(wbase, (size_t)(g.Ncols - n0 < BN ? g.Ncols - n0 : BN) * g.Kp * 2);
+    int bh_[4], bw_[4], rowbase_[4];
+    bool rv_[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + 8 * (wave + 8 * j) + lrow;
+        const bool v = m < Mc;
+        const int mm = v ? m : m0;
+        const int ow = mm % OWc, t = mm / OWc;
+        const int oh = t % OHc, n = t / OHc - img0;
+        int bh, bw;
+        if constexpr (PARITY) {
+            const int shift_h = g.sh == 2 ? 1 : 0, shift_w = g.sw == 2 ? 1 : 0;
+            bh = (oh * g.sh + cls_a + g.ph - tap_r0 * g.dh) >> shift_h;
+            bw = (ow * g.sw + cls_b + g.pw - tap_s0 * g.dw) >> shift_w;
+        } else {
+            bh = oh * g.mul_h + g.add_h;
+            bw = ow * g.mul_w + g.add_w;
+        }
+        rv_[j] = v;
+        bh_[j] = bh;
+        bw_[j] = bw;
+        rowbase_[j] = (((n * g.IH + bh) * g.IW + bw) * g.IC) * 2 + cin_b;
+    }
+    unsigned rowoffB[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = 8 * (wave + 8 * j) + lrow;
+        rowoffB[j] = (n0 + row < g.Ncols) ? (unsigned)row * (unsigned)g.Kp * 2u + (unsigned)cin_b : OOB;
+    }
+    // ---- scalar walk over (chunk, tap row, tap col): NSUB walkers, walker u starts at position u, moves NSUB per step
+    int w_js[NSUB], w_jr[NSUB], w_ch[NSUB];
+#pragma unroll
+    for (int u = 0; u < NSUB; ++u) {
+        int js = u, jr = 0, ch = (nR > 0 && nS > 0) ? 0 : g.nchunks;
+        if (nS > 0) { while (js >= nS) { js -= nS; ++jr; } }
+        if (nR > 0) { while (jr >= nR) { jr -= nR; ++ch; } }
+        w_js[u] = js; w_jr[u] = jr; w_ch[u] = ch;
+    }
+    const int RS = g.R * g.S;
+    auto issue = [&](int stage) {
+        int hoff, woff, aoff, bcol;
+        bool kv;
+#pragma unroll
+        for (int u = 0; u < NSUB; ++u) {
+            const int h_u = w_jr[u] * step_h, w_u = w_js[u] * step_w;
+            const int a_u = ((h_u * g.IW + w_u) * g.IC + w_ch[u] * CBK) * 2;
+            const int tr = PARITY ? tap_r0 + w_jr[u] * tap_rstep : w_jr[u];
+            const int ts = PARITY ? tap_s0 + w_js[u] * tap_sstep : w_js[u];
+            const int b_u = ((w_ch[u] * RS + tr * g.S + ts) * CBK) * 2;
+            const bool k_u = w_ch[u] < g.nchunks;
+            if (u == 0 || sub == u) { hoff = h_u; woff = w_u; aoff = a_u; bcol = b_u; kv = k_u; }
+            // advance this walker by NSUB positions (scalar unit)
+#pragma unroll
+            for (int i = 0; i < NSUB; ++i) {
+                ++w_js[u];
+                const bool c2 = w_js[u] >= nS;
+                w_js[u] = c2 ? 0 : w_js[u];
+                w_jr[u] += c2 ? 1 : 0;
+                const bool c3 = w_jr[u] >= nR;
+                w_jr[u] = c3 ? 0 : w_jr[u];
+                w_ch[u] += c3 ? 1 : 0;
+            }
+        }
+        char *sa = smem + stage * STAGE + wave * 1024;
+        char *sb = sa + H2_BM * H2_ROWB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = rv_[j] && kv && (unsigned)(bh_[j] + hoff) < (unsigned)g.IH && (unsigned)(bw_[j] + woff) < (unsigned)g.IW;
+            const unsigned vo = ok ? (unsigned)(rowbase_[j] + aoff) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, lds_ptr(sa + j * 8192), 16, vo, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const unsigned vo = (rowoffB[j] != OOB && kv) ? rowoffB[j] + (unsigned)bcol : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, lds_ptr(sb + j * 8192), 16, vo, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int qx = lh ^ ((li >> 1) & 7);
+    int aoffs[4], boffs[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        aoffs[s] = (wm * 64 + li) * H2_ROWB + (((2 * s) ^ qx) << 4);
+        boffs[s] = H2_BM * H2_ROWB + (wn * 32 * TN + li) * H2_ROWB + (((2 * s) ^ qx) << 4);
+    }
+    const int npos = g.nchunks * nR * nS;
+    const int nk = (npos + NSUB - 1) / NSUB;
+    constexpr int LPT = 4 + TN;                                   // DMA instructions per wave and tile
+#pragma unroll
+    for (int p = 0; p < NSTAGE - 1; ++p) issue(p);
+    if constexpr (NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+    __builtin_amdgcn_s_barrier();
+
+    auto compute = [&](int stage) {
+        const char *base = smem + stage * STAGE;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 a[2], b[TN];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) a[t] = *reinterpret_cast<const bf16x8 *>(base + aoffs[s] + t * 32 * H2_ROWB);
+#pragma unroll
+            for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const bf16x8 *>(base + boffs[s] + t * 32 * H2_ROWB);
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+        }
+    };
+    // Tile t + NSTAGE - 1 goes into the stage that was read in iteration t - 1: every wave has passed the barrier that
+    // ended that iteration.  Past the end of K the walkers sit beyond the last chunk and the DMA writes zeros.
+    int st_c = 0, st_i = NSTAGE - 1;
+    for (int t = 0; t < nk; ++t) {
+        issue(st_i);
+        compute(st_c);
+        if constexpr (NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");       // tile t + 1 landed, t + 2 stays in flight
+        __builtin_amdgcn_s_barrier();
+        st_c = st_c + 1 == NSTAGE ? 0 : st_c + 1;
+        st_i = st_i + 1 == NSTAGE ? 0 : st_i + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // trailing (zero-filling) DMAs must not outlive the block's LDS
+
+    // ---- epilogue
+    unsigned char *padf = reinterpret_cast<unsigned char *>(smem);
+    const bool fused = epi.act != 0;
+    if (fused) {                                                  // LDS is free: every DMA has landed, every read is done
+        __builtin_amdgcn_s_barrier();
+        if (tid < H2_BM) {
+            const int m = m0 + tid;
+            unsigned char pd = 0;
+            if (epi.mask != nullptr && m < Mc) {
+                const int64_t mg = (int64_t)grp * Mc + m;
+                pd = epi.mask[(mg / epi.d1) * epi.d2 + (mg % epi.d3)] != 0;
+            }
+            padf[tid] = pd;
+        }
+        __syncthreads();
+    }
+    float *of = reinterpret_cast<float *>(out);
+    unsigned short *oh_ = reinterpret_cast<unsigned short *>(out);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + wn * 32 * TN + tn * 32 + li;
+        if (n >= g.Ncols) continue;
+        const float bv = epi.bias ? epi.bias[(size_t)grp * g.Ncols + n] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int m = m0 + row;
+                if (m >= Mc) continue;
+                float v = acc[tm][tn][r] + bv;
+                if (fused) {
+                    v = v > 0.f ? v : epi.slope * v;
+                    v = padf[row] ? 0.f : v;
+                }
+                size_t o;
+                if constexpr (PARITY) {
+                    const int iwq = m % OWc, t2 = m / OWc;
+                    const int ihq = t2 % OHc, nimg = t2 / OHc;
+                    o = ((((size_t)grp * g.ng + nimg) * g.OH + ihq * g.sh + cls_a) * g.OW + iwq * g.sw + cls_b) * g.Ncols + n;
+                } else {
+                    o = ((size_t)grp * Mc + m) * g.Ncols + n;
+                }
+                if (epi.out_f32) of[o] = v;
+                else oh_[o] = f2bf(v);
+            }
+    }
+}
+
+template <int TN, int NSTAGE, int CBK, bool PARITY>
+__global__ __launch_bounds__(512, 2) void conv_h2_kernel(const unsigned short *__restrict__ act, const unsigned short *__restrict__ wgt,
+                                                         void *__restrict__ out, H2Geom g, H2Parity pi, H2Epi epi,
+                                                         size_t act_group_stride)
+{
+    __shared__ __attribute__((aligned(1024))) char smem[NSTAGE * (H2_BM + 64 * TN) * H2_ROWB];
+    conv_h2_body<TN, NSTAGE, CBK, PARITY>(act, wgt, out, g, pi, epi, act_group_stride, smem);
+}
+
+// ------------------------------------------------------------------------------------------ wgrad
+// dw[k][kk] = sum_m dy[m][k] * x[pixel(m) + tap(kk)][channel(kk)], kk in plain (tap, channel) order, reduction over the
+// pixels m of one group, split over `splits` pixel ranges (slabs reduced in a fixed order afterwards).
+// Both operands are pixel-major in HBM, so the LDS images are [64 pixels][256 channels] (512-byte rows) filled by
+// LDS-DMA; the MFMA wants 8 consecutive PIXELS of one channel per lane, i.e. the transpose:
+// ds_read_b64_tr_b16 (lane 4q+p of a 16-lane group addresses pixel P+q, channels 4p..4p+3; lane i receives channel i of
+// the 4 pixels), two reads per 32x32x16 operand.  Bank rule for that read: the 32 lanes of a half touch 4 pixel rows x
+// 64 bytes, which must differ mod 256: the 16-byte chunk index of a row is XORed with (pixel & 3) << 2 (on the DMA's
+// source side and on the reads).
+// Block tile (WM * 32 * TM) output channels x 256 filter columns, 8 waves as WM x (8 / WM):
+//   <4, 2> 256 x 256 (K >= 256);   <2, 3> 192 x 256 (K = 192, 384, ...);   <2, 2> 128 x 256 (the rest).
+struct H2Wgrad {
+    int OH, OW, IH, IW, IC;
+    int S, sh, sw, ph, pw, dh, dw;
+    int Mtot, K, RSC, RS;
+    int nKt, nCt;
+    int splits, chunk;         // pixels per split (multiple of 64)
+};
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+template <int WM, int TM, int WRAPS>
+__device__ __forceinline__ void conv_wgrad_h2_body(const unsigned short *__restrict__ x, const unsigned short *__restrict__ dy,
+                                                   float *__restrict__ out, const H2Wgrad &g, int groups, char *smem)
+{
+    constexpr int WN = 8 / WM, TNW = WM;           // wave grid and 32-column tiles per wave (WN * 32 * TNW = 256)
+    constexpr int BMK = WM * 32 * TM;
+    constexpr int IMG = 64 * 512;                  // one operand image: 64 pixels x 512 bytes
+    constexpr int STAGE = 2 * IMG;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    // all tiles of one (split, group) share a pixel range: keep them on one XCD (see igemm.hip)
+    const int ntile = gridDim.x;
+    const int lin = blockIdx.x + ntile * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int virt = xcd_remap(lin, ntile * gridDim.y * gridDim.z);
+    const int tile = virt % ntile, sg = virt / ntile;
+    const int grp = sg % gridDim.y, split = sg / gridDim.y;
+    const int kt = tile / g.nCt, ct = tile - kt * g.nCt;
+    const int k0 = kt * BMK, c0 = ct * 256;
+    const int m_begin = split * g.chunk;
+    const int m_end = min(g.Mtot, m_begin + g.chunk);
+    const int ng = g.Mtot / (g.OH * g.OW);
+    const int img0 = m_begin / (g.OH * g.OW);
+
+    // ---- DMA slots: piece p = wave + 8 j = pixels 2p, 2p+1 of the step; lane -> pixel 2p + (lane >> 5), physical chunk lane & 31
+    const int pixl = 2 * wave + (lane >> 5);                       // pixel of slot 0; slot j adds 16 j
+    const int lc = (lane & 31) ^ ((pixl & 3) << 2);                // logical chunk = 8 channels / columns
+    const unsigned short *dyg = dy + ((size_t)grp * g.Mtot + m_begin) * g.K;
+    const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(dyg, (size_t)(m_end - m_begin) * g.K * 2);   // rows >= m_end: zeros
+    const unsigned short *xg = x + ((size_t)grp * ng + img0) * g.IH * g.IW * g.IC;
+    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(xg, (size_t)(ng - img0) * g.IH * g.IW * g.IC * 2);
+    const int chA = 8 * lc;
+    const bool okA = chA < BMK && k0 + chA < g.K;
+    unsigned voA[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) voA[j] = okA ? (unsigned)(((pixl + 16 * j) * g.K + k0 + chA) * 2) : OOB;
+    const int kkB = c0 + 8 * lc;
+    const bool okB = kkB < g.RSC;
+    const int tapB = okB ? kkB / g.IC : 0, cB = okB ? kkB - tapB * g.IC : 0;
+    const int tap_h = (tapB / g.S) * g.dh - g.ph, tap_w = (tapB % g.S) * g.dw - g.pw;
+    const int tap_off = ((tap_h * g.IW + tap_w) * g.IC + cB) * 2;
+    int b_ow[4], b_ohs[4], b_base[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m_begin + pixl + 16 * j;
+        const int mm = m < g.Mtot ? m : m_begin;
+        const int ow = mm % g.OW, t2 = mm / g.OW;
+        const int oh = t2 % g.OH, n = t2 / g.OH - img0;
+        b_ow[j] = ow;
+        b_ohs[j] = oh * g.sh;
+        b_base[j] = (((n * g.IH + oh * g.sh) * g.IW + ow * g.sw) * g.IC) * 2;
+    }
+    int left = m_end - m_begin;                                    // pixels of this split from the staged step's first one on
+    unsigned soffA = 0;
+    auto issue = [&](int stage) {
+        char *sa = smem + stage * STAGE + wave * 1024;
+        char *sb = sa + IMG;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, lds_ptr(sa + j * 8192), 16, voA[j], soffA, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = okB && (pixl + 16 * j) < left && (unsigned)(b_ohs[j] + tap_h) < (unsigned)g.IH &&
+                            (unsigned)(b_ow[j] * g.sw + tap_w) < (unsigned)g.IW;
+            const unsigned vo = ok ? (unsigned)(b_base[j] + tap_off) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, lds_ptr(sb + j * 8192), 16, vo, 0, 0, 0);
+        }
+        // advance by 64 pixels
+        soffA += 64u * (unsigned)g.K * 2u;
+        left -= 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            b_ow[j] += 64;
+            b_base[j] += 64 * g.sw * g.IC * 2;
+#pragma unroll
+            for (int i = 0; i < WRAPS; ++i) {
+                const bool w1 = b_ow[j] >= g.OW;
+                b_ow[j] -= w1 ? g.OW : 0;
+                b_ohs[j] += w1 ? g.sh : 0;
+                b_base[j] += w1 ? (g.sh * g.IW - g.OW * g.sw) * g.IC * 2 : 0;
+                const bool w2 = b_ohs[j] >= g.OH * g.sh;
+                b_ohs[j] -= w2 ? g.OH * g.sh : 0;
+                b_base[j] += w2 ? (g.IH - g.OH * g.sh) * g.IW * g.IC * 2 : 0;
+            }
+        }
+    };
+
+    f32x16 acc[TM][TNW];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TNW; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // transposed-read lane constants: 16-lane group gsel -> channels +16 gsel; lane 4q+p -> pixel row q, channels 4p..4p+3
+    const int trq = (lane & 15) >> 2, trp = lane & 3, gsel = (lane >> 4) & 1;
+    int aad[TM], bad[TNW];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        const int chan = wm * 32 * TM + t * 32 + 16 * gsel + 4 * trp;
+        aad[t] = (8 * lh + trq) * 512 + ((((chan * 2) >> 4) ^ (trq << 2)) << 4) + ((chan * 2) & 15);
+    }
+#pragma unroll
+    for (int t = 0; t < TNW; ++t) {
+        const int chan = wn * 32 * TNW + t * 32 + 16 * gsel + 4 * trp;
+        bad[t] = IMG + (8 * lh + trq) * 512 + ((((chan * 2) >> 4) ^ (trq << 2)) << 4) + ((chan * 2) & 15);
+    }
+    const int nsteps = (m_end - m_begin + 63) / 64;
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    auto compute = [&](int stage) {
+        const char *base = smem + stage * STAGE;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 a[TM], b[TNW];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)lds_ptr(base + aad[t] + (16 * s) * 512));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)lds_ptr(base + aad[t] + (16 * s + 4) * 512));
+                a[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int t = 0; t < TNW; ++t) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)lds_ptr(base + bad[t] + (16 * s) * 512));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)lds_ptr(base + bad[t] + (16 * s + 4) * 512));
+                b[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TNW; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+        }
+    };
+    int st_c = 0;
+    for (int t = 0; t < nsteps; ++t) {
+        issue(st_c ^ 1);                 // past the end of the split: every lane is out of range, the DMA writes zeros
+        compute(st_c);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        st_c ^= 1;
+    }
+
+    // slab [split][group][K][RSC], columns scattered into the channel-blocked filter layout (common.h: kidx)
+    float *o = out + ((size_t)split * groups + grp) * (size_t)g.K * g.RSC;
+    const int cbs = chan_block(g.IC);
+#pragma unroll
+    for (int tn = 0; tn < TNW; ++tn) {
+        const int colp = c0 + wn * 32 * TNW + tn * 32 + li;
+        if (colp >= g.RSC) continue;
+        const int tap = colp / g.IC;
+        const int col = kidx(tap, colp - tap * g.IC, g.RS, cbs);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rloc = wm * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int row = k0 + rloc;
+                if (row < g.K) o[(size_t)row * g.RSC + col] = acc[tm][tn][r];
+            }
+    }
+}
+
+template <int WM, int TM, int WRAPS>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_h2_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ dy,
+                                                               float *__restrict__ out, H2Wgrad g, int groups)
+{
+    __shared__ __attribute__((aligned(1024))) char smem[2 * 2 * 64 * 512];
+    conv_wgrad_h2_body<WM, TM, WRAPS>(x, dy, out, g, groups, smem);
+}
+
+// out[i] = sum_k slabs[k][i] in the fixed order k = 0, 1, ... (deterministic)
+__global__ void h2_slab_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ out, size_t n4, int splits)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 *p = reinterpret_cast<const float4 *>(slabs) + i;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        int k = 0;
+        for (; k + 4 <= splits; k += 4) {
+            const float4 a = p[(size_t)k * n4], b = p[(size_t)(k + 1) * n4], c = p[(size_t)(k + 2) * n4], d = p[(size_t)(k + 3) * n4];
+            s.x = (((s.x + a.x) + b.x) + c.x) + d.x;
+            s.y = (((s.y + a.y) + b.y) + c.y) + d.y;
+            s.z = (((s.z + a.z) + b.z) + c.z) + d.z;
+            s.w = (((s.w + a.w) + b.w) + c.w) + d.w;
+        }
+        for (; k < splits; ++k) {
+            const float4 a = p[(size_t)k * n4];
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
+        reinterpret_cast<float4 *>(out)[i] = s;
+    }
+}
+
+// bias gradient of a bf16 dy (rows x cols): partial column sums per row chunk, then a fixed-order combine
+__global__ void h2_colsum_partial_kernel(const unsigned short *__restrict__ x, int64_t rows, int cols, float *__restrict__ part, int nchunks)
+{
+    // grid (ceil(cols / 512), nchunks), block (64, 4): thread (cx, ry) sums 8 columns of rows ry, ry + 4, ... of its chunk
+    __shared__ float red[4][64][8];
+    const int c8 = (blockIdx.x * 64 + threadIdx.x) * 8;
+    const int64_t per = (rows + nchunks - 1) / nchunks;
+    const int64_t r0 = (int64_t)blockIdx.y * per, r1 = min(rows, r0 + per);
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c8 < cols)
+        for (int64_t r = r0 + threadIdx.y; r < r1; r += 4) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(x + r * cols + c8);
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s[2 * i] += __builtin_bit_cast(float, w[i] << 16);
+                s[2 * i + 1] += __builtin_bit_cast(float, w[i] & 0xFFFF0000u);
+            }
+        }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[threadIdx.y][threadIdx.x][i] = s[i];
+    __syncthreads();
+    if (threadIdx.y == 0 && c8 < cols)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            part[(size_t)blockIdx.y * cols + c8 + i] = (red[0][threadIdx.x][i] + red[1][threadIdx.x][i]) + (red[2][threadIdx.x][i] + red[3][threadIdx.x][i]);
+}
+__global__ void h2_colsum_final_kernel(const float *__restrict__ part, int cols, int nchunks, float *__restrict__ out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float t = 0.f;
+    for (int k = 0; k < nchunks; ++k) t += part[(size_t)k * cols + c];
+    out[c] = t;
+}
+
+// ------------------------------------------------------------------------------------------ weight images
+// src: f32 filter bank rows [rows][RS * Cin] in the channel-blocked order of common.h (kidx with CB = chan_block(Cin));
+// dst: bf16 [rows][Kp], index (chunk * RS + tap) * CBdst + ci, zero beyond RS * Cin.
+__global__ void h2_weight_image_kernel(const float *__restrict__ src, int64_t rows, int RS, int Cin, int CBsrc, int CBdst, int Kp,
+                                       unsigned short *__restrict__ dst)
+{
+    const int64_t total = rows * Kp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / Kp;
+        const int k = (int)(i - row * Kp);
+        float v = 0.f;
+        if (k < RS * Cin) {
+            const int ch = k / (RS * CBdst), rem = k - ch * RS * CBdst;
+            const int tap = rem / CBdst, ci = rem - tap * CBdst;
+            v = src[row * (int64_t)(RS * Cin) + kidx(tap, ch * CBdst + ci, RS, CBsrc)];
+        }
+        dst[i] = f2bf(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+static int h2_check(const mqConvDesc *d, const char *who)
+{
+    MQ_REQUIRE(d != nullptr, "%s: null descriptor", who);
+    MQ_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->K > 0 && d->R > 0 && d->S > 0 && d->P > 0 && d->Q > 0,
+               "%s: non-positive dimension", who);
+    MQ_REQUIRE(d->stride_h > 0 && d->stride_w > 0 && d->dil_h > 0 && d->dil_w > 0 && d->pad_h >= 0 && d->pad_w >= 0,
+               "%s: bad stride/dilation/padding", who);
+    MQ_REQUIRE(d->groups > 0 && d->N % d->groups == 0, "%s: N=%d not divisible by groups=%d", who, d->N, d->groups);
+    MQ_REQUIRE((int64_t)(d->P - 1) * d->stride_h - d->pad_h < d->H && (int64_t)(d->Q - 1) * d->stride_w - d->pad_w < d->W,
+               "%s: output extent (%d,%d) inconsistent with input (%d,%d)", who, d->P, d->Q, d->H, d->W);
+    MQ_REQUIRE((int64_t)d->N * d->H * d->W * d->C < (int64_t)1 << 40 && (int64_t)d->N * d->P * d->Q < INT32_MAX &&
+               (int64_t)d->N * d->H * d->W < INT32_MAX, "%s: tensor too large", who);
+    return 0;
+}
+
+static bool h2_shape_ok(const mqConvDesc *d)
+{
+    if (d->C % 32 != 0 || d->K % 32 != 0) return false;
+    if (d->stride_h > 2 || d->stride_w > 2) return false;
+    // 32-bit byte offsets inside the images one 256-row tile can touch (both passes)
+    const int64_t img_x = (int64_t)d->H * d->W * d->C * 2, img_y = (int64_t)d->P * d->Q * d->K * 2;
+    const int64_t t_x = cdiv(H2_BM, (int64_t)d->P * d->Q) + 2, t_y = cdiv(H2_BM, (int64_t)d->H * d->W) + 2;
+    if (img_x * t_x >= 0x7FFFFFF0ll || img_y * t_y >= 0x7FFFFFF0ll) return false;
+    if ((int64_t)std::max(d->K, d->C) * (int64_t)(cdiv((int64_t)d->R * d->S * std::max(d->C, d->K), 64) * 64) * 2 >= 0xFFFFFFF0ll) return false;
+    return true;
+}
+
+static int h2_kp(int RS, int Cin) { return (int)(cdiv((int64_t)RS * Cin, 64) * 64); }
+
+static int pick_tn(int ncols)
+{
+    // column tile 64 * TN that wastes the fewest MFMAs on padding, weighted by the relative efficiency of the tile
+    // shapes (wider tiles reuse the A fragments more and need fewer bytes per flop)
+    const int cand[4] = {4, 3, 2, 1};
+    const double eff[4] = {1.0, 0.93, 0.85, 0.65};
+    double best = 1e30;
+    int tn = 4;
+    for (int i = 0; i < 4; ++i) {
+        const int bn = 64 * cand[i];
+        const double cost = (double)cdiv(ncols, bn) * bn / eff[i];
+        if (cost < best - 1e-9) { best = cost; tn = cand[i]; }
+    }
+    return tn;
+}
+
+template <bool DGRAD>
+static int launch_h2(const mqConvDesc *d, const unsigned short *act, const unsigned short *w, void *out, const H2Epi &epi_in,
+                     hipStream_t st, const char *who)
+{
+    MQ_REQUIRE(h2_shape_ok(d), "%s: shape not supported by the bf16-storage kernels (need C %% 32 == 0, K %% 32 == 0, strides <= 2; "
+               "got C=%d K=%d stride=(%d,%d)); ask mq_h2_supported first", who, d->C, d->K, d->stride_h, d->stride_w);
+    MQ_REQUIRE((uintptr_t)act % 16 == 0 && (uintptr_t)w % 16 == 0, "%s: operands must be 16-byte aligned", who);
+    H2Geom g;
+    memset(&g, 0, sizeof(g));
+    H2Parity pi;
+    memset(&pi, 0, sizeof(pi));
+    const int ng = d->N / d->groups;
+    g.ng = ng;
+    g.R = d->R; g.S = d->S; g.sh = d->stride_h; g.sw = d->stride_w; g.ph = d->pad_h; g.pw = d->pad_w; g.dh = d->dil_h; g.dw = d->dil_w;
+    if (!DGRAD) {
+        g.OH = d->P; g.OW = d->Q; g.IH = d->H; g.IW = d->W; g.IC = d->C; g.Ncols = d->K;
+        g.mul_h = d->stride_h; g.mul_w = d->stride_w; g.add_h = -d->pad_h; g.add_w = -d->pad_w;
+        g.step_h = d->dil_h; g.step_w = d->dil_w;
+    } else {
+        g.OH = d->H; g.OW = d->W; g.IH = d->P; g.IW = d->Q; g.IC = d->K; g.Ncols = d->C;
+        g.mul_h = 1; g.mul_w = 1; g.add_h = d->pad_h; g.add_w = d->pad_w;
+        g.step_h = -d->dil_h; g.step_w = -d->dil_w;
+    }
+    g.nR = g.R; g.nS = g.S;
+    g.Mtot = ng * g.OH * g.OW;
+    g.CB = g.IC % 64 == 0 ? 64 : 32;
+    g.nchunks = g.IC / g.CB;
+    g.Kp = h2_kp(d->R * d->S, g.IC);
+    const int TN = pick_tn(g.Ncols);
+    const int BN = 64 * TN;
+    g.nMt = (int)cdiv(g.Mtot, H2_BM);
+    g.nNt = (int)cdiv(g.Ncols, BN);
+    const size_t act_gs = (size_t)ng * g.IH * g.IW * g.IC;
+    const bool parity = DGRAD && (g.sh > 1 || g.sw > 1);
+    H2Epi epi = epi_in;
+    dim3 grid((unsigned)(g.nMt * g.nNt), d->groups), block(512);
+    if (parity) {
+        int t0 = 0;
+        for (int a = 0; a < g.sh; ++a)
+            for (int b = 0; b < g.sw; ++b) {
+                const int c = pi.ncls++;
+                pi.a[c] = a; pi.b[c] = b;
+                pi.Ha[c] = g.OH > a ? (g.OH - a + g.sh - 1) / g.sh : 0;
+                pi.Wb[c] = g.OW > b ? (g.OW - b + g.sw - 1) / g.sw : 0;
+                int first = -1, second = -1;
+                for (int r = 0; r < g.R; ++r)
+                    if ((((a + g.ph - r * g.dh) % g.sh) + g.sh) % g.sh == 0) {
+                        if (first < 0) first = r; else if (second < 0) second = r;
+                        pi.nr[c]++;
+                    }
+                pi.r0[c] = first < 0 ? 0 : first;
+                pi.rstep[c] = second < 0 ? 1 : second - first;
+                first = second = -1;
+                for (int s = 0; s < g.S; ++s)
+                    if ((((b + g.pw - s * g.dw) % g.sw) + g.sw) % g.sw == 0) {
+                        if (first < 0) first = s; else if (second < 0) second = s;
+                        pi.ns[c]++;
+                    }
+                pi.s0[c] = first < 0 ? 0 : first;
+                pi.sstep[c] = second < 0 ? 1 : second - first;
+                pi.tile0[c] = t0;
+                t0 += (int)cdiv((int64_t)ng * pi.Ha[c] * pi.Wb[c], H2_BM);
+            }
+        pi.tile0[pi.ncls] = t0;
+        grid = dim3((unsigned)(t0 * g.nNt), d->groups);
+    }
+#define MQ_H2(TN_, NS_, CB_, PAR_) hipLaunchKernelGGL((conv_h2_kernel<TN_, NS_, CB_, PAR_>), grid, block, 0, st, act, w, out, g, pi, epi, act_gs)
+#define MQ_H2_CB(TN_, NS_, PAR_) do { if (g.CB == 64) MQ_H2(TN_, NS_, 64, PAR_); else MQ_H2(TN_, NS_, 32, PAR_); } while (0)
+#define MQ_H2_TN(PAR_) do { if (TN == 4) MQ_H2_CB(4, 2, PAR_); else if (TN == 3) MQ_H2_CB(3, 2, PAR_); \
+                            else if (TN == 2) MQ_H2_CB(2, 3, PAR_); else MQ_H2_CB(1, 3, PAR_); } while (0)
+    if (parity) MQ_H2_TN(true);
+    else MQ_H2_TN(false);
+#undef MQ_H2_TN
+#undef MQ_H2_CB
+#undef MQ_H2
+    MQ_LAUNCH_CHECK(who);
+    return 0;
+}
+
+}  // namespace mq
+
+using namespace mq;
+
+extern "C" int mq_h2_supported(const mqConvDesc *d)
+{
+    if (d == nullptr || d->precision != MQ_PRECISION_BF16) return 0;
+    if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->K <= 0 || d->R <= 0 || d->S <= 0 || d->P <= 0 || d->Q <= 0 || d->groups <= 0) return 0;
+    return h2_shape_ok(d) ? 1 : 0;
+}
+
+extern "C" size_t mq_h2_weight_elems(const mqConvDesc *d, int dgrad)
+{
+    if (d == nullptr || d->C <= 0 || d->K <= 0 || d->R <= 0 || d->S <= 0 || d->groups <= 0) return 0;
+    const int rows = dgrad ? d->C : d->K, cin = dgrad ? d->K : d->C;
+    return (size_t)d->groups * rows * h2_kp(d->R * d->S, cin);
+}
+
+extern "C" int mq_h2_weight_image(const mqConvDesc *d, int dgrad, const float *w, uint16_t *w_h2, mqStream stream)
+{
+    if (h2_check(d, "mq_h2_weight_image")) return 1;
+    MQ_REQUIRE(w && w_h2, "mq_h2_weight_image: null pointer");
+    const int rows = dgrad ? d->C : d->K, cin = dgrad ? d->K : d->C;
+    MQ_REQUIRE(cin % 32 == 0, "mq_h2_weight_image: reduction channel count %d is not a multiple of 32", cin);
+    const int RS = d->R * d->S, Kp = h2_kp(RS, cin);
+    const int64_t nrows = (int64_t)d->groups * rows;
+    hipLaunchKernelGGL(h2_weight_image_kernel, dim3(ew_grid(nrows * Kp, 256)), dim3(256), 0, S(stream), w, nrows, RS, cin,
+                       chan_block(cin), cin % 64 == 0 ? 64 : 32, Kp, w_h2);
+    MQ_LAUNCH_CHECK("mq_h2_weight_image");
+    return 0;
+}
+
+extern "C" int mq_conv_fprop_h2(const mqConvDesc *d, const uint16_t *x, const uint16_t *w_h2, const float *bias,
+                                const uint8_t *mask, int64_t d1, int64_t d2, int64_t d3, int act, float slope, int out_f32, void *y,
+                                mqStream stream)
+{
+    if (h2_check(d, "mq_conv_fprop_h2")) return 1;
+    MQ_REQUIRE(x && w_h2 && y, "mq_conv_fprop_h2: null pointer");
+    MQ_REQUIRE(act == 0 || act == 2, "mq_conv_fprop_h2: act must be 0 (none) or 2 (LeakyReLU + mask)");
+    MQ_REQUIRE(mask == nullptr || (d1 > 0 && d3 > 0 && d2 >= 0 && d1 < INT32_MAX && d2 < INT32_MAX && d3 < INT32_MAX),
+               "mq_conv_fprop_h2: bad mask map");
+    H2Epi epi{bias, act ? mask : nullptr, (int)(mask ? d1 : 1), (int)(mask ? d2 : 0), (int)(mask ? d3 : 1), act, slope, out_f32};
+    return launch_h2<false>(d, x, w_h2, y, epi, S(stream), "mq_conv_fprop_h2");
+}
+
+extern "C" int mq_conv_dgrad_h2(const mqConvDesc *d, const uint16_t *dy, const uint16_t *wt_h2, int out_f32, void *dx, mqStream stream)
+{
+    if (h2_check(d, "mq_conv_dgrad_h2")) return 1;
+    MQ_REQUIRE(dy && wt_h2 && dx, "mq_conv_dgrad_h2: null pointer");
+    H2Epi epi{nullptr, nullptr, 1, 0, 1, 0, 0.f, out_f32};
+    return launch_h2<true>(d, dy, wt_h2, dx, epi, S(stream), "mq_conv_dgrad_h2");
+}
+
+namespace mq {
+static bool h2_wgrad_ok(const mqConvDesc *d)
+{
+    if (!h2_shape_ok(d)) return false;
+    if (d->Q < 16) return false;                      // the pixel walk handles at most 4 row wraps per 64-pixel step
+    return true;
+}
+static void h2_wgrad_plan(const mqConvDesc *d, H2Wgrad &g, int &wm, int &tm)
+{
+    const int ng = d->N / d->groups;
+    g.OH = d->P; g.OW = d->Q; g.IH = d->H; g.IW = d->W; g.IC = d->C;
+    g.S = d->S; g.sh = d->stride_h; g.sw = d->stride_w; g.ph = d->pad_h; g.pw = d->pad_w; g.dh = d->dil_h; g.dw = d->dil_w;
+    g.Mtot = ng * d->P * d->Q;
+    g.K = d->K;
+    g.RS = d->R * d->S;
+    g.RSC = g.RS * d->C;
+    // row tile: 256 when K fills it, 192 for multiples of 192, else 128
+    if (g.K % 256 == 0 || (g.K > 256 && g.K % 192 != 0)) { wm = 4; tm = 2; }
+    else if (g.K % 192 == 0) { wm = 2; tm = 3; }
+    else { wm = 2; tm = 2; }
+    const int bmk = wm * 32 * tm;
+    g.nKt = (int)cdiv(g.K, bmk);
+    g.nCt = (int)cdiv(g.RSC, 256);
+    const int64_t tiles = (int64_t)g.nKt * g.nCt * d->groups;
+    const int64_t slots = 256;                        // one 512-thread block per CU
+    int64_t max_splits = cdiv(g.Mtot, 64 * 16);       // >= 16 K-steps per split
+    if (max_splits > 512) max_splits = 512;
+    if (max_splits < 1) max_splits = 1;
+    int64_t lo = slots / tiles, hi = 4 * slots / tiles + 1;
+    if (lo < 1) lo = 1;
+    if (lo > max_splits) lo = max_splits;
+    if (hi > max_splits) hi = max_splits;
+    int64_t splits = lo;
+    double best = -1.0;
+    for (int64_t sp = lo; sp <= hi; ++sp) {
+        const int64_t blocks = tiles * sp;
+        const double rounds = (double)cdiv(blocks, slots);
+        const double score = (double)blocks / (rounds * (double)slots) - 0.004 * rounds;
+        if (score > best + 1e-12) { best = score; splits = sp; }
+    }
+    {   // 32-bit byte offsets inside one split
+        const int64_t pq = (int64_t)d->P * d->Q;
+        const int64_t img = 2 * std::max((int64_t)d->H * d->W * d->C, pq * (int64_t)d->K);
+        while (splits < max_splits && (cdiv(cdiv(g.Mtot, splits), pq) + 2) * img >= 0x7FFFFFF0ll) ++splits;
+    }
+    const int64_t chunk = cdiv(cdiv(g.Mtot, splits), 64) * 64;
+    g.chunk = (int)chunk;
+    g.splits = (int)cdiv(g.Mtot, chunk);
+}
+}  // namespace mq
+
+extern "C" int mq_h2_wgrad_supported(const mqConvDesc *d)
+{
+    if (!mq_h2_supported(d)) return 0;
+    return h2_wgrad_ok(d) ? 1 : 0;
+}
+
+extern "C" size_t mq_conv_wgrad_h2_workspace(const mqConvDesc *d)
+{
+    if (!mq_h2_wgrad_supported(d)) return 0;
+    H2Wgrad g;
+    int wm, tm;
+    h2_wgrad_plan(d, g, wm, tm);
+    const size_t slabs = g.splits > 1 ? (size_t)g.splits * d->groups * g.K * g.RSC * sizeof(float) : 0;
+    return slabs + (size_t)1024 * d->groups * g.K * sizeof(float);          // + column-sum partials of the bias gradient
+}
+
+extern "C" int mq_conv_wgrad_h2(const mqConvDesc *d, const uint16_t *x, const uint16_t *dy, float *dw, float *dbias, void *workspace,
+                                size_t workspace_bytes, mqStream stream)
+{
+    if (h2_check(d, "mq_conv_wgrad_h2")) return 1;
+    MQ_REQUIRE(x && dy && dw && workspace, "mq_conv_wgrad_h2: null pointer");
+    MQ_REQUIRE(h2_wgrad_ok(d), "mq_conv_wgrad_h2: shape not supported (ask mq_h2_wgrad_supported first)");
+    MQ_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)dw % 16 == 0, "mq_conv_wgrad_h2: 16-byte alignment");
+    MQ_REQUIRE(workspace_bytes >= mq_conv_wgrad_h2_workspace(d), "mq_conv_wgrad_h2: workspace too small");
+    H2Wgrad g;
+    int wm, tm;
+    h2_wgrad_plan(d, g, wm, tm);
+    hipStream_t st = S(stream);
+    const size_t n = (size_t)d->groups * g.K * g.RSC;
+    float *target = g.splits > 1 ? reinterpret_cast<float *>(workspace) : dw;
+    float *bias_ws = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + (g.splits > 1 ? (size_t)g.splits * n * sizeof(float) : 0));
+    dim3 grid(g.nKt * g.nCt, d->groups, g.splits), block(512);
+    const int wraps = d->Q >= 64 ? 1 : 4;
+#define MQ_WH(WM_, TM_) do { if (wraps == 1) hipLaunchKernelGGL((conv_wgrad_h2_kernel<WM_, TM_, 1>), grid, block, 0, st, x, dy, target, g, d->groups); \
+                             else hipLaunchKernelGGL((conv_wgrad_h2_kernel<WM_, TM_, 4>), grid, block, 0, st, x, dy, target, g, d->groups); } while (0)
+    if (wm == 4) MQ_WH(4, 2);
+    else if (tm == 3) MQ_WH(2, 3);
+    else MQ_WH(2, 2);
+#undef MQ_WH
+    MQ_LAUNCH_CHECK("mq_conv_wgrad_h2");
+    if (g.splits > 1) {
+        MQ_REQUIRE(n % 4 == 0, "mq_conv_wgrad_h2: filter bank size not a multiple of 4");
+        hipLaunchKernelGGL(h2_slab_reduce_kernel, dim3(ew_grid((int64_t)n / 4, 256)), dim3(256), 0, st, target, dw, n / 4, g.splits);
+        MQ_LAUNCH_CHECK("mq_conv_wgrad_h2(reduce)");
+    }
+    if (dbias) {
+        for (int grp = 0; grp < d->groups; ++grp) {
+            const int64_t rows = g.Mtot;
+            const int cols = g.K;
+            int64_t want = cdiv(2048, cdiv(cols, 512));
+            if (want > rows / 32) want = rows / 32;
+            if (want > 1024) want = 1024;
+            if (want < 1) want = 1;
+            float *ws = bias_ws + (size_t)grp * 1024 * cols;
+            hipLaunchKernelGGL(h2_colsum_partial_kernel, dim3((unsigned)cdiv(cols, 512), (unsigned)want), dim3(64, 4), 0, st,
+                               dy + (size_t)grp * rows * cols, rows, cols, ws, (int)want);
+            hipLaunchKernelGGL(h2_colsum_final_kernel, dim3((unsigned)cdiv(cols, 256)), dim3(256), 0, st, ws, cols, (int)want,
+                               dbias + (size_t)grp * cols);
+        }
+        MQ_LAUNCH_CHECK("mq_conv_wgrad_h2(bias)");
+    }
+    return 0;
+}

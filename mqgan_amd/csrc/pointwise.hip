@@ -35,11 +35,45 @@ __device__ __forceinline__ float act_bwd(int act, float t, float beta, float gam
     return 1.0f;
 }
 
-// one thread = one group of 8 consecutive flat elements (= one Philox call)
-template <bool VEC8>
-__global__ void pointwise_fwd_kernel(PwParams p, const float *__restrict__ h, const float *__restrict__ rpre,
-                                     const float *__restrict__ rpost, const uint8_t *__restrict__ mask,
-                                     const float *__restrict__ beta_p, const float *__restrict__ gamma_p, float *__restrict__ out)
+// 8 consecutive elements <-> registers; T = float (two 16-byte accesses) or bf16 stored as unsigned short (one)
+typedef unsigned short bf16_t;
+__device__ __forceinline__ void ld8(const float *p, int64_t e0, float v[8])
+{
+    const float4 a = *reinterpret_cast<const float4 *>(p + e0), b = *reinterpret_cast<const float4 *>(p + e0 + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void ld8(const bf16_t *p, int64_t e0, float v[8])
+{
+    const uint4 a = *reinterpret_cast<const uint4 *>(p + e0);
+    const unsigned w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __builtin_bit_cast(float, w[i] << 16);
+        v[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xFFFF0000u);
+    }
+}
+__device__ __forceinline__ void st8(float *p, int64_t e0, const float v[8])
+{
+    *reinterpret_cast<float4 *>(p + e0) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4 *>(p + e0 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void st8(bf16_t *p, int64_t e0, const float v[8])
+{
+    typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+    typedef float f32x8v __attribute__((ext_vector_type(8)));
+    const f32x8v f = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+    *reinterpret_cast<bf16x8v *>(p + e0) = __builtin_convertvector(f, bf16x8v);       // RNE, NaN-safe
+}
+__device__ __forceinline__ float ld1(const float *p, int64_t e) { return p[e]; }
+__device__ __forceinline__ float ld1(const bf16_t *p, int64_t e) { return __builtin_bit_cast(float, (unsigned)p[e] << 16); }
+__device__ __forceinline__ void st1(float *p, int64_t e, float v) { p[e] = v; }
+__device__ __forceinline__ void st1(bf16_t *p, int64_t e, float v) { p[e] = __builtin_bit_cast(unsigned short, (__bf16)v); }
+
+// one thread = one group of 8 consecutive flat elements (= one Philox call).  T: storage type of the activations.
+template <bool VEC8, typename T>
+__global__ void pointwise_fwd_kernel(PwParams p, const T *__restrict__ h, const T *__restrict__ rpre,
+                                     const T *__restrict__ rpost, const uint8_t *__restrict__ mask,
+                                     const float *__restrict__ beta_p, const float *__restrict__ gamma_p, T *__restrict__ out)
 {
     const int64_t total = p.rows * p.C;
     const int64_t ngroups = (total + 7) >> 3;
@@ -49,11 +83,12 @@ __global__ void pointwise_fwd_kernel(PwParams p, const float *__restrict__ h, co
         float t[8], a[8];
         bool pad[8];
         if (VEC8) {
-            const float4 x0 = *reinterpret_cast<const float4 *>(h + e0), x1 = *reinterpret_cast<const float4 *>(h + e0 + 4);
-            t[0] = x0.x; t[1] = x0.y; t[2] = x0.z; t[3] = x0.w; t[4] = x1.x; t[5] = x1.y; t[6] = x1.z; t[7] = x1.w;
+            ld8(h, e0, t);
             if (rpre) {
-                const float4 r0 = *reinterpret_cast<const float4 *>(rpre + e0), r1 = *reinterpret_cast<const float4 *>(rpre + e0 + 4);
-                t[0] += r0.x; t[1] += r0.y; t[2] += r0.z; t[3] += r0.w; t[4] += r1.x; t[5] += r1.y; t[6] += r1.z; t[7] += r1.w;
+                float r[8];
+                ld8(rpre, e0, r);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) t[i] += r[i];
             }
             bool pd = false;
             if (mask) {
@@ -69,7 +104,7 @@ __global__ void pointwise_fwd_kernel(PwParams p, const float *__restrict__ h, co
                 t[i] = 0.f;
                 pad[i] = false;
                 if (e < total) {
-                    t[i] = h[e] + (rpre ? rpre[e] : 0.f);
+                    t[i] = ld1(h, e) + (rpre ? ld1(rpre, e) : 0.f);
                     if (mask) {
                         const int64_t m = e / p.C;
                         pad[i] = mask[(m / p.d1) * p.d2 + (m % p.d3)] != 0;
@@ -89,34 +124,35 @@ __global__ void pointwise_fwd_kernel(PwParams p, const float *__restrict__ h, co
         }
         if (VEC8) {
             if (rpost) {
-                const float4 r0 = *reinterpret_cast<const float4 *>(rpost + e0), r1 = *reinterpret_cast<const float4 *>(rpost + e0 + 4);
-                a[0] += r0.x; a[1] += r0.y; a[2] += r0.z; a[3] += r0.w; a[4] += r1.x; a[5] += r1.y; a[6] += r1.z; a[7] += r1.w;
+                float r[8];
+                ld8(rpost, e0, r);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a[i] += r[i];
             }
             if (p.mask_post && pad[0]) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) a[i] = 0.f;
             }
-            *reinterpret_cast<float4 *>(out + e0) = make_float4(a[0], a[1], a[2], a[3]);
-            *reinterpret_cast<float4 *>(out + e0 + 4) = make_float4(a[4], a[5], a[6], a[7]);
+            st8(out, e0, a);
         } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int64_t e = e0 + i;
                 if (e < total) {
-                    float av = a[i] + (rpost ? rpost[e] : 0.f);
+                    float av = a[i] + (rpost ? ld1(rpost, e) : 0.f);
                     if (p.mask_post && pad[i]) av = 0.f;
-                    out[e] = av;
+                    st1(out, e, av);
                 }
             }
         }
     }
 }
 
-template <bool VEC8>
-__global__ void pointwise_bwd_kernel(PwParams p, const float *__restrict__ dout, const float *__restrict__ h,
-                                     const float *__restrict__ rpre, const uint8_t *__restrict__ mask,
-                                     const float *__restrict__ beta_p, const float *__restrict__ gamma_p, float *__restrict__ dt,
-                                     float *__restrict__ dpost, float *__restrict__ part)
+template <bool VEC8, typename T>
+__global__ void pointwise_bwd_kernel(PwParams p, const T *__restrict__ dout, const T *__restrict__ h,
+                                     const T *__restrict__ rpre, const uint8_t *__restrict__ mask,
+                                     const float *__restrict__ beta_p, const float *__restrict__ gamma_p, T *__restrict__ dt,
+                                     T *__restrict__ dpost, float *__restrict__ part)
 {
     __shared__ float red[4];
     const int64_t total = p.rows * p.C;
@@ -128,14 +164,14 @@ __global__ void pointwise_bwd_kernel(PwParams p, const float *__restrict__ dout,
         float t[8], g[8];
         bool pad[8], live[8];
         if (VEC8) {
-            const float4 x0 = *reinterpret_cast<const float4 *>(h + e0), x1 = *reinterpret_cast<const float4 *>(h + e0 + 4);
-            t[0] = x0.x; t[1] = x0.y; t[2] = x0.z; t[3] = x0.w; t[4] = x1.x; t[5] = x1.y; t[6] = x1.z; t[7] = x1.w;
+            ld8(h, e0, t);
             if (rpre) {
-                const float4 r0 = *reinterpret_cast<const float4 *>(rpre + e0), r1 = *reinterpret_cast<const float4 *>(rpre + e0 + 4);
-                t[0] += r0.x; t[1] += r0.y; t[2] += r0.z; t[3] += r0.w; t[4] += r1.x; t[5] += r1.y; t[6] += r1.z; t[7] += r1.w;
+                float r[8];
+                ld8(rpre, e0, r);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) t[i] += r[i];
             }
-            const float4 g0 = *reinterpret_cast<const float4 *>(dout + e0), g1 = *reinterpret_cast<const float4 *>(dout + e0 + 4);
-            g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
+            ld8(dout, e0, g);
             bool pd = false;
             if (mask) {
                 const int64_t m = e0 / p.C;
@@ -150,8 +186,8 @@ __global__ void pointwise_bwd_kernel(PwParams p, const float *__restrict__ dout,
                 t[i] = 0.f; g[i] = 0.f; pad[i] = false;
                 live[i] = e < total;
                 if (live[i]) {
-                    t[i] = h[e] + (rpre ? rpre[e] : 0.f);
-                    g[i] = dout[e];
+                    t[i] = ld1(h, e) + (rpre ? ld1(rpre, e) : 0.f);
+                    g[i] = ld1(dout, e);
                     if (mask) {
                         const int64_t m = e / p.C;
                         pad[i] = mask[(m / p.d1) * p.d2 + (m % p.d3)] != 0;
@@ -176,18 +212,14 @@ __global__ void pointwise_bwd_kernel(PwParams p, const float *__restrict__ dout,
             dv[i] = mp ? 0.f : gv * d;
         }
         if (VEC8) {
-            *reinterpret_cast<float4 *>(dt + e0) = make_float4(dv[0], dv[1], dv[2], dv[3]);
-            *reinterpret_cast<float4 *>(dt + e0 + 4) = make_float4(dv[4], dv[5], dv[6], dv[7]);
-            if (dpost) {
-                *reinterpret_cast<float4 *>(dpost + e0) = make_float4(po[0], po[1], po[2], po[3]);
-                *reinterpret_cast<float4 *>(dpost + e0 + 4) = make_float4(po[4], po[5], po[6], po[7]);
-            }
+            st8(dt, e0, dv);
+            if (dpost) st8(dpost, e0, po);
         } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
                 if (live[i]) {
-                    dt[e0 + i] = dv[i];
-                    if (dpost) dpost[e0 + i] = po[i];
+                    st1(dt, e0 + i, dv[i]);
+                    if (dpost) st1(dpost, e0 + i, po[i]);
                 }
         }
     }
@@ -417,6 +449,93 @@ __global__ void cast_bf16_kernel(const float *__restrict__ in, unsigned short *_
         }
 }
 
+// bf16 -> f32
+__global__ void cast_f32_kernel(const bf16_t *__restrict__ in, float *__restrict__ out, int64_t n8, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float v[8];
+        ld8(in, i * 8, v);
+        st8(out, i * 8, v);
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = n8 * 8 + threadIdx.x; i < n; i += blockDim.x) out[i] = ld1(in, i);
+}
+
+// ---- bf16 UNet data movement: 8 channels (16 bytes) per thread, C % 8 == 0
+// x (N, T, F*C) -> y (N, T/2, F*C)
+__global__ void avgpool_t2_fwd_h_kernel(const bf16_t *__restrict__ x, int64_t N, int T, int64_t FC8, bf16_t *__restrict__ y)
+{
+    const int To = T / 2;
+    const int64_t total = N * To * FC8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t fc = i % FC8, r = i / FC8;
+        const int64_t t = r % To, n = r / To;
+        float a[8], b[8];
+        ld8(x, ((n * T + 2 * t) * FC8 + fc) * 8, a);
+        ld8(x, ((n * T + 2 * t + 1) * FC8 + fc) * 8, b);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = (a[k] + b[k]) * 0.5f;
+        st8(y, i * 8, a);
+    }
+}
+__global__ void avgpool_t2_bwd_h_kernel(const bf16_t *__restrict__ dy, int64_t N, int T, int64_t FC8, bf16_t *__restrict__ dx)
+{
+    const int To = T / 2;
+    const int64_t total = N * To * FC8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t fc = i % FC8, r = i / FC8;
+        const int64_t t = r % To, n = r / To;
+        float a[8];
+        ld8(dy, i * 8, a);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] *= 0.5f;
+        st8(dx, ((n * T + 2 * t) * FC8 + fc) * 8, a);
+        st8(dx, ((n * T + 2 * t + 1) * FC8 + fc) * 8, a);
+    }
+}
+// out (N, 2T, F, C1 + C2) = cat(upsample2(x (N,T,F,C1)), skip (N,2T,F,C2)); one thread = 8 channels of one output pixel
+__global__ void upcat_fwd_h_kernel(const bf16_t *__restrict__ x, const bf16_t *__restrict__ skip, int64_t N, int T, int F, int C1,
+                                   int C2, bf16_t *__restrict__ out)
+{
+    const int Co8 = (C1 + C2) / 8, C18 = C1 / 8;
+    const int64_t total = N * 2 * T * F * Co8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % Co8);
+        const int64_t r = i / Co8;           // (n, t2, f)
+        const int64_t f = r % F, r2 = r / F;
+        const int64_t t2 = r2 % (2 * T), n = r2 / (2 * T);
+        const uint4 v = c8 < C18 ? *reinterpret_cast<const uint4 *>(x + (((n * T + (t2 >> 1)) * F + f) * C1 + c8 * 8))
+                                 : *reinterpret_cast<const uint4 *>(skip + (r * C2 + (c8 - C18) * 8));
+        *reinterpret_cast<uint4 *>(out + i * 8) = v;
+    }
+}
+// dx (N,T,F,C1) = sum of the two upsampled rows; dskip (N,2T,F,C2) = copy
+__global__ void upcat_bwd_h_kernel(const bf16_t *__restrict__ dout, int64_t N, int T, int F, int C1, int C2, bf16_t *__restrict__ dx,
+                                   bf16_t *__restrict__ dskip)
+{
+    const int Co = C1 + C2, Co8 = Co / 8, C18 = C1 / 8;
+    const int64_t total = N * T * F * Co8;          // one thread: 8 channels of an INPUT-resolution pixel (both output rows)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % Co8);
+        const int64_t r = i / Co8;           // (n, t, f)
+        const int64_t f = r % F, r2 = r / F;
+        const int64_t t = r2 % T, n = r2 / T;
+        const int64_t o0 = ((n * 2 * T + 2 * t) * F + f), o1 = o0 + F;
+        if (c8 < C18) {
+            float a[8], b[8];
+            ld8(dout, o0 * Co + c8 * 8, a);
+            ld8(dout, o1 * Co + c8 * 8, b);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] += b[k];
+            st8(dx, r * C1 + c8 * 8, a);
+        } else {
+            const int cs = (c8 - C18) * 8;
+            *reinterpret_cast<uint4 *>(dskip + o0 * C2 + cs) = *reinterpret_cast<const uint4 *>(dout + o0 * Co + C1 + cs);
+            *reinterpret_cast<uint4 *>(dskip + o1 * C2 + cs) = *reinterpret_cast<const uint4 *>(dout + o1 * Co + C1 + cs);
+        }
+    }
+}
+
 }  // namespace mq
 
 using namespace mq;
@@ -432,10 +551,10 @@ extern "C" int mq_pointwise_fwd(const mqPointwiseDesc *d, const float *h, const 
     const bool vec = (p.C % 8 == 0) && al16(h) && al16(r_pre) && al16(r_post) && al16(out);
     const int grid = ew_grid(groups, 256);
     if (vec)
-        hipLaunchKernelGGL((pointwise_fwd_kernel<true>), dim3(grid), dim3(256), 0, S(stream), p, h, r_pre, r_post, mask, beta,
+        hipLaunchKernelGGL((pointwise_fwd_kernel<true, float>), dim3(grid), dim3(256), 0, S(stream), p, h, r_pre, r_post, mask, beta,
                            gamma, out);
     else
-        hipLaunchKernelGGL((pointwise_fwd_kernel<false>), dim3(grid), dim3(256), 0, S(stream), p, h, r_pre, r_post, mask, beta,
+        hipLaunchKernelGGL((pointwise_fwd_kernel<false, float>), dim3(grid), dim3(256), 0, S(stream), p, h, r_pre, r_post, mask, beta,
                            gamma, out);
     MQ_LAUNCH_CHECK("mq_pointwise_fwd");
     return 0;
@@ -457,10 +576,10 @@ extern "C" int mq_pointwise_bwd(const mqPointwiseDesc *d, const float *dout, con
     if (grid > 1024) grid = 1024;
     float *part = want_bg ? workspace : nullptr;
     if (vec)
-        hipLaunchKernelGGL((pointwise_bwd_kernel<true>), dim3(grid), dim3(256), 0, S(stream), p, dout, h, r_pre, mask, beta,
+        hipLaunchKernelGGL((pointwise_bwd_kernel<true, float>), dim3(grid), dim3(256), 0, S(stream), p, dout, h, r_pre, mask, beta,
                            gamma, dt, dpost, part);
     else
-        hipLaunchKernelGGL((pointwise_bwd_kernel<false>), dim3(grid), dim3(256), 0, S(stream), p, dout, h, r_pre, mask, beta,
+        hipLaunchKernelGGL((pointwise_bwd_kernel<false, float>), dim3(grid), dim3(256), 0, S(stream), p, dout, h, r_pre, mask, beta,
                            gamma, dt, dpost, part);
     if (want_bg) hipLaunchKernelGGL(pw_final_kernel, dim3(1), dim3(256), 0, S(stream), part, grid, dbeta, dgamma);
     MQ_LAUNCH_CHECK("mq_pointwise_bwd");
@@ -597,5 +716,94 @@ extern "C" int mq_cast_bf16(const float *in, uint16_t *out, int64_t n, mqStream 
     const int64_t n8 = n / 8;
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(ew_grid(n8 > 0 ? n8 : 1, 256)), dim3(256), 0, S(stream), in, out, n8, n);
     MQ_LAUNCH_CHECK("mq_cast_bf16");
+    return 0;
+}
+
+extern "C" int mq_cast_f32(const uint16_t *in, float *out, int64_t n, mqStream stream)
+{
+    if (n == 0) return 0;
+    MQ_REQUIRE(in && out && n > 0, "mq_cast_f32: bad arguments");
+    MQ_REQUIRE((uintptr_t)in % 16 == 0 && (uintptr_t)out % 16 == 0, "mq_cast_f32: pointers must be 16-byte aligned");
+    const int64_t n8 = n / 8;
+    hipLaunchKernelGGL(cast_f32_kernel, dim3(ew_grid(n8 > 0 ? n8 : 1, 256)), dim3(256), 0, S(stream), in, out, n8, n);
+    MQ_LAUNCH_CHECK("mq_cast_f32");
+    return 0;
+}
+
+extern "C" int mq_pointwise_fwd_h(const mqPointwiseDesc *d, const uint16_t *h, const uint16_t *r_pre, const uint16_t *r_post,
+                                  const uint8_t *mask, const float *beta, const float *gamma, uint16_t *out, mqStream stream)
+{
+    PwParams p;
+    if (make_pw(d, p, "mq_pointwise_fwd_h")) return 1;
+    MQ_REQUIRE(h && out, "mq_pointwise_fwd_h: null pointer");
+    MQ_REQUIRE(mask || !(p.mask_pre || p.mask_post), "mq_pointwise_fwd_h: mask flags set but mask is null");
+    MQ_REQUIRE(p.C % 8 == 0 && al16(h) && al16(r_pre) && al16(r_post) && al16(out),
+               "mq_pointwise_fwd_h: bf16 tensors need C %% 8 == 0 and 16-byte alignment (C=%d)", p.C);
+    const int64_t groups = p.rows * p.C / 8;
+    hipLaunchKernelGGL((pointwise_fwd_kernel<true, bf16_t>), dim3(ew_grid(groups, 256)), dim3(256), 0, S(stream), p, h, r_pre, r_post,
+                       mask, beta, gamma, out);
+    MQ_LAUNCH_CHECK("mq_pointwise_fwd_h");
+    return 0;
+}
+
+extern "C" int mq_pointwise_bwd_h(const mqPointwiseDesc *d, const uint16_t *dout, const uint16_t *h, const uint16_t *r_pre,
+                                  const uint8_t *mask, const float *beta, const float *gamma, uint16_t *dt, uint16_t *dpost,
+                                  float *dbeta, float *dgamma, float *workspace, mqStream stream)
+{
+    PwParams p;
+    if (make_pw(d, p, "mq_pointwise_bwd_h")) return 1;
+    MQ_REQUIRE(dout && h && dt, "mq_pointwise_bwd_h: null pointer");
+    MQ_REQUIRE(mask || !(p.mask_pre || p.mask_post), "mq_pointwise_bwd_h: mask flags set but mask is null");
+    const bool want_bg = dbeta || dgamma;
+    MQ_REQUIRE(!want_bg || workspace, "mq_pointwise_bwd_h: dbeta/dgamma need a workspace");
+    MQ_REQUIRE(p.C % 8 == 0 && al16(h) && al16(r_pre) && al16(dout) && al16(dt) && al16(dpost),
+               "mq_pointwise_bwd_h: bf16 tensors need C %% 8 == 0 and 16-byte alignment (C=%d)", p.C);
+    const int64_t groups = p.rows * p.C / 8;
+    int grid = ew_grid(groups, 256);
+    if (grid > 1024) grid = 1024;
+    float *part = want_bg ? workspace : nullptr;
+    hipLaunchKernelGGL((pointwise_bwd_kernel<true, bf16_t>), dim3(grid), dim3(256), 0, S(stream), p, dout, h, r_pre, mask, beta, gamma,
+                       dt, dpost, part);
+    if (want_bg) hipLaunchKernelGGL(pw_final_kernel, dim3(1), dim3(256), 0, S(stream), part, grid, dbeta, dgamma);
+    MQ_LAUNCH_CHECK("mq_pointwise_bwd_h");
+    return 0;
+}
+
+extern "C" int mq_avgpool_t2_fwd_h(const uint16_t *x, int N, int T, int F, int C, uint16_t *y, mqStream stream)
+{
+    MQ_REQUIRE(x && y && N > 0 && T > 0 && T % 2 == 0 && F > 0 && C > 0 && C % 8 == 0 && al16(x) && al16(y),
+               "mq_avgpool_t2_fwd_h: bad arguments (T even, C %% 8 == 0, 16-byte alignment)");
+    const int64_t FC8 = (int64_t)F * C / 8;
+    hipLaunchKernelGGL(avgpool_t2_fwd_h_kernel, dim3(ew_grid((int64_t)N * (T / 2) * FC8, 256)), dim3(256), 0, S(stream), x, (int64_t)N,
+                       T, FC8, y);
+    MQ_LAUNCH_CHECK("mq_avgpool_t2_fwd_h");
+    return 0;
+}
+extern "C" int mq_avgpool_t2_bwd_h(const uint16_t *dy, int N, int T, int F, int C, uint16_t *dx, mqStream stream)
+{
+    MQ_REQUIRE(dy && dx && N > 0 && T > 0 && T % 2 == 0 && F > 0 && C > 0 && C % 8 == 0 && al16(dy) && al16(dx),
+               "mq_avgpool_t2_bwd_h: bad arguments (T even, C %% 8 == 0, 16-byte alignment)");
+    const int64_t FC8 = (int64_t)F * C / 8;
+    hipLaunchKernelGGL(avgpool_t2_bwd_h_kernel, dim3(ew_grid((int64_t)N * (T / 2) * FC8, 256)), dim3(256), 0, S(stream), dy, (int64_t)N,
+                       T, FC8, dx);
+    MQ_LAUNCH_CHECK("mq_avgpool_t2_bwd_h");
+    return 0;
+}
+extern "C" int mq_upcat_fwd_h(const uint16_t *x, const uint16_t *skip, int N, int T, int F, int C1, int C2, uint16_t *out, mqStream stream)
+{
+    MQ_REQUIRE(x && skip && out && N > 0 && T > 0 && F > 0 && C1 > 0 && C2 > 0 && C1 % 8 == 0 && C2 % 8 == 0 && al16(x) && al16(skip) && al16(out),
+               "mq_upcat_fwd_h: bad arguments (C1, C2 multiples of 8, 16-byte alignment)");
+    hipLaunchKernelGGL(upcat_fwd_h_kernel, dim3(ew_grid((int64_t)N * 2 * T * F * ((C1 + C2) / 8), 256)), dim3(256), 0, S(stream), x, skip,
+                       (int64_t)N, T, F, C1, C2, out);
+    MQ_LAUNCH_CHECK("mq_upcat_fwd_h");
+    return 0;
+}
+extern "C" int mq_upcat_bwd_h(const uint16_t *dout, int N, int T, int F, int C1, int C2, uint16_t *dx, uint16_t *dskip, mqStream stream)
+{
+    MQ_REQUIRE(dout && dx && dskip && N > 0 && T > 0 && F > 0 && C1 > 0 && C2 > 0 && C1 % 8 == 0 && C2 % 8 == 0 && al16(dout) && al16(dx) && al16(dskip),
+               "mq_upcat_bwd_h: bad arguments (C1, C2 multiples of 8, 16-byte alignment)");
+    hipLaunchKernelGGL(upcat_bwd_h_kernel, dim3(ew_grid((int64_t)N * T * F * ((C1 + C2) / 8), 256)), dim3(256), 0, S(stream), dout,
+                       (int64_t)N, T, F, C1, C2, dx, dskip);
+    MQ_LAUNCH_CHECK("mq_upcat_bwd_h");
     return 0;
 }

@@ -124,6 +124,11 @@ def run_discriminators(bands: List[MelSpectrogramPatchDiscriminator2D], x, x_len
     """Shared forward.  x (B, T, F) -> logits (G*B, H, W, 1) channels-last, padded mask uint8 (G*B, W) and
     [(feature (G*B, H, W, C), padded mask (G*B, W))].  G = len(bands); band j owns rows [jB, (j+1)B).
     ``detach_params``: treat the weights as constants (generator step: no discriminator weight gradients)."""
+    with ops.act_storage(ops.ACT_BF16_REQUESTED):                  # bf16 feature maps inside, f32 logits / features out
+        return _run_discriminators(bands, x, x_lengths, return_features, need_input_grad, detach_params)
+
+
+def _run_discriminators(bands, x, x_lengths, return_features, need_input_grad, detach_params):
     G = len(bands)
     d0 = bands[0]
     B, T, Fq = x.shape
@@ -138,6 +143,7 @@ def run_discriminators(bands: List[MelSpectrogramPatchDiscriminator2D], x, x_len
     for i in range(n):
         N, H, W, Cin = out.shape
         if i == n - 1:                                                        # masked SE before the logits conv (:216-217)
+            out = ops.to_f32(out)
             sq = ops.SeSqueezeFn.apply(out, mask)                             # (G*B, C)
             w1k, w1c, b1 = _stacked(bands, lambda d: d.se_block.fc1, detach=detach_params)
             w2k, w2c, b2 = _stacked(bands, lambda d: d.se_block.fc2, detach=detach_params)
@@ -157,7 +163,8 @@ def run_discriminators(bands: List[MelSpectrogramPatchDiscriminator2D], x, x_len
         if sw > 1:                                                            # ceil-mode max-pool of the mask (:223-229)
             mask = ops.mask_pool(mask, sw, ceil_mode=True)
         # conv -> LeakyReLU(0.2) -> masked_fill (:219, :232), fused into the conv's store where the kernel allows it
-        out = ops.conv_leaky(out, wk, wc, bias, desc, mask, (desc.P * desc.Q, desc.Q, desc.Q))
+        # (the layer in front of the squeeze-excite block and the logits conv hand f32 tensors on)
+        out = ops.conv_leaky(out, wk, wc, bias, desc, mask, (desc.P * desc.Q, desc.Q, desc.Q), out_f32=(i >= n - 2))
         if return_features and d0.ret_features_map[i]:
-            feats.append((out, mask))
-    return out, mask, feats
+            feats.append((ops.to_f32(out), mask))
+    return ops.to_f32(out), mask, feats

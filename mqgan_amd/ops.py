@@ -76,6 +76,47 @@ class conv_precision:
         return False
 
 
+# bf16 STORAGE of activations (training.precision: bf16): inside the refiner and the discriminators every tensor between
+# two convolutions is a bf16 tensor - what the reference's autocast region stores (train.py:220, 523) - and the layers
+# whose shapes allow it run on the LDS-DMA kernels of csrc/igemm_h2.hip.  Off by default (f32 tensors everywhere).
+ACT_BF16 = False
+# what the caller asked for (Trainer: training.precision == "bf16"); the modules that support bf16 storage (UNetRefiner,
+# the discriminators) switch ACT_BF16 on for their own body and hand f32 tensors back at their boundary
+ACT_BF16_REQUESTED = False
+
+
+class request_act_storage:
+    def __init__(self, on: bool):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global ACT_BF16_REQUESTED
+        self.prev, ACT_BF16_REQUESTED = ACT_BF16_REQUESTED, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global ACT_BF16_REQUESTED
+        ACT_BF16_REQUESTED = self.prev
+        return False
+
+
+class act_storage:
+    """``with ops.act_storage(True): ...`` - scoped switch of ACT_BF16."""
+
+    def __init__(self, on: bool):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global ACT_BF16
+        self.prev, ACT_BF16 = ACT_BF16, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global ACT_BF16
+        ACT_BF16 = self.prev
+        return False
+
+
 def conv_desc(N, H, W, Cin, K, R, S, stride=(1, 1), pad=(0, 0), dil=(1, 1), groups=1, out_hw=None,
               precision=None) -> ConvDesc:
     if out_hw is None:
@@ -133,8 +174,20 @@ def _timed(tag, flops, fn, detail=None):
         TIMER.run(tag, flops, fn, detail)
 
 
-def _conv_tag(kind, d: ConvDesc):
-    """Name of the kernel instantiation the C side picks (igemm.hip: launch_nt / mq_conv_wgrad)."""
+def _h2_tn(ncols):
+    return min((4, 3, 2, 1), key=lambda t: (-(-ncols // (64 * t)) * 64 * t / {4: 1.0, 3: 0.93, 2: 0.85, 1: 0.65}[t], -t))
+
+
+def _conv_tag(kind, d: ConvDesc, h2=False):
+    """Name of the kernel instantiation the C side picks (igemm.hip: launch_nt / mq_conv_wgrad; igemm_h2.hip)."""
+    if h2:
+        if kind == "wgrad":
+            wmtm = "4, 2" if (d.K % 256 == 0 or (d.K > 256 and d.K % 192 != 0)) else ("2, 3" if d.K % 192 == 0 else "2, 2")
+            return f"conv_wgrad_h2_kernel<{wmtm}, {1 if d.Q >= 64 else 4}>"
+        ncols, ic = (d.K, d.C) if kind == "fprop" else (d.C, d.K)
+        tn = _h2_tn(ncols)
+        par = kind == "dgrad" and (d.stride_h > 1 or d.stride_w > 1)
+        return f"conv_h2_kernel<{tn}, {2 if tn >= 3 else 3}, {64 if ic % 64 == 0 else 32}, {str(par).lower()}>"
     eng = {0: "", 1: "bf16_", 2: "x3_"}[d.precision]
     if kind == "wgrad":
         vec = d.C % 4 == 0 and d.K % 4 == 0
@@ -181,6 +234,43 @@ def cast_bf16(t: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def cast_f32(t: torch.Tensor) -> torch.Tensor:
+    t = t.contiguous()
+    out = torch.empty(t.shape, dtype=F32, device=t.device)
+    check(L().mq_cast_f32(ptr(t, BF16), fptr(out), t.numel(), stream()), "mq_cast_f32")
+    return out
+
+
+class CastFn(torch.autograd.Function):
+    """dtype change between f32 and bf16 tensors (the gradient is cast back)."""
+
+    @staticmethod
+    def forward(ctx, t, to_bf16):
+        ctx.to_bf16 = to_bf16
+        return cast_bf16(t) if to_bf16 else cast_f32(t)
+
+    @staticmethod
+    def backward(ctx, d):
+        if d.dtype == (BF16 if ctx.to_bf16 else F32):
+            return (cast_f32(d) if ctx.to_bf16 else cast_bf16(d)), None
+        return d.contiguous(), None
+
+
+def to_bf16(t):
+    return t if t.dtype == BF16 else CastFn.apply(t, True)
+
+
+def to_f32(t):
+    return t if t.dtype == F32 else CastFn.apply(t, False)
+
+
+def to_storage(t):
+    """Activation tensor in the storage dtype of the current mode (bf16 needs a channel count that is a multiple of 8)."""
+    if ACT_BF16 and t.shape[-1] % 8 == 0:
+        return to_bf16(t)
+    return to_f32(t)
+
+
 # bf16-storage conv kernels (mq_conv_*_h): 10-17 % faster than rounding inside the kernel and bit-identical, but here the
 # bf16 copies are made by a separate cast pass per conv, which costs as much as the kernels gain (measured: 143.8 vs
 # 143.0 ms/step at C2).  They pay off once the producing kernels emit the copies; until then they are off by default.
@@ -191,6 +281,106 @@ def _h_ok(d: ConvDesc, reduce_channels: int) -> bool:
     """bf16-storage kernels: bf16 engine, reduction channel count a multiple of 16, strides <= 2."""
     return (BF16_STORAGE and d.precision == PRECISIONS["bf16"] and reduce_channels % 16 == 0 and d.stride_h <= 2
             and d.stride_w <= 2)
+
+
+# ----------------------------------------------------------------------------- bf16-storage convolution (H2 kernels)
+def h2_supported(d: ConvDesc) -> bool:
+    return bool(L().mq_h2_supported(C.byref(d)))
+
+
+def h2_wgrad_supported(d: ConvDesc) -> bool:
+    return bool(L().mq_h2_wgrad_supported(C.byref(d)))
+
+
+def h2_weight_image(d: ConvDesc, w: torch.Tensor, dgrad: bool) -> torch.Tensor:
+    """bf16 weight image of the H2 kernels from the f32 effective weights (KRSC for fprop, CRSK for dgrad)."""
+    n = L().mq_h2_weight_elems(C.byref(d), int(dgrad))
+    out = torch.empty((n,), dtype=BF16, device=w.device)
+    check(L().mq_h2_weight_image(C.byref(d), int(dgrad), fptr(w), ptr(out, BF16), stream()), "mq_h2_weight_image")
+    return out
+
+
+def conv_fprop_h2(d: ConvDesc, x, w_h2, bias=None, mask=None, dmap=(1, 0, 1), act=0, slope=0.2, out_dtype=None):
+    out_dtype = BF16 if out_dtype is None else out_dtype
+    y = torch.empty((d.N, d.P, d.Q, d.K), dtype=out_dtype, device=x.device)
+    _timed(_conv_tag("fprop", d, h2=True), _conv_flops(d), lambda: check(
+        L().mq_conv_fprop_h2(C.byref(d), ptr(x, BF16), ptr(w_h2, BF16), fptr(bias, True), ptr(mask, torch.uint8, True), dmap[0],
+                             dmap[1], dmap[2], int(act), float(slope), int(out_dtype == F32), ptr(y, out_dtype), stream()),
+        "mq_conv_fprop_h2"), _desc_key(d))
+    return y
+
+
+def conv_dgrad_h2(d: ConvDesc, dy, wt_h2, out_dtype=None):
+    out_dtype = BF16 if out_dtype is None else out_dtype
+    dx = torch.empty((d.N, d.H, d.W, d.C), dtype=out_dtype, device=dy.device)
+    _timed(_conv_tag("dgrad", d, h2=True), _conv_flops(d), lambda: check(
+        L().mq_conv_dgrad_h2(C.byref(d), ptr(dy, BF16), ptr(wt_h2, BF16), int(out_dtype == F32), ptr(dx, out_dtype), stream()),
+        "mq_conv_dgrad_h2"), _desc_key(d))
+    return dx
+
+
+def conv_wgrad_h2(d: ConvDesc, x, dy, w_shape, want_bias: bool):
+    dw = torch.empty(w_shape, dtype=F32, device=x.device)
+    db = torch.empty((d.groups * d.K,), dtype=F32, device=x.device) if want_bias else None
+    nbytes = L().mq_conv_wgrad_h2_workspace(C.byref(d))
+    ws = _ws_bytes(nbytes, x)
+    _timed(_conv_tag("wgrad", d, h2=True), _conv_flops(d), lambda: check(
+        L().mq_conv_wgrad_h2(C.byref(d), ptr(x, BF16), ptr(dy, BF16), fptr(dw), fptr(db, True), ptr(ws), nbytes, stream()),
+        "mq_conv_wgrad_h2"), _desc_key(d))
+    return dw, db
+
+
+class ConvH2Fn(torch.autograd.Function):
+    """Convolution on the bf16-storage kernels: x bf16, y bf16 (or f32), effective weights f32 (``w_krsc`` carries the
+    gradient).  ``epi`` = None, or (mask, dmap, slope): LeakyReLU + masked_fill fused into the store (the backward pass
+    reads LeakyReLU's derivative off the sign of y)."""
+
+    @staticmethod
+    def forward(ctx, x, w_krsc, w_crsk, bias, key, epi, out_f32):
+        d = _desc_from_key(key)
+        w_h2 = h2_weight_image(d, w_krsc, False)
+        if epi is None:
+            y = conv_fprop_h2(d, x, w_h2, bias, out_dtype=F32 if out_f32 else BF16)
+            mask = None
+        else:
+            mask, dmap, slope = epi
+            y = conv_fprop_h2(d, x, w_h2, bias, mask=mask, dmap=dmap, act=ACT_LEAKY, slope=slope, out_dtype=F32 if out_f32 else BF16)
+        ctx.key, ctx.epi_cfg = key, (None if epi is None else (epi[1], epi[2]))
+        ctx.w_shape = tuple(w_krsc.shape)
+        ctx.has_bias = bias is not None
+        ctx.have_crsk = w_crsk is not None
+        ctx.save_for_backward(x, w_crsk if w_crsk is not None else w_krsc, y if epi is not None else None, mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w_crsk, y, mask = ctx.saved_tensors
+        d = _desc_from_key(ctx.key)
+        dout = dout.contiguous()
+        if ctx.epi_cfg is not None:
+            dmap, slope = ctx.epi_cfg
+            if slope != 0.2:
+                raise _lib.MqganHipError("the pointwise backward kernel implements LeakyReLU(0.2) only")
+            dy = pointwise_bwd_raw(dout if dout.dtype == y.dtype else (cast_bf16(dout) if y.dtype == BF16 else cast_f32(dout)), y,
+                                   act=ACT_LEAKY, mask=mask, mask_post=mask is not None, dmap=dmap)
+        else:
+            dy = dout
+        if dy.dtype != BF16:
+            dy = cast_bf16(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if not ctx.have_crsk:
+                raise _lib.MqganHipError("conv backward wrt the input needs the CRSK weights")
+            dx = conv_dgrad_h2(d, dy, h2_weight_image(d, w_crsk, True), out_dtype=x.dtype)
+        want_db = ctx.has_bias and ctx.needs_input_grad[3]
+        if ctx.needs_input_grad[1]:
+            if h2_wgrad_supported(d):
+                dw, db = conv_wgrad_h2(d, x, dy, ctx.w_shape, want_db)
+            else:                       # narrow images (Q < 16): the f32 weight-gradient kernel on f32 copies
+                _, dw, db = _conv_backward_f32(d, ctx.key, cast_f32(x), None, cast_f32(dy), ctx.w_shape, False, True, want_db)
+        elif want_db:
+            db = _bias_grad(d, cast_f32(dy))
+        return dx, dw, None, db, None, None, None
 
 
 class ConvFn(torch.autograd.Function):
@@ -223,14 +413,32 @@ class ConvFn(torch.autograd.Function):
         return dx, dw, None, db, None
 
 
+def _bias_grad(d, dy):
+    rows_per_group = (d.N // d.groups) * d.P * d.Q
+    if d.groups == 1:
+        return colsum(dy.view(-1, d.K))
+    return torch.cat([colsum(dy.view(d.groups, rows_per_group, d.K)[g]) for g in range(d.groups)])
+
+
 def _conv_backward(ctx, x, w_crsk, dy):
     """dgrad / wgrad (+ fused bias gradient) of a conv whose forward stored key, w_shape, has_bias, have_crsk on ctx;
     inputs 0, 1, 3 of the Function are x, w_krsc, bias."""
+    if ctx.needs_input_grad[0] and not ctx.have_crsk:
+        raise _lib.MqganHipError("conv backward wrt the input needs the CRSK weights")
     d = _desc_from_key(ctx.key)
+    return _conv_backward_f32(d, ctx.key, x, w_crsk, dy, ctx.w_shape, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                              ctx.has_bias and ctx.needs_input_grad[3])
+
+
+def _conv_backward_f32(d, key, x, w_crsk, dy, w_shape, want_dx, want_dw, want_db):
+    class _C:       # the body below was written against an autograd ctx
+        pass
+    ctx = _C()
+    ctx.key, ctx.w_shape = key, w_shape
+    ctx.needs_input_grad = (want_dx, want_dw, False, want_db)
+    ctx.has_bias = want_db
     dx = dw = db = None
     if ctx.needs_input_grad[0]:
-        if not ctx.have_crsk:
-            raise _lib.MqganHipError("conv backward wrt the input needs the CRSK weights")
         dx = torch.empty_like(x)
         if _h_ok(d, d.K):
             dy_h, wc_h = cast_bf16(dy), cast_bf16(w_crsk)
@@ -257,11 +465,7 @@ def _conv_backward(ctx, x, w_crsk, dy):
                 L().mq_conv_wgrad(C.byref(d), fptr(x), fptr(dy), fptr(dw), ptr(ws), nbytes, stream()), "mq_conv_wgrad"),
                 ctx.key)
     elif want_db:
-        rows_per_group = (d.N // d.groups) * d.P * d.Q
-        if d.groups == 1:
-            db = colsum(dy.view(-1, d.K))
-        else:
-            db = torch.cat([colsum(dy.view(d.groups, rows_per_group, d.K)[g]) for g in range(d.groups)])
+        db = _bias_grad(d, dy)
     return dx, dw, db
 
 
@@ -365,8 +569,16 @@ def _thin_conv(x, w_krsc, w_crsk, bias, desc: ConvDesc, leaky=None):
     return TapsReduceFn.apply(u, bias, key, T).view(desc.N, desc.P, desc.Q, 1)
 
 
-def conv_leaky(x, w_krsc, w_crsk, bias, desc: ConvDesc, mask, dmap, slope: float = 0.2):
+def _use_h2(desc: ConvDesc) -> bool:
+    # (tiny GEMMs - the squeeze-excite linears - stay on the f32 path: a 256-row tile would be mostly padding)
+    return (ACT_BF16 and desc.precision == PRECISIONS["bf16"] and desc.N * desc.P * desc.Q >= 2048 and h2_supported(desc))
+
+
+def conv_leaky(x, w_krsc, w_crsk, bias, desc: ConvDesc, mask, dmap, slope: float = 0.2, out_f32: bool = False):
     """LeakyReLU(conv) with padded frames zeroed - one kernel where the fused epilogue applies, conv + pointwise otherwise."""
+    if _use_h2(desc):
+        return ConvH2Fn.apply(to_bf16(x), w_krsc, w_crsk, bias, _desc_key(desc), (mask, tuple(dmap), slope), out_f32)
+    x = to_f32(x)
     thin = desc.R * desc.S > 1 and ((desc.C == 1) != (desc.K == 1)) and (desc.C % 4 == 0 or desc.K % 4 == 0)
     if thin and desc.C == 1:
         return _thin_conv(x, w_krsc, w_crsk, bias, desc, leaky=(mask, tuple(dmap), slope))
@@ -375,7 +587,12 @@ def conv_leaky(x, w_krsc, w_crsk, bias, desc: ConvDesc, mask, dmap, slope: float
     return ConvLeakyFn.apply(x, w_krsc, w_crsk, bias, mask, _desc_key(desc), tuple(dmap), slope)
 
 
-def conv(x, w_krsc, w_crsk, bias, desc: ConvDesc):
+def conv(x, w_krsc, w_crsk, bias, desc: ConvDesc, out_f32: bool = False):
+    """Convolution on the engine the descriptor names.  With bf16 activation storage on, layers the H2 kernels take read
+    and write bf16 tensors (f32 output on request); every other layer reads and writes f32 tensors."""
+    if _use_h2(desc):
+        return ConvH2Fn.apply(to_bf16(x), w_krsc, w_crsk, bias, _desc_key(desc), None, out_f32)
+    x = to_f32(x)
     if desc.R * desc.S > 1 and ((desc.C == 1) != (desc.K == 1)) and (desc.C % 4 == 0 or desc.K % 4 == 0):
         return _thin_conv(x, w_krsc, w_crsk, bias, desc)
     return ConvFn.apply(x, w_krsc, w_crsk, bias, _desc_key(desc))
@@ -465,8 +682,13 @@ class PointwiseFn(torch.autograd.Function):
         d = PointwiseDesc(rows=rows, C=Cc, act=act, mask_pre=int(mask_pre), mask_post=int(mask_post), d1=dmap[0], d2=dmap[1],
                           d3=dmap[2], p_drop=float(p_drop), seed=seed)
         out = torch.empty_like(h)
-        check(L().mq_pointwise_fwd(C.byref(d), fptr(h), fptr(r_pre, True), fptr(r_post, True), ptr(mask, torch.uint8, True),
-                                   fptr(beta, True), fptr(gamma, True), fptr(out), stream()), "mq_pointwise_fwd")
+        if h.dtype == BF16:
+            check(L().mq_pointwise_fwd_h(C.byref(d), ptr(h, BF16), ptr(r_pre, BF16, True), ptr(r_post, BF16, True),
+                                         ptr(mask, torch.uint8, True), fptr(beta, True), fptr(gamma, True), ptr(out, BF16), stream()),
+                  "mq_pointwise_fwd_h")
+        else:
+            check(L().mq_pointwise_fwd(C.byref(d), fptr(h), fptr(r_pre, True), fptr(r_post, True), ptr(mask, torch.uint8, True),
+                                       fptr(beta, True), fptr(gamma, True), fptr(out), stream()), "mq_pointwise_fwd")
         ctx.cfg = cfg
         ctx.save_for_backward(h, r_pre, mask, beta, gamma)
         ctx.has_post = r_post is not None
@@ -481,6 +703,8 @@ class PointwiseFn(torch.autograd.Function):
         d = PointwiseDesc(rows=rows, C=Cc, act=act, mask_pre=int(mask_pre), mask_post=int(mask_post), d1=dmap[0], d2=dmap[1],
                           d3=dmap[2], p_drop=float(p_drop), seed=seed)
         dout = dout.contiguous()
+        if dout.dtype != h.dtype:
+            dout = cast_bf16(dout) if h.dtype == BF16 else cast_f32(dout)
         dt = torch.empty_like(h)
         dpost = torch.empty_like(h) if (ctx.has_post and ctx.needs_input_grad[2]) else None
         want_b = beta is not None and ctx.needs_input_grad[4]
@@ -488,10 +712,30 @@ class PointwiseFn(torch.autograd.Function):
         dbeta = torch.empty_like(beta) if want_b else None
         dgamma = torch.empty_like(gamma) if want_g else None
         ws = _empty((2 * 1024,), h) if (want_b or want_g) else None
-        check(L().mq_pointwise_bwd(C.byref(d), fptr(dout), fptr(h), fptr(r_pre, True), ptr(mask, torch.uint8, True),
-                                   fptr(beta, True), fptr(gamma, True), fptr(dt), fptr(dpost, True), fptr(dbeta, True),
-                                   fptr(dgamma, True), fptr(ws, True), stream()), "mq_pointwise_bwd")
+        if h.dtype == BF16:
+            check(L().mq_pointwise_bwd_h(C.byref(d), ptr(dout, BF16), ptr(h, BF16), ptr(r_pre, BF16, True), ptr(mask, torch.uint8, True),
+                                         fptr(beta, True), fptr(gamma, True), ptr(dt, BF16), ptr(dpost, BF16, True), fptr(dbeta, True),
+                                         fptr(dgamma, True), fptr(ws, True), stream()), "mq_pointwise_bwd_h")
+        else:
+            check(L().mq_pointwise_bwd(C.byref(d), fptr(dout), fptr(h), fptr(r_pre, True), ptr(mask, torch.uint8, True),
+                                       fptr(beta, True), fptr(gamma, True), fptr(dt), fptr(dpost, True), fptr(dbeta, True),
+                                       fptr(dgamma, True), fptr(ws, True), stream()), "mq_pointwise_bwd")
         return dt, (dt if r_pre is not None else None), dpost, None, dbeta, dgamma, None
+
+
+def pointwise_bwd_raw(dout, h, *, act, mask=None, mask_post=False, dmap=(1, 1, 1)):
+    """dt of a parameter-free pointwise stage (no residuals, no dropout) - used by the fused conv epilogues' backward."""
+    Cc = h.shape[-1]
+    pd = PointwiseDesc(rows=h.numel() // Cc, C=Cc, act=act, mask_pre=0, mask_post=int(mask_post), d1=dmap[0], d2=dmap[1], d3=dmap[2],
+                       p_drop=0.0, seed=0)
+    dt = torch.empty_like(h)
+    if h.dtype == BF16:
+        check(L().mq_pointwise_bwd_h(C.byref(pd), ptr(dout, BF16), ptr(h, BF16), None, ptr(mask, torch.uint8, True), None, None,
+                                     ptr(dt, BF16), None, None, None, None, stream()), "mq_pointwise_bwd_h")
+    else:
+        check(L().mq_pointwise_bwd(C.byref(pd), fptr(dout), fptr(h), None, ptr(mask, torch.uint8, True), None, None, fptr(dt), None,
+                                   None, None, None, stream()), "mq_pointwise_bwd")
+    return dt
 
 
 def pointwise(h, *, act=ACT_NONE, r_pre=None, r_post=None, mask=None, mask_pre=False, mask_post=False, dmap=(1, 1, 1),
@@ -500,6 +744,12 @@ def pointwise(h, *, act=ACT_NONE, r_pre=None, r_post=None, mask=None, mask_pre=F
     index of row m is (m // d1) * d2 + (m % d3)."""
     p = float(p_drop) if training else 0.0
     seed = next_seed() if p > 0 else 0
+    if h.dtype == BF16:         # one storage type per launch
+        r_pre = None if r_pre is None else to_bf16(r_pre)
+        r_post = None if r_post is None else to_bf16(r_post)
+    else:
+        r_pre = None if r_pre is None else to_f32(r_pre)
+        r_post = None if r_post is None else to_f32(r_post)
     return PointwiseFn.apply(h, r_pre, r_post, mask, beta, gamma, (act, bool(mask_pre), bool(mask_post), tuple(dmap), p, seed))
 
 
@@ -532,16 +782,23 @@ class AvgPoolT2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         N, T, Fq, Cc = x.shape
-        y = _empty((N, T // 2, Fq, Cc), x)
-        check(L().mq_avgpool_t2_fwd(fptr(x), N, T, Fq, Cc, fptr(y), stream()), "mq_avgpool_t2_fwd")
+        y = _empty((N, T // 2, Fq, Cc), x, x.dtype)
+        if x.dtype == BF16:
+            check(L().mq_avgpool_t2_fwd_h(ptr(x, BF16), N, T, Fq, Cc, ptr(y, BF16), stream()), "mq_avgpool_t2_fwd_h")
+        else:
+            check(L().mq_avgpool_t2_fwd(fptr(x), N, T, Fq, Cc, fptr(y), stream()), "mq_avgpool_t2_fwd")
         ctx.shape = (N, T, Fq, Cc)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         N, T, Fq, Cc = ctx.shape
-        dx = _empty(ctx.shape, dy)
-        check(L().mq_avgpool_t2_bwd(fptr(dy.contiguous()), N, T, Fq, Cc, fptr(dx), stream()), "mq_avgpool_t2_bwd")
+        dy = dy.contiguous()
+        dx = _empty(ctx.shape, dy, dy.dtype)
+        if dy.dtype == BF16:
+            check(L().mq_avgpool_t2_bwd_h(ptr(dy, BF16), N, T, Fq, Cc, ptr(dx, BF16), stream()), "mq_avgpool_t2_bwd_h")
+        else:
+            check(L().mq_avgpool_t2_bwd(fptr(dy), N, T, Fq, Cc, fptr(dx), stream()), "mq_avgpool_t2_bwd")
         return dx
 
 
@@ -552,17 +809,26 @@ class UpCatFn(torch.autograd.Function):
         C2 = skip.shape[-1]
         if tuple(skip.shape[:3]) != (N, 2 * T, Fq):
             raise _lib.MqganHipError(f"upcat: skip {tuple(skip.shape)} does not match upsampled {(N, 2 * T, Fq)}")
-        out = _empty((N, 2 * T, Fq, C1 + C2), x)
-        check(L().mq_upcat_fwd(fptr(x), fptr(skip), N, T, Fq, C1, C2, fptr(out), stream()), "mq_upcat_fwd")
+        if x.dtype != skip.dtype:
+            raise _lib.MqganHipError(f"upcat: dtype mismatch {x.dtype} vs {skip.dtype}")
+        out = _empty((N, 2 * T, Fq, C1 + C2), x, x.dtype)
+        if x.dtype == BF16:
+            check(L().mq_upcat_fwd_h(ptr(x, BF16), ptr(skip, BF16), N, T, Fq, C1, C2, ptr(out, BF16), stream()), "mq_upcat_fwd_h")
+        else:
+            check(L().mq_upcat_fwd(fptr(x), fptr(skip), N, T, Fq, C1, C2, fptr(out), stream()), "mq_upcat_fwd")
         ctx.dims = (N, T, Fq, C1, C2)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         N, T, Fq, C1, C2 = ctx.dims
-        dx = _empty((N, T, Fq, C1), dout)
-        ds = _empty((N, 2 * T, Fq, C2), dout)
-        check(L().mq_upcat_bwd(fptr(dout.contiguous()), N, T, Fq, C1, C2, fptr(dx), fptr(ds), stream()), "mq_upcat_bwd")
+        dout = dout.contiguous()
+        dx = _empty((N, T, Fq, C1), dout, dout.dtype)
+        ds = _empty((N, 2 * T, Fq, C2), dout, dout.dtype)
+        if dout.dtype == BF16:
+            check(L().mq_upcat_bwd_h(ptr(dout, BF16), N, T, Fq, C1, C2, ptr(dx, BF16), ptr(ds, BF16), stream()), "mq_upcat_bwd_h")
+        else:
+            check(L().mq_upcat_bwd(fptr(dout), N, T, Fq, C1, C2, fptr(dx), fptr(ds), stream()), "mq_upcat_bwd")
         return dx, ds
 
 

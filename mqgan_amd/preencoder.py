@@ -48,11 +48,12 @@ class ConvBlock(nn.Module):
         Fq = x.shape[2]
         dmap = (Fq, 1, 1)
         b, g = self.act.params()
+        x = ops.to_storage(x)                                      # bf16 tensors between the convs when storage is on
         if not input_is_masked:
             x = ops.pointwise(x, mask=mask, mask_post=True, dmap=dmap)
-        y = conv2d(x, self.conv1, need_dx=need_dx)
+        y = ops.to_storage(conv2d(x, self.conv1, need_dx=need_dx))
         y = ops.pointwise(y, act=ops.ACT_APTX, beta=b, gamma=g, p_drop=self.p_drop, training=self.training)
-        y = conv2d(y, self.conv2)
+        y = ops.to_storage(conv2d(y, self.conv2))
         return ops.pointwise(y, act=ops.ACT_APTX, beta=b, gamma=g, p_drop=self.p_drop, training=self.training,
                              r_post=x if self.match else None, mask=mask, mask_post=True, dmap=dmap)
 
@@ -99,6 +100,10 @@ class UNetRefiner(nn.Module):
         self.reproj = ConvParams(input_out_channels[1], input_out_channels[0], (), bias=False)
 
     def forward(self, x, x_mask):
+        with ops.act_storage(ops.ACT_BF16_REQUESTED):              # bf16 tensors inside, f32 in and out
+            return self._forward(x, x_mask)
+
+    def _forward(self, x, x_mask):
         B, T0, Fq, _ = x.shape
         mult = 1 << self.depth
         pad = (mult - T0 % mult) % mult                            # pad_to_pow2_4d (:29-47)
@@ -120,7 +125,7 @@ class UNetRefiner(nn.Module):
         for up in self.ups:
             x, cur = up(x, skips.pop(), cur)
         # x is already masked with `cur` by the last block, so apply_mask(x, cur_mask) (:191) is a no-op
-        out = conv2d(x, self.post).view(B, T0 + pad, Fq)
+        out = ops.to_f32(conv2d(x, self.post)).view(B, T0 + pad, Fq)
         if pad:
             out = out[:, :T0].contiguous()
         out = ops.pointwise(out, mask=x_mask, mask_post=True)      # (:197-198)

@@ -197,6 +197,9 @@ class Trainer:
         if prec not in ("fp32", "f32", "bf16", "f32x3", "fp32x3"):
             raise ValueError(f"training.precision must be fp32, fp32x3 or bf16, got {prec!r}")
         self.use_bf16 = prec == "bf16"
+        # bf16 mode stores the refiner's and the discriminators' activations as bf16 tensors, as the reference's autocast
+        # region does (train.py:220, 523); training.bf16_storage: false keeps f32 tensors with in-kernel rounding
+        self.bf16_storage = bool(config["training"].get("bf16_storage", True))
         # "fp32x3": f32 results from the bf16 matrix pipe (exact three-term split of every operand, 6 cross products);
         # opt-in - it has the error of an f32 FMA chain but is not bit-identical to the default engine
         self.conv_precision = "bf16" if self.use_bf16 else ("f32x3" if prec.endswith("x3") else "f32")
@@ -435,7 +438,7 @@ class Trainer:
     # -- one optimisation step on a device batch (train.py:516-537) --------------------------------
     def train_step(self, real, lens):
         """real (B, T, mel) fp32 and lens (B,) int32, both on the device -> dict of device scalars."""
-        with ops.conv_precision(self.conv_precision):
+        with ops.conv_precision(self.conv_precision), ops.request_act_storage(self.use_bf16 and self.bf16_storage):
             recon_pre, recon_post = self.generator(real, lens)
             out = {"loss_d": torch.zeros((), device=self.device)}
             if self.epoch >= self.config["training"]["discriminator_train_start_epoch"]:

@@ -1,0 +1,208 @@
+"""-m gpu: the bf16-storage convolution kernels (csrc/igemm_h2.hip) through the C ABI against float64 CPU convolutions.
+
+Operands are drawn bf16-representable, so every product is exact and the f32 accumulation carries the only error:
+with f32 output the kernels must meet the same 2e-5 bound as the f32 engine; with bf16 output the result must be the
+correctly rounded reference to within one bf16 ulp (2^-8 relative)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import DEV, assert_rel  # noqa: E402
+from test_gpu_kernels import _torch_conv  # noqa: E402
+
+BF16 = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def env():
+    import __graft_entry__ as g
+    g.build()
+    assert torch.cuda.is_available()
+    from mqgan_amd import ops
+    return ops
+
+
+H2_CASES = [
+    dict(N=2, H=24, W=18, C=64, K=64, R=3, S=3, pad=(1, 1)),                                  # CB = 64, TN = 1
+    dict(N=2, H=20, W=33, C=96, K=96, R=3, S=3, pad=(1, 1)),                                  # CB = 32, odd position count
+    dict(N=1, H=1, W=300, C=32, K=128, R=1, S=1),                                             # linear
+    dict(N=1, H=40, W=18, C=288, K=96, R=3, S=3, pad=(1, 1)),                                 # refiner ups.2.conv1 (C3 widths)
+    dict(N=1, H=8, W=32, C=384, K=768, R=3, S=3, pad=(1, 1)),                                 # TN = 4, three N tiles
+    dict(N=1, H=16, W=40, C=192, K=192, R=3, S=3, pad=(1, 1)),                                # TN = 3
+    dict(N=2, H=16, W=20, C=64, K=128, R=5, S=5, stride=(2, 2), pad=(2, 2)),                  # stride (2,2): parity dgrad
+    dict(N=2, H=9, W=21, C=32, K=64, R=3, S=3, stride=(2, 1), pad=(1, 1)),                    # stride (2,1), odd H
+    dict(N=1, H=12, W=40, C=96, K=32, R=7, S=7, stride=(2, 2), pad=(3, 3)),                   # 7x7 s2, CB = 32
+    dict(N=16, H=2, W=40, C=32, K=64, R=3, S=5, stride=(1, 2), pad=(1, 2), groups=8),         # multibin: 8 groups
+    dict(N=1, H=5, W=37, C=64, K=32, R=3, S=3, pad=(2, 2), dil=(2, 2)),                       # dilation
+    dict(N=1, H=1, W=70, C=128, K=160, R=1, S=7, pad=(0, 6), out_hw=(1, 70)),                 # causal 1-D, ragged N tile
+    dict(N=3, H=30, W=90, C=64, K=64, R=3, S=3, pad=(1, 1)),                                  # Q >= 64: one-wrap pixel walk
+]
+
+
+def _ids(c):
+    return "N{N}H{H}W{W}C{C}K{K}R{R}S{S}".format(**c) + f"g{c.get('groups', 1)}"
+
+
+def _setup(ops, c):
+    torch.manual_seed(0)
+    G = c.get("groups", 1)
+    rb = lambda v: v.bfloat16().double()
+    x = rb(torch.randn(c["N"], c["H"], c["W"], c["C"], dtype=torch.float64))
+    w = rb(torch.randn(G * c["K"], c["C"], c["R"], c["S"], dtype=torch.float64) * 0.2)
+    b = torch.randn(G * c["K"], dtype=torch.float64).float().double()
+    desc = ops.conv_desc(c["N"], c["H"], c["W"], c["C"], c["K"], c["R"], c["S"], stride=c.get("stride", (1, 1)),
+                         pad=c.get("pad", (0, 0)), dil=c.get("dil", (1, 1)), groups=G, out_hw=c.get("out_hw"), precision="bf16")
+    wd = w.float().to(DEV)
+    ks, cs = [], []
+    for gi in range(G):
+        a, bb = ops.weight_prep(wd[gi * c["K"]:(gi + 1) * c["K"]].contiguous(), None, True)
+        ks.append(a); cs.append(bb)
+    wk, wc = torch.cat(ks, 0), torch.cat(cs, 0)
+    return x, w, b, desc, wk, wc
+
+
+@pytest.mark.parametrize("c", H2_CASES, ids=_ids)
+def test_h2_fprop_dgrad_wgrad_vs_float64(env, c):
+    ops = env
+    x, w, b, desc, wk, wc = _setup(ops, c)
+    assert ops.h2_supported(desc)
+    x.requires_grad_(True); w.requires_grad_(True); b.requires_grad_(True)
+    y_ref = _torch_conv(x, w, b, c)
+    r = torch.randn_like(y_ref).bfloat16().double()
+    (y_ref * r).sum().backward()
+
+    xh = x.detach().to(DEV).to(BF16)
+    w_h2 = ops.h2_weight_image(desc, wk, False)
+    wt_h2 = ops.h2_weight_image(desc, wc, True)
+    bd = b.float().to(DEV)
+    y32 = ops.conv_fprop_h2(desc, xh, w_h2, bd, out_dtype=torch.float32)
+    assert tuple(y32.shape) == tuple(y_ref.shape)
+    assert_rel(y32, y_ref, 2e-5, "fprop (f32 out)")
+    y16 = ops.conv_fprop_h2(desc, xh, w_h2, bd)
+    assert y16.dtype == BF16
+    want16 = y_ref.detach().float().to(BF16).float()
+    got16 = y16.float().cpu()
+    # one bf16 ulp is <= 2^-7 of the value; the f32 accumulation error (1e-5 of the tensor's scale) can move a value
+    # across a rounding boundary
+    ulp = want16.abs() * 2.0 ** -7 + 1e-5 * float(y_ref.detach().pow(2).mean().sqrt())
+    assert bool(((got16 - want16).abs() <= ulp).all()), "fprop (bf16 out) is off by more than one ulp"
+    rh = r.to(DEV).to(BF16)
+    dx = ops.conv_dgrad_h2(desc, rh, wt_h2, out_dtype=torch.float32)
+    assert_rel(dx, x.grad, 2e-5, "dgrad")
+    dx16 = ops.conv_dgrad_h2(desc, rh, wt_h2)
+    assert_rel(dx16.float(), x.grad, 4e-3, "dgrad (bf16 out)")
+    if ops.h2_wgrad_supported(desc):
+        dw, db = ops.conv_wgrad_h2(desc, xh, rh, tuple(wk.shape), True)
+        # bring dw (KRSC, channel-blocked) back to the reference layout through the weight-prep backward
+        G = c.get("groups", 1)
+        dws = []
+        for gi in range(G):
+            v = torch.zeros(c["K"], c["C"], c["R"] * c["S"], device=DEV)
+            dv = torch.empty_like(v)
+            from mqgan_amd.ops import check, fptr, stream
+            check(ops.L().mq_weight_prep_bwd(0, fptr(dw[gi * c["K"]:(gi + 1) * c["K"]].contiguous()), fptr(v), None, None, c["K"],
+                                             c["C"], c["R"] * c["S"], fptr(dv), None, stream()), "mq_weight_prep_bwd")
+            dws.append(dv.view(c["K"], c["C"], c["R"], c["S"]))
+        assert_rel(torch.cat(dws, 0), w.grad, 2e-5, "wgrad")
+        assert_rel(db, b.grad, 2e-5, "bias grad")
+    else:
+        assert desc.Q < 16
+
+
+def test_h2_leaky_mask_epilogue(env):
+    ops = env
+    c = dict(N=4, H=6, W=40, C=64, K=96, R=3, S=3, stride=(1, 2), pad=(1, 1))
+    x, w, b, desc, wk, wc = _setup(ops, c)
+    y_ref = _torch_conv(x, w, b, c)                                             # (N, P, Q, K)
+    mask = torch.zeros(c["N"], desc.Q, dtype=torch.uint8)
+    mask[1, 13:] = 1
+    mask[3, 5:] = 1
+    want = F.leaky_relu(y_ref, 0.2) * (1 - mask[:, None, :, None].double())
+    y = ops.conv_fprop_h2(desc, x.to(DEV).to(BF16), ops.h2_weight_image(desc, wk, False), b.float().to(DEV), mask=mask.to(DEV),
+                          dmap=(desc.P * desc.Q, desc.Q, desc.Q), act=2, slope=0.2, out_dtype=torch.float32)
+    assert_rel(y, want, 2e-5, "leaky + mask")
+    assert float(y[1, :, 13:].abs().max()) == 0.0
+
+
+def test_h2_full_size_refiner_layer_and_addressing(env):
+    """C3's deepest refiner level at full size (16 x 128 x 144 pixels, 768 -> 768 channels): the H2 kernels against the
+    f32-tensor bf16 engine of igemm.hip on the same bf16-representable operands (both have exact products and f32
+    accumulation: agreement to f32 rounding), and an image copied to the end of the batch reproduces the first one."""
+    ops = env
+    torch.manual_seed(4)
+    N, H, W, Cc, K = 16, 128, 144, 768, 768
+    x = torch.randn(N, H, W, Cc, device=DEV).to(BF16)
+    x[N - 1] = x[0]
+    w = (torch.randn(K, Cc, 3, 3, device=DEV) * 0.02).to(BF16).float()
+    wk, wc = ops.weight_prep(w, None, True)
+    d = ops.conv_desc(N, H, W, Cc, K, 3, 3, pad=(1, 1), precision="bf16")
+    y = ops.conv_fprop_h2(d, x, ops.h2_weight_image(d, wk, False), None, out_dtype=torch.float32)
+    assert torch.equal(y[N - 1], y[0])
+    y_old = ops.conv(x.float(), wk, wc, None, d)
+    scale = float(y_old.pow(2).mean().sqrt())
+    assert float((y - y_old).abs().max()) / scale < 2e-5
+    r = torch.randn(N, H, W, K, device=DEV).to(BF16)
+    dx = ops.conv_dgrad_h2(d, r, ops.h2_weight_image(d, wc, True), out_dtype=torch.float32)
+    dw, _ = ops.conv_wgrad_h2(d, x, r, tuple(wk.shape), False)
+    xf = x.float().requires_grad_(True)
+    wkf = wk.clone().requires_grad_(True)
+    (ops.conv(xf, wkf, wc, None, d) * r.float()).sum().backward()
+    assert float((dx - xf.grad).abs().max()) / float(xf.grad.pow(2).mean().sqrt()) < 2e-5
+    assert float((dw - wkf.grad).abs().max()) / float(wkf.grad.pow(2).mean().sqrt()) < 3e-4      # 295k pixel terms per weight in f32
+
+
+MID_CFG = {
+    "model": {"mel_channels": 32,
+              "generator": {"channels": [32, 32, 64], "kernel_sizes": [3, 5], "fsq_levels": [8, 5, 5, 5],
+                            "dropout": 0.1, "refiner_base_channels": 32, "refiner_depth": 3},
+              "discriminator_patch": {"hidden_channels": [32, 32, 64, 64, 64], "kernel_sizes": [5, 5, 5, 3, 3, 3],
+                                      "strides": [[1, 2], [2, 2], [2, 2], [2, 1], [2, 1], [2, 1]]},
+              "discriminator_multibin": {"hidden_channels": [32, 32, 64, 64, 96], "kernel_sizes": [7, 5, 3, 3, 3, 3],
+                                         "n_bins": 8, "n_no_strides": 2}},
+    "training": {"lr": 1e-4, "beta1": 0.9, "beta2": 0.999, "lr_d_factor": 1.15, "d_beta1": 0.5, "d_beta2": 0.999,
+                 "warmup_steps": 1000, "discriminator_train_start_epoch": 0,
+                 "loss_weights": {"fm_lambda": 0.25, "Gloss_lambda": 15.0, "recon_lambda": 15.0},
+                 "use_fm_loss": False, "seed": 42},
+}
+
+
+@pytest.mark.parametrize("use_fm", [False, True])
+def test_bf16_storage_train_step_tracks_fp32(env, use_fm):
+    """A model wide enough for the H2 kernels (all channel counts multiples of 32): two optimisation steps with
+    training.precision = bf16 (bf16 activations in the refiner and the discriminators, H2 convolutions, fused
+    LeakyReLU epilogues) against the same steps on the exact f32 engine: every loss within 3 %, gradient norms within
+    6 %, and the H2 kernels must really have run."""
+    ops = env
+    from mqgan_amd.train import Trainer, synthetic_mel
+    B, T, mel = 4, 128, 32
+    x = torch.from_numpy(np.stack([synthetic_mel(T, mel, 40 + b) for b in range(B)])).to(DEV)
+    lens = torch.tensor([T, 100, T, 77], dtype=torch.int32, device=DEV)
+    res = {}
+    for prec in ("fp32", "bf16"):
+        cfg = {"model": MID_CFG["model"], "training": dict(MID_CFG["training"], use_fm_loss=use_fm, pretrained=None, precision=prec)}
+        torch.manual_seed(7)
+        tr = Trainer(cfg, device=DEV, build_data=False)
+        tr.generator.eval()
+        tr.epoch = 1
+        timer = ops.KernelTimer()
+        ops.TIMER = timer
+        try:
+            outs = []
+            for _ in range(2):
+                out = tr.train_step(x, lens)
+                outs.append({k: float(v) for k, v in out.items()} | {"ng": float(tr.optimizer_g.grad_norm()), "nd": float(tr.optimizer_d.grad_norm())})
+        finally:
+            ops.TIMER = None
+        torch.cuda.synchronize()
+        res[prec] = (outs, set(timer.summary()))
+    tags = res["bf16"][1]
+    assert any("conv_h2_kernel" in t for t in tags) and any("conv_wgrad_h2_kernel" in t for t in tags), tags
+    assert not any("h2" in t for t in res["fp32"][1])
+    for s_ in range(2):
+        a, b = res["bf16"][0][s_], res["fp32"][0][s_]
+        for k in ("loss_d", "loss_g_total", "loss_recon_pre", "loss_recon_post", "loss_gan") + (("loss_fm",) if use_fm else ()):
+            np.testing.assert_allclose(a[k], b[k], rtol=3e-2, atol=1e-4, err_msg=f"step {s_} {k}")
+        np.testing.assert_allclose([a["ng"], a["nd"]], [b["ng"], b["nd"]], rtol=6e-2, err_msg=f"step {s_} norms")
