@@ -46,17 +46,29 @@ def synthetic_batches(B, T, mel, n, device, rank):
     return out
 
 
+def kernel_build_id():
+    """Hash of the conv kernel sources: ties a PMC traffic file to the build it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("gemm_core.h", "igemm.hip", "igemm_h2.hip", "common.h"):
+        with open(os.path.join(ROOT, "mqgan_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel_tag):
     """HBM-side bytes per launch of `kernel_tag` from the last committed PMC pass (tools/pmc_traffic.sh: FETCH_SIZE
     and WRITE_SIZE in separate rocprofv3 --pmc runs of this same bench, FETCH_SIZE x2 as the gfx950 note in
     MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside the process, so the figure is taken
-    from profiles/; None when no pass covers this kernel."""
+    from profiles/; None when no pass covers this kernel or when the pass was taken on other kernel sources."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
         return None, None
     with open(files[-1]) as f:
         t = json.load(f)
+    if t.get("_build") != kernel_build_id():
+        return None, os.path.relpath(files[-1], ROOT) + " (stale: measured on other kernel sources)"
     e = t.get(kernel_tag)
     if not e:
         return None, None
@@ -107,33 +119,65 @@ def bench_vq(device):
     return out
 
 
-def cpu_baseline(seconds_budget=30.0):
-    """The oracle's train step on the host cores: hifispeech architecture, mel 80, batch 2 x 256 frames
-    (BASELINE config 1), discriminators active, generator in train mode.  One untimed tiny step to page
-    things in, then as many timed steps as fit the budget (at least one)."""
+def _oracle_trainer(cfg):
     from oracle import train_step as TS
-    from mqgan_amd.train import synthetic_mel
-    cfg = load_config("hifispeech")
-    threads = torch.get_num_threads()
     Pg = TS.make_leaves(TS.init_generator_params(cfg))
     pc, mc = cfg["model"]["discriminator_patch"], cfg["model"]["discriminator_multibin"]
     Pp = TS.make_leaves(TS.init_patch_params(80, pc["hidden_channels"], pc["kernel_sizes"]))
     Pm = TS.make_leaves(TS.init_multibin_params(80, mc["n_bins"], mc["hidden_channels"], mc["kernel_sizes"]))
-    tr = TS.OracleTrainer(Pg, Pp, Pm, cfg, gen_training=True)
-    warm = torch.from_numpy(np.stack([synthetic_mel(32, 80, 900 + b) for b in range(1)]))
-    tr.step(warm, torch.tensor([32], dtype=torch.int32))
+    return TS.OracleTrainer(Pg, Pp, Pm, cfg, gen_training=True)
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """The oracle's train step on the host cores: hifispeech architecture, mel 80, batch 2 x 256 frames (BASELINE
+    config 1), discriminators active, generator in train mode.  The thread count is picked by a short sweep on a
+    small probe step (more threads than the cgroup's share of cores only adds contention), then one untimed warm-up
+    step of the SAME shape and at least three timed steps."""
+    from mqgan_amd.train import synthetic_mel
+    cfg = load_config("hifispeech")
     B, T = 2, 256
+
+    def batch(n0, b, t):
+        return (torch.from_numpy(np.stack([synthetic_mel(t, 80, n0 + i) for i in range(b)])), torch.tensor([t] * b, dtype=torch.int32))
+
+    ncpu = os.cpu_count() or 8
+    try:
+        ncpu = min(ncpu, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    cands = sorted({c for c in (8, 16, 32, 64, ncpu // 2) if 1 <= c <= ncpu} | {min(8, ncpu)})
+    tr = _oracle_trainer(cfg)
+    probe = {}
+    xs, ls = batch(900, 1, 64)
+    torch.set_num_threads(cands[0])
+    tr.step(xs, ls)                                   # page everything in
+    for c in cands:
+        torch.set_num_threads(c)
+        t0 = time.time()
+        tr.step(xs, ls)
+        probe[c] = time.time() - t0
+    threads = min(probe, key=probe.get)
+    torch.set_num_threads(threads)
+    tr = _oracle_trainer(cfg)                         # fresh optimiser state for the measured run
+    x, l = batch(0, B, T)
+    t0 = time.time()
+    tr.step(x, l)                                     # warm-up: same shape as the timed steps
+    warm = time.time() - t0
     n, t0 = 0, time.time()
     while True:
-        x = torch.from_numpy(np.stack([synthetic_mel(T, 80, n * B + b) for b in range(B)]))
-        tr.step(x, torch.tensor([T] * B, dtype=torch.int32))
+        x, l = batch((n + 1) * B, B, T)
+        tr.step(x, l)
         n += 1
         el = time.time() - t0
-        if el + el / n > seconds_budget:
+        if n >= 3 and el + el / n > seconds_budget:
+            break
+        if n >= 3 and el > seconds_budget:
             break
     return {"value": n * B * T / el, "unit": "mel-frames/s", "cores": threads, "kind": "port",
-            "sample": f"{n} step(s) of batch {B} x {T} frames, hifispeech@80, D active, fp32, oracle/train_step.py, "
-                      f"{el:.1f} s on {threads} threads ({os.cpu_count()} logical CPUs visible)"}
+            "sample": f"{n} timed steps (after a same-shape warm-up step of {warm:.1f} s) of batch {B} x {T} frames, hifispeech@80, "
+                      f"D active, fp32, oracle/train_step.py, {el:.1f} s on {threads} threads; thread sweep on a 1 x 64 probe step: "
+                      + ", ".join(f"{c}: {v:.2f} s" for c, v in sorted(probe.items()))
+                      + f" ({os.cpu_count()} logical CPUs visible); reference's own figure on 8 threads: 38 frames/s (BASELINE.md)"}
 
 
 def quick_engine(cfg, precision, device, batches, lens, B, T, steps=4, warmup=1):
@@ -157,8 +201,99 @@ def quick_engine(cfg, precision, device, batches, lens, B, T, steps=4, warmup=1)
            "losses_finite": all(np.isfinite(float(v)) for v in last.values()),
            "arithmetic": {"fp32x3": "f32 operands split exactly into 3 bf16 terms in-kernel, 6 cross products on the bf16 MFMA, "
                                     "f32 accumulate; passes the reference fixtures at the f32 tolerances",
-                          "bf16": "operands rounded to bf16 in-kernel, f32 accumulate, f32 tensors (reference autocast mode)"}[precision]}
+                          "bf16": "bf16 MFMA operands, f32 accumulate; refiner / discriminator activations stored as bf16 tensors "
+                                  "(reference autocast mode), elsewhere f32 tensors rounded in-kernel"}[precision]}
     del tr
+    torch.cuda.empty_cache()
+    return out
+
+
+def peak_of(tag):
+    """Dense MFMA peak of the engine a conv kernel instantiation runs on (MI355X_MICROARCH.md)."""
+    if "_x3_" in tag:
+        return PEAK_BF16_MFMA_TFLOPS / 6      # the split engine spends 6 bf16 MFMAs per f32 product block
+    if "bf16" in tag or "_h2_" in tag or "_h_" in tag:
+        return PEAK_BF16_MFMA_TFLOPS
+    return PEAK_F32_MFMA_TFLOPS
+
+
+def roofline_of(timer, steps, elapsed, step_peak):
+    """Dominant-kernel roofline (live HIP-event timing of every conv launch of the timed region) plus the whole-step
+    figure: executed conv FLOP / wall time against the engine's peak."""
+    summ = timer.summary()
+    total_conv_ms = sum(v["ms"] for v in summ.values())
+    total_flop = sum(v["flops"] for v in summ.values())
+    dom_tag, dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
+    ach = dom["flops"] / (dom["ms"] / 1e3) / 1e12
+    traffic, traffic_src = pmc_traffic(dom_tag)
+    peak = peak_of(dom_tag)
+    step_tf = total_flop / elapsed / 1e12
+    return {"bound": "mfma", "kernel": dom_tag, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_flop_per_launch": dom["flops"] / dom["launches"], "launches_per_step": dom["launches"] / steps,
+            "avg_launch_ms": dom["ms"] / dom["launches"], "share_of_step_time": dom["ms"] / 1e3 / elapsed,
+            "step": {"flop_executed_per_step": total_flop / steps, "TFLOP/s": step_tf, "peak": step_peak, "frac": step_tf / step_peak,
+                     "note": "conv / linear FLOP actually executed (all timed launches) over wall time of the timed steps"},
+            "all_conv_kernels": {k: {"ms_per_step": v["ms"] / steps, "TFLOPs": v["flops"] / (v["ms"] / 1e3) / 1e12,
+                                     "launches_per_step": v["launches"] / steps} for k, v in sorted(summ.items())},
+            "conv_share_of_step_time": total_conv_ms / 1e3 / elapsed}
+
+
+def timed_run(cfg, precision, B, T, steps, warmup, device, world, rank):
+    """W untimed + K timed optimisation steps of one configuration; returns the trainer, inputs, kernel timer, wall
+    seconds of the timed region (max over ranks) and the last step's losses."""
+    import copy
+    from mqgan_amd import ops
+    from mqgan_amd.train import Trainer
+    cfg = copy.deepcopy(cfg)
+    cfg["training"]["precision"] = precision
+    mel = cfg["model"]["mel_channels"]
+    tr = Trainer(cfg, device=device, build_data=False)
+    tr.generator.train()
+    tr.patch_discriminator.train()
+    tr.multibin_discriminator.train()
+    tr.epoch = 1
+    batches = synthetic_batches(B, T, mel, 4, device, rank)
+    lens = torch.full((B,), T, dtype=torch.int32, device=device)
+    for i in range(warmup):
+        tr.train_step(batches[i % len(batches)], lens)
+    timer = ops.KernelTimer()
+    ops.TIMER = timer
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(steps):
+        last = tr.train_step(batches[i % len(batches)], lens)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.TIMER = None
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    return tr, batches, lens, timer, elapsed, last
+
+
+def config3_line(device):
+    """BASELINE config 3 (hifimusic, 16 x 128 mels x 1024 frames, bf16 convs / fp32 VQ) on this GPU: 3 timed steps after
+    one warm-up, with its own dominant-kernel and whole-step roofline.  Reported under `configs`, never as `value`."""
+    cfg = load_config("hifimusic")
+    B, T = cfg["data"]["batch_size"], cfg["data"]["crop_len"]
+    steps, warmup = 3, 1
+    tr, batches, lens, timer, elapsed, last = timed_run(cfg, "bf16", B, T, steps, warmup, device, 1, 0)
+    out = {"workload": f"hifimusic PreEncoder VQ-GAN train step, {cfg['model']['mel_channels']} mels x {T} frames, batch {B}, "
+                       "bf16 convolutions with bf16 activation storage (refiner, discriminators), f32 accumulation, f32 VQ / losses / "
+                       "optimiser", "dtype": "bf16 convs / f32 VQ", "value": B * T * steps / elapsed, "unit": "mel-frames/s",
+           "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup,
+           "losses_finite": all(np.isfinite(float(v)) for v in last.values()),
+           "roofline": roofline_of(timer, steps, elapsed, PEAK_BF16_MFMA_TFLOPS)}
+    del tr, batches
     torch.cuda.empty_cache()
     return out
 
@@ -176,6 +311,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vq", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary fp32x3 / bf16 engine timings")
+    ap.add_argument("--no-configs", action="store_true", help="skip the 3-step BASELINE config-3 (hifimusic, bf16) line")
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     args = ap.parse_args()
 
@@ -208,59 +344,16 @@ def main():
     B = args.batch or cfg["data"]["batch_size"]
     T = args.frames or cfg["data"]["crop_len"]
     mel = cfg["model"]["mel_channels"]
-    cfg["training"]["precision"] = args.precision
-    tr = Trainer(cfg, device=device, build_data=False)
-    tr.generator.train()
-    tr.patch_discriminator.train()
-    tr.multibin_discriminator.train()
-    tr.epoch = 1
-    batches = synthetic_batches(B, T, mel, 4, device, rank)
-    lens = torch.full((B,), T, dtype=torch.int32, device=device)
-
-    for i in range(args.warmup):
-        tr.train_step(batches[i % len(batches)], lens)
-    timer = ops.KernelTimer()
-    ops.TIMER = timer
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    last = None
-    for i in range(args.steps):
-        last = tr.train_step(batches[i % len(batches)], lens)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    ops.TIMER = None
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    tr, batches, lens, timer, elapsed, last = timed_run(cfg, args.precision, B, T, args.steps, args.warmup, device, world, rank)
     finite = all(np.isfinite(float(v)) for v in last.values())
 
     if rank == 0:
         frames = world * B * T * args.steps
-        summ = timer.summary()
-        total_conv_ms = sum(v["ms"] for v in summ.values())
-        dom_tag, dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
-        ach = dom["flops"] / (dom["ms"] / 1e3) / 1e12
-        traffic, traffic_src = pmc_traffic(dom_tag)
-        # the split engine spends 6 bf16 MFMAs per f32 product block: its ceiling is a sixth of the bf16 peak
-        peak = PEAK_BF16_MFMA_TFLOPS if "bf16" in dom_tag else (PEAK_BF16_MFMA_TFLOPS / 6 if "_x3_" in dom_tag else PEAK_F32_MFMA_TFLOPS)
-        roof = {"bound": "mfma", "kernel": dom_tag, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_flop_per_launch": dom["flops"] / dom["launches"],
-                "launches_per_step": dom["launches"] / args.steps,
-                "avg_launch_ms": dom["ms"] / dom["launches"], "share_of_step_time": dom["ms"] / 1e3 / elapsed,
-                "all_conv_kernels": {k: {"ms_per_step": v["ms"] / args.steps, "TFLOPs": v["flops"] / (v["ms"] / 1e3) / 1e12,
-                                         "launches_per_step": v["launches"] / args.steps} for k, v in sorted(summ.items())},
-                "conv_share_of_step_time": total_conv_ms / 1e3 / elapsed}
+        step_peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "fp32x3": PEAK_BF16_MFMA_TFLOPS / 6}[args.precision]
+        roof = roofline_of(timer, args.steps, elapsed, step_peak)
         line = {"metric": METRIC, "value": frames / elapsed, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16 convs (f32 accumulate, f32 tensors) / f32 VQ",
+                "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16 convs (f32 accumulate, bf16 activation storage) / f32 VQ",
                                               "fp32x3": "f32 via 3-term bf16 split (6 products, f32 accumulate) / f32 VQ"}[args.precision],
                 "data": "synthetic",
                 "config": {"workload": f"{args.config} PreEncoder VQ-GAN train step (G fwd + D step + G step + clip/Adam), "
@@ -268,11 +361,15 @@ def main():
                                        "D active, FM off, train-mode dropout", "global_batch": world * B, "frames": T,
                            "parallelism": f"dp{world}"},
                 "losses_finite": bool(finite), "roofline": roof}
+        del tr
+        torch.cuda.empty_cache()
         if world == 1 and not args.no_alt and args.precision == "fp32":
             # secondary figures, same workload, opt-in engines (never `value`): see DESIGN.md section 3
-            del tr
-            torch.cuda.empty_cache()
             line["other_engines"] = {p: quick_engine(cfg, p, device, batches, lens, B, T) for p in ("fp32x3", "bf16")}
+        if world == 1 and not args.no_configs and args.config == "hifispeech" and args.precision == "fp32":
+            del batches
+            torch.cuda.empty_cache()
+            line["configs"] = {"config3_hifimusic_bf16": config3_line(device)}
         if not args.no_vq:
             line["vq"] = bench_vq(device)
         if world == 1 and not args.no_cpu_baseline:

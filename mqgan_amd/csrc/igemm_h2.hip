@@ -558,13 +558,22 @@ __global__ void h2_colsum_partial_kernel(const unsigned short *__restrict__ x, i
         for (int i = 0; i < 8; ++i)
             part[(size_t)blockIdx.y * cols + c8 + i] = (red[0][threadIdx.x][i] + red[1][threadIdx.x][i]) + (red[2][threadIdx.x][i] + red[3][threadIdx.x][i]);
 }
+// grid (ceil(cols / 64)), block (64, 16): thread (c, ty) sums chunks ty, ty + 16, ...; fixed-order LDS combine
 __global__ void h2_colsum_final_kernel(const float *__restrict__ part, int cols, int nchunks, float *__restrict__ out)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
-    float t = 0.f;
-    for (int k = 0; k < nchunks; ++k) t += part[(size_t)k * cols + c];
-    out[c] = t;
+    __shared__ float red[16][64];
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    float s = 0.f;
+    if (c < cols)
+        for (int k = threadIdx.y; k < nchunks; k += 16) s += part[(size_t)k * cols + c];
+    red[threadIdx.y][threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.y == 0 && c < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+        out[c] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------ weight images
@@ -872,7 +881,7 @@ extern "C" int mq_conv_wgrad_h2(const mqConvDesc *d, const uint16_t *x, const ui
             float *ws = bias_ws + (size_t)grp * 1024 * cols;
             hipLaunchKernelGGL(h2_colsum_partial_kernel, dim3((unsigned)cdiv(cols, 512), (unsigned)want), dim3(64, 4), 0, st,
                                dy + (size_t)grp * rows * cols, rows, cols, ws, (int)want);
-            hipLaunchKernelGGL(h2_colsum_final_kernel, dim3((unsigned)cdiv(cols, 256)), dim3(256), 0, st, ws, cols, (int)want,
+            hipLaunchKernelGGL(h2_colsum_final_kernel, dim3((unsigned)cdiv(cols, 64)), dim3(64, 16), 0, st, ws, cols, (int)want,
                                dbias + (size_t)grp * cols);
         }
         MQ_LAUNCH_CHECK("mq_conv_wgrad_h2(bias)");

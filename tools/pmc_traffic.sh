@@ -8,7 +8,9 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 500 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vq --no-alt > $OUT/$C.log 2>&1 || { echo "pass $C failed"; tail -5 $OUT/$C.log; exit 1; }
 done
 python3 - <<PY
-import csv, glob, collections, json
+import csv, glob, collections, json, sys
+sys.path.insert(0, "$R")
+import bench
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
@@ -20,7 +22,9 @@ for k, cs in agg.items():
     f, w = cs.get("FETCH_SIZE", [0]), cs.get("WRITE_SIZE", [0])
     # gfx950: FETCH_SIZE (KB) reports half of a wide coalesced read stream -> x2 (MI355X_MICROARCH.md, HBM section)
     out[name] = {"launches": len(f), "fetch_bytes_per_launch": 2 * 1024 * sum(f) / len(f), "write_bytes_per_launch": 1024 * sum(w) / len(w)}
+out["_build"] = bench.kernel_build_id()
 json.dump(out, open("$OUT/traffic.json", "w"), indent=1, sort_keys=True)
+out.pop("_build")
 for k, v in sorted(out.items(), key=lambda kv: -(kv[1]["fetch_bytes_per_launch"] + kv[1]["write_bytes_per_launch"]) * kv[1]["launches"])[:12]:
     print(f"{k[:50]:50s} n={v['launches']:4d} fetch={v['fetch_bytes_per_launch']/1e6:9.1f} MB write={v['write_bytes_per_launch']/1e6:9.1f} MB")
 PY
