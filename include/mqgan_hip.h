@@ -321,34 +321,53 @@ int mq_se_squeeze_bwd(const float *dsq, const uint8_t *mask, int B, int H, int W
                       mqStream stream);
 
 /* ------------------------------------------------------------------ losses
- * MaskedMelLoss("mse") (losses.py:146-182): loss = mean_g( sum_g / (count_g + 1e-12) ), for
- * group sizes g1 and g2 at once: out[0] = loss(g1), out[1] = loss(g2).  x, y (B, T, C). */
-/* workspace: 64*C floats */
-int mq_mel_loss_fwd(const float *x, const float *y, const int32_t *lengths, int B, int T, int C, int g1, int g2,
-                    float *out2, float *workspace, mqStream stream);
+ * Every loss on the path is a ratio of sums over the batch (losses.py:26-32, 40-50, 178-181; train.py:38-45).  The
+ * kernels are split into *_sums (per-rank numerators and counts in a small device buffer), *_final (the loss from the
+ * sums) and the backward pass (which reads the counts from the same buffer).  Between the two the host may all-reduce
+ * the buffer over the data-parallel ranks: the normalisers are then GLOBAL, every rank computes the global loss value,
+ * and the SUM of the ranks' gradients is the gradient of the single-device step on the global batch, ragged or not
+ * (SURVEY.md 8e).  With one process the buffers are used as they are.
+ *
+ * MaskedMelLoss("mse") (losses.py:146-182): loss = mean_g( sum_g / (count_g + 1e-12) ) for group sizes g1 and g2 at
+ * once.  x, y (B, T, C).  sums: C per-column sums of (x-y)^2 over valid frames + 1 (number of valid frames).
+ * workspace: 64*C floats. */
+int mq_mel_loss_sums(const float *x, const float *y, const int32_t *lengths, int B, int T, int C, float *sums,
+                     float *workspace, mqStream stream);
+int mq_mel_loss_final(const float *sums, int C, int g1, int g2, float *out2, mqStream stream);
 /* dx = (w1 * dloss(g1) + w2 * dloss(g2)) * gout[0] */
 int mq_mel_loss_bwd(const float *x, const float *y, const int32_t *lengths, int B, int T, int C, int g1, int g2,
-                    float w1, float w2, const float *gout, float *dx, mqStream stream);
-/* LSGANLoss (losses.py:5-116).  Logits are single-channel maps (B, H, W); `padded` is the
- * discriminator's padded-patch mask (B, W), 1 = padded (constant along H); the loss mask is its
- * complement, as train.py:385,395 passes it.  state (4 floats): ema_real, ema_fake, initialised
- * flag, unused - one state is shared by all nine discriminators (train.py:216).
- * discriminator_loss: out[0] = 0.5*(mse(real,1)+mse(fake,0)) + lecam, EMA updated first.
- * saved: 4 floats kept for backward. */
-int mq_lsgan_d_fwd(const float *real, const float *fake, const uint8_t *padded, int B, int H, int W, float decay,
-                   float *state, float *out, float *saved, mqStream stream);
-int mq_lsgan_d_bwd(const float *real, const float *fake, const uint8_t *padded, int B, int H, int W, const float *saved,
-                   const float *gout, float *dreal, float *dfake, mqStream stream);
-int mq_lsgan_g_fwd(const float *fake, const uint8_t *padded, int B, int H, int W, float *out, float *saved,
-                   mqStream stream);
-int mq_lsgan_g_bwd(const float *fake, const uint8_t *padded, int B, int H, int W, const float *saved, const float *gout,
-                   float *dfake, mqStream stream);
-/* masked_mae (train.py:38-45): pred/target (B, H, W, C), padded mask (B, W).  out2: [loss, valid count];
- * workspace: 512 floats. */
-int mq_masked_mae_fwd(const float *pred, const float *target, const uint8_t *padded, int B, int H, int W, int C,
-                      float *out2, float *workspace, mqStream stream);
+                    float w1, float w2, const float *sums, const float *gout, float *dx, mqStream stream);
+/* LSGANLoss (losses.py:5-116).  Logits are single-channel maps (B, H, W).  Masks mark PADDED elements (1), the loss
+ * mask of the reference is their complement: mask_mode 0 = frame mask (B, W), constant along H (what the
+ * discriminators produce and train.py:385,395 passes); mask_mode 1 = one byte per element (B, H, W) - any mask the
+ * reference accepts; NULL = everything valid.  real and fake have their own masks (losses.py:103-104).
+ *   mq_lsgan_d_sums : sums6 = [S m_r (r-1)^2, S m_f f^2, S m_r r, S m_f f, S m_r, S m_f]
+ *   mq_lsgan_ema    : the EMA chain of n consecutive calls (losses.py:36-58) from n x 6 sums: state (4 floats:
+ *                     ema_real, ema_fake, initialised, unused - ONE state shared by all nine discriminators,
+ *                     train.py:216) is advanced n times; ema_out[i] = the two EMAs call i's LeCam term uses
+ *   mq_lsgan_d_lecam: lsums2 = [S m_r relu(r - ema_f)^2, S m_f relu(ema_r - f)^2]
+ *   mq_lsgan_d_final: out[0] = 0.5*(mse_real + mse_fake) + lecam_real + lecam_fake */
+int mq_lsgan_d_sums(const float *real, const float *fake, const uint8_t *real_padded, const uint8_t *fake_padded,
+                    int mask_mode, int B, int H, int W, float *sums6, mqStream stream);
+int mq_lsgan_ema(const float *sums6, int n, float decay, float *state, float *ema_out, mqStream stream);
+int mq_lsgan_d_lecam(const float *real, const float *fake, const uint8_t *real_padded, const uint8_t *fake_padded,
+                     int mask_mode, int B, int H, int W, const float *ema2, float *lsums2, mqStream stream);
+int mq_lsgan_d_final(const float *sums6, const float *lsums2, float *out, mqStream stream);
+int mq_lsgan_d_bwd(const float *real, const float *fake, const uint8_t *real_padded, const uint8_t *fake_padded,
+                   int mask_mode, int B, int H, int W, const float *sums6, const float *ema2, const float *gout,
+                   float *dreal, float *dfake, mqStream stream);
+/* generator_loss: sums2 = [S m (f-1)^2, S m]; loss = mq_ratio_final(sums2, 0) = (count > 0 ? sum / count : 0) */
+int mq_lsgan_g_sums(const float *fake, const uint8_t *padded, int mask_mode, int B, int H, int W, float *sums2,
+                    mqStream stream);
+int mq_ratio_final(const float *sums2, float eps, float *out, mqStream stream);   /* eps > 0: sum / (count + eps) */
+int mq_lsgan_g_bwd(const float *fake, const uint8_t *padded, int mask_mode, int B, int H, int W, const float *sums2,
+                   const float *gout, float *dfake, mqStream stream);
+/* masked_mae (train.py:38-45): pred/target (B, H, W, C), padded mask (B, W).  sums2: [sum |pred - target|, valid
+ * count]; loss = mq_ratio_final(sums2, 1e-8).  workspace: 512 floats. */
+int mq_masked_mae_sums(const float *pred, const float *target, const uint8_t *padded, int B, int H, int W, int C,
+                       float *sums2, float *workspace, mqStream stream);
 int mq_masked_mae_bwd(const float *pred, const float *target, const uint8_t *padded, int B, int H, int W, int C,
-                      const float *out2, const float *gout, float *dpred, mqStream stream);
+                      const float *sums2, const float *gout, float *dpred, mqStream stream);
 
 /* ------------------------------------------------------------------ optimiser
  * clip_grad_norm_ + Adam on flat arenas (train.py:401-407,485-492; torch.optim.Adam

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MQGAN_HIP_LIB: load another build of the same ABI (kernel experiments); the default is the in-tree library
 LIB_PATH = os.environ.get("MQGAN_HIP_LIB") or os.path.join(_HERE, "libmqgan_hip.so")
 _lib = None
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class MqganHipError(RuntimeError):
@@ -119,13 +119,18 @@ SIGNATURES = {
     "mq_se_scale_fwd": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "mq_se_scale_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "mq_se_squeeze_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
-    "mq_mel_loss_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
-    "mq_mel_loss_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P]),
-    "mq_lsgan_d_fwd": (_I, [_P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P]),
-    "mq_lsgan_d_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
-    "mq_lsgan_g_fwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
-    "mq_lsgan_g_bwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
-    "mq_masked_mae_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "mq_mel_loss_sums": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "mq_mel_loss_final": (_I, [_P, _I, _I, _I, _P, _P]),
+    "mq_mel_loss_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P]),
+    "mq_lsgan_d_sums": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "mq_lsgan_ema": (_I, [_P, _I, _F, _P, _P, _P]),
+    "mq_lsgan_d_lecam": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "mq_lsgan_d_final": (_I, [_P, _P, _P, _P]),
+    "mq_lsgan_d_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "mq_lsgan_g_sums": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "mq_ratio_final": (_I, [_P, _F, _P, _P]),
+    "mq_lsgan_g_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "mq_masked_mae_sums": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "mq_masked_mae_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "mq_sumsq": (_I, [_P, _L, _P, _P, _P]),
     "mq_adam_step": (_I, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _I, _P, _F, _F, _P]),

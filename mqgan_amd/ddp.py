@@ -66,10 +66,13 @@ class FlatArena:
 
 
 class GradReducer:
-    def __init__(self, arena: FlatArena, process_group=None, bucket_bytes: int = 32 << 20, average: bool = False):
+    def __init__(self, arena: FlatArena, process_group=None, bucket_bytes: int = 32 << 20, average: bool = False, comm=None):
         self.arena = arena
         self.pg = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # ``comm``: a non-torch.distributed communicator (mqgan_amd.comm.Comm with world > 1, e.g. a test double): the whole
+        # gradient arena is then summed in finish() with one blocking call instead of hooked, bucketed async all-reduces
+        self.comm = comm if (comm is not None and comm.world > 1 and not dist.is_initialized()) else None
+        self.world = self.comm.world if self.comm is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
         self.average = average
         self.buckets = []                      # (start, end) element ranges of flat_grad, reverse order
         self.param_bucket = {}
@@ -88,7 +91,7 @@ class GradReducer:
         self._launched = [False] * len(self.buckets)
         self._handles = []
         self._hooks = []
-        self.enabled = self.world > 1
+        self.enabled = self.world > 1 and self.comm is None
         if self.enabled:
             for p in arena.params:
                 if p.requires_grad:
@@ -123,6 +126,11 @@ class GradReducer:
         """Call after backward: flush buckets that are still waiting (parameters without gradient),
         wait for every collective.  The arena then holds SUMS over ranks; the 1 / world factor is
         applied inside the clip / Adam kernel (``grad_scale``) unless ``average`` asks for it here."""
+        if self.comm is not None:
+            self.comm.all_reduce_sum(self.arena.flat_grad)
+            if self.average:
+                self.arena.flat_grad.mul_(1.0 / self.world)
+            return
         if not self.enabled:
             return
         for b in range(len(self.buckets)):

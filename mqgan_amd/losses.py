@@ -1,22 +1,37 @@
 """LSGANLoss (+ LeCam) and MaskedMelLoss with the reference's API (reference losses.py:5-116,
 121-182) and masked_mae (train.py:38-45), on the HIP kernels.  No host synchronisation: the
 reference's ``valid.item() > 0`` branch (losses.py:29) is taken on the device.
+
+Every loss is a ratio of sums over the batch.  The modules / functions take an optional ``comm``
+(mqgan_amd.comm): with more than one data-parallel rank the numerators and counts are all-reduced before
+the division, so the normalisers are those of the GLOBAL batch - every rank then holds the
+global loss value and the SUM of the ranks' gradients is the single-device gradient, ragged shards included.
 """
 import torch
 import torch.nn as nn
 
 from . import ops
+from .comm import Comm
 
 
-def _padded_bw(mask, logits):
-    """Loss mask of the reference (bool, True = VALID, shape of the logits (B, 1, H, W)) -> uint8 padded
-    mask (B, W).  Discriminator masks are constant along H, which is all the kernels need."""
+def _padded_map(mask, logits):
+    """Loss mask of the reference (True / non-zero = VALID, broadcastable to the logits (B, 1, H, W)) -> (uint8
+    PADDED map, mask_mode) for the kernels: mode 0 = frame mask (B, W) - the uint8 masks the discriminators
+    hand out, already 1 = padded -; mode 1 = one byte per element (B, H, W); (None, 0) = everything valid."""
     if mask is None:
-        return torch.zeros((logits.shape[0], logits.shape[-1]), dtype=torch.uint8, device=logits.device)
+        return None, 0
+    B, H, W = logits.shape
     if mask.dtype == torch.uint8 and mask.dim() == 2:
-        return mask
-    m = mask.reshape(mask.shape[0], -1, mask.shape[-1])[:, 0, :]
-    return (~m.bool()).to(torch.uint8).contiguous()
+        if tuple(mask.shape) != (B, W):
+            raise ValueError(f"frame mask {tuple(mask.shape)} does not match logits (B, W) = {(B, W)}")
+        return mask.contiguous(), 0
+    m = mask
+    if m.dim() == 4:
+        m = m.reshape(m.shape[0], m.shape[2], m.shape[3]) if m.shape[1] == 1 else m.reshape(m.shape[0], m.shape[1], m.shape[2])
+    if m.dim() != 3:
+        raise ValueError(f"mask of shape {tuple(mask.shape)} cannot be broadcast to logits {(B, 1, H, W)}")
+    valid = m != 0
+    return (~valid).expand(B, H, W).to(torch.uint8).contiguous(), 1
 
 
 def _bhw(logits):
@@ -24,16 +39,17 @@ def _bhw(logits):
     if logits.dim() != 4:
         raise ValueError(f"expected 4-D single-channel logits, got {tuple(logits.shape)}")
     if logits.shape[1] == 1 and logits.shape[3] != 1:
-        return logits.reshape(logits.shape[0], logits.shape[2], logits.shape[3])
-    return logits.reshape(logits.shape[0], logits.shape[1], logits.shape[2])
+        return logits.reshape(logits.shape[0], logits.shape[2], logits.shape[3]).contiguous()
+    return logits.reshape(logits.shape[0], logits.shape[1], logits.shape[2]).contiguous()
 
 
 class LSGANLoss(nn.Module):
-    def __init__(self, real_label=1.0, fake_label=0.0, decay=0.99, use_lecam=True):
+    def __init__(self, real_label=1.0, fake_label=0.0, decay=0.99, use_lecam=True, comm: Comm = None):
         super().__init__()
         if real_label != 1.0 or fake_label != 0.0 or not use_lecam:
             raise NotImplementedError("the HIP LSGAN kernel implements labels (1, 0) with LeCam, as train.py uses it")
         self.real_label, self.fake_label, self.decay, self.use_lecam = real_label, fake_label, decay, use_lecam
+        self.comm = comm
         # [ema_real, ema_fake, initialised, unused]; ONE state shared by every discriminator (train.py:216)
         self.register_buffer("_state", torch.zeros(4), persistent=False)
 
@@ -49,36 +65,55 @@ class LSGANLoss(nn.Module):
     def ema_initialized(self):
         return bool(self._state[2].item() != 0)
 
+    def discriminator_losses(self, calls):
+        """n consecutive ``discriminator_loss`` calls as one unit: ``calls`` = [(real_output, fake_output, real_mask,
+        fake_mask)].  Same results as calling discriminator_loss n times in this order (the EMA chain is followed call
+        by call), but the sums of all calls travel in two small all-reduces instead of 2n."""
+        pairs = []
+        for real_output, fake_output, real_mask, fake_mask in calls:
+            r, f = _bhw(real_output), _bhw(fake_output)
+            rp, mr = _padded_map(real_mask, r)
+            fp, mf = _padded_map(fake_mask, f)
+            if mr != mf:                                # one mode per launch: lift the frame mask to a per-element map
+                if mr == 0 and rp is not None:
+                    rp = rp[:, None, :].expand(r.shape).contiguous()
+                if mf == 0 and fp is not None:
+                    fp = fp[:, None, :].expand(f.shape).contiguous()
+                mr = mf = 1
+            pairs.append((r, f, rp, fp, mr))
+        sums, ema, lsums = ops.lsgan_d_prepare(pairs, self._state, self.decay, self.comm)
+        return [ops.LsganDFn.apply(r, f, rp, fp, mode, sums[i], ema[i], lsums[i]) for i, (r, f, rp, fp, mode) in enumerate(pairs)]
+
     def discriminator_loss(self, real_output, fake_output, real_mask=None, fake_mask=None):
-        padded = _padded_bw(real_mask, real_output)
-        return ops.LsganDFn.apply(_bhw(real_output).contiguous(), _bhw(fake_output).contiguous(), padded, self._state,
-                                  float(self.decay))
+        return self.discriminator_losses([(real_output, fake_output, real_mask, fake_mask)])[0]
 
     def generator_loss(self, fake_output, fake_mask=None):
-        return ops.LsganGFn.apply(_bhw(fake_output).contiguous(), _padded_bw(fake_mask, fake_output))
+        f = _bhw(fake_output)
+        pad, mode = _padded_map(fake_mask, f)
+        return ops.LsganGFn.apply(f, pad, mode, self.comm)
 
 
 class MaskedMelLoss(nn.Module):
-    def __init__(self, loss_type: str = "charbonnier", group_size: int = 1, eps: float = 1e-6):
+    def __init__(self, loss_type: str = "charbonnier", group_size: int = 1, eps: float = 1e-6, comm: Comm = None):
         super().__init__()
         assert loss_type in {"charbonnier", "mse"}
         if loss_type != "mse":
             raise NotImplementedError("only loss_type='mse' is on the hot path (train.py:217-218)")
-        self.loss_type, self.group_size, self.eps = loss_type, group_size, eps
+        self.loss_type, self.group_size, self.eps, self.comm = loss_type, group_size, eps, comm
 
     def forward(self, x, y, lengths):
         assert x.shape == y.shape, "x and y must have the same shape"
         assert x.shape[-1] % self.group_size == 0, "C (n_mels) must be divisible by group_size"
         return ops.MelLossFn.apply(x.contiguous(), y.contiguous(), lengths.to(torch.int32).contiguous(), self.group_size,
-                                   self.group_size, 1.0, 0.0)
+                                   self.group_size, 1.0, 0.0, self.comm)
 
 
-def recon_loss(x, y, lengths, group_size=16, group_weight=0.25):
+def recon_loss(x, y, lengths, group_size=16, group_weight=0.25, comm: Comm = None):
     """loss_all + 0.25 * loss_group in ONE pass (train.py:419-425)."""
     return ops.MelLossFn.apply(x.contiguous(), y.contiguous(), lengths.to(torch.int32).contiguous(), 1, group_size, 1.0,
-                               float(group_weight))
+                               float(group_weight), comm)
 
 
-def masked_mae(pred, target, mask, eps: float = 1e-8):
+def masked_mae(pred, target, mask, eps: float = 1e-8, comm: Comm = None):
     """train.py:38-45 on channels-last features (B, H, W, C) with a uint8 padded mask (B, W)."""
-    return ops.MaskedMaeFn.apply(pred.contiguous(), target.contiguous(), mask)
+    return ops.MaskedMaeFn.apply(ops.to_f32(pred).contiguous(), ops.to_f32(target).contiguous(), mask, comm)

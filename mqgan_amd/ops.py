@@ -1122,17 +1122,29 @@ def codebook_ema_update(x, idx, cluster_size, embed_sum, codebook, decay=0.99, e
 
 
 # ----------------------------------------------------------------------------- losses
+# Every loss is computed in two halves so that the normalisers can be made global under data parallelism: the *_sums
+# kernels leave numerators and counts in a small device buffer, ``comm.all_reduce_sum`` (identity for one process) sums it
+# over the ranks, and the *_final / backward kernels work from the reduced buffer (see include/mqgan_hip.h).
+def _reduce(comm, buf):
+    if comm is not None and comm.world > 1:
+        comm.all_reduce_sum(buf)
+    return buf
+
+
 class MelLossFn(torch.autograd.Function):
     """MaskedMelLoss('mse') for group sizes g1 and g2 in one pass: returns w1*loss(g1) + w2*loss(g2)."""
 
     @staticmethod
-    def forward(ctx, x, y, lengths, g1, g2, w1, w2):
+    def forward(ctx, x, y, lengths, g1, g2, w1, w2, comm):
         B, T, Cc = x.shape
-        out2 = _empty((2,), x)
+        sums = _empty((Cc + 1,), x)
         ws = _empty((64 * Cc,), x)
-        check(L().mq_mel_loss_fwd(fptr(x), fptr(y), ptr(lengths, torch.int32), B, T, Cc, g1, g2, fptr(out2), fptr(ws), stream()),
-              "mq_mel_loss_fwd")
-        ctx.save_for_backward(x, y, lengths)
+        check(L().mq_mel_loss_sums(fptr(x), fptr(y), ptr(lengths, torch.int32), B, T, Cc, fptr(sums), fptr(ws), stream()),
+              "mq_mel_loss_sums")
+        _reduce(comm, sums)
+        out2 = _empty((2,), x)
+        check(L().mq_mel_loss_final(fptr(sums), Cc, g1, g2, fptr(out2), stream()), "mq_mel_loss_final")
+        ctx.save_for_backward(x, y, lengths, sums)
         ctx.cfg = (g1, g2, w1, w2)
         out = _empty((1,), x)
         check(L().mq_axpby(fptr(out2[0:1]), fptr(out2[1:2]), float(w1), float(w2), 1, fptr(out), stream()), "mq_axpby")
@@ -1140,72 +1152,99 @@ class MelLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        x, y, lengths = ctx.saved_tensors
+        x, y, lengths, sums = ctx.saved_tensors
         g1, g2, w1, w2 = ctx.cfg
         B, T, Cc = x.shape
         dx = torch.empty_like(x)
-        check(L().mq_mel_loss_bwd(fptr(x), fptr(y), ptr(lengths, torch.int32), B, T, Cc, g1, g2, w1, w2, fptr(gout.contiguous().view(1)),
-                                  fptr(dx), stream()), "mq_mel_loss_bwd")
-        return dx, None, None, None, None, None, None
+        check(L().mq_mel_loss_bwd(fptr(x), fptr(y), ptr(lengths, torch.int32), B, T, Cc, g1, g2, w1, w2, fptr(sums),
+                                  fptr(gout.contiguous().view(1)), fptr(dx), stream()), "mq_mel_loss_bwd")
+        return dx, None, None, None, None, None, None, None
+
+
+def lsgan_d_prepare(pairs, state, decay, comm=None):
+    """First half of n consecutive LSGANLoss.discriminator_loss calls that share one EMA state (train.py:385-396):
+    ``pairs`` = [(real (B,H,W), fake, real_pad, fake_pad, mask_mode)]; returns (sums (n,6), ema (n,2), lsums (n,2)).
+    Two small all-reduces for the whole set (sums before the EMA update, LeCam sums after it)."""
+    n = len(pairs)
+    like = pairs[0][0]
+    sums, ema, lsums = _empty((n, 6), like), _empty((n, 2), like), _empty((n, 2), like)
+    for i, (r, f, rp, fp, mode) in enumerate(pairs):
+        B, H, W = r.shape
+        check(L().mq_lsgan_d_sums(fptr(r), fptr(f), ptr(rp, torch.uint8, True), ptr(fp, torch.uint8, True), mode, B, H, W, fptr(sums[i]),
+                                  stream()), "mq_lsgan_d_sums")
+    _reduce(comm, sums)
+    check(L().mq_lsgan_ema(fptr(sums), n, float(decay), fptr(state), fptr(ema), stream()), "mq_lsgan_ema")
+    for i, (r, f, rp, fp, mode) in enumerate(pairs):
+        B, H, W = r.shape
+        check(L().mq_lsgan_d_lecam(fptr(r), fptr(f), ptr(rp, torch.uint8, True), ptr(fp, torch.uint8, True), mode, B, H, W, fptr(ema[i]),
+                                   fptr(lsums[i]), stream()), "mq_lsgan_d_lecam")
+    _reduce(comm, lsums)
+    return sums, ema, lsums
 
 
 class LsganDFn(torch.autograd.Function):
+    """Second half: the loss of one (real, fake) pair from its prepared sums."""
+
     @staticmethod
-    def forward(ctx, real, fake, padded, state, decay):
-        B, H, W = real.shape[0], real.shape[1], real.shape[2]
-        out, saved = _empty((1,), real), _empty((4,), real)
-        check(L().mq_lsgan_d_fwd(fptr(real), fptr(fake), ptr(padded, torch.uint8), B, H, W, decay, fptr(state), fptr(out), fptr(saved),
-                                 stream()), "mq_lsgan_d_fwd")
-        ctx.save_for_backward(real, fake, padded, saved)
+    def forward(ctx, real, fake, rpad, fpad, mode, sums6, ema2, lsums2):
+        out = _empty((1,), real)
+        check(L().mq_lsgan_d_final(fptr(sums6), fptr(lsums2), fptr(out), stream()), "mq_lsgan_d_final")
+        ctx.save_for_backward(real, fake, rpad, fpad, sums6, ema2)
+        ctx.mode = mode
         return out.view(())
 
     @staticmethod
     def backward(ctx, gout):
-        real, fake, padded, saved = ctx.saved_tensors
-        B, H, W = real.shape[0], real.shape[1], real.shape[2]
+        real, fake, rpad, fpad, sums6, ema2 = ctx.saved_tensors
+        B, H, W = real.shape
         dr, df = torch.empty_like(real), torch.empty_like(fake)
-        check(L().mq_lsgan_d_bwd(fptr(real), fptr(fake), ptr(padded, torch.uint8), B, H, W, fptr(saved), fptr(gout.contiguous().view(1)),
-                                 fptr(dr), fptr(df), stream()), "mq_lsgan_d_bwd")
-        return dr, df, None, None, None
+        check(L().mq_lsgan_d_bwd(fptr(real), fptr(fake), ptr(rpad, torch.uint8, True), ptr(fpad, torch.uint8, True), ctx.mode, B, H, W,
+                                 fptr(sums6), fptr(ema2), fptr(gout.contiguous().view(1)), fptr(dr), fptr(df), stream()), "mq_lsgan_d_bwd")
+        return dr, df, None, None, None, None, None, None
 
 
 class LsganGFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, fake, padded):
-        B, H, W = fake.shape[0], fake.shape[1], fake.shape[2]
-        out, saved = _empty((1,), fake), _empty((4,), fake)
-        check(L().mq_lsgan_g_fwd(fptr(fake), ptr(padded, torch.uint8), B, H, W, fptr(out), fptr(saved), stream()), "mq_lsgan_g_fwd")
-        ctx.save_for_backward(fake, padded, saved)
+    def forward(ctx, fake, pad, mode, comm):
+        B, H, W = fake.shape
+        sums2, out = _empty((2,), fake), _empty((1,), fake)
+        check(L().mq_lsgan_g_sums(fptr(fake), ptr(pad, torch.uint8, True), mode, B, H, W, fptr(sums2), stream()), "mq_lsgan_g_sums")
+        _reduce(comm, sums2)
+        check(L().mq_ratio_final(fptr(sums2), 0.0, fptr(out), stream()), "mq_ratio_final")
+        ctx.save_for_backward(fake, pad, sums2)
+        ctx.mode = mode
         return out.view(())
 
     @staticmethod
     def backward(ctx, gout):
-        fake, padded, saved = ctx.saved_tensors
-        B, H, W = fake.shape[0], fake.shape[1], fake.shape[2]
+        fake, pad, sums2 = ctx.saved_tensors
+        B, H, W = fake.shape
         df = torch.empty_like(fake)
-        check(L().mq_lsgan_g_bwd(fptr(fake), ptr(padded, torch.uint8), B, H, W, fptr(saved), fptr(gout.contiguous().view(1)), fptr(df),
-                                 stream()), "mq_lsgan_g_bwd")
-        return df, None
+        check(L().mq_lsgan_g_bwd(fptr(fake), ptr(pad, torch.uint8, True), ctx.mode, B, H, W, fptr(sums2), fptr(gout.contiguous().view(1)),
+                                 fptr(df), stream()), "mq_lsgan_g_bwd")
+        return df, None, None, None
 
 
 class MaskedMaeFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred, target, padded):
+    def forward(ctx, pred, target, padded, comm):
         B, H, W, Cc = pred.shape
-        out2, ws = _empty((2,), pred), _empty((512,), pred)
-        check(L().mq_masked_mae_fwd(fptr(pred), fptr(target), ptr(padded, torch.uint8), B, H, W, Cc, fptr(out2), fptr(ws), stream()),
-              "mq_masked_mae_fwd")
-        ctx.save_for_backward(pred, target, padded, out2)
-        return out2[0].clone()
+        sums2, ws, out = _empty((2,), pred), _empty((512,), pred), _empty((1,), pred)
+        check(L().mq_masked_mae_sums(fptr(pred), fptr(target), ptr(padded, torch.uint8), B, H, W, Cc, fptr(sums2), fptr(ws), stream()),
+              "mq_masked_mae_sums")
+        _reduce(comm, sums2)
+        check(L().mq_ratio_final(fptr(sums2), 1e-8, fptr(out), stream()), "mq_ratio_final")
+        ctx.save_for_backward(pred, target, padded, sums2)
+        return out.view(())
 
     @staticmethod
     def backward(ctx, gout):
-        pred, target, padded, out2 = ctx.saved_tensors
+        pred, target, padded, sums2 = ctx.saved_tensors
         B, H, W, Cc = pred.shape
         dp = torch.empty_like(pred)
-        check(L().mq_masked_mae_bwd(fptr(pred), fptr(target), ptr(padded, torch.uint8), B, H, W, Cc, fptr(out2),
+        check(L().mq_masked_mae_bwd(fptr(pred), fptr(target), ptr(padded, torch.uint8), B, H, W, Cc, fptr(sums2),
                                     fptr(gout.contiguous().view(1)), fptr(dp), stream()), "mq_masked_mae_bwd")
-        return dp, None, None
+        return dp, None, None, None
 
 
 # ----------------------------------------------------------------------------- optimiser

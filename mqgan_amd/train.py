@@ -25,6 +25,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
+from .comm import Comm, default_comm
 from .ddp import FlatArena, GradReducer, broadcast_arena
 from .discriminators import MelSpectrogramPatchDiscriminator2D, MultiBinDiscriminator, run_discriminators
 from .losses import LSGANLoss, masked_mae, recon_loss
@@ -165,10 +166,11 @@ class WarmupLR:
 
 # ----------------------------------------------------------------------------- trainer
 class Trainer:
-    def __init__(self, config, device=None, build_data=True, log_fn=None):
+    def __init__(self, config, device=None, build_data=True, log_fn=None, comm: Comm = None):
         self.config = config
-        self.rank = dist.get_rank() if dist.is_initialized() else 0
-        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        # data-parallel communicator: torch.distributed when a process group is up, else the single-process identity
+        self.comm = comm if comm is not None else default_comm()
+        self.rank, self.world = self.comm.rank, self.comm.world
         self.device = torch.device(device) if device is not None else self._get_device()
         if self.device.type == "cuda":
             if self.device.index is None:
@@ -187,9 +189,9 @@ class Trainer:
         broadcast_arena(self.arena_d)
         self.optimizer_g, self.optimizer_d = self._init_optimizers()
         self.scheduler_g = WarmupLR(self.optimizer_g, config["training"]["warmup_steps"])
-        self.reducer_g = GradReducer(self.arena_g)
-        self.reducer_d = GradReducer(self.arena_d)
-        self.gan_loss = LSGANLoss().to(self.device)      # ONE instance for all nine discriminators (train.py:216)
+        self.reducer_g = GradReducer(self.arena_g, comm=self.comm)
+        self.reducer_d = GradReducer(self.arena_d, comm=self.comm)
+        self.gan_loss = LSGANLoss(comm=self.comm).to(self.device)   # ONE instance for all nine discriminators (train.py:216)
         # The reference picks bf16 autocast whenever the GPU supports it (train.py:220, 523); here the engine is an
         # explicit knob: training.precision = "fp32" (default; the 1e-4 parity path, BASELINE config 2), "fp32x3" or "bf16"
         # (bf16 MFMA operands in every conv / linear, f32 accumulation, f32 tensors; BASELINE config 3).
@@ -343,7 +345,7 @@ class Trainer:
             both, lens2 = torch.cat([real, fake], 0), torch.cat([lens, lens], 0)
             al, amask, _ = self._d1(both, lens2)
             rmask = amask[:B]
-            loss = self.gan_loss.discriminator_loss(al[:B], al[B:], rmask, rmask)
+            first = (al[:B], al[B:], rmask, rmask)
             al2, amask2, _ = self._d2(both, lens2)       # band j owns rows [2jB, 2(j+1)B): real first, then fake
             m0 = amask2[:B].contiguous()                 # the reference uses the mask of bin 0 for every bin (:392-393)
             pairs = [(al2[2 * j * B:(2 * j + 1) * B], al2[(2 * j + 1) * B:(2 * j + 2) * B]) for j in range(G)]
@@ -351,26 +353,25 @@ class Trainer:
             # train mode: every forward runs one power iteration (u, v change between passes), so the passes stay separate
             rl, rmask, _ = self._d1(real, lens)
             fl, _, _ = self._d1(fake, lens)
-            loss = self.gan_loss.discriminator_loss(rl, fl, rmask, rmask)
+            first = (rl, fl, rmask, rmask)
             rl2, rmask2, _ = self._d2(real, lens)
             fl2, _, _ = self._d2(fake, lens)
             m0 = rmask2[:B].contiguous()
             pairs = list(zip(self._bands(rl2), self._bands(fl2)))
+        # nine LSGANLoss.discriminator_loss calls in the reference's order (patch D, then bins 0..7: one EMA chain,
+        # train.py:385-396).  Their numerators and counts are summed over the data-parallel ranks before the division
+        # and before the EMA update: global normalisers, replica-consistent LeCam state, exact for ragged shards.
+        losses = self.gan_loss.discriminator_losses([first] + [(r, f, m0, m0) for r, f in pairs])
+        loss = losses[0]
         mbd = None
-        for r, f in pairs:
-            l = self.gan_loss.discriminator_loss(r, f, m0, m0)
+        for l in losses[1:]:
             mbd = l if mbd is None else ops.add(mbd, l)
         loss_d = ops.add(loss, mbd, 1.0, 1.0 / G)
         loss_d.backward()
-        if self.world > 1:
-            # The LeCam EMAs are linear in the batch means they are fed: averaging the two scalars over the ranks after
-            # the nine updates of this step leaves every replica with the EMA of the GLOBAL means (equal shard sizes).
-            ema = self.gan_loss._state[:2]
-            dist.all_reduce(ema)
-            ema.mul_(1.0 / self.world)
         self.reducer_d.finish()
         clip = self.config["training"].get("clip_grad_norm", 1.0)
-        self.optimizer_d.step(max_norm=clip or 0.0, grad_scale=1.0 / self.world)
+        # every loss is normalised by GLOBAL counts, so the SUM of the ranks' gradients is the global-batch gradient
+        self.optimizer_d.step(max_norm=clip or 0.0, grad_scale=1.0)
         return loss_d.detach()
 
     # -- train.py:412-501 -----------------------------------------------------------------------
@@ -380,8 +381,8 @@ class Trainer:
         self.reducer_g.start()
         self.patch_discriminator.eval()                  # never undone until the next epoch (:415-416 vs :505-506)
         self.multibin_discriminator.eval()
-        loss_pre = recon_loss(recon_pre, real, lens)     # all + 0.25 * group16 (:419-425)
-        loss_post = recon_loss(recon_post, real, lens)
+        loss_pre = recon_loss(recon_pre, real, lens, comm=self.comm)     # all + 0.25 * group16 (:419-425)
+        loss_post = recon_loss(recon_post, real, lens, comm=self.comm)
         d_active = self.epoch >= t["discriminator_train_start_epoch"]
         zero = torch.zeros((), device=self.device)
         loss_gan, loss_fm = zero, zero
@@ -408,7 +409,7 @@ class Trainer:
             if use_fm:
                 f1 = None
                 for (r, m), (f, _) in zip(rf, gf):
-                    l = masked_mae(f, r, m)
+                    l = masked_mae(f, r, m, comm=self.comm)
                     f1 = l if f1 is None else ops.add(f1, l)
                 f1 = ops.scale(f1, 1.0 / len(rf))
                 f2 = None
@@ -416,7 +417,7 @@ class Trainer:
                 for j in range(G):                       # train.py:466-472: cumulative division inside the bin loop
                     for (r, m), (f, _) in zip(rf2, gf2):
                         Bn = r.shape[0] // G
-                        l = masked_mae(f[j * Bn:(j + 1) * Bn], r[j * Bn:(j + 1) * Bn], m[:Bn].contiguous())
+                        l = masked_mae(f[j * Bn:(j + 1) * Bn], r[j * Bn:(j + 1) * Bn], m[:Bn].contiguous(), comm=self.comm)
                         f2 = l if f2 is None else ops.add(f2, l)
                     f2 = ops.scale(f2, 1.0 / nf)
                 f2 = ops.scale(f2, 1.0 / G)
@@ -430,7 +431,7 @@ class Trainer:
         total.backward()
         self.reducer_g.finish()
         clip = t.get("clip_grad_norm", 1.0)
-        self.optimizer_g.step(max_norm=clip or 0.0, grad_scale=1.0 / self.world)
+        self.optimizer_g.step(max_norm=clip or 0.0, grad_scale=1.0)       # sum of the ranks' gradients (global normalisers)
         self.scheduler_g.step()
         return {"loss_g_total": total.detach(), "loss_recon_pre": loss_pre.detach(), "loss_recon_post": loss_post.detach(),
                 "loss_gan": loss_gan.detach(), "loss_fm": loss_fm.detach()}
@@ -462,9 +463,9 @@ class Trainer:
             empty = real is None or real.size(0) == 0   # every file of the batch failed to load (train.py:512-514)
             if self.world > 1:
                 # the step is full of collectives: either every rank takes it or none does
-                flag = torch.tensor([0.0 if empty else 1.0], device=self.device)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                empty = float(flag.item()) == 0.0
+                flag = torch.tensor([1.0 if empty else 0.0], device=self.device)
+                self.comm.all_reduce_sum(flag)
+                empty = float(flag.item()) > 0.0
             if empty:
                 continue
             out = self.train_step(real, lens)

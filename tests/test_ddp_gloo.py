@@ -118,3 +118,66 @@ def test_arena_survives_load_state_dict_and_zero_grad():
     arena.zero_grad()
     net(torch.randn(2, 13)).sum().backward()
     assert float(arena.flat_grad.abs().sum()) > 0
+
+
+def _norm_worker(rank, world, port, out_q):
+    """The global-normaliser protocol of the data-parallel step on two ragged shards (plain torch on CPU, gloo):
+    per-rank numerators and counts -> TorchComm.all_reduce_sum -> loss from the reduced sums -> local backward with the
+    GLOBAL count -> SUM all-reduce of the gradients.  Must equal the single-process gradient on the whole batch."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mqgan_amd.comm import TorchComm, default_comm
+        from mqgan_amd.ddp import FlatArena, GradReducer
+        comm = default_comm()
+        assert isinstance(comm, TorchComm) and comm.world == world and comm.rank == rank
+        torch.manual_seed(3)
+        net = Net()
+        arena = FlatArena([net])
+        red = GradReducer(arena, bucket_bytes=1024)
+        torch.manual_seed(11)
+        x_all, valid_all = torch.randn(7, 13), (torch.rand(7, 2) > 0.35).float()
+        lo, hi = (0, 3) if rank == 0 else (3, 7)              # unequal shards: 3 and 4 rows, different valid counts
+        x, valid = x_all[lo:hi], valid_all[lo:hi]
+        arena.zero_grad()
+        red.start()
+        y = net(x)
+        sums = torch.stack([((y - 1.0) ** 2 * valid).sum().detach(), valid.sum()])
+        comm.all_reduce_sum(sums)                             # [global numerator, global count]
+        loss_value = sums[0] / sums[1]                        # every rank holds the GLOBAL loss
+        local = ((y - 1.0) ** 2 * valid).sum() / sums[1]      # its own numerator over the global count
+        local.backward()
+        red.finish()                                          # SUM over ranks, no 1 / world factor
+        flag = torch.tensor([1.0 if rank == 1 else 0.0])      # "my batch failed to load" on one rank only ...
+        comm.all_reduce_sum(flag)
+        out_q.put((rank, float(loss_value), arena.flat_grad.clone(), float(flag)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_global_normalisers_protocol_world2():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_norm_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=60) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from mqgan_amd.ddp import FlatArena
+    torch.manual_seed(3)
+    net = Net()
+    arena = FlatArena([net])
+    torch.manual_seed(11)
+    x_all, valid_all = torch.randn(7, 13), (torch.rand(7, 2) > 0.35).float()
+    arena.zero_grad()
+    loss = ((net(x_all) - 1.0) ** 2 * valid_all).sum() / valid_all.sum()
+    loss.backward()
+    for rank, lv, grad, flag in got:
+        assert abs(lv - loss.item()) < 1e-6 * max(1.0, abs(loss.item()))
+        torch.testing.assert_close(grad, arena.flat_grad, rtol=1e-5, atol=1e-6)
+        assert flag == 1.0                                    # ... is seen by every rank: all of them skip the step
+    assert torch.equal(got[0][2], got[1][2])

@@ -1,0 +1,158 @@
+"""-m gpu: data-parallel EXACTNESS on one GPU.  Two shards of a ragged batch go through two Trainer
+instances that stand for two ranks; their only link is a world-2 communicator (the same `Comm` interface the real run
+implements over torch.distributed / RCCL).  The two "ranks" are threads of this process that run strictly one at a
+time and hand over at every all-reduce, so the whole exchange - loss numerators and counts, the LeCam EMA chain, the
+gradient sum - happens exactly as it would between processes.  After each optimisation step every rank must hold
+
+    * the same losses as ONE trainer stepping on the concatenated (global) batch,
+    * a gradient arena equal to the global-batch gradient (1e-5 relative), i.e. sum over ranks == global,
+    * the same LeCam EMA state and the same updated weights.
+"""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import DEV, npz_state_dict, rel_err  # noqa: E402
+from test_oracle_trainstep import TINY_CFG  # noqa: E402
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    import __graft_entry__ as g
+    g.build()
+    assert torch.cuda.is_available()
+
+
+class _Shared:
+    def __init__(self, world):
+        self.world = world
+        self.run = threading.Lock()            # the baton: whoever holds it executes model code
+        self.cv = threading.Condition()
+        self.slots = [None] * world
+        self.arrived = 0
+        self.gen = 0
+        self.calls = 0
+
+
+def make_comm(shared, rank):
+    from mqgan_amd.comm import Comm
+
+    class BatonComm(Comm):
+        world = shared.world
+
+        def __init__(self):
+            self.rank = rank
+
+        def all_reduce_sum(self, t):
+            shared.run.release()
+            try:
+                with shared.cv:
+                    shared.slots[rank] = t
+                    shared.arrived += 1
+                    if shared.arrived == shared.world:
+                        total = shared.slots[0].clone()
+                        for o in shared.slots[1:]:
+                            assert o.shape == total.shape, "mismatched collectives across ranks"
+                            total += o
+                        for o in shared.slots:
+                            o.copy_(total)
+                        shared.arrived = 0
+                        shared.gen += 1
+                        shared.calls += 1
+                        shared.cv.notify_all()
+                    else:
+                        g = shared.gen
+                        while shared.gen == g:
+                            if not shared.cv.wait(timeout=120):
+                                raise RuntimeError("rank %d: peer never reached the all-reduce" % rank)
+            finally:
+                shared.run.acquire()
+            return t
+
+    return BatonComm()
+
+
+def _trainer(g, use_fm, comm=None):
+    from mqgan_amd.train import Trainer
+    cfg = {"model": TINY_CFG["model"], "training": dict(TINY_CFG["training"], use_fm_loss=use_fm, pretrained=None, precision="fp32")}
+    tr = Trainer(cfg, device=DEV, build_data=False, comm=comm)
+    tr.generator.load_state_dict(npz_state_dict(g, "g0/"), strict=True)
+    tr.patch_discriminator.load_state_dict(npz_state_dict(g, "p0/"), strict=True)
+    tr.multibin_discriminator.load_state_dict(npz_state_dict(g, "m0/"), strict=True)
+    tr.arena_g.rebind()
+    tr.arena_d.rebind()
+    tr.generator.eval()                       # no dropout: the step is a deterministic function of the batch
+    tr.patch_discriminator.train()
+    tr.multibin_discriminator.train()
+    tr.epoch = 1
+    return tr
+
+
+@pytest.mark.parametrize("use_fm", [False, True])
+def test_two_ragged_shards_equal_the_global_batch(use_fm):
+    from mqgan_amd.train import synthetic_mel
+    g = load_golden("g7_trainstep.npz")
+    T, mel = 40, 16
+    xs = torch.from_numpy(np.stack([synthetic_mel(T, mel, 300 + b) for b in range(5)])).to(DEV)
+    lens_all = torch.tensor([40, 23, 31, 40, 17], dtype=torch.int32, device=DEV)
+    for b in range(5):
+        xs[b, int(lens_all[b]):] = 0.0
+    shards = [(xs[:2].contiguous(), lens_all[:2].contiguous()), (xs[2:].contiguous(), lens_all[2:].contiguous())]   # 2 + 3 items: unequal shards
+
+    # ---- one trainer on the global batch
+    ref = _trainer(g, use_fm)
+    ref_out = []
+    for _ in range(2):                        # step 0: train-mode discriminators; step 1: eval mode, real + fake as one batch
+        out = ref.train_step(xs, lens_all)
+        ref_out.append(({k: float(v) for k, v in out.items()}, ref.arena_g.flat_grad.clone(), ref.arena_d.flat_grad.clone(),
+                        ref.gan_loss._state.clone(), ref.arena_g.flat_param.clone(), ref.arena_d.flat_param.clone()))
+
+    # ---- two ranks
+    shared = _Shared(2)
+    got, errors = [None, None], []
+
+    def rank_main(r):
+        with shared.run:
+            try:
+                tr = _trainer(g, use_fm, comm=make_comm(shared, r))
+                assert tr.world == 2 and tr.rank == r
+                res = []
+                for _ in range(2):
+                    out = tr.train_step(*shards[r])
+                    res.append(({k: float(v) for k, v in out.items()}, tr.arena_g.flat_grad.clone(), tr.arena_d.flat_grad.clone(),
+                                tr.gan_loss._state.clone(), tr.arena_g.flat_param.clone(), tr.arena_d.flat_param.clone()))
+                got[r] = res
+            except BaseException as e:        # noqa: BLE001 - reported by the main thread
+                errors.append((r, e))
+                with shared.cv:               # let the peer fail fast instead of waiting for us
+                    shared.gen += 1
+                    shared.cv.notify_all()
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join(timeout=300)
+    assert not errors, errors
+    assert got[0] is not None and got[1] is not None
+    assert shared.calls >= 2 * (2 + 1 + 2)     # per step: 2 (D sums, LeCam) + 1+ (G losses) + 2 gradient arenas
+
+    for s in range(2):
+        want = ref_out[s]
+        for r in range(2):
+            have = got[r][s]
+            for k in ("loss_d", "loss_g_total", "loss_recon_pre", "loss_recon_post", "loss_gan", "loss_fm"):
+                np.testing.assert_allclose(have[0][k], want[0][k], rtol=2e-5, atol=1e-7, err_msg=f"step {s} rank {r} {k}")
+            assert rel_err(have[1], want[1]) < 2e-5, f"step {s} rank {r}: generator gradient {rel_err(have[1], want[1]):.2e}"
+            assert rel_err(have[2], want[2]) < 2e-5, f"step {s} rank {r}: discriminator gradient {rel_err(have[2], want[2]):.2e}"
+            np.testing.assert_allclose(have[3].cpu().numpy(), want[3].cpu().numpy(), rtol=1e-5, atol=1e-7, err_msg="LeCam EMA state")
+            assert rel_err(have[4], want[4]) < 1e-6 and rel_err(have[5], want[5]) < 1e-6, "updated weights"
+        # replicas stay bit-identical to each other
+        assert torch.equal(got[0][s][3], got[1][s][3])
+        assert torch.equal(got[0][s][1], got[1][s][1]) and torch.equal(got[0][s][2], got[1][s][2])

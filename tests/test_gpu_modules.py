@@ -189,40 +189,51 @@ def test_discriminators_g5(tag):
 
 
 def test_losses_g6():
+    """LSGANLoss against the reference's own numbers (fixture G6): the masks are ARBITRARY per-element masks, real and
+    fake share one here; loss values, gradients and the EMA trajectory of nine consecutive calls come straight from
+    the golden file (no projection onto frame masks)."""
     from mqgan_amd.losses import LSGANLoss, MaskedMelLoss, masked_mae, recon_loss
+    from oracle import nn as O
     g = load_golden("g6_losses.npz")
     gl = LSGANLoss().to(DEV)
     for i in range(9):
         real, fake = t(g[f"d{i}/real"], True), t(g[f"d{i}/fake"], True)
         mask = t(g[f"d{i}/mask"])
-        # fixture masks are arbitrary per element; the kernels take masks constant along H (as the
-        # discriminators produce).  Project the fixture onto that family: use row h = 0 for all h.
-        mrow = mask[:, :, :1, :].expand_as(mask)
-        from oracle import nn as O
-        if i == 0:
-            st = O.LSGANState()
-        rr, fr = real.detach().cpu().requires_grad_(True), fake.detach().cpu().requires_grad_(True)
-        want = O.lsgan_d_loss(st, rr, fr, mrow.cpu(), mrow.cpu())
-        loss = gl.discriminator_loss(real, fake, mrow, mrow)
-        close(loss, want, rtol=1e-5, atol=1e-7)
-        if want.requires_grad:
-            want.backward()
-            loss.backward()
-            close(real.grad, rr.grad, rtol=1e-4, atol=1e-7)
-            close(fake.grad, fr.grad, rtol=1e-4, atol=1e-7)
-        close(gl.ema_real, st.ema_real, rtol=1e-5, atol=1e-7)
-        close(gl.ema_fake, st.ema_fake, rtol=1e-5, atol=1e-7)
+        loss = gl.discriminator_loss(real, fake, mask, mask)
+        close(loss, g[f"d{i}/loss"], rtol=1e-5, atol=1e-7)
+        loss.backward()
+        close(real.grad, g[f"d{i}/grad_real"], rtol=1e-4, atol=1e-7)
+        close(fake.grad, g[f"d{i}/grad_fake"], rtol=1e-4, atol=1e-7)
+        close(gl.ema_real, g[f"d{i}/ema_real"], rtol=1e-5, atol=1e-7)
+        close(gl.ema_fake, g[f"d{i}/ema_fake"], rtol=1e-5, atol=1e-7)
     for i in range(3):
         fake = t(g[f"g{i}/fake"], True)
-        mask = t(g[f"g{i}/mask"])
-        mrow = mask[:, :, :1, :].expand_as(mask)
-        fr = fake.detach().cpu().requires_grad_(True)
-        want = O.lsgan_g_loss(fr, mrow.cpu())
-        want.backward()
-        loss = gl.generator_loss(fake, mrow)
+        loss = gl.generator_loss(fake, t(g[f"g{i}/mask"]))
         loss.backward()
-        close(loss, want, rtol=1e-5)
+        close(loss, g[f"g{i}/loss"], rtol=1e-5)
+        close(fake.grad, g[f"g{i}/grad_fake"], rtol=1e-4, atol=1e-7)
+    # the batched form (one EMA chain, two reductions) gives the same nine losses as nine single calls
+    gl2 = LSGANLoss().to(DEV)
+    calls = [(t(g[f"d{i}/real"]), t(g[f"d{i}/fake"]), t(g[f"d{i}/mask"]), t(g[f"d{i}/mask"])) for i in range(9)]
+    for i, l in enumerate(gl2.discriminator_losses(calls)):
+        close(l, g[f"d{i}/loss"], rtol=1e-5, atol=1e-7)
+    close(gl2.ema_real, g["d8/ema_real"], rtol=1e-5, atol=1e-7)
+    # distinct real / fake masks, one of them a frame mask (B, W) and an empty one: against the oracle
+    st = O.LSGANState()
+    gl3 = LSGANLoss().to(DEV)
+    rng = np.random.default_rng(0)
+    for trial in range(3):
+        real, fake = t(g["d0/real"], True), t(g["d1/fake"], True)
+        mr = rng.random(g["d0/mask"].shape) > 0.4
+        mf = rng.random(g["d0/mask"].shape) > (0.5 if trial < 2 else 2.0)          # trial 2: nothing valid on the fake side
+        rr, fr = real.detach().cpu().requires_grad_(True), fake.detach().cpu().requires_grad_(True)
+        want = O.lsgan_d_loss(st, rr, fr, torch.from_numpy(mr), torch.from_numpy(mf))
+        loss = gl3.discriminator_loss(real, fake, t(mr), t(mf))
+        close(loss, want, rtol=1e-5, atol=1e-7)
+        want.backward(); loss.backward()
+        close(real.grad, rr.grad, rtol=1e-4, atol=1e-7)
         close(fake.grad, fr.grad, rtol=1e-4, atol=1e-7)
+        close(gl3.ema_fake, st.ema_fake, rtol=1e-5, atol=1e-7)
     y, lens = t(g["mel/y"]), t(g["mel/lens"])
     for key, gs in (("mel1", 1), ("mel16", 16)):
         x = t(g["mel/x"], True)
