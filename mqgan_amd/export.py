@@ -1,8 +1,13 @@
 """Exporter: training checkpoint + YAML -> model directory for ScriptedPreEncoder (the role of the
 reference's convert_to_torchscript.py:42-122, same CLI).  Writes ``model_config.yaml`` (verbatim copy)
-and ``model_hip.pt`` (state_dict in the reference's key layout; the legacy weight-norm convs of the
-decoder stay unfolded so the file still loads with strict=True), then runs the reference's post-export
-self-check: encode -> decode at a length different from anything seen before returns the input's shape."""
+and ``model_hip.pt``, then runs the reference's post-export self-check: encode -> decode at a length different
+from anything seen before returns the input's shape.
+
+Two payload formats, both read by ScriptedPreEncoder:
+  * ``mqgan_amd/2-folded`` (default): every weight-normed conv - the legacy flavour of the decoder, which the reference
+    strips (preencoder.py:507-514), AND the ``parametrizations`` flavour it leaves in place - is folded into its plain
+    effective weight ``g * v / ||v||``: the wire format carries inference weights only, 30 % smaller;
+  * ``mqgan_amd/1``: the training state_dict in the reference's key layout, unfolded (``--unfolded``)."""
 import argparse
 import os
 
@@ -13,7 +18,16 @@ from .preencoder import get_pre_encoder
 from .scripted_preencoder import PAYLOAD, ScriptedPreEncoder
 
 
-def export(checkpoint: str, config_path: str, output_dir: str, verify: bool = True):
+def folded_state_dict(model):
+    """state_dict of ``model`` with every weight-normed conv folded (keys become <name>.weight / <name>.bias)."""
+    from .nn_base import ConvParams
+    for mod in model.modules():
+        if isinstance(mod, ConvParams):
+            mod.fold_weight_norm_(both=True)
+    return model.state_dict()
+
+
+def export(checkpoint: str, config_path: str, output_dir: str, verify: bool = True, folded: bool = True):
     with open(config_path, "r") as f:
         config_str = f.read()
     config = yaml.safe_load(config_str)
@@ -23,7 +37,11 @@ def export(checkpoint: str, config_path: str, output_dir: str, verify: bool = Tr
                             kernel_sizes=g["kernel_sizes"], fsq_levels=g["fsq_levels"],
                             refiner_base_channels=g.get("refiner_base_channels", 128), refiner_depth=g.get("refiner_depth", 3),
                             refiner_hidden_proj_divisor=g.get("refiner_hidden_proj_divisor", 8), inference=False)
-    torch.save({"model_state_dict": model.state_dict(), "format": "mqgan_amd/1"}, os.path.join(output_dir, PAYLOAD))
+    if folded:
+        payload = {"model_state_dict": folded_state_dict(model), "format": "mqgan_amd/2-folded", "folded": True}
+    else:
+        payload = {"model_state_dict": model.state_dict(), "format": "mqgan_amd/1", "folded": False}
+    torch.save(payload, os.path.join(output_dir, PAYLOAD))
     with open(os.path.join(output_dir, "model_config.yaml"), "w") as f:
         f.write(config_str)
     if verify and torch.cuda.is_available():
@@ -41,8 +59,9 @@ def main(argv=None):
     ap.add_argument("--checkpoint", type=str, required=True)
     ap.add_argument("--config", type=str, required=True)
     ap.add_argument("--output_dir", type=str, required=True)
+    ap.add_argument("--unfolded", action="store_true", help="write the training state_dict (format mqgan_amd/1) instead of folded weights")
     a = ap.parse_args(argv)
-    export(a.checkpoint, a.config, a.output_dir)
+    export(a.checkpoint, a.config, a.output_dir, folded=not a.unfolded)
     print(f"exported to {a.output_dir}")
 
 

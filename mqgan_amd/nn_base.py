@@ -131,14 +131,22 @@ class ConvParams(nn.Module):
             return ops.weight_prep(self.weight_v, self.weight_g, need_crsk)
         return ops.spectral_prep(self.weight_orig, self.weight_u, self.weight_v, power_iteration, need_crsk)
 
-    def fold_weight_norm_(self):
-        """strip_weight_norm (preencoder.py:507-514) for the legacy flavour: weight_g/weight_v -> weight."""
-        if self.flavour != "wn_legacy":
+    def fold_weight_norm_(self, both: bool = False):
+        """strip_weight_norm (preencoder.py:507-514): the LEGACY flavour's weight_g/weight_v -> weight.  ``both=True`` also
+        folds the ``parametrizations`` flavour, which the reference leaves in place (the exported wire format
+        carries plain effective weights only)."""
+        if self.flavour == "wn_legacy":
+            v, g = self.weight_v, self.weight_g
+        elif self.flavour == "wn" and both:
+            v, g = self.parametrizations.weight.original1, self.parametrizations.weight.original0
+        else:
             return
         with torch.no_grad():
-            v, g = self.weight_v, self.weight_g
             w = v * (g / v.flatten(1).norm(dim=1).view(-1, *([1] * (v.dim() - 1))))
-        del self.weight_g, self.weight_v
+        if self.flavour == "wn_legacy":
+            del self.weight_g, self.weight_v
+        else:
+            del self.parametrizations
         bias = self.bias
         del self.bias
         self.weight = nn.Parameter(w)

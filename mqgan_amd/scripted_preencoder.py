@@ -2,8 +2,8 @@
 scripted_preencoder.py:24-175), backed by the HIP PreEncoder instead of a TorchScript trace.
 
 Model directory = ``model_config.yaml`` (the training YAML, copied verbatim as the reference's exporter
-does, convert_to_torchscript.py:94-97) + ``model_hip.pt`` (a ``torch.save`` of ``{"model_state_dict": ...}``
-in the reference's key layout, written by ``mqgan_amd.export``).  The reference's ``model_cpu.pt`` /
+does, convert_to_torchscript.py:94-97) + ``model_hip.pt`` (a ``torch.save`` of ``{"model_state_dict": ..., "folded": bool}``
+written by ``mqgan_amd.export``: folded inference weights by default, or the reference's training key layout).  The reference's ``model_cpu.pt`` /
 ``model_cuda.pt`` are TorchScript traces of the reference's own Python and are not read.
 """
 import os
@@ -58,6 +58,11 @@ class ScriptedPreEncoder:
         try:
             payload = torch.load(model_path, map_location="cpu", weights_only=False)
             self.model = build_from_config(self.config)
+            if payload.get("folded"):                  # format mqgan_amd/2-folded: plain effective weights everywhere
+                from .nn_base import ConvParams
+                for mod in self.model.modules():
+                    if isinstance(mod, ConvParams):
+                        mod.fold_weight_norm_(both=True)
             self.model.load_state_dict(payload["model_state_dict"], strict=True)
             self.model.to(self.device).eval()
             freeze_weights(self.model)

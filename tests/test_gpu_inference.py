@@ -27,9 +27,10 @@ def model_dir(tmp_path_factory):
     cfg = d / "cfg.yaml"
     cfg.write_text(yaml.safe_dump({"model": TINY_CFG["model"]}))
     out = d / "model"
-    export(str(ckpt), str(cfg), str(out))
+    export(str(ckpt), str(cfg), str(out))                         # default payload: folded weights
     assert (out / "model_config.yaml").read_text() == cfg.read_text()
-    return str(out), str(ckpt), str(cfg)
+    export(str(ckpt), str(cfg), str(d / "model_unfolded"), folded=False)
+    return str(out), str(ckpt), str(cfg), str(d / "model_unfolded")
 
 
 def test_scripted_preencoder_matches_reference_fixture(model_dir):
@@ -77,3 +78,65 @@ def test_reencode_tree_and_bad_files(model_dir, tmp_path):
             assert np.isfinite(a).all()
             found += 1
     assert found == n1
+
+
+def test_folded_and_unfolded_payloads_agree(model_dir):
+    """Export formats: the folded payload holds plain effective weights only - no weight-norm keys of
+    either flavour -, is smaller, and ScriptedPreEncoder gives the same indices and mels from both."""
+    from mqgan_amd.scripted_preencoder import PAYLOAD, ScriptedPreEncoder
+    g = load_golden("g9_encdec.npz")
+    pf = torch.load(os.path.join(model_dir[0], PAYLOAD), map_location="cpu", weights_only=False)
+    pu = torch.load(os.path.join(model_dir[3], PAYLOAD), map_location="cpu", weights_only=False)
+    assert pf["folded"] and pf["format"] == "mqgan_amd/2-folded" and not pu["folded"]
+    assert not any(("original" in k) or k.endswith("weight_g") or k.endswith("weight_v") for k in pf["model_state_dict"])
+    assert any("parametrizations.weight.original0" in k for k in pu["model_state_dict"])
+    assert set(pu["model_state_dict"]) == set(npz_state_dict(g, "sd/"))          # the reference's training key layout
+    assert sum(v.numel() for v in pf["model_state_dict"].values()) < sum(v.numel() for v in pu["model_state_dict"].values())
+    a, b = ScriptedPreEncoder(model_dir[0], device="cuda"), ScriptedPreEncoder(model_dir[3], device="cuda")
+    x, lens = torch.from_numpy(g["x"]), g["lens"].tolist()
+    ia, ib = a.encode(x, lengths=lens), b.encode(x, lengths=lens)
+    np.testing.assert_array_equal(ia.cpu().numpy(), g["idx"])
+    np.testing.assert_array_equal(ib.cpu().numpy(), g["idx"])
+    close(a.decode(ia, lengths=lens), b.decode(ib, lengths=lens), rtol=1e-5, atol=1e-6)
+    close(a.decode(ia, lengths=lens), g["dec"], rtol=1e-4, atol=2e-5)
+
+
+def test_length_bucketed_reencode(model_dir, tmp_path):
+    """SURVEY 8f N2.  'exact' buckets (identical lengths only, no padding): every file gets bit-for-bit the result of being
+    processed alone, whatever the directory order.  'sorted' buckets (length-sorted neighbours under a padding budget):
+    every file is written with its own length, the longest file of each batch still equals its stand-alone result bit
+    for bit, the padded ones agree with it on frames away from their end (the reference's padded frames leak into the
+    last valid ones), and much less padding is processed than in directory order."""
+    from mqgan_amd.reencode_spectrograms import _find_npy, _length_of, plan_batches, reencode_spectrograms
+    src = tmp_path / "in"
+    (src / "x" / "y").mkdir(parents=True)
+    rng = np.random.default_rng(1)
+    lens = [40, 12, 33, 40, 12, 64, 33, 12, 57, 40, 5, 64]
+    for i, L in enumerate(lens):
+        np.save(src / ("x" if i % 3 == 0 else ("x/y" if i % 3 == 1 else "")) / f"u{i:02d}.npy",
+                (rng.standard_normal((L, 16)) * 2 - 4).astype(np.float32))
+    outs, stats = {}, {}
+    for name, kw in (("alone", dict(batch_size=1, bucket="order")), ("exact", dict(batch_size=4, bucket="exact")),
+                     ("sorted", dict(batch_size=4, bucket="sorted", max_pad=0.25)), ("order", dict(batch_size=4, bucket="order"))):
+        dst = tmp_path / name
+        stats[name] = {}
+        n = reencode_spectrograms(model_dir[0], str(src), str(dst), "cuda", stats=stats[name], **kw)
+        assert n == len(lens)
+        outs[name] = {os.path.relpath(p, dst): np.load(p) for p in _find_npy(str(dst))}
+        assert len(outs[name]) == len(lens)
+    for rel, a in outs["alone"].items():
+        L = np.load(src / rel).shape[0]
+        assert a.shape == (L, 16)
+        np.testing.assert_array_equal(outs["exact"][rel], a)                       # no padding -> identical bits
+        b = outs["sorted"][rel]
+        assert b.shape == a.shape
+        if L > 16:
+            np.testing.assert_allclose(b[:L - 12], a[:L - 12], rtol=2e-3, atol=2e-3)
+    files = _find_npy(str(src))
+    plan = plan_batches(files, [_length_of(p) for p in files], 4, "sorted", 0.25)
+    for batch in plan:                                                             # the longest member of a batch is unpadded
+        rel = os.path.relpath(max(batch, key=_length_of), src)
+        np.testing.assert_array_equal(outs["sorted"][rel], outs["alone"][rel])
+    assert stats["exact"]["pad_fraction"] == 0.0
+    assert stats["sorted"]["pad_fraction"] <= 0.25 + 1e-9 and stats["order"]["pad_fraction"] > 0.0
+    assert stats["sorted"]["frames"] == sum(lens) and stats["sorted"]["frames_per_s"] > 0
