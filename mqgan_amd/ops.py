@@ -545,10 +545,13 @@ class TapsReduceFn(torch.autograd.Function):
         return du, db, None, None
 
 
-def _thin_conv(x, w_krsc, w_crsk, bias, desc: ConvDesc, leaky=None):
-    """C = 1 or K = 1 with more than one tap (csrc/taps.hip): tap gather / fold around a 1x1 GEMM."""
+def _thin_conv(x, w_krsc, w_crsk, bias, desc: ConvDesc, leaky=None, out_f32=True):
+    """C = 1 or K = 1 with more than one tap (csrc/taps.hip): tap gather / fold around a 1x1 GEMM.  With bf16 activation
+    storage the tap axis is padded to a multiple of 32 so that the 1x1 GEMM (the only pass over the wide tensor) runs on
+    the bf16-storage kernels and the wide tensor is a bf16 tensor from the start."""
     G, K, Cin, RS = desc.groups, desc.K, desc.C, desc.R * desc.S
-    T = (RS + 3) // 4 * 4
+    storage = ACT_BF16 and desc.precision == PRECISIONS["bf16"]
+    T = (RS + 31) // 32 * 32 if storage else (RS + 3) // 4 * 4
     key = _desc_key(desc)
     need_dx = x.requires_grad
     if Cin == 1:
@@ -556,16 +559,25 @@ def _thin_conv(x, w_krsc, w_crsk, bias, desc: ConvDesc, leaky=None):
         wk = torch.nn.functional.pad(w_krsc.view(G * K, RS), (0, T - RS)).contiguous().view(G * K, 1, T)         # KRSC of the 1x1 conv
         wc = wk.view(G, K, T).transpose(1, 2).contiguous().view(G * T, 1, K) if need_dx else None              # its CRSK
         d1 = conv_desc(desc.N, desc.P, desc.Q, T, K, 1, 1, groups=G, precision=desc.precision)
+        if _use_h2(d1):
+            epi = None if leaky is None else (leaky[0], leaky[1], leaky[2])
+            return ConvH2Fn.apply(to_bf16(cols), wk, wc, bias, _desc_key(d1), epi, False)
         if leaky is not None and not _h_ok(d1, T):          # same output rows (n, p, q): the fused activation applies
             return ConvLeakyFn.apply(cols, wk, wc, bias, leaky[0], _desc_key(d1), leaky[1], leaky[2])
-        return ConvFn.apply(cols, wk, wc, bias, _desc_key(d1))
+        y = ConvFn.apply(cols, wk, wc, bias, _desc_key(d1))
+        if leaky is not None:
+            y = pointwise(y, act=ACT_LEAKY, mask=leaky[0], mask_post=leaky[0] is not None, dmap=leaky[1])
+        return y
     # K = 1: w_krsc is (G, RS, C) in the channel-blocked order [C/CB][RS][CB] -> rows = taps, plain channels
     CB = 16 if Cin % 16 == 0 else Cin
     wt = w_krsc.view(G, Cin // CB, RS, CB).permute(0, 2, 1, 3).contiguous().view(G, RS, Cin)
     wk = torch.nn.functional.pad(wt, (0, 0, 0, T - RS)).contiguous().view(G * T, 1, Cin)                        # KRSC: T "output channels"
     wc = wk.view(G, T, Cin).transpose(1, 2).contiguous().view(G * Cin, 1, T) if need_dx else None
     d1 = conv_desc(desc.N, desc.H, desc.W, Cin, T, 1, 1, groups=G, precision=desc.precision)
-    u = ConvFn.apply(x, wk, wc, None, _desc_key(d1))
+    if _use_h2(d1):
+        u = ConvH2Fn.apply(to_bf16(x), wk, wc, None, _desc_key(d1), None, True)                                 # u: f32 (N, H, W, T)
+    else:
+        u = ConvFn.apply(to_f32(x), wk, wc, None, _desc_key(d1))
     return TapsReduceFn.apply(u, bias, key, T).view(desc.N, desc.P, desc.Q, 1)
 
 
@@ -574,15 +586,21 @@ def _use_h2(desc: ConvDesc) -> bool:
     return (ACT_BF16 and desc.precision == PRECISIONS["bf16"] and desc.N * desc.P * desc.Q >= 2048 and h2_supported(desc))
 
 
+def _is_thin(desc: ConvDesc) -> bool:
+    return desc.R * desc.S > 1 and ((desc.C == 1) != (desc.K == 1)) and (desc.C % 4 == 0 or desc.K % 4 == 0)
+
+
 def conv_leaky(x, w_krsc, w_crsk, bias, desc: ConvDesc, mask, dmap, slope: float = 0.2, out_f32: bool = False):
     """LeakyReLU(conv) with padded frames zeroed - one kernel where the fused epilogue applies, conv + pointwise otherwise."""
     if _use_h2(desc):
         return ConvH2Fn.apply(to_bf16(x), w_krsc, w_crsk, bias, _desc_key(desc), (mask, tuple(dmap), slope), out_f32)
-    x = to_f32(x)
-    thin = desc.R * desc.S > 1 and ((desc.C == 1) != (desc.K == 1)) and (desc.C % 4 == 0 or desc.K % 4 == 0)
+    thin = _is_thin(desc)
     if thin and desc.C == 1:
-        return _thin_conv(x, w_krsc, w_crsk, bias, desc, leaky=(mask, tuple(dmap), slope))
-    if thin or desc.C % 4 != 0 or _h_ok(desc, desc.C):
+        return _thin_conv(to_f32(x), w_krsc, w_crsk, bias, desc, leaky=(mask, tuple(dmap), slope))
+    if thin:
+        return pointwise(_thin_conv(x, w_krsc, w_crsk, bias, desc), act=ACT_LEAKY, mask=mask, mask_post=mask is not None, dmap=dmap)
+    x = to_f32(x)
+    if desc.C % 4 != 0 or _h_ok(desc, desc.C):
         return pointwise(conv(x, w_krsc, w_crsk, bias, desc), act=ACT_LEAKY, mask=mask, mask_post=mask is not None, dmap=dmap)
     return ConvLeakyFn.apply(x, w_krsc, w_crsk, bias, mask, _desc_key(desc), tuple(dmap), slope)
 
@@ -592,10 +610,9 @@ def conv(x, w_krsc, w_crsk, bias, desc: ConvDesc, out_f32: bool = False):
     and write bf16 tensors (f32 output on request); every other layer reads and writes f32 tensors."""
     if _use_h2(desc):
         return ConvH2Fn.apply(to_bf16(x), w_krsc, w_crsk, bias, _desc_key(desc), None, out_f32)
-    x = to_f32(x)
-    if desc.R * desc.S > 1 and ((desc.C == 1) != (desc.K == 1)) and (desc.C % 4 == 0 or desc.K % 4 == 0):
-        return _thin_conv(x, w_krsc, w_crsk, bias, desc)
-    return ConvFn.apply(x, w_krsc, w_crsk, bias, _desc_key(desc))
+    if _is_thin(desc):
+        return _thin_conv(x if desc.K == 1 else to_f32(x), w_krsc, w_crsk, bias, desc)
+    return ConvFn.apply(to_f32(x), w_krsc, w_crsk, bias, _desc_key(desc))
 
 
 # ----------------------------------------------------------------------------- weight preparation
