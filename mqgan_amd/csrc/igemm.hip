@@ -1,5 +1,7 @@
 // Implicit-GEMM convolution (fprop / dgrad / wgrad) on f32 MFMA for gfx950, NHWC.
 // See include/mqgan_hip.h (mq_conv_*) for the interface and gemm_core.h for the tile engine.
+#include <stdlib.h>
+
 #include <algorithm>
 #include <type_traits>
 
@@ -10,6 +12,20 @@
 #endif
 
 namespace mq {
+
+// LDS-DMA f32 kernels (igemm_h2.hip): fprop / dgrad of the layers with C % 16 == 0 and enough rows for 256-row tiles
+bool d32_nt_ok(const mqConvDesc *d, bool dgrad);
+int d32_nt_launch(const mqConvDesc *d, bool dgrad, const float *act, const float *w, const float *bias, const uint8_t *mask, int d1,
+                  int d2, int d3, int act_kind, float slope, float *out, hipStream_t st);
+// Measured (tools/f32_micro.py, round 2): on the f32 engine the LDS-DMA structure is SLOWER than the register-staged
+// kernels below (126-135 vs 131-142 TF/s on the 256-768 channel layers): f32 MFMA runs at the vector rate, so neither L2
+// bandwidth nor staging instructions bound it, and one 512-thread block per CU loses more to the tile tail than four
+// 256-thread blocks do.  The f32 instantiations stay available for A/B runs (MQGAN_D32=1) but are off by default.
+static bool use_d32()
+{
+    static const bool on = getenv("MQGAN_D32") != nullptr;
+    return on;
+}
 
 struct ConvGeom {
     // GEMM view:  rows m = (n, oh, ow) of the OUTPUT of this pass, cols = Ncols, reduction kk = (r, s, ic)
@@ -1113,6 +1129,9 @@ static int launch_nt(const mqConvDesc *d, const float *act, const float *w, cons
 {
     const bool want_bf16 = d->precision == MQ_PRECISION_BF16 && !hmode;
     const bool want_x3 = d->precision == MQ_PRECISION_F32X3;
+    if (use_d32() && d->precision == MQ_PRECISION_F32 && !hmode && ((uintptr_t)act % 16 == 0) && ((uintptr_t)w % 16 == 0) &&
+        d32_nt_ok(d, DGRAD))
+        return d32_nt_launch(d, DGRAD, act, w, bias, epi.mask, epi.d1, epi.d2, epi.d3, epi.act, epi.slope, out, st);
     ConvGeom g;
     const int ng = d->N / d->groups;
     if (!DGRAD) {

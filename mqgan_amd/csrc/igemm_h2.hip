@@ -63,17 +63,29 @@ __device__ __forceinline__ unsigned short f2bf(float v)
     return __builtin_bit_cast(unsigned short, (__bf16)v);          // v_cvt_pk_bf16_f32 (RNE, NaN-safe)
 }
 
-// TN: 32-column MFMA tiles per wave along N (block tile N = 64 * TN); CBK: channel block (64 or 32);
-// PARITY: dgrad by stride parity (tap subset and output scatter per class)
-template <int TN, int NSTAGE, int CBK, bool PARITY>
-__device__ __forceinline__ void conv_h2_body(const unsigned short *__restrict__ act, const unsigned short *__restrict__ wgt,
+// Element policies.  The same structure serves the exact-product f32 engine (MQ_PRECISION_F32: f32 tensors,
+// v_mfma_f32_32x32x2_f32): a K-step is then 32 k's (the same 128-byte LDS rows), each lane half reads one float2 per
+// k-quad = the operands of two MFMA steps, and every accumulator sums k in the order 4q, 4q+2, 4q+1, 4q+3 - the order of
+// igemm.hip's f32 engine, so the two are bit-identical.  There the gain is not bandwidth but issue slots: f32 MFMA runs
+// at the vector rate and every other instruction a wave issues comes out of the matrix pipe's time; LDS-DMA removes the
+// staging loads, the LDS stores and their address arithmetic from the loop.
+struct ElemBF16 { static constexpr int ESZ = 2; static constexpr bool F32 = false; };
+struct ElemF32 { static constexpr int ESZ = 4; static constexpr bool F32 = true; };
+
+// TN: 32-column MFMA tiles per wave along N (block tile N = 64 * TN); CBK: channel block in ELEMENTS (bf16: 64 or 32,
+// f32: 16, i.e. 128- or 64-byte runs); PARITY: dgrad by stride parity (tap subset and output scatter per class)
+template <class ET, int TN, int NSTAGE, int CBK, bool PARITY>
+__device__ __forceinline__ void conv_h2_body(const void *__restrict__ act_v, const void *__restrict__ wgt_v,
                                              void *__restrict__ out, const H2Geom &g, const H2Parity &pi, const H2Epi &epi,
                                              size_t act_group_stride, char *smem)
 {
+    constexpr int ESZ = ET::ESZ;
     constexpr int BN = 64 * TN;
     constexpr int STAGE = (H2_BM + BN) * H2_ROWB;
-    constexpr int NSUB = 64 / CBK;                 // (chunk, tap) positions per K-step
-    constexpr int CPB = CBK / 8;                   // 16-byte chunks per position
+    constexpr int NSUB = 128 / (CBK * ESZ);        // (chunk, tap) positions per K-step
+    constexpr int CPB = CBK * ESZ / 16;            // 16-byte chunks per position
+    const char *act = reinterpret_cast<const char *>(act_v);
+    const char *wgt = reinterpret_cast<const char *>(wgt_v);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -120,10 +132,10 @@ __device__ __forceinline__ void conv_h2_body(const unsigned short *__restrict__ 
     const int cin_b = (lc % CPB) * 16;                         // byte offset inside the position's channel run
     const int img0 = (OHc * OWc) > 0 ? m0 / (OHc * OWc) : 0;
     const size_t img_elems = (size_t)g.IH * g.IW * g.IC;
-    const unsigned short *abase = act + (size_t)grp * act_group_stride + (size_t)img0 * img_elems;
-    const __amdgpu_buffer_rsrc_t ra = make_rsrc(abase, (act_group_stride - (size_t)img0 * img_elems) * 2);
-    const unsigned short *wbase = wgt + ((size_t)grp * g.Ncols + n0) * g.Kp;
-    const __amdgpu_buffer_rsrc_t rb = make_rsrc(wbase, (size_t)(g.Ncols - n0 < BN ? g.Ncols - n0 : BN) * g.Kp * 2);
+    const char *abase = act + ((size_t)grp * act_group_stride + (size_t)img0 * img_elems) * ESZ;
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(abase, (act_group_stride - (size_t)img0 * img_elems) * ESZ);
+    const char *wbase = wgt + ((size_t)grp * g.Ncols + n0) * g.Kp * ESZ;
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(wbase, (size_t)(g.Ncols - n0 < BN ? g.Ncols - n0 : BN) * g.Kp * ESZ);
     int bh_[4], bw_[4], rowbase_[4];
     bool rv_[4];
 #pragma unroll
@@ -145,13 +157,13 @@ __device__ __forceinline__ void conv_h2_body(const unsigned short *__restrict__ 
         rv_[j] = v;
         bh_[j] = bh;
         bw_[j] = bw;
-        rowbase_[j] = (((n * g.IH + bh) * g.IW + bw) * g.IC) * 2 + cin_b;
+        rowbase_[j] = (((n * g.IH + bh) * g.IW + bw) * g.IC) * ESZ + cin_b;
     }
     unsigned rowoffB[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int row = 8 * (wave + 8 * j) + lrow;
-        rowoffB[j] = (n0 + row < g.Ncols) ? (unsigned)row * (unsigned)g.Kp * 2u + (unsigned)cin_b : OOB;
+        rowoffB[j] = (n0 + row < g.Ncols) ? (unsigned)row * (unsigned)g.Kp * (unsigned)ESZ + (unsigned)cin_b : OOB;
     }
     // ---- scalar walk over (chunk, tap row, tap col): NSUB walkers, walker u starts at position u, moves NSUB per step
     int w_js[NSUB], w_jr[NSUB], w_ch[NSUB];
@@ -169,10 +181,10 @@ __device__ __forceinline__ void conv_h2_body(const unsigned short *__restrict__ 
 #pragma unroll
         for (int u = 0; u < NSUB; ++u) {
             const int h_u = w_jr[u] * step_h, w_u = w_js[u] * step_w;
-            const int a_u = ((h_u * g.IW + w_u) * g.IC + w_ch[u] * CBK) * 2;
+            const int a_u = ((h_u * g.IW + w_u) * g.IC + w_ch[u] * CBK) * ESZ;
             const int tr = PARITY ? tap_r0 + w_jr[u] * tap_rstep : w_jr[u];
             const int ts = PARITY ? tap_s0 + w_js[u] * tap_sstep : w_js[u];
-            const int b_u = ((w_ch[u] * RS + tr * g.S + ts) * CBK) * 2;
+            const int b_u = ((w_ch[u] * RS + tr * g.S + ts) * CBK) * ESZ;
             const bool k_u = w_ch[u] < g.nchunks;
             if (u == 0 || sub == u) { hoff = h_u; woff = w_u; aoff = a_u; bcol = b_u; kv = k_u; }
             // advance this walker by NSUB positions (scalar unit)
@@ -210,12 +222,18 @@ __device__ __forceinline__ void conv_h2_body(const unsigned short *__restrict__ 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int qx = lh ^ ((li >> 1) & 7);
-    int aoffs[4], boffs[4];
+    // Fragment reads.  bf16: lane (r, h) reads the 16 bytes of chunk 2s + h (8 k's) of row r per 32x32x16 MFMA.
+    // f32: lane (r, h) reads the float2 at byte 8h of chunk q (k = 4q + 2h, 4q + 2h + 1) per pair of 32x32x2 MFMAs.
+    // Either way the chunk index is XORed with (row >> 1) & 7, which depends on the lane only.
+    constexpr int NFR = ET::F32 ? 8 : 4;
+    const int sw = (li >> 1) & 7;
+    int aoffs[NFR], boffs[NFR];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        aoffs[s] = (wm * 64 + li) * H2_ROWB + (((2 * s) ^ qx) << 4);
-        boffs[s] = H2_BM * H2_ROWB + (wn * 32 * TN + li) * H2_ROWB + (((2 * s) ^ qx) << 4);
+    for (int s = 0; s < NFR; ++s) {
+        const int chunk = ET::F32 ? (s ^ sw) : ((2 * s) ^ (lh ^ sw));
+        const int inner = ET::F32 ? 8 * lh : 0;
+        aoffs[s] = (wm * 64 + li) * H2_ROWB + (chunk << 4) + inner;
+        boffs[s] = H2_BM * H2_ROWB + (wn * 32 * TN + li) * H2_ROWB + (chunk << 4) + inner;
     }
     const int npos = g.nchunks * nR * nS;
     const int nk = (npos + NSUB - 1) / NSUB;
@@ -228,18 +246,39 @@ __device__ __forceinline__ void conv_h2_body(const unsigned short *__restrict__ 
 
     auto compute = [&](int stage) {
         const char *base = smem + stage * STAGE;
+        if constexpr (ET::F32) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            bf16x8 a[2], b[TN];
+            for (int q = 0; q < 8; ++q) {
+                float2 a[2], b[TN];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) a[t] = *reinterpret_cast<const bf16x8 *>(base + aoffs[s] + t * 32 * H2_ROWB);
+                for (int t = 0; t < 2; ++t) a[t] = *reinterpret_cast<const float2 *>(base + aoffs[q] + t * 32 * H2_ROWB);
 #pragma unroll
-            for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const bf16x8 *>(base + boffs[s] + t * 32 * H2_ROWB);
+                for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const float2 *>(base + boffs[q] + t * 32 * H2_ROWB);
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
+                for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].x, b[tn].x, acc[tm][tn], 0, 0, 0);
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].y, b[tn].y, acc[tm][tn], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                bf16x8 a[2], b[TN];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) a[t] = *reinterpret_cast<const bf16x8 *>(base + aoffs[s] + t * 32 * H2_ROWB);
+#pragma unroll
+                for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const bf16x8 *>(base + boffs[s] + t * 32 * H2_ROWB);
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+            }
         }
     };
     // Tile t + NSTAGE - 1 goes into the stage that was read in iteration t - 1: every wave has passed the barrier that
@@ -299,7 +338,7 @@ __device__ __forceinline__ void conv_h2_body(const unsigned short *__restrict__ 
                 } else {
                     o = ((size_t)grp * Mc + m) * g.Ncols + n;
                 }
-                if (epi.out_f32) of[o] = v;
+                if (ET::F32 || epi.out_f32) of[o] = v;
                 else oh_[o] = f2bf(v);
             }
     }
@@ -311,7 +350,17 @@ __global__ __launch_bounds__(512, 2) void conv_h2_kernel(const unsigned short *_
                                                          size_t act_group_stride)
 {
     __shared__ __attribute__((aligned(1024))) char smem[NSTAGE * (H2_BM + 64 * TN) * H2_ROWB];
-    conv_h2_body<TN, NSTAGE, CBK, PARITY>(act, wgt, out, g, pi, epi, act_group_stride, smem);
+    conv_h2_body<ElemBF16, TN, NSTAGE, CBK, PARITY>(act, wgt, out, g, pi, epi, act_group_stride, smem);
+}
+// exact f32 products on the same LDS-DMA structure (MQ_PRECISION_F32, C % 16 == 0): f32 tensors, the existing KRSC / CRSK
+// weight layouts (channel blocks of 16 = 64-byte runs, two (chunk, tap) positions per K-step)
+template <int TN, int NSTAGE, bool PARITY>
+__global__ __launch_bounds__(512, 2) void conv_d32_kernel(const float *__restrict__ act, const float *__restrict__ wgt,
+                                                          float *__restrict__ out, H2Geom g, H2Parity pi, H2Epi epi,
+                                                          size_t act_group_stride)
+{
+    __shared__ __attribute__((aligned(1024))) char smem[NSTAGE * (H2_BM + 64 * TN) * H2_ROWB];
+    conv_h2_body<ElemF32, TN, NSTAGE, 16, PARITY>(act, wgt, out, g, pi, epi, act_group_stride, smem);
 }
 
 // ------------------------------------------------------------------------------------------ wgrad
@@ -642,12 +691,29 @@ static int pick_tn(int ncols)
     return tn;
 }
 
-template <bool DGRAD>
-static int launch_h2(const mqConvDesc *d, const unsigned short *act, const unsigned short *w, void *out, const H2Epi &epi_in,
+// f32 engine on the same structure: reduction channels in blocks of 16 (the layout mq_weight_prep writes)
+static bool d32_shape_ok(const mqConvDesc *d, bool dgrad)
+{
+    const int ic = dgrad ? d->K : d->C;
+    if (ic % 16 != 0) return false;
+    if (d->stride_h > 2 || d->stride_w > 2) return false;
+    const int64_t img_x = (int64_t)d->H * d->W * d->C * 4, img_y = (int64_t)d->P * d->Q * d->K * 4;
+    const int64_t t_x = cdiv(H2_BM, (int64_t)d->P * d->Q) + 2, t_y = cdiv(H2_BM, (int64_t)d->H * d->W) + 2;
+    if ((dgrad ? img_y * t_y : img_x * t_x) >= 0x7FFFFFF0ll) return false;
+    if ((int64_t)(dgrad ? d->C : d->K) * d->R * d->S * ic * 4 >= 0xFFFFFFF0ll) return false;
+    if ((int64_t)(d->N / d->groups) * (dgrad ? (int64_t)d->H * d->W : (int64_t)d->P * d->Q) < 4 * H2_BM) return false;   // small problems: 128-row tiles
+    return true;
+}
+
+template <class ET, bool DGRAD>
+static int launch_h2(const mqConvDesc *d, const void *act, const void *w, void *out, const H2Epi &epi_in,
                      hipStream_t st, const char *who)
 {
-    MQ_REQUIRE(h2_shape_ok(d), "%s: shape not supported by the bf16-storage kernels (need C %% 32 == 0, K %% 32 == 0, strides <= 2; "
-               "got C=%d K=%d stride=(%d,%d)); ask mq_h2_supported first", who, d->C, d->K, d->stride_h, d->stride_w);
+    if constexpr (ET::F32)
+        MQ_REQUIRE(d32_shape_ok(d, DGRAD), "%s: shape not supported by the LDS-DMA f32 kernels", who);
+    else
+        MQ_REQUIRE(h2_shape_ok(d), "%s: shape not supported by the bf16-storage kernels (need C %% 32 == 0, K %% 32 == 0, strides <= 2; "
+                   "got C=%d K=%d stride=(%d,%d)); ask mq_h2_supported first", who, d->C, d->K, d->stride_h, d->stride_w);
     MQ_REQUIRE((uintptr_t)act % 16 == 0 && (uintptr_t)w % 16 == 0, "%s: operands must be 16-byte aligned", who);
     H2Geom g;
     memset(&g, 0, sizeof(g));
@@ -667,9 +733,9 @@ static int launch_h2(const mqConvDesc *d, const unsigned short *act, const unsig
     }
     g.nR = g.R; g.nS = g.S;
     g.Mtot = ng * g.OH * g.OW;
-    g.CB = g.IC % 64 == 0 ? 64 : 32;
+    g.CB = ET::F32 ? 16 : (g.IC % 64 == 0 ? 64 : 32);
     g.nchunks = g.IC / g.CB;
-    g.Kp = h2_kp(d->R * d->S, g.IC);
+    g.Kp = ET::F32 ? d->R * d->S * g.IC : h2_kp(d->R * d->S, g.IC);
     const int TN = pick_tn(g.Ncols);
     const int BN = 64 * TN;
     g.nMt = (int)cdiv(g.Mtot, H2_BM);
@@ -708,17 +774,31 @@ static int launch_h2(const mqConvDesc *d, const unsigned short *act, const unsig
         pi.tile0[pi.ncls] = t0;
         grid = dim3((unsigned)(t0 * g.nNt), d->groups);
     }
-#define MQ_H2(TN_, NS_, CB_, PAR_) hipLaunchKernelGGL((conv_h2_kernel<TN_, NS_, CB_, PAR_>), grid, block, 0, st, act, w, out, g, pi, epi, act_gs)
-#define MQ_H2_CB(TN_, NS_, PAR_) do { if (g.CB == 64) MQ_H2(TN_, NS_, 64, PAR_); else MQ_H2(TN_, NS_, 32, PAR_); } while (0)
+#define MQ_H2(TN_, NS_, CB_, PAR_) hipLaunchKernelGGL((conv_h2_kernel<TN_, NS_, CB_, PAR_>), grid, block, 0, st, reinterpret_cast<const unsigned short *>(act), \
+                                                      reinterpret_cast<const unsigned short *>(w), out, g, pi, epi, act_gs)
+#define MQ_D32(TN_, NS_, PAR_) hipLaunchKernelGGL((conv_d32_kernel<TN_, NS_, PAR_>), grid, block, 0, st, reinterpret_cast<const float *>(act), \
+                                                  reinterpret_cast<const float *>(w), reinterpret_cast<float *>(out), g, pi, epi, act_gs)
+#define MQ_H2_CB(TN_, NS_, PAR_) do { if constexpr (ET::F32) MQ_D32(TN_, NS_, PAR_); else if (g.CB == 64) MQ_H2(TN_, NS_, 64, PAR_); else MQ_H2(TN_, NS_, 32, PAR_); } while (0)
 #define MQ_H2_TN(PAR_) do { if (TN == 4) MQ_H2_CB(4, 2, PAR_); else if (TN == 3) MQ_H2_CB(3, 2, PAR_); \
                             else if (TN == 2) MQ_H2_CB(2, 3, PAR_); else MQ_H2_CB(1, 3, PAR_); } while (0)
     if (parity) MQ_H2_TN(true);
     else MQ_H2_TN(false);
 #undef MQ_H2_TN
 #undef MQ_H2_CB
+#undef MQ_D32
 #undef MQ_H2
     MQ_LAUNCH_CHECK(who);
     return 0;
+}
+
+// hooks for igemm.hip's dispatcher (MQ_PRECISION_F32)
+bool d32_nt_ok(const mqConvDesc *d, bool dgrad) { return d32_shape_ok(d, dgrad); }
+int d32_nt_launch(const mqConvDesc *d, bool dgrad, const float *act, const float *w, const float *bias, const uint8_t *mask, int d1,
+                  int d2, int d3, int act_kind, float slope, float *out, hipStream_t st)
+{
+    H2Epi epi{bias, act_kind ? mask : nullptr, mask ? d1 : 1, mask ? d2 : 0, mask ? d3 : 1, act_kind, slope, 1};
+    if (dgrad) return launch_h2<ElemF32, true>(d, act, w, out, epi, st, "mq_conv_dgrad(lds-dma)");
+    return launch_h2<ElemF32, false>(d, act, w, out, epi, st, "mq_conv_fprop(lds-dma)");
 }
 
 }  // namespace mq
@@ -763,7 +843,7 @@ extern "C" int mq_conv_fprop_h2(const mqConvDesc *d, const uint16_t *x, const ui
     MQ_REQUIRE(mask == nullptr || (d1 > 0 && d3 > 0 && d2 >= 0 && d1 < INT32_MAX && d2 < INT32_MAX && d3 < INT32_MAX),
                "mq_conv_fprop_h2: bad mask map");
     H2Epi epi{bias, act ? mask : nullptr, (int)(mask ? d1 : 1), (int)(mask ? d2 : 0), (int)(mask ? d3 : 1), act, slope, out_f32};
-    return launch_h2<false>(d, x, w_h2, y, epi, S(stream), "mq_conv_fprop_h2");
+    return launch_h2<ElemBF16, false>(d, x, w_h2, y, epi, S(stream), "mq_conv_fprop_h2");
 }
 
 extern "C" int mq_conv_dgrad_h2(const mqConvDesc *d, const uint16_t *dy, const uint16_t *wt_h2, int out_f32, void *dx, mqStream stream)
@@ -771,7 +851,7 @@ extern "C" int mq_conv_dgrad_h2(const mqConvDesc *d, const uint16_t *dy, const u
     if (h2_check(d, "mq_conv_dgrad_h2")) return 1;
     MQ_REQUIRE(dy && wt_h2 && dx, "mq_conv_dgrad_h2: null pointer");
     H2Epi epi{nullptr, nullptr, 1, 0, 1, 0, 0.f, out_f32};
-    return launch_h2<true>(d, dy, wt_h2, dx, epi, S(stream), "mq_conv_dgrad_h2");
+    return launch_h2<ElemBF16, true>(d, dy, wt_h2, dx, epi, S(stream), "mq_conv_dgrad_h2");
 }
 
 namespace mq {
