@@ -1,5 +1,7 @@
 // Vector-quantiser kernels for gfx950: FSQ (the reference's quantiser) and the generic L2
 // nearest-neighbour search + codebook EMA (north-star micro-benchmark shapes).
+#include <type_traits>
+
 #include "gemm_core.h"
 
 namespace mq {
@@ -114,27 +116,34 @@ __global__ void codebook_norms_kernel(const float *__restrict__ c, int k, int d,
     cn[j] = acc;
 }
 
-struct DenseRowLoader {   // rows of a dense [rows][d] matrix, K-contiguous; contract of gemm_core.h
+// Row loader of the streaming search loop: rows of a dense [rows][d] matrix, K-contiguous.  stage() is called once per
+// K-step in order and keeps its own position: k runs 0, 16, ... over one pass, then wraps and the loader moves on by
+// `tile_stride` bytes (the next 128 codes; 0 for the x tile, which is simply re-read).  Everything outside the buffer
+// descriptor - rows past the end, code tiles past the block's range - reads as zeros.
+struct StreamRowLoader {
     __amdgpu_buffer_rsrc_t rsrc;
-    int d;
-    unsigned rowoff[2], off_[2];
-    __device__ __forceinline__ void init(const float *base, int64_t rows_here, int d_)
+    int d, nk, kstep;
+    unsigned rowoff[2], off_[2], tile_off, tile_stride;
+    __device__ __forceinline__ void init(const float *base, int64_t rows_here, int d_, int nk_, unsigned tile_stride_)
     {
-        // `base` already points at the tile's first row; rows_here = rows available from there
         d = d_;
-        const int64_t lim = rows_here < 128 ? rows_here : 128;
-        rsrc = make_rsrc(base, (size_t)(lim > 0 ? lim : 0) * d_ * sizeof(float));
+        nk = nk_;
+        kstep = 0;
+        tile_off = 0;
+        tile_stride = tile_stride_;
+        rsrc = make_rsrc(base, (size_t)(rows_here > 0 ? rows_here : 0) * d_ * sizeof(float));
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = (threadIdx.x >> 2) + 64 * j;
-            rowoff[j] = r < lim ? (unsigned)r * (unsigned)d_ * 4u : OOB;
-        }
+        for (int j = 0; j < 2; ++j) rowoff[j] = (unsigned)((threadIdx.x >> 2) + 64 * j) * (unsigned)d_ * 4u;
     }
-    __device__ __forceinline__ void stage(int k0)
+    __device__ __forceinline__ void stage(int)
     {
-        const int kbase = k0 + 4 * (threadIdx.x & 3);
+        const int kbase = kstep * GEMM_BK + 4 * (threadIdx.x & 3);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) off_[j] = (rowoff[j] != OOB && kbase < d) ? rowoff[j] + (unsigned)kbase * 4u : OOB;
+        for (int j = 0; j < 2; ++j) off_[j] = kbase < d ? rowoff[j] + tile_off + (unsigned)kbase * 4u : OOB;
+        ++kstep;
+        const bool wrap = kstep >= nk;                  // wave-uniform
+        kstep = wrap ? 0 : kstep;
+        tile_off += wrap ? tile_stride : 0u;
     }
     __device__ __forceinline__ float4 fetch(int j) const { return buf_load4(rsrc, off_[j]); }
 };
@@ -146,8 +155,41 @@ __device__ __forceinline__ unsigned long long pack_dist_idx(float dist, int idx)
     return ((unsigned long long)u << 32) | (unsigned)idx;
 }
 
-// grid (row tiles, code splits).  Each block: 128 rows x its range of 128-code tiles.
-__global__ __launch_bounds__(256) void l2_argmin_kernel(const float *__restrict__ x, const float *__restrict__ cb,
+// distances of a finished code tile -> running minimum; clears the accumulators
+__device__ __forceinline__ void argmin_fold(f32x16 (&acc)[GemmCfg<128>::TM][GemmCfg<128>::TN], float (&best)[GemmCfg<128>::TM][16],
+                                            int (&bidx)[GemmCfg<128>::TM][16], int tile, int k, const float *__restrict__ cn)
+{
+    using Cfg = GemmCfg<128>;
+#pragma unroll
+    for (int tn = 0; tn < Cfg::TN; ++tn) {
+        const int col = tile * 128 + acc_col<128>(tn);
+        const bool cv = col < k;
+        const float cnv = cv ? cn[col] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < Cfg::TM; ++tm) {
+            f32x16 v = acc[tm][tn];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float dist = fmaf(-2.0f, v[r], cnv);
+                dist = dist != dist ? -INFINITY : dist;      // NaN counts as -inf: the first NaN column wins
+                const bool take = cv && dist < best[tm][r];  // strict: lowest index wins ties inside a lane
+                best[tm][r] = take ? dist : best[tm][r];
+                bidx[tm][r] = take ? col : bidx[tm][r];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = 0.f;
+            acc[tm][tn] = v;
+        }
+    }
+}
+
+// grid (row tiles, code splits).  Each block: 128 rows x its range of 128-code tiles, as ONE software-pipelined loop
+// over (code tile, k): the loads of the next code tile are already in flight while the distances of the finished one
+// are folded into the running minimum (r1 restarted the pipeline - first loads, first LDS fill, barrier - once per code
+// tile).  Measured: the same 88-103 TFLOP/s as before - the kernel is bound by its register footprint (64 accumulators +
+// 64 running (distance, index) registers: 2 blocks per CU), not by the restarts.  The accumulation order inside a tile is
+// unchanged (k in natural order, see gemm_core.h), so indices and distances stay bit-exact against oracle/vq_ref.c.
+__global__ __launch_bounds__(256, 2) void l2_argmin_kernel(const float *__restrict__ x, const float *__restrict__ cb,
                                                         const float *__restrict__ cn, int64_t n, int k, int d,
                                                         int tiles_per_split, unsigned long long *__restrict__ packed)
 {
@@ -169,40 +211,93 @@ __global__ __launch_bounds__(256) void l2_argmin_kernel(const float *__restrict_
             best[a][r] = INFINITY;
             bidx[a][r] = 0x7fffffff;
         }
+    f32x16 acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+    for (int a = 0; a < Cfg::TM; ++a)
+#pragma unroll
+        for (int b = 0; b < Cfg::TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    for (int t = t_begin; t < t_end; ++t) {
-        DenseRowLoader la, lb;
-        la.init(x + m0 * d, n - m0, d);
-        lb.init(cb + (size_t)t * BN * d, (int64_t)k - (int64_t)t * BN, d);
-        f32x16 acc[Cfg::TM][Cfg::TN];
+    StreamRowLoader la, lb;
+    la.init(x + m0 * d, n - m0 < 128 ? n - m0 : 128, d, nk, 0u);
+    const int64_t code0 = (int64_t)t_begin * BN;
+    const int64_t codes_here = min((int64_t)k, (int64_t)t_end * BN) - code0;
+    lb.init(cb + code0 * d, codes_here, d, nk, (unsigned)BN * (unsigned)d * 4u);
+
+    // ---- the mainloop of gemm_core.h (KORDER image, three pinned phases per K-step) over nk * (t_end - t_begin) steps
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+    const int li = lane & 31, lh = lane >> 5;
+    float *As = smem;
+    float *Bs = smem + 2 * GEMM_BM * GEMM_LD;
+    const int ld_row = tid >> 2, ld_kq = tid & 3;
+    float4 ra[2], rb[2];
+    la.stage(0);
+    lb.stage(0);
 #pragma unroll
-        for (int a = 0; a < Cfg::TM; ++a)
+    for (int j = 0; j < 2; ++j) { ra[j] = la.fetch(j); rb[j] = lb.fetch(j); }
 #pragma unroll
-            for (int b = 0; b < Cfg::TN; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-        nt_gemm_mainloop<BN>(la, lb, nk, smem, acc);
-#pragma unroll
-        for (int tn = 0; tn < Cfg::TN; ++tn) {
-            const int col = t * BN + acc_col<BN>(tn);
-            if (col < k) {
-                const float cnv = cn[col];
-#pragma unroll
-                for (int tm = 0; tm < Cfg::TM; ++tm)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float dist = fmaf(-2.0f, acc[tm][tn][r], cnv);
-                        dist = dist != dist ? -INFINITY : dist;      // NaN counts as -inf: the first NaN column wins
-                        if (dist < best[tm][r]) {       // strict: lowest index wins ties inside a lane
-                            best[tm][r] = dist;
-                            bidx[tm][r] = col;
-                        }
-                    }
-            }
-        }
+    for (int j = 0; j < 2; ++j) {
+        lds_store_k4<true>(&As[(ld_row + 64 * j) * GEMM_LD + 4 * ld_kq], ra[j]);
+        lds_store_k4<true>(&Bs[(ld_row + 64 * j) * GEMM_LD + 4 * ld_kq], rb[j]);
     }
+    la.stage(0);
+    lb.stage(0);
+    __syncthreads();
+    int tile = t_begin, kin = 0;                         // code tile and K-step inside it of the step being computed
+    auto k_step = [&](auto cur_tag) {
+        constexpr int cur = decltype(cur_tag)::value;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { ra[j] = la.fetch(j); rb[j] = lb.fetch(j); }
+        __builtin_amdgcn_sched_barrier(0);
+        const float *Ac = As + cur * GEMM_BM * GEMM_LD + (wm * Cfg::TM * 32 + li) * GEMM_LD + 2 * lh;
+        const float *Bc = Bs + cur * BN * GEMM_LD + (wn * Cfg::TN * 32 + li) * GEMM_LD + 2 * lh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float2 a[Cfg::TM], b[Cfg::TN];
+#pragma unroll
+            for (int t = 0; t < Cfg::TM; ++t) a[t] = *reinterpret_cast<const float2 *>(Ac + t * 32 * GEMM_LD + 4 * q);
+#pragma unroll
+            for (int t = 0; t < Cfg::TN; ++t) b[t] = *reinterpret_cast<const float2 *>(Bc + t * 32 * GEMM_LD + 4 * q);
+#pragma unroll
+            for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < Cfg::TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].x, b[tn].x, acc[tm][tn], 0, 0, 0);
+#pragma unroll
+            for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < Cfg::TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].y, b[tn].y, acc[tm][tn], 0, 0, 0);
+        }
+        la.stage(0);
+        lb.stage(0);
+        __builtin_amdgcn_sched_barrier(0);
+        float *An = As + (cur ^ 1) * GEMM_BM * GEMM_LD;
+        float *Bn = Bs + (cur ^ 1) * BN * GEMM_LD;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            lds_store_k4<true>(&An[(ld_row + 64 * j) * GEMM_LD + 4 * ld_kq], ra[j]);
+            lds_store_k4<true>(&Bn[(ld_row + 64 * j) * GEMM_LD + 4 * ld_kq], rb[j]);
+        }
+        __syncthreads();
+        if (++kin == nk) {                               // wave-uniform
+            argmin_fold(acc, best, bidx, tile, k, cn);
+            kin = 0;
+            ++tile;
+        }
+    };
+    const int total = nk * (t_end - t_begin);
+    int st = 0;
+    for (; st + 1 < total; st += 2) {
+        k_step(std::integral_constant<int, 0>{});
+        k_step(std::integral_constant<int, 1>{});
+    }
+    if (st < total) k_step(std::integral_constant<int, 0>{});
+
     // reduce over the 32 lanes that hold different columns of the same row, then one atomic per row
-    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int tm = 0; tm < Cfg::TM; ++tm)
 #pragma unroll

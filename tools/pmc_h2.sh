@@ -1,8 +1,9 @@
 #!/bin/bash
 # MFMA / VALU / LDS counters of the conv kernels on single layers (tools/h2_micro.py), separate --pmc passes.
-# usage (on the GPU box): bash tools/pmc_h2.sh <tag> <h2_micro.py filter args...>     -> gpurun_out/pmc_<tag>.json
+# usage (on the GPU box): bash tools/pmc_h2.sh <tag> <script in tools/: h2_micro.py | f32_micro.py> <args...>     -> gpurun_out/pmc_<tag>.json
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=$1; shift
+SCRIPT=${1:-h2_micro.py}; shift
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -13,7 +14,7 @@ P4="WRITE_SIZE"
 i=0
 for P in "$P1" "$P2" "$P3" "$P4"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/p$i -- python3 $R/tools/h2_micro.py "$@" > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/p$i.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/p$i -- python3 $R/tools/$SCRIPT "$@" > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/p$i.log; exit 1; }
 done
 python3 - <<PY
 import csv, glob, collections, json
