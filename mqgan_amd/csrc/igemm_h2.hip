@@ -17,6 +17,7 @@
 // K-step, the whole walk on the scalar unit) or CB = 32 (two consecutive taps per K-step).  Every DMA instruction
 // moves 8 pixels x 128 contiguous bytes (CB = 64) - whole cache lines.
 #include <algorithm>
+#include <type_traits>
 
 #include "gemm_core.h"
 
@@ -244,53 +245,79 @@ __device__ __forceinline__ void conv_h2_body(const void *__restrict__ act_v, con
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
     __builtin_amdgcn_s_barrier();
 
-    auto compute = [&](int stage) {
+    // Fragment pipeline: two register sets.  The fragments of substep s + 1 are requested BEFORE the MFMAs of substep s are
+    // issued, so an LDS read has a whole substep (8 x 32 cycles of bf16 MFMAs, 16 x 64 of f32 ones) to come back; the
+    // K-step's barrier sits in front of the LAST substep's MFMAs, which then cover the first fragment reads of the next
+    // tile and the DMA issue at the top of the next iteration.  (r2 counters before this: waves parked at waitcnt / barrier
+    // 37 % of their cycles with the reads issued two MFMAs ahead of their use.)
+    using Frag = typename std::conditional<ET::F32, float2, bf16x8>::type;
+    Frag fa[2][2], fb[2][TN];
+    auto load_frags = [&](int stage, auto s_tag, auto set_tag) {
+        constexpr int sx = decltype(s_tag)::value, set = decltype(set_tag)::value;
         const char *base = smem + stage * STAGE;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) fa[set][t] = *reinterpret_cast<const Frag *>(base + aoffs[sx] + t * 32 * H2_ROWB);
+#pragma unroll
+        for (int t = 0; t < TN; ++t) fb[set][t] = *reinterpret_cast<const Frag *>(base + boffs[sx] + t * 32 * H2_ROWB);
+    };
+    auto mfmas = [&](auto set_tag) {
+        constexpr int set = decltype(set_tag)::value;
         if constexpr (ET::F32) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                float2 a[2], b[TN];
+            for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) a[t] = *reinterpret_cast<const float2 *>(base + aoffs[q] + t * 32 * H2_ROWB);
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][tm].x, fb[set][tn].x, acc[tm][tn], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const float2 *>(base + boffs[q] + t * 32 * H2_ROWB);
+            for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-                for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < TN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].x, b[tn].x, acc[tm][tn], 0, 0, 0);
-#pragma unroll
-                for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < TN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].y, b[tn].y, acc[tm][tn], 0, 0, 0);
-            }
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][tm].y, fb[set][tn].y, acc[tm][tn], 0, 0, 0);
         } else {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                bf16x8 a[2], b[TN];
+            for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) a[t] = *reinterpret_cast<const bf16x8 *>(base + aoffs[s] + t * 32 * H2_ROWB);
-#pragma unroll
-                for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const bf16x8 *>(base + boffs[s] + t * 32 * H2_ROWB);
-#pragma unroll
-                for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < TN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
-            }
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][tm], fb[set][tn], acc[tm][tn], 0, 0, 0);
         }
     };
     // Tile t + NSTAGE - 1 goes into the stage that was read in iteration t - 1: every wave has passed the barrier that
     // ended that iteration.  Past the end of K the walkers sit beyond the last chunk and the DMA writes zeros.
     int st_c = 0, st_i = NSTAGE - 1;
+    load_frags(0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
     for (int t = 0; t < nk; ++t) {
-        issue(st_i);
-        compute(st_c);
-        if constexpr (NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");       // tile t + 1 landed, t + 2 stays in flight
-        __builtin_amdgcn_s_barrier();
-        st_c = st_c + 1 == NSTAGE ? 0 : st_c + 1;
+        const int st_n = st_c + 1 == NSTAGE ? 0 : st_c + 1;
+        auto substep = [&](auto s_tag) {
+            constexpr int sx = decltype(s_tag)::value;
+            if constexpr (sx + 1 < NFR) {
+                load_frags(st_c, std::integral_constant<int, sx + 1>{}, std::integral_constant<int, (sx + 1) & 1>{});
+            } else {
+                // every fragment of this tile is in registers or on its way: retire the reads (the stage may then be
+                // overwritten), make sure the next tile has landed, meet the other waves, and start on the next tile
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if constexpr (NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");   // tile t + 1 landed, t + 2 stays in flight
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                load_frags(st_n, std::integral_constant<int, 0>{}, std::integral_constant<int, (sx + 1) & 1>{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(std::integral_constant<int, sx & 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        substep(std::integral_constant<int, 0>{});
+        issue(st_i);                     // behind the first MFMA group: the DMA's address arithmetic rides in its shadow
+        __builtin_amdgcn_sched_barrier(0);
+        substep(std::integral_constant<int, 1>{});
+        substep(std::integral_constant<int, 2>{});
+        substep(std::integral_constant<int, 3>{});
+        if constexpr (NFR == 8) {
+            substep(std::integral_constant<int, 4>{});
+            substep(std::integral_constant<int, 5>{});
+            substep(std::integral_constant<int, 6>{});
+            substep(std::integral_constant<int, 7>{});
+        }
+        st_c = st_n;
         st_i = st_i + 1 == NSTAGE ? 0 : st_i + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // trailing (zero-filling) DMAs must not outlive the block's LDS
