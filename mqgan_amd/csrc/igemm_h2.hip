@@ -16,6 +16,8 @@
 // Reduction order: (channel chunk of CB, tap row, tap col, channel in chunk) with CB = 64 (C % 64 == 0: one tap per
 // K-step, the whole walk on the scalar unit) or CB = 32 (two consecutive taps per K-step).  Every DMA instruction
 // moves 8 pixels x 128 contiguous bytes (CB = 64) - whole cache lines.
+#include <stdlib.h>
+
 #include <algorithm>
 #include <type_traits>
 
@@ -322,11 +324,14 @@ __device__ __forceinline__ void conv_h2_body(const void *__restrict__ act_v, con
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // trailing (zero-filling) DMAs must not outlive the block's LDS
 
-    // ---- epilogue
-    unsigned char *padf = reinterpret_cast<unsigned char *>(smem);
+    // ---- epilogue.  LDS is free once every wave's DMAs have landed and its fragment reads are back.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    constexpr int STG_ROWB = 64 * TN;                             // bytes of one staged bf16 row: 32 * TN columns
+    constexpr int STG_WAVE = 32 * STG_ROWB;                       // one wave stages 32 rows (one tm) at a time
+    unsigned char *padf = reinterpret_cast<unsigned char *>(smem) + 8 * STG_WAVE;
     const bool fused = epi.act != 0;
-    if (fused) {                                                  // LDS is free: every DMA has landed, every read is done
-        __builtin_amdgcn_s_barrier();
+    if (fused) {
         if (tid < H2_BM) {
             const int m = m0 + tid;
             unsigned char pd = 0;
@@ -338,36 +343,78 @@ __device__ __forceinline__ void conv_h2_body(const void *__restrict__ act_v, con
         }
         __syncthreads();
     }
-    float *of = reinterpret_cast<float *>(out);
-    unsigned short *oh_ = reinterpret_cast<unsigned short *>(out);
+    auto out_index = [&](int m) -> size_t {                       // element offset of column 0 of output row m
+        if constexpr (PARITY) {
+            const int iwq = m % OWc, t2 = m / OWc;
+            const int ihq = t2 % OHc, nimg = t2 / OHc;
+            return ((((size_t)grp * g.ng + nimg) * g.OH + ihq * g.sh + cls_a) * g.OW + iwq * g.sw + cls_b) * g.Ncols;
+        } else {
+            return ((size_t)grp * Mc + m) * g.Ncols;
+        }
+    };
+    float bv[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int n = n0 + wn * 32 * TN + tn * 32 + li;
-        if (n >= g.Ncols) continue;
-        const float bv = epi.bias ? epi.bias[(size_t)grp * g.Ncols + n] : 0.f;
+        bv[tn] = (epi.bias && n < g.Ncols) ? epi.bias[(size_t)grp * g.Ncols + n] : 0.f;
+    }
+    if (ET::F32 || epi.out_f32) {
+        // f32 output: a lane-group's 32 columns are 128 contiguous bytes per row - stored straight from the accumulators
+        float *of = reinterpret_cast<float *>(out);
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = n0 + wn * 32 * TN + tn * 32 + li;
+            if (n >= g.Ncols) continue;
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int m = m0 + row;
+                    if (m >= Mc) continue;
+                    float v = acc[tm][tn][r] + bv[tn];
+                    if (fused) {
+                        v = v > 0.f ? v : epi.slope * v;
+                        v = padf[row] ? 0.f : v;
+                    }
+                    of[out_index(m) + n] = v;
+                }
+        }
+        return;
+    }
+    // bf16 output: 2-byte stores straight from the MFMA layout (one column per lane) were measured SLOWER than f32 output
+    // with twice the bytes.  Each wave transposes its tile through a private LDS patch instead - written element-wise,
+    // read back row-wise - and stores 16 bytes per lane: 4 * TN lanes cover the 64 * TN contiguous bytes of a row.
+    unsigned short *oh_ = reinterpret_cast<unsigned short *>(out);
+    char *stg = smem + wave * STG_WAVE;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int m = m0 + row;
-                if (m >= Mc) continue;
-                float v = acc[tm][tn][r] + bv;
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * lh;       // row inside this 32-row half
+                float v = acc[tm][tn][r] + bv[tn];
                 if (fused) {
                     v = v > 0.f ? v : epi.slope * v;
-                    v = padf[row] ? 0.f : v;
+                    v = padf[wm * 64 + tm * 32 + rl] ? 0.f : v;
                 }
-                size_t o;
-                if constexpr (PARITY) {
-                    const int iwq = m % OWc, t2 = m / OWc;
-                    const int ihq = t2 % OHc, nimg = t2 / OHc;
-                    o = ((((size_t)grp * g.ng + nimg) * g.OH + ihq * g.sh + cls_a) * g.OW + iwq * g.sw + cls_b) * g.Ncols + n;
-                } else {
-                    o = ((size_t)grp * Mc + m) * g.Ncols + n;
-                }
-                if (ET::F32 || epi.out_f32) of[o] = v;
-                else oh_[o] = f2bf(v);
+                *reinterpret_cast<unsigned short *>(stg + rl * STG_ROWB + (tn * 32 + li) * 2) = f2bf(v);
             }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // own writes (the patch is private to the wave)
+        constexpr int CPR = 4 * TN;                                   // 16-byte chunks per row
+#pragma unroll
+        for (int i = 0; i < (32 * CPR + 63) / 64; ++i) {
+            const int q = i * 64 + lane;
+            const int rl = q / CPR, c16 = q - rl * CPR;
+            const int m = m0 + wm * 64 + tm * 32 + rl;
+            const int n = n0 + wn * 32 * TN + c16 * 8;
+            if (rl < 32 && m < Mc && n < g.Ncols) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(stg + rl * STG_ROWB + c16 * 16);
+                *reinterpret_cast<uint4 *>(oh_ + out_index(m) + n) = v;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // reads done before the second half overwrites the patch
     }
 }
 
@@ -763,7 +810,11 @@ static int launch_h2(const mqConvDesc *d, const void *act, const void *w, void *
     g.CB = ET::F32 ? 16 : (g.IC % 64 == 0 ? 64 : 32);
     g.nchunks = g.IC / g.CB;
     g.Kp = ET::F32 ? d->R * d->S * g.IC : h2_kp(d->R * d->S, g.IC);
-    const int TN = pick_tn(g.Ncols);
+    int TN = pick_tn(g.Ncols);
+    if (const char *e = getenv("MQGAN_H2_TN")) {                 // experiments only
+        const int v = atoi(e);
+        if (v >= 1 && v <= 4) TN = v;
+    }
     const int BN = 64 * TN;
     g.nMt = (int)cdiv(g.Mtot, H2_BM);
     g.nNt = (int)cdiv(g.Ncols, BN);
@@ -807,7 +858,7 @@ static int launch_h2(const mqConvDesc *d, const void *act, const void *w, void *
                                                   reinterpret_cast<const float *>(w), reinterpret_cast<float *>(out), g, pi, epi, act_gs)
 #define MQ_H2_CB(TN_, NS_, PAR_) do { if constexpr (ET::F32) MQ_D32(TN_, NS_, PAR_); else if (g.CB == 64) MQ_H2(TN_, NS_, 64, PAR_); else MQ_H2(TN_, NS_, 32, PAR_); } while (0)
 #define MQ_H2_TN(PAR_) do { if (TN == 4) MQ_H2_CB(4, 2, PAR_); else if (TN == 3) MQ_H2_CB(3, 2, PAR_); \
-                            else if (TN == 2) MQ_H2_CB(2, 3, PAR_); else MQ_H2_CB(1, 3, PAR_); } while (0)
+                            else if (TN == 2) MQ_H2_CB(2, 3, PAR_); else MQ_H2_CB(1, 2, PAR_); } while (0)
     if (parity) MQ_H2_TN(true);
     else MQ_H2_TN(false);
 #undef MQ_H2_TN

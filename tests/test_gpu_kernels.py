@@ -354,6 +354,44 @@ def test_f32x3_engine_has_the_error_of_the_f32_engine(env):
     assert errs["f32x3"][1] < 2.0 * errs["f32"][1] + 1e-7, errs
 
 
+def test_f32x3_error_bound_at_config2_depths(env):
+    """Written-down bound of the fp32x3 engine, tested at the deepest reductions of BASELINE
+    config 2 (K = 3*3*768 = 6912 in the refiner, 5*5*256 = 6400 in the patch discriminator):
+
+        |y - y_exact| <= ( 2^-20  +  (6K + 2) * 2^-24 ) * sum_k |a_k * b_k|
+
+    First term: every operand is split EXACTLY into three bf16 terms x = h + m + l (|m| < 2^-7 |x|, |l| < 2^-14 |x|) and the
+    three cross products the kernel drops (m*l, l*m, l*l) are below 2 * 2^-21 + 2^-28 < 2^-20 of |a*b|; the six it keeps are
+    exact in the f32 accumulator's input.  Second term: 6K f32 additions, each rounding once.  The input here is built to
+    sit near the worst case of the first term (all 24 significand bits set: m and l as large as they can be, same sign for
+    every product so nothing cancels); random data stays 30 x below it and at the f32 engine's own error."""
+    ops = env
+    rng = np.random.default_rng(17)
+    for (Cc, R, S) in ((768, 3, 3), (256, 5, 5)):
+        N, H, W, K = 1, 8, 16, 32
+        Kd = Cc * R * S
+        bound = 2.0 ** -20 + (6 * Kd + 2) * 2.0 ** -24
+        ones = np.float32(2.0) - np.float32(2.0 ** -23)                       # 1.111...1 (24 ones) x 2^0
+        cases = {"adversarial": (np.full((N, H, W, Cc), ones, np.float32) * (2.0 ** rng.integers(-3, 4, (N, H, W, Cc))).astype(np.float32),
+                                 np.full((K, Cc, R, S), ones, np.float32) * (2.0 ** rng.integers(-6, -2, (K, Cc, R, S))).astype(np.float32)),
+                 "random": (rng.standard_normal((N, H, W, Cc)).astype(np.float32),
+                            (rng.standard_normal((K, Cc, R, S)) * 0.05).astype(np.float32))}
+        for name, (x, w) in cases.items():
+            xt, wt = torch.from_numpy(x), torch.from_numpy(w)
+            ref = F.conv2d(xt.double().permute(0, 3, 1, 2), wt.double(), padding=(R // 2, S // 2)).permute(0, 2, 3, 1)
+            mag = F.conv2d(xt.double().abs().permute(0, 3, 1, 2), wt.double().abs(), padding=(R // 2, S // 2)).permute(0, 2, 3, 1)
+            wk, wc = ops.weight_prep(wt.to(DEV), None, True)
+            errs = {}
+            for prec in ("f32", "f32x3"):
+                d = ops.conv_desc(N, H, W, Cc, K, R, S, pad=(R // 2, S // 2), precision=prec)
+                y = ops.conv(xt.to(DEV), wk, wc, None, d).double().cpu()
+                errs[prec] = float(((y - ref).abs() / mag).max())
+            assert errs["f32x3"] <= bound, (name, Cc, errs, bound)
+            assert errs["f32"] <= (Kd + 1) * 2.0 ** -24, (name, Cc, errs)
+            if name == "random":
+                assert errs["f32x3"] <= bound / 30 and errs["f32x3"] <= 3 * errs["f32"] + 1e-9, (Cc, errs, bound)
+
+
 def test_full_size_conv_beyond_4gb_engines_agree(env):
     """BASELINE config 3 refiner shape (16 x 1024 x 144 pixels, 384 channels: x and y are 3.6 GB each, past the 32-bit
     offset range): the f32 MFMA engine and the fp32x3 engine are independent code paths over the same loaders with

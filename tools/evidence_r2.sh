@@ -7,9 +7,9 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 echo "== kernel stats, config 2 f32"; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c2 -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-vq --no-alt --no-configs > $O/c2_under_rocprof.json 2> $O/c2.err || { echo FAILED c2; tail -3 $O/c2.err; exit 1; }
 echo "== kernel stats, config 3 bf16"; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3 -- python3 $R/bench.py --config hifimusic --precision bf16 --steps 3 --warmup 2 --no-cpu-baseline --no-vq --no-alt > $O/c3_under_rocprof.json 2> $O/c3.err || { echo FAILED c3; tail -3 $O/c3.err; exit 1; }
-echo "== pmc traffic"; bash $R/tools/pmc_traffic.sh > $O/pmc_traffic.log 2>&1 || { echo FAILED traffic; tail -5 $O/pmc_traffic.log; exit 1; }
+echo "== pmc traffic"; bash $R/tools/pmc_traffic.sh 2>&1 | tee $O/pmc_traffic.log || { echo FAILED traffic; tail -5 $O/pmc_traffic.log; exit 1; }
 cp $R/gpurun_out/pmc_traffic/traffic.json $O/pmc_traffic.json
-echo "== counters"; bash $R/tools/pmc_h2.sh h2 h2_micro.py "c2 mid" "c3 mid" --old > $O/counters_h2.log 2>&1 && bash $R/tools/pmc_h2.sh f32 f32_micro.py > $O/counters_f32.log 2>&1 || { echo FAILED counters; tail -5 $O/counters_h2.log $O/counters_f32.log; exit 1; }
+echo "== counters"; bash $R/tools/pmc_h2.sh h2 h2_micro.py "c2 mid" "c3 mid" --old 2>&1 | tee $O/counters_h2.log && bash $R/tools/pmc_h2.sh f32 f32_micro.py 2>&1 | tee $O/counters_f32.log || { echo FAILED counters; tail -5 $O/counters_h2.log $O/counters_f32.log; exit 1; }
 cp $R/gpurun_out/pmc_h2.json $R/gpurun_out/pmc_f32.json $O/
 tail -4 $O/counters_h2.log $O/counters_f32.log
 echo DONE

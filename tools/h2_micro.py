@@ -39,7 +39,7 @@ CASES = [  # name, N, H, W, C, K, R, S, stride, pad
     ("c2 D1.convs1 256->256 5x5 s2", 32, 80, 256, 256, 256, 5, 5, (2, 2), (2, 2)),
 ]
 if len(sys.argv) > 1:
-    CASES = [c for c in CASES if any(a in c[0] for a in sys.argv[1:])]
+    CASES = [c for c in CASES if any(a in c[0] for a in sys.argv[1:] if not a.startswith('--'))] or CASES
 for name, N, H, W, Cc, K, R, S, st, pad in CASES:
     torch.manual_seed(0)
     d = ops.conv_desc(N, H, W, Cc, K, R, S, stride=st, pad=pad, precision="bf16")
@@ -51,6 +51,8 @@ for name, N, H, W, Cc, K, R, S, st, pad in CASES:
     dy = torch.randn(N, d.P, d.Q, K, device=DEV).to(BF16)
     res = {}
     res["fprop"] = tm(lambda: ops.conv_fprop_h2(d, x, wh, None))
+    if "--f32out" in sys.argv:
+        res["fprop(f32 out)"] = tm(lambda: ops.conv_fprop_h2(d, x, wh, None, out_dtype=torch.float32))
     res["dgrad"] = tm(lambda: ops.conv_dgrad_h2(d, dy, wth))
     res["wgrad"] = tm(lambda: ops.conv_wgrad_h2(d, x, dy, tuple(wk.shape), True))
     line = f"{name:32s} " + "  ".join(f"{k} {v:7.3f} ms {flops / v / 1e9:7.1f} TF/s" for k, v in res.items())

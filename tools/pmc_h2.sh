@@ -14,6 +14,7 @@ P4="WRITE_SIZE"
 i=0
 for P in "$P1" "$P2" "$P3" "$P4"; do
   i=$((i+1))
+  echo "pmc_$TAG: pass $i $(date +%T)" | tee -a $OUT/progress.log
   timeout -k 10 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/p$i -- python3 $R/tools/$SCRIPT "$@" > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/p$i.log; exit 1; }
 done
 python3 - <<PY

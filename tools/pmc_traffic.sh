@@ -5,7 +5,8 @@ OUT=$R/gpurun_out/pmc_traffic
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 500 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vq --no-alt > $OUT/$C.log 2>&1 || { echo "pass $C failed"; tail -5 $OUT/$C.log; exit 1; }
+  echo "pmc_traffic: pass $C $(date +%T)" | tee -a $OUT/progress.log
+  timeout -k 10 500 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vq --no-alt --no-configs > $OUT/$C.log 2>&1 || { echo "pass $C failed"; tail -5 $OUT/$C.log; exit 1; }
 done
 python3 - <<PY
 import csv, glob, collections, json, sys
