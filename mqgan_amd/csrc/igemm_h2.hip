@@ -77,7 +77,7 @@ struct ElemF32 { static constexpr int ESZ = 4; static constexpr bool F32 = true;
 
 // TN: 32-column MFMA tiles per wave along N (block tile N = 64 * TN); CBK: channel block in ELEMENTS (bf16: 64 or 32,
 // f32: 16, i.e. 128- or 64-byte runs); PARITY: dgrad by stride parity (tap subset and output scatter per class)
-template <class ET, int TN, int NSTAGE, int CBK, bool PARITY>
+template <class ET, int TN, int NSTAGE, int CBK, bool PARITY, bool MF16 = false>
 __device__ __forceinline__ void conv_h2_body(const void *__restrict__ act_v, const void *__restrict__ wgt_v,
                                              void *__restrict__ out, const H2Geom &g, const H2Parity &pi, const H2Epi &epi,
                                              size_t act_group_stride, char *smem)
@@ -217,13 +217,21 @@ __device__ __forceinline__ void conv_h2_body(const void *__restrict__ act_v, con
         }
     };
 
-    f32x16 acc[2][TN];
+    // accumulators: 2 x TN tiles of 32x32 (16 registers each) or, MF16, 4 x 2TN tiles of 16x16 (4 registers each)
+    f32x16 acc[MF16 ? 1 : 2][MF16 ? 1 : TN];
+    f32x4v acc16[MF16 ? 4 : 1][MF16 ? 2 * TN : 1];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < (MF16 ? 1 : 2); ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b)
+        for (int b = 0; b < (MF16 ? 1 : TN); ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+#pragma unroll
+    for (int a = 0; a < (MF16 ? 4 : 1); ++a)
+#pragma unroll
+        for (int b = 0; b < (MF16 ? 2 * TN : 1); ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc16[a][b][r] = 0.f;
 
     // Fragment reads.  bf16: lane (r, h) reads the 16 bytes of chunk 2s + h (8 k's) of row r per 32x32x16 MFMA.
     // f32: lane (r, h) reads the float2 at byte 8h of chunk q (k = 4q + 2h, 4q + 2h + 1) per pair of 32x32x2 MFMAs.
@@ -247,80 +255,116 @@ __device__ __forceinline__ void conv_h2_body(const void *__restrict__ act_v, con
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
     __builtin_amdgcn_s_barrier();
 
-    // Fragment pipeline: two register sets.  The fragments of substep s + 1 are requested BEFORE the MFMAs of substep s are
-    // issued, so an LDS read has a whole substep (8 x 32 cycles of bf16 MFMAs, 16 x 64 of f32 ones) to come back; the
-    // K-step's barrier sits in front of the LAST substep's MFMAs, which then cover the first fragment reads of the next
-    // tile and the DMA issue at the top of the next iteration.  (r2 counters before this: waves parked at waitcnt / barrier
-    // 37 % of their cycles with the reads issued two MFMAs ahead of their use.)
-    using Frag = typename std::conditional<ET::F32, float2, bf16x8>::type;
-    Frag fa[2][2], fb[2][TN];
-    auto load_frags = [&](int stage, auto s_tag, auto set_tag) {
-        constexpr int sx = decltype(s_tag)::value, set = decltype(set_tag)::value;
-        const char *base = smem + stage * STAGE;
+    if constexpr (MF16) {
+        // v_mfma_f32_16x16x32_bf16: the same bytes from LDS per flop and the same cycles per flop as 32x32x16, but the chip
+        // holds a higher clock on this shape under load (MI355X_MICROARCH.md, DVFS give-back item 7).  Lane (r = l & 15,
+        // g = l >> 4) holds k = 8g .. 8g+7 of a 32-deep substep: chunk 4s + g of row r, swizzled with (r >> 1) & 7.
+        const int r16 = lane & 15, g4 = lane >> 4, sw16 = (r16 >> 1) & 7;
+        int a16[2], b16[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) fa[set][t] = *reinterpret_cast<const Frag *>(base + aoffs[sx] + t * 32 * H2_ROWB);
-#pragma unroll
-        for (int t = 0; t < TN; ++t) fb[set][t] = *reinterpret_cast<const Frag *>(base + boffs[sx] + t * 32 * H2_ROWB);
-    };
-    auto mfmas = [&](auto set_tag) {
-        constexpr int set = decltype(set_tag)::value;
-        if constexpr (ET::F32) {
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][tm].x, fb[set][tn].x, acc[tm][tn], 0, 0, 0);
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][tm].y, fb[set][tn].y, acc[tm][tn], 0, 0, 0);
-        } else {
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][tm], fb[set][tn], acc[tm][tn], 0, 0, 0);
+        for (int sx = 0; sx < 2; ++sx) {
+            a16[sx] = (wm * 64 + r16) * H2_ROWB + (((4 * sx + g4) ^ sw16) << 4);
+            b16[sx] = H2_BM * H2_ROWB + (wn * 32 * TN + r16) * H2_ROWB + (((4 * sx + g4) ^ sw16) << 4);
         }
-    };
-    // Tile t + NSTAGE - 1 goes into the stage that was read in iteration t - 1: every wave has passed the barrier that
-    // ended that iteration.  Past the end of K the walkers sit beyond the last chunk and the DMA writes zeros.
-    int st_c = 0, st_i = NSTAGE - 1;
-    load_frags(0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-    for (int t = 0; t < nk; ++t) {
-        const int st_n = st_c + 1 == NSTAGE ? 0 : st_c + 1;
-        auto substep = [&](auto s_tag) {
-            constexpr int sx = decltype(s_tag)::value;
-            if constexpr (sx + 1 < NFR) {
-                load_frags(st_c, std::integral_constant<int, sx + 1>{}, std::integral_constant<int, (sx + 1) & 1>{});
-            } else {
-                // every fragment of this tile is in registers or on its way: retire the reads (the stage may then be
-                // overwritten), make sure the next tile has landed, meet the other waves, and start on the next tile
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if constexpr (NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");   // tile t + 1 landed, t + 2 stays in flight
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                load_frags(st_n, std::integral_constant<int, 0>{}, std::integral_constant<int, (sx + 1) & 1>{});
+        int st_c = 0, st_i = NSTAGE - 1;
+        for (int t = 0; t < nk; ++t) {
+            issue(st_i);
+            const char *base = smem + st_c * STAGE;
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+                bf16x8 a[4], b[2 * TN];
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) a[tt] = *reinterpret_cast<const bf16x8 *>(base + a16[sx] + tt * 16 * H2_ROWB);
+#pragma unroll
+                for (int tt = 0; tt < 2 * TN; ++tt) b[tt] = *reinterpret_cast<const bf16x8 *>(base + b16[sx] + tt * 16 * H2_ROWB);
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 2 * TN; ++tn)
+                        acc16[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[tm], b[tn], acc16[tm][tn], 0, 0, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            mfmas(std::integral_constant<int, sx & 1>{});
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        substep(std::integral_constant<int, 0>{});
-        issue(st_i);                     // behind the first MFMA group: the DMA's address arithmetic rides in its shadow
-        __builtin_amdgcn_sched_barrier(0);
-        substep(std::integral_constant<int, 1>{});
-        substep(std::integral_constant<int, 2>{});
-        substep(std::integral_constant<int, 3>{});
-        if constexpr (NFR == 8) {
-            substep(std::integral_constant<int, 4>{});
-            substep(std::integral_constant<int, 5>{});
-            substep(std::integral_constant<int, 6>{});
-            substep(std::integral_constant<int, 7>{});
+            if constexpr (NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");       // tile t + 1 landed, t + 2 stays in flight
+            __builtin_amdgcn_s_barrier();
+            st_c = st_c + 1 == NSTAGE ? 0 : st_c + 1;
+            st_i = st_i + 1 == NSTAGE ? 0 : st_i + 1;
         }
-        st_c = st_n;
-        st_i = st_i + 1 == NSTAGE ? 0 : st_i + 1;
+    } else {
+        // Fragment pipeline: two register sets.  The fragments of substep s + 1 are requested BEFORE the MFMAs of substep s are
+        // issued, so an LDS read has a whole substep (8 x 32 cycles of bf16 MFMAs, 16 x 64 of f32 ones) to come back; the
+        // K-step's barrier sits in front of the LAST substep's MFMAs, which then cover the first fragment reads of the next
+        // tile and the DMA issue at the top of the next iteration.  (r2 counters before this: waves parked at waitcnt / barrier
+        // 37 % of their cycles with the reads issued two MFMAs ahead of their use.)
+        using Frag = typename std::conditional<ET::F32, float2, bf16x8>::type;
+        Frag fa[2][2], fb[2][TN];
+        auto load_frags = [&](int stage, auto s_tag, auto set_tag) {
+            constexpr int sx = decltype(s_tag)::value, set = decltype(set_tag)::value;
+            const char *base = smem + stage * STAGE;
+    #pragma unroll
+            for (int t = 0; t < 2; ++t) fa[set][t] = *reinterpret_cast<const Frag *>(base + aoffs[sx] + t * 32 * H2_ROWB);
+    #pragma unroll
+            for (int t = 0; t < TN; ++t) fb[set][t] = *reinterpret_cast<const Frag *>(base + boffs[sx] + t * 32 * H2_ROWB);
+        };
+        auto mfmas = [&](auto set_tag) {
+            constexpr int set = decltype(set_tag)::value;
+            if constexpr (ET::F32) {
+    #pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+    #pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][tm].x, fb[set][tn].x, acc[tm][tn], 0, 0, 0);
+    #pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+    #pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][tm].y, fb[set][tn].y, acc[tm][tn], 0, 0, 0);
+            } else {
+    #pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+    #pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][tm], fb[set][tn], acc[tm][tn], 0, 0, 0);
+            }
+        };
+        // Tile t + NSTAGE - 1 goes into the stage that was read in iteration t - 1: every wave has passed the barrier that
+        // ended that iteration.  Past the end of K the walkers sit beyond the last chunk and the DMA writes zeros.
+        int st_c = 0, st_i = NSTAGE - 1;
+        load_frags(0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        for (int t = 0; t < nk; ++t) {
+            const int st_n = st_c + 1 == NSTAGE ? 0 : st_c + 1;
+            auto substep = [&](auto s_tag) {
+                constexpr int sx = decltype(s_tag)::value;
+                if constexpr (sx + 1 < NFR) {
+                    load_frags(st_c, std::integral_constant<int, sx + 1>{}, std::integral_constant<int, (sx + 1) & 1>{});
+                } else {
+                    // every fragment of this tile is in registers or on its way: retire the reads (the stage may then be
+                    // overwritten), make sure the next tile has landed, meet the other waves, and start on the next tile
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if constexpr (NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");   // tile t + 1 landed, t + 2 stays in flight
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    load_frags(st_n, std::integral_constant<int, 0>{}, std::integral_constant<int, (sx + 1) & 1>{});
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(std::integral_constant<int, sx & 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            substep(std::integral_constant<int, 0>{});
+            issue(st_i);                     // behind the first MFMA group: the DMA's address arithmetic rides in its shadow
+            __builtin_amdgcn_sched_barrier(0);
+            substep(std::integral_constant<int, 1>{});
+            substep(std::integral_constant<int, 2>{});
+            substep(std::integral_constant<int, 3>{});
+            if constexpr (NFR == 8) {
+                substep(std::integral_constant<int, 4>{});
+                substep(std::integral_constant<int, 5>{});
+                substep(std::integral_constant<int, 6>{});
+                substep(std::integral_constant<int, 7>{});
+            }
+            st_c = st_n;
+            st_i = st_i + 1 == NSTAGE ? 0 : st_i + 1;
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // trailing (zero-filling) DMAs must not outlive the block's LDS
 
@@ -352,34 +396,53 @@ __device__ __forceinline__ void conv_h2_body(const void *__restrict__ act_v, con
             return ((size_t)grp * Mc + m) * g.Ncols;
         }
     };
-    float bv[TN];
+    // visit the accumulator elements of one 32-row half of the wave tile: fn(row in half, column in wave tile, value)
+    auto for_half = [&](auto half_tag, auto &&fn) {
+        constexpr int half = decltype(half_tag)::value;
+        if constexpr (MF16) {
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int n = n0 + wn * 32 * TN + tn * 32 + li;
+            for (int th = 0; th < 2; ++th)
+#pragma unroll
+                for (int tn = 0; tn < 2 * TN; ++tn)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        fn(th * 16 + (lane >> 4) * 4 + j, tn * 16 + (lane & 15), acc16[2 * half + th][tn][j]);
+        } else {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) fn((r & 3) + 8 * (r >> 2) + 4 * lh, tn * 32 + li, acc[half][tn][r]);
+        }
+    };
+    // bias of this lane's columns: column index inside the wave tile -> slot
+    constexpr int NBV = MF16 ? 2 * TN : TN;
+    float bv[NBV];
+#pragma unroll
+    for (int tn = 0; tn < NBV; ++tn) {
+        const int n = n0 + wn * 32 * TN + (MF16 ? tn * 16 + (lane & 15) : tn * 32 + li);
         bv[tn] = (epi.bias && n < g.Ncols) ? epi.bias[(size_t)grp * g.Ncols + n] : 0.f;
     }
+    auto bias_of = [&](int cl) { return bv[MF16 ? cl >> 4 : cl >> 5]; };
     if (ET::F32 || epi.out_f32) {
         // f32 output: a lane-group's 32 columns are 128 contiguous bytes per row - stored straight from the accumulators
         float *of = reinterpret_cast<float *>(out);
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int n = n0 + wn * 32 * TN + tn * 32 + li;
-            if (n >= g.Ncols) continue;
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const int m = m0 + row;
-                    if (m >= Mc) continue;
-                    float v = acc[tm][tn][r] + bv[tn];
+        auto store_half = [&](auto half_tag) {
+            constexpr int half = decltype(half_tag)::value;
+            for_half(half_tag, [&](int rl, int cl, float a) {
+                const int row = wm * 64 + half * 32 + rl;
+                const int m = m0 + row, n = n0 + wn * 32 * TN + cl;
+                if (m < Mc && n < g.Ncols) {
+                    float v = a + bias_of(cl);
                     if (fused) {
                         v = v > 0.f ? v : epi.slope * v;
                         v = padf[row] ? 0.f : v;
                     }
                     of[out_index(m) + n] = v;
                 }
-        }
+            });
+        };
+        store_half(std::integral_constant<int, 0>{});
+        store_half(std::integral_constant<int, 1>{});
         return;
     }
     // bf16 output: 2-byte stores straight from the MFMA layout (one column per lane) were measured SLOWER than f32 output
@@ -387,27 +450,23 @@ __device__ __forceinline__ void conv_h2_body(const void *__restrict__ act_v, con
     // read back row-wise - and stores 16 bytes per lane: 4 * TN lanes cover the 64 * TN contiguous bytes of a row.
     unsigned short *oh_ = reinterpret_cast<unsigned short *>(out);
     char *stg = smem + wave * STG_WAVE;
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = (r & 3) + 8 * (r >> 2) + 4 * lh;       // row inside this 32-row half
-                float v = acc[tm][tn][r] + bv[tn];
-                if (fused) {
-                    v = v > 0.f ? v : epi.slope * v;
-                    v = padf[wm * 64 + tm * 32 + rl] ? 0.f : v;
-                }
-                *reinterpret_cast<unsigned short *>(stg + rl * STG_ROWB + (tn * 32 + li) * 2) = f2bf(v);
+    auto stage_half = [&](auto half_tag) {
+        constexpr int half = decltype(half_tag)::value;
+        for_half(half_tag, [&](int rl, int cl, float a) {
+            float v = a + bias_of(cl);
+            if (fused) {
+                v = v > 0.f ? v : epi.slope * v;
+                v = padf[wm * 64 + half * 32 + rl] ? 0.f : v;
             }
+            *reinterpret_cast<unsigned short *>(stg + rl * STG_ROWB + cl * 2) = f2bf(v);
+        });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // own writes (the patch is private to the wave)
         constexpr int CPR = 4 * TN;                                   // 16-byte chunks per row
 #pragma unroll
         for (int i = 0; i < (32 * CPR + 63) / 64; ++i) {
             const int q = i * 64 + lane;
             const int rl = q / CPR, c16 = q - rl * CPR;
-            const int m = m0 + wm * 64 + tm * 32 + rl;
+            const int m = m0 + wm * 64 + half * 32 + rl;
             const int n = n0 + wn * 32 * TN + c16 * 8;
             if (rl < 32 && m < Mc && n < g.Ncols) {
                 const uint4 v = *reinterpret_cast<const uint4 *>(stg + rl * STG_ROWB + c16 * 16);
@@ -415,16 +474,18 @@ __device__ __forceinline__ void conv_h2_body(const void *__restrict__ act_v, con
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // reads done before the second half overwrites the patch
-    }
+    };
+    stage_half(std::integral_constant<int, 0>{});
+    stage_half(std::integral_constant<int, 1>{});
 }
 
-template <int TN, int NSTAGE, int CBK, bool PARITY>
+template <int TN, int NSTAGE, int CBK, bool PARITY, bool MF16 = false>
 __global__ __launch_bounds__(512, 2) void conv_h2_kernel(const unsigned short *__restrict__ act, const unsigned short *__restrict__ wgt,
                                                          void *__restrict__ out, H2Geom g, H2Parity pi, H2Epi epi,
                                                          size_t act_group_stride)
 {
     __shared__ __attribute__((aligned(1024))) char smem[NSTAGE * (H2_BM + 64 * TN) * H2_ROWB];
-    conv_h2_body<ElemBF16, TN, NSTAGE, CBK, PARITY>(act, wgt, out, g, pi, epi, act_group_stride, smem);
+    conv_h2_body<ElemBF16, TN, NSTAGE, CBK, PARITY, MF16>(act, wgt, out, g, pi, epi, act_group_stride, smem);
 }
 // exact f32 products on the same LDS-DMA structure (MQ_PRECISION_F32, C % 16 == 0): f32 tensors, the existing KRSC / CRSK
 // weight layouts (channel blocks of 16 = 64-byte runs, two (chunk, tap) positions per K-step)
@@ -810,6 +871,11 @@ static int launch_h2(const mqConvDesc *d, const void *act, const void *w, void *
     g.CB = ET::F32 ? 16 : (g.IC % 64 == 0 ? 64 : 32);
     g.nchunks = g.IC / g.CB;
     g.Kp = ET::F32 ? d->R * d->S * g.IC : h2_kp(d->R * d->S, g.IC);
+    // MFMA shape of the bf16 kernels: 16x16x32 by default - same LDS bytes and cycles per flop as 32x32x16, but the chip
+    // holds a higher clock on it (measured +3..13 % on the 384-1152-channel layers, tools/h2_micro.py); MQGAN_H2_MF32=1
+    // switches back for A/B runs
+    static const bool mf16 = getenv("MQGAN_H2_MF32") == nullptr;
+    (void)mf16;
     int TN = pick_tn(g.Ncols);
     if (const char *e = getenv("MQGAN_H2_TN")) {                 // experiments only
         const int v = atoi(e);
@@ -852,8 +918,10 @@ static int launch_h2(const mqConvDesc *d, const void *act, const void *w, void *
         pi.tile0[pi.ncls] = t0;
         grid = dim3((unsigned)(t0 * g.nNt), d->groups);
     }
-#define MQ_H2(TN_, NS_, CB_, PAR_) hipLaunchKernelGGL((conv_h2_kernel<TN_, NS_, CB_, PAR_>), grid, block, 0, st, reinterpret_cast<const unsigned short *>(act), \
-                                                      reinterpret_cast<const unsigned short *>(w), out, g, pi, epi, act_gs)
+#define MQ_H2(TN_, NS_, CB_, PAR_) do { if (mf16) hipLaunchKernelGGL((conv_h2_kernel<TN_, NS_, CB_, PAR_, true>), grid, block, 0, st, reinterpret_cast<const unsigned short *>(act), \
+                                                      reinterpret_cast<const unsigned short *>(w), out, g, pi, epi, act_gs); \
+                                        else hipLaunchKernelGGL((conv_h2_kernel<TN_, NS_, CB_, PAR_, false>), grid, block, 0, st, reinterpret_cast<const unsigned short *>(act), \
+                                                      reinterpret_cast<const unsigned short *>(w), out, g, pi, epi, act_gs); } while (0)
 #define MQ_D32(TN_, NS_, PAR_) hipLaunchKernelGGL((conv_d32_kernel<TN_, NS_, PAR_>), grid, block, 0, st, reinterpret_cast<const float *>(act), \
                                                   reinterpret_cast<const float *>(w), reinterpret_cast<float *>(out), g, pi, epi, act_gs)
 #define MQ_H2_CB(TN_, NS_, PAR_) do { if constexpr (ET::F32) MQ_D32(TN_, NS_, PAR_); else if (g.CB == 64) MQ_H2(TN_, NS_, 64, PAR_); else MQ_H2(TN_, NS_, 32, PAR_); } while (0)

@@ -187,7 +187,7 @@ def _conv_tag(kind, d: ConvDesc, h2=False):
         ncols, ic = (d.K, d.C) if kind == "fprop" else (d.C, d.K)
         tn = _h2_tn(ncols)
         par = kind == "dgrad" and (d.stride_h > 1 or d.stride_w > 1)
-        return f"conv_h2_kernel<{tn}, {3 if tn == 2 else 2}, {64 if ic % 64 == 0 else 32}, {str(par).lower()}>"
+        return f"conv_h2_kernel<{tn}, {3 if tn == 2 else 2}, {64 if ic % 64 == 0 else 32}, {str(par).lower()}, true>"
     eng = {0: "", 1: "bf16_", 2: "x3_"}[d.precision]
     if kind == "wgrad":
         vec = d.C % 4 == 0 and d.K % 4 == 0
