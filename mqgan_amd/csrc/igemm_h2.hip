@@ -519,7 +519,7 @@ struct H2Wgrad {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-template <int WM, int TM, int WRAPS>
+template <int WM, int TM, int WRAPS, bool MF16>
 __device__ __forceinline__ void conv_wgrad_h2_body(const unsigned short *__restrict__ x, const unsigned short *__restrict__ dy,
                                                    float *__restrict__ out, const H2Wgrad &g, int groups, char *smem)
 {
@@ -546,7 +546,11 @@ __device__ __forceinline__ void conv_wgrad_h2_body(const unsigned short *__restr
 
     // ---- DMA slots: piece p = wave + 8 j = pixels 2p, 2p+1 of the step; lane -> pixel 2p + (lane >> 5), physical chunk lane & 31
     const int pixl = 2 * wave + (lane >> 5);                       // pixel of slot 0; slot j adds 16 j
-    const int lc = (lane & 31) ^ ((pixl & 3) << 2);                // logical chunk = 8 channels / columns
+    // logical chunk (8 channels / columns) this lane fetches = physical chunk XOR the read-side swizzle of its pixel row:
+    // (pixel & 3) << 2 spreads the four pixel rows of a transposed read over the four 64-byte windows of the bank space;
+    // the 16x16x32 shape reads the SAME channels of two row quads 8 pixels apart in one half-wave: ((pixel >> 3) & 1) << 1
+    // puts those on opposite 32-byte halves of the window
+    const int lc = (lane & 31) ^ (((pixl & 3) << 2) | (MF16 ? (((pixl >> 3) & 1) << 1) : 0));
     const unsigned short *dyg = dy + ((size_t)grp * g.Mtot + m_begin) * g.K;
     const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(dyg, (size_t)(m_end - m_begin) * g.K * 2);   // rows >= m_end: zeros
     const unsigned short *xg = x + ((size_t)grp * ng + img0) * g.IH * g.IW * g.IC;
@@ -607,53 +611,78 @@ __device__ __forceinline__ void conv_wgrad_h2_body(const unsigned short *__restr
         }
     };
 
-    f32x16 acc[TM][TNW];
+    f32x16 acc[MF16 ? 1 : TM][MF16 ? 1 : TNW];
+    f32x4v acc16[MF16 ? 2 * TM : 1][MF16 ? 2 * TNW : 1];
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+    for (int a = 0; a < (MF16 ? 1 : TM); ++a)
 #pragma unroll
-        for (int b = 0; b < TNW; ++b)
+        for (int b = 0; b < (MF16 ? 1 : TNW); ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    // transposed-read lane constants: 16-lane group gsel -> channels +16 gsel; lane 4q+p -> pixel row q, channels 4p..4p+3
-    const int trq = (lane & 15) >> 2, trp = lane & 3, gsel = (lane >> 4) & 1;
-    int aad[TM], bad[TNW];
 #pragma unroll
-    for (int t = 0; t < TM; ++t) {
-        const int chan = wm * 32 * TM + t * 32 + 16 * gsel + 4 * trp;
-        aad[t] = (8 * lh + trq) * 512 + ((((chan * 2) >> 4) ^ (trq << 2)) << 4) + ((chan * 2) & 15);
+    for (int a = 0; a < (MF16 ? 2 * TM : 1); ++a)
+#pragma unroll
+        for (int b = 0; b < (MF16 ? 2 * TNW : 1); ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc16[a][b][r] = 0.f;
+
+    // transposed-read lane constants: lane 4q+p of a 16-lane group addresses pixel row q, channels 4p..4p+3 and receives
+    // channel (lane & 15) of the four rows.  32x32x16: group gsel = (lane >> 4) & 1 -> channels +16 gsel, lane half lh ->
+    // pixels +8 lh.  16x16x32: all four groups read the same 16 channels, group g4 = lane >> 4 -> pixels +8 g4.
+    const int trq = (lane & 15) >> 2, trp = lane & 3, gsel = (lane >> 4) & 1, g4 = lane >> 4;
+    constexpr int NTA = MF16 ? 2 * TM : TM, NTB = MF16 ? 2 * TNW : TNW;
+    int aad[NTA], bad[NTB];
+#pragma unroll
+    for (int t = 0; t < NTA; ++t) {
+        const int chan = MF16 ? wm * 32 * TM + t * 16 + 4 * trp : wm * 32 * TM + t * 32 + 16 * gsel + 4 * trp;
+        const int swz = MF16 ? ((trq << 2) | ((g4 & 1) << 1)) : (trq << 2);
+        aad[t] = (8 * (MF16 ? g4 : lh) + trq) * 512 + ((((chan * 2) >> 4) ^ swz) << 4) + ((chan * 2) & 15);
     }
 #pragma unroll
-    for (int t = 0; t < TNW; ++t) {
-        const int chan = wn * 32 * TNW + t * 32 + 16 * gsel + 4 * trp;
-        bad[t] = IMG + (8 * lh + trq) * 512 + ((((chan * 2) >> 4) ^ (trq << 2)) << 4) + ((chan * 2) & 15);
+    for (int t = 0; t < NTB; ++t) {
+        const int chan = MF16 ? wn * 32 * TNW + t * 16 + 4 * trp : wn * 32 * TNW + t * 32 + 16 * gsel + 4 * trp;
+        const int swz = MF16 ? ((trq << 2) | ((g4 & 1) << 1)) : (trq << 2);
+        bad[t] = IMG + (8 * (MF16 ? g4 : lh) + trq) * 512 + ((((chan * 2) >> 4) ^ swz) << 4) + ((chan * 2) & 15);
     }
     const int nsteps = (m_end - m_begin + 63) / 64;
     issue(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    auto tr8 = [&](const char *p0, int row_off) {                      // 8 pixels of one channel per lane: two transposed reads
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)lds_ptr(p0 + row_off * 512));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)lds_ptr(p0 + (row_off + 4) * 512));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
     auto compute = [&](int stage) {
         const char *base = smem + stage * STAGE;
+        if constexpr (MF16) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            bf16x8 a[TM], b[TNW];
+            for (int sx = 0; sx < 2; ++sx) {                            // 32 pixels per substep
+                bf16x8 a[NTA], b[NTB];
 #pragma unroll
-            for (int t = 0; t < TM; ++t) {
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)lds_ptr(base + aad[t] + (16 * s) * 512));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)lds_ptr(base + aad[t] + (16 * s + 4) * 512));
-                a[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                for (int t = 0; t < NTA; ++t) a[t] = tr8(base + aad[t], 32 * sx);
+#pragma unroll
+                for (int t = 0; t < NTB; ++t) b[t] = tr8(base + bad[t], 32 * sx);
+#pragma unroll
+                for (int tm = 0; tm < NTA; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < NTB; ++tn)
+                        acc16[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[tm], b[tn], acc16[tm][tn], 0, 0, 0);
             }
+        } else {
 #pragma unroll
-            for (int t = 0; t < TNW; ++t) {
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)lds_ptr(base + bad[t] + (16 * s) * 512));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)lds_ptr(base + bad[t] + (16 * s + 4) * 512));
-                b[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            for (int sx = 0; sx < 4; ++sx) {
+                bf16x8 a[NTA], b[NTB];
+#pragma unroll
+                for (int t = 0; t < NTA; ++t) a[t] = tr8(base + aad[t], 16 * sx);
+#pragma unroll
+                for (int t = 0; t < NTB; ++t) b[t] = tr8(base + bad[t], 16 * sx);
+#pragma unroll
+                for (int tm = 0; tm < NTA; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < NTB; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
             }
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TNW; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
         }
     };
     int st_c = 0;
@@ -669,28 +698,36 @@ __device__ __forceinline__ void conv_wgrad_h2_body(const unsigned short *__restr
     float *o = out + ((size_t)split * groups + grp) * (size_t)g.K * g.RSC;
     const int cbs = chan_block(g.IC);
 #pragma unroll
-    for (int tn = 0; tn < TNW; ++tn) {
-        const int colp = c0 + wn * 32 * TNW + tn * 32 + li;
+    for (int tn = 0; tn < NTB; ++tn) {
+        const int colp = c0 + wn * 32 * TNW + (MF16 ? tn * 16 + (lane & 15) : tn * 32 + li);
         if (colp >= g.RSC) continue;
         const int tap = colp / g.IC;
         const int col = kidx(tap, colp - tap * g.IC, g.RS, cbs);
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+        for (int tm = 0; tm < NTA; ++tm) {
+            if constexpr (MF16) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rloc = wm * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int row = k0 + rloc;
-                if (row < g.K) o[(size_t)row * g.RSC + col] = acc[tm][tn][r];
+                for (int j = 0; j < 4; ++j) {
+                    const int row = k0 + wm * 32 * TM + tm * 16 + (lane >> 4) * 4 + j;
+                    if (row < g.K) o[(size_t)row * g.RSC + col] = acc16[tm][tn][j];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = k0 + wm * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (row < g.K) o[(size_t)row * g.RSC + col] = acc[tm][tn][r];
+                }
             }
+        }
     }
 }
 
-template <int WM, int TM, int WRAPS>
+template <int WM, int TM, int WRAPS, bool MF16>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_h2_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ dy,
                                                                float *__restrict__ out, H2Wgrad g, int groups)
 {
     __shared__ __attribute__((aligned(1024))) char smem[2 * 2 * 64 * 512];
-    conv_wgrad_h2_body<WM, TM, WRAPS>(x, dy, out, g, groups, smem);
+    conv_wgrad_h2_body<WM, TM, WRAPS, MF16>(x, dy, out, g, groups, smem);
 }
 
 // out[i] = sum_k slabs[k][i] in the fixed order k = 0, 1, ... (deterministic)
@@ -1084,12 +1121,17 @@ extern "C" int mq_conv_wgrad_h2(const mqConvDesc *d, const uint16_t *x, const ui
     float *bias_ws = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + (g.splits > 1 ? (size_t)g.splits * n * sizeof(float) : 0));
     dim3 grid(g.nKt * g.nCt, d->groups, g.splits), block(512);
     const int wraps = d->Q >= 64 ? 1 : 4;
-#define MQ_WH(WM_, TM_) do { if (wraps == 1) hipLaunchKernelGGL((conv_wgrad_h2_kernel<WM_, TM_, 1>), grid, block, 0, st, x, dy, target, g, d->groups); \
-                             else hipLaunchKernelGGL((conv_wgrad_h2_kernel<WM_, TM_, 4>), grid, block, 0, st, x, dy, target, g, d->groups); } while (0)
+    // the weight gradient stays on 32x32x16: its 16x16x32 instantiation (conflict-free too) measured 3-5 % slower
+    // (twice the transposed LDS reads per flop); MQGAN_H2_WG16=1 selects it for A/B runs
+    static const bool mf16 = getenv("MQGAN_H2_WG16") != nullptr;
+#define MQ_WH2(WM_, TM_, WR_) do { if (mf16) hipLaunchKernelGGL((conv_wgrad_h2_kernel<WM_, TM_, WR_, true>), grid, block, 0, st, x, dy, target, g, d->groups); \
+                                   else hipLaunchKernelGGL((conv_wgrad_h2_kernel<WM_, TM_, WR_, false>), grid, block, 0, st, x, dy, target, g, d->groups); } while (0)
+#define MQ_WH(WM_, TM_) do { if (wraps == 1) MQ_WH2(WM_, TM_, 1); else MQ_WH2(WM_, TM_, 4); } while (0)
     if (wm == 4) MQ_WH(4, 2);
     else if (tm == 3) MQ_WH(2, 3);
     else MQ_WH(2, 2);
 #undef MQ_WH
+#undef MQ_WH2
     MQ_LAUNCH_CHECK("mq_conv_wgrad_h2");
     if (g.splits > 1) {
         MQ_REQUIRE(n % 4 == 0, "mq_conv_wgrad_h2: filter bank size not a multiple of 4");

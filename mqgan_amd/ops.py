@@ -183,7 +183,7 @@ def _conv_tag(kind, d: ConvDesc, h2=False):
     if h2:
         if kind == "wgrad":
             wmtm = "4, 2" if (d.K % 256 == 0 or (d.K > 256 and d.K % 192 != 0)) else ("2, 3" if d.K % 192 == 0 else "2, 2")
-            return f"conv_wgrad_h2_kernel<{wmtm}, {1 if d.Q >= 64 else 4}>"
+            return f"conv_wgrad_h2_kernel<{wmtm}, {1 if d.Q >= 64 else 4}, false>"
         ncols, ic = (d.K, d.C) if kind == "fprop" else (d.C, d.K)
         tn = _h2_tn(ncols)
         par = kind == "dgrad" and (d.stride_h > 1 or d.stride_w > 1)
