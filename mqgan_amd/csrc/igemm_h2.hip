@@ -752,17 +752,35 @@ __global__ void h2_slab_reduce_kernel(const float *__restrict__ slabs, float *__
     }
 }
 
-// bias gradient of a bf16 dy (rows x cols): partial column sums per row chunk, then a fixed-order combine
-__global__ void h2_colsum_partial_kernel(const unsigned short *__restrict__ x, int64_t rows, int cols, float *__restrict__ part, int nchunks)
+// bias gradient of a bf16 dy (rows x cols): partial column sums per row chunk, then a fixed-order combine.
+// grid (ceil(cols / 128), nchunks), block (16, 16): thread (cx, ry) sums 8 columns (one 16-byte load) of rows ry, ry + 16, ...
+// of its chunk - 16 lanes cover 256 contiguous bytes of a row, so narrow layers (96 columns = 12 lanes) keep most lanes busy
+__global__ __launch_bounds__(256) void h2_colsum_partial_kernel(const unsigned short *__restrict__ x, int64_t rows, int cols,
+                                                                float *__restrict__ part, int nchunks)
 {
-    // grid (ceil(cols / 512), nchunks), block (64, 4): thread (cx, ry) sums 8 columns of rows ry, ry + 4, ... of its chunk
-    __shared__ float red[4][64][8];
-    const int c8 = (blockIdx.x * 64 + threadIdx.x) * 8;
+    __shared__ float red[16][16][8];
+    const int c8 = (blockIdx.x * 16 + threadIdx.x) * 8;
     const int64_t per = (rows + nchunks - 1) / nchunks;
     const int64_t r0 = (int64_t)blockIdx.y * per, r1 = min(rows, r0 + per);
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (c8 < cols)
-        for (int64_t r = r0 + threadIdx.y; r < r1; r += 4) {
+    if (c8 < cols) {
+        int64_t r = r0 + threadIdx.y;
+        for (; r + 16 < r1; r += 32) {                 // two independent loads in flight
+            const uint4 v = *reinterpret_cast<const uint4 *>(x + r * cols + c8);
+            const uint4 u = *reinterpret_cast<const uint4 *>(x + (r + 16) * cols + c8);
+            const unsigned w[4] = {v.x, v.y, v.z, v.w}, z[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s[2 * i] += __builtin_bit_cast(float, w[i] << 16);
+                s[2 * i + 1] += __builtin_bit_cast(float, w[i] & 0xFFFF0000u);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s[2 * i] += __builtin_bit_cast(float, z[i] << 16);
+                s[2 * i + 1] += __builtin_bit_cast(float, z[i] & 0xFFFF0000u);
+            }
+        }
+        for (; r < r1; r += 16) {
             const uint4 v = *reinterpret_cast<const uint4 *>(x + r * cols + c8);
             const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -771,13 +789,18 @@ __global__ void h2_colsum_partial_kernel(const unsigned short *__restrict__ x, i
                 s[2 * i + 1] += __builtin_bit_cast(float, w[i] & 0xFFFF0000u);
             }
         }
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) red[threadIdx.y][threadIdx.x][i] = s[i];
     __syncthreads();
     if (threadIdx.y == 0 && c8 < cols)
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            part[(size_t)blockIdx.y * cols + c8 + i] = (red[0][threadIdx.x][i] + red[1][threadIdx.x][i]) + (red[2][threadIdx.x][i] + red[3][threadIdx.x][i]);
+        for (int i = 0; i < 8; ++i) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x][i];
+            part[(size_t)blockIdx.y * cols + c8 + i] = t;
+        }
 }
 // grid (ceil(cols / 64)), block (64, 16): thread (c, ty) sums chunks ty, ty + 16, ...; fixed-order LDS combine
 __global__ void h2_colsum_final_kernel(const float *__restrict__ part, int cols, int nchunks, float *__restrict__ out)
@@ -1142,12 +1165,12 @@ extern "C" int mq_conv_wgrad_h2(const mqConvDesc *d, const uint16_t *x, const ui
         for (int grp = 0; grp < d->groups; ++grp) {
             const int64_t rows = g.Mtot;
             const int cols = g.K;
-            int64_t want = cdiv(2048, cdiv(cols, 512));
-            if (want > rows / 32) want = rows / 32;
+            int64_t want = cdiv(4096, cdiv(cols, 128));              // ~4096 blocks in total: 16 per CU
+            if (want > rows / 64) want = rows / 64;
             if (want > 1024) want = 1024;
             if (want < 1) want = 1;
             float *ws = bias_ws + (size_t)grp * 1024 * cols;
-            hipLaunchKernelGGL(h2_colsum_partial_kernel, dim3((unsigned)cdiv(cols, 512), (unsigned)want), dim3(64, 4), 0, st,
+            hipLaunchKernelGGL(h2_colsum_partial_kernel, dim3((unsigned)cdiv(cols, 128), (unsigned)want), dim3(16, 16), 0, st,
                                dy + (size_t)grp * rows * cols, rows, cols, ws, (int)want);
             hipLaunchKernelGGL(h2_colsum_final_kernel, dim3((unsigned)cdiv(cols, 64)), dim3(64, 16), 0, st, ws, cols, (int)want,
                                dbias + (size_t)grp * cols);
