@@ -178,9 +178,12 @@ __device__ __forceinline__ void conv_h2_body(const void *__restrict__ act_v, con
         w_js[u] = js; w_jr[u] = jr; w_ch[u] = ch;
     }
     const int RS = g.R * g.S;
-    auto issue = [&](int stage) {
-        int hoff, woff, aoff, bcol;
-        bool kv;
+    // One tile's DMA work in pieces, so that the 16x16x32 loop can put a piece after every row of MFMAs instead of a
+    // hundred scalar / vector instructions in front of them: walk() advances the scalar tap walkers and leaves the tile's
+    // offsets in (hoff, woff, aoff, bcol, kv); dma_a(stage, j) / dma_b(stage, j) issue one 8 KB piece each.
+    int hoff = 0, woff = 0, aoff = 0, bcol = 0;
+    bool kv = false;
+    auto walk = [&]() {
 #pragma unroll
         for (int u = 0; u < NSUB; ++u) {
             const int h_u = w_jr[u] * step_h, w_u = w_js[u] * step_w;
@@ -202,19 +205,23 @@ __device__ __forceinline__ void conv_h2_body(const void *__restrict__ act_v, con
                 w_ch[u] += c3 ? 1 : 0;
             }
         }
-        char *sa = smem + stage * STAGE + wave * 1024;
-        char *sb = sa + H2_BM * H2_ROWB;
+    };
+    auto dma_a = [&](int stage, int j) {
+        const bool ok = rv_[j] & kv & ((unsigned)(bh_[j] + hoff) < (unsigned)g.IH) & ((unsigned)(bw_[j] + woff) < (unsigned)g.IW);
+        const unsigned vo = ok ? (unsigned)(rowbase_[j] + aoff) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, lds_ptr(smem + stage * STAGE + wave * 1024 + j * 8192), 16, vo, 0, 0, 0);
+    };
+    auto dma_b = [&](int stage, int j) {
+        const unsigned vo = ((rowoffB[j] != OOB) & kv) ? rowoffB[j] + (unsigned)bcol : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, lds_ptr(smem + stage * STAGE + H2_BM * H2_ROWB + wave * 1024 + j * 8192), 16,
+                                                 vo, 0, 0, 0);
+    };
+    auto issue = [&](int stage) {
+        walk();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool ok = rv_[j] && kv && (unsigned)(bh_[j] + hoff) < (unsigned)g.IH && (unsigned)(bw_[j] + woff) < (unsigned)g.IW;
-            const unsigned vo = ok ? (unsigned)(rowbase_[j] + aoff) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, lds_ptr(sa + j * 8192), 16, vo, 0, 0, 0);
-        }
+        for (int j = 0; j < 4; ++j) dma_a(stage, j);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const unsigned vo = (rowoffB[j] != OOB && kv) ? rowoffB[j] + (unsigned)bcol : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, lds_ptr(sb + j * 8192), 16, vo, 0, 0, 0);
-        }
+        for (int j = 0; j < TN; ++j) dma_b(stage, j);
     };
 
     // accumulators: 2 x TN tiles of 32x32 (16 registers each) or, MF16, 4 x 2TN tiles of 16x16 (4 registers each)
@@ -266,29 +273,98 @@ __device__ __forceinline__ void conv_h2_body(const void *__restrict__ act_v, con
             a16[sx] = (wm * 64 + r16) * H2_ROWB + (((4 * sx + g4) ^ sw16) << 4);
             b16[sx] = H2_BM * H2_ROWB + (wn * 32 * TN + r16) * H2_ROWB + (((4 * sx + g4) ^ sw16) << 4);
         }
+        // Four phases per K-step (substep x column half), two register sets: the fragments of the next phase are requested
+        // before the 4 x TN MFMAs of the current one, and the K-step's barrier sits in front of the last phase, whose MFMAs
+        // cover the first reads of the next tile.  The DMA work of the next ring slot is spread over the MFMA rows of the
+        // phase behind the barrier (walker + activation pieces) and of the following phase (weight pieces): both waves of a
+        // SIMD leave the barrier together, so a block of scalar work in front of the MFMAs would idle the pipe for both.
+        bf16x8 fa[2][4], fb[2][TN];
+        auto ld_a = [&](const char *base, int sx, auto set_tag) {
+            constexpr int set = decltype(set_tag)::value;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) fa[set][tt] = *reinterpret_cast<const bf16x8 *>(base + a16[sx] + tt * 16 * H2_ROWB);
+        };
+        auto ld_b = [&](const char *base, int sx, int h, auto set_tag) {
+            constexpr int set = decltype(set_tag)::value;
+#pragma unroll
+            for (int tt = 0; tt < TN; ++tt)
+                fb[set][tt] = *reinterpret_cast<const bf16x8 *>(base + b16[sx] + (h * TN + tt) * 16 * H2_ROWB);
+        };
+        auto mm_row = [&](auto sa_tag, auto sb_tag, auto h_tag, auto tm_tag) {
+            constexpr int sa = decltype(sa_tag)::value, sb = decltype(sb_tag)::value, h = decltype(h_tag)::value;
+            constexpr int tm = decltype(tm_tag)::value;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                acc16[tm][h * TN + tn] =
+                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[sa][tm], fb[sb][tn], acc16[tm][h * TN + tn], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>;
+        auto mm = [&](auto sa_tag, auto sb_tag, auto h_tag) {
+            mm_row(sa_tag, sb_tag, h_tag, I0{});
+            mm_row(sa_tag, sb_tag, h_tag, I1{});
+            mm_row(sa_tag, sb_tag, h_tag, I2{});
+            mm_row(sa_tag, sb_tag, h_tag, I3{});
+        };
         int st_c = 0, st_i = NSTAGE - 1;
+        walk();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma_a(st_i, j);
+        ld_a(smem, 0, I0{});
+        ld_b(smem, 0, 0, I0{});
         for (int t = 0; t < nk; ++t) {
-            issue(st_i);
             const char *base = smem + st_c * STAGE;
-#pragma unroll
-            for (int sx = 0; sx < 2; ++sx) {
-                bf16x8 a[4], b[2 * TN];
-#pragma unroll
-                for (int tt = 0; tt < 4; ++tt) a[tt] = *reinterpret_cast<const bf16x8 *>(base + a16[sx] + tt * 16 * H2_ROWB);
-#pragma unroll
-                for (int tt = 0; tt < 2 * TN; ++tt) b[tt] = *reinterpret_cast<const bf16x8 *>(base + b16[sx] + tt * 16 * H2_ROWB);
-#pragma unroll
-                for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < 2 * TN; ++tn)
-                        acc16[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[tm], b[tn], acc16[tm][tn], 0, 0, 0);
-            }
-            if constexpr (NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");       // tile t + 1 landed, t + 2 stays in flight
+            ld_b(base, 0, 1, I1{});
+            __builtin_amdgcn_sched_barrier(0);
+            mm_row(I0{}, I0{}, I0{}, I0{});
+            dma_b(st_i, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mm_row(I0{}, I0{}, I0{}, I1{});
+            if constexpr (TN > 1) dma_b(st_i, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm_row(I0{}, I0{}, I0{}, I2{});
+            if constexpr (TN > 2) dma_b(st_i, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mm_row(I0{}, I0{}, I0{}, I3{});
+            if constexpr (TN > 3) dma_b(st_i, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            ld_a(base, 1, I1{});
+            ld_b(base, 1, 0, I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            mm(I0{}, I1{}, I1{});
+            ld_b(base, 1, 1, I1{});
+            __builtin_amdgcn_sched_barrier(0);
+            mm(I1{}, I0{}, I0{});
+            // ring slot t + 1 landed (its last piece was issued three phases ago); every fragment read of slot t is back
+            if constexpr (NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPT) : "memory");   // slot t + 2 stays in flight
             __builtin_amdgcn_s_barrier();
             st_c = st_c + 1 == NSTAGE ? 0 : st_c + 1;
             st_i = st_i + 1 == NSTAGE ? 0 : st_i + 1;
+            const char *nbase = smem + st_c * STAGE;
+            ld_a(nbase, 0, I0{});
+            ld_b(nbase, 0, 0, I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            mm_row(I1{}, I1{}, I1{}, I0{});
+            walk();
+            dma_a(st_i, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mm_row(I1{}, I1{}, I1{}, I1{});
+            dma_a(st_i, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm_row(I1{}, I1{}, I1{}, I2{});
+            dma_a(st_i, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mm_row(I1{}, I1{}, I1{}, I3{});
+            dma_a(st_i, 3);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        // the last iteration's activation pieces (all out of range: zeros) still write LDS, which the epilogue reuses
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     } else {
         // Fragment pipeline: two register sets.  The fragments of substep s + 1 are requested BEFORE the MFMAs of substep s are
         // issued, so an LDS read has a whole substep (8 x 32 cycles of bf16 MFMAs, 16 x 64 of f32 ones) to come back; the
