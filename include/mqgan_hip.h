@@ -255,10 +255,12 @@ int mq_pointwise_bwd_h(const mqPointwiseDesc *desc_host, const uint16_t *dout, c
                        const uint8_t *mask, const float *beta, const float *gamma, uint16_t *dt, uint16_t *dpost,
                        float *dbeta, float *dgamma, float *workspace, mqStream stream);
 int mq_cast_f32(const uint16_t *in_bf16, float *out, int64_t n, mqStream stream);
-int mq_avgpool_t2_fwd_h(const uint16_t *x, int N, int T, int F, int C, uint16_t *y, mqStream stream);
-int mq_avgpool_t2_bwd_h(const uint16_t *dy, int N, int T, int F, int C, uint16_t *dx, mqStream stream);
-int mq_upcat_fwd_h(const uint16_t *x, const uint16_t *skip, int N, int T, int F, int C1, int C2, uint16_t *out, mqStream stream);
-int mq_upcat_bwd_h(const uint16_t *dout, int N, int T, int F, int C1, int C2, uint16_t *dx, uint16_t *dskip, mqStream stream);
+int mq_avgpool_t2_fwd_h(const uint16_t *x, int N, int T, int F, int C, const uint8_t *mask, uint16_t *y, mqStream stream);
+int mq_avgpool_t2_bwd_h(const uint16_t *dy, int N, int T, int F, int C, const uint8_t *mask, uint16_t *dx, mqStream stream);
+int mq_upcat_fwd_h(const uint16_t *x, const uint16_t *skip, int N, int T, int F, int C1, int C2, const uint8_t *mask,
+                   uint16_t *out, mqStream stream);
+int mq_upcat_bwd_h(const uint16_t *dout, int N, int T, int F, int C1, int C2, const uint8_t *mask, uint16_t *dx,
+                   uint16_t *dskip, mqStream stream);
 
 /* frame masks */
 int mq_sequence_mask(const int32_t *lengths, int B, int T, uint8_t *mask, mqStream stream);           /* preencoder.py:15-24 */
@@ -268,12 +270,17 @@ int mq_mask_pool(const uint8_t *in, int B, int Tin, int Tout, int stride, uint8_
 int mq_mask_upsample2(const uint8_t *in, int B, int Tin, uint8_t *out, mqStream stream);              /* preencoder.py:68-70 */
 
 /* UNet data movement (preencoder.py:105-130): time-only avg-pool /2, nearest x2 fused with
- * the channel concat, and their backward passes.  x (N, T, F, C). */
-int mq_avgpool_t2_fwd(const float *x, int N, int T, int F, int C, float *y, mqStream stream);
-int mq_avgpool_t2_bwd(const float *dy, int N, int T, int F, int C, float *dx, mqStream stream);
+ * the channel concat, and their backward passes.  x (N, T, F, C).  `mask` (optional, uint8, nonzero = padded)
+ * has the OUTPUT's (N, T_out) frames: the consuming ConvBlock's entry masked_fill (preencoder.py:93) applied
+ * in the same pass (forward: padded output frames are zeros; backward: their gradient is dropped).  It needs
+ * the vectorised path (C, C1, C2 multiples of 8). */
+int mq_avgpool_t2_fwd(const float *x, int N, int T, int F, int C, const uint8_t *mask, float *y, mqStream stream);
+int mq_avgpool_t2_bwd(const float *dy, int N, int T, int F, int C, const uint8_t *mask, float *dx, mqStream stream);
 /* out (N, 2T, F, C1+C2) = cat(upsample2(x (N,T,F,C1)), skip (N,2T,F,C2)) */
-int mq_upcat_fwd(const float *x, const float *skip, int N, int T, int F, int C1, int C2, float *out, mqStream stream);
-int mq_upcat_bwd(const float *dout, int N, int T, int F, int C1, int C2, float *dx, float *dskip, mqStream stream);
+int mq_upcat_fwd(const float *x, const float *skip, int N, int T, int F, int C1, int C2, const uint8_t *mask, float *out,
+                 mqStream stream);
+int mq_upcat_bwd(const float *dout, int N, int T, int F, int C1, int C2, const uint8_t *mask, float *dx, float *dskip,
+                 mqStream stream);
 /* band split for the multi-bin discriminator (discriminators.py:298, 211):
  * x (B, T, F) -> out (n_bins*B, F/n_bins, T): out[j*B+b][f][t] = x[b][t][j*bs+f]; bwd is the inverse. */
 int mq_band_split_fwd(const float *x, int B, int T, int F, int n_bins, float *out, mqStream stream);

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MQGAN_HIP_LIB: load another build of the same ABI (kernel experiments); the default is the in-tree library
 LIB_PATH = os.environ.get("MQGAN_HIP_LIB") or os.path.join(_HERE, "libmqgan_hip.so")
 _lib = None
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class MqganHipError(RuntimeError):
@@ -90,17 +90,17 @@ SIGNATURES = {
     "mq_pointwise_fwd_h": (_I, [C.POINTER(PointwiseDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "mq_pointwise_bwd_h": (_I, [C.POINTER(PointwiseDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mq_cast_f32": (_I, [_P, _P, _L, _P]),
-    "mq_avgpool_t2_fwd_h": (_I, [_P, _I, _I, _I, _I, _P, _P]),
-    "mq_avgpool_t2_bwd_h": (_I, [_P, _I, _I, _I, _I, _P, _P]),
-    "mq_upcat_fwd_h": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
-    "mq_upcat_bwd_h": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "mq_avgpool_t2_fwd_h": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
+    "mq_avgpool_t2_bwd_h": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
+    "mq_upcat_fwd_h": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "mq_upcat_bwd_h": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "mq_sequence_mask": (_I, [_P, _I, _I, _P, _P]),
     "mq_mask_pool": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "mq_mask_upsample2": (_I, [_P, _I, _I, _P, _P]),
-    "mq_avgpool_t2_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P]),
-    "mq_avgpool_t2_bwd": (_I, [_P, _I, _I, _I, _I, _P, _P]),
-    "mq_upcat_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
-    "mq_upcat_bwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "mq_avgpool_t2_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
+    "mq_avgpool_t2_bwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
+    "mq_upcat_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "mq_upcat_bwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "mq_band_split_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "mq_band_split_bwd": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "mq_concat2": (_I, [_P, _P, _L, _I, _I, _P, _P]),

@@ -464,23 +464,31 @@ __global__ void cast_f32_kernel(const bf16_t *__restrict__ in, float *__restrict
 // ---- UNet data movement, 8 channels per thread (C % 8 == 0); T = bf16 storage or f32
 // x (N, T, F*C) -> y (N, T/2, F*C)
 template <typename T>
-__global__ void avgpool_t2_fwd_h_kernel(const T *__restrict__ x, int64_t N, int Tt, int64_t FC8, T *__restrict__ y)
+__global__ void avgpool_t2_fwd_h_kernel(const T *__restrict__ x, int64_t N, int Tt, int64_t FC8, const uint8_t *__restrict__ mask,
+                                        T *__restrict__ y)
 {
+    // mask (N, Tt / 2), nonzero = padded frame of the OUTPUT: written as zeros (the consumer block's masked_fill, fused)
     const int To = Tt / 2;
     const int64_t total = N * To * FC8;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t fc = i % FC8, r = i / FC8;
         const int64_t t = r % To, n = r / To;
         float a[8], b[8];
-        ld8(x, ((n * Tt + 2 * t) * FC8 + fc) * 8, a);
-        ld8(x, ((n * Tt + 2 * t + 1) * FC8 + fc) * 8, b);
+        if (mask && mask[r]) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) a[k] = (a[k] + b[k]) * 0.5f;
+            for (int k = 0; k < 8; ++k) a[k] = 0.f;
+        } else {
+            ld8(x, ((n * Tt + 2 * t) * FC8 + fc) * 8, a);
+            ld8(x, ((n * Tt + 2 * t + 1) * FC8 + fc) * 8, b);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = (a[k] + b[k]) * 0.5f;
+        }
         st8(y, i * 8, a);
     }
 }
 template <typename T>
-__global__ void avgpool_t2_bwd_h_kernel(const T *__restrict__ dy, int64_t N, int Tt, int64_t FC8, T *__restrict__ dx)
+__global__ void avgpool_t2_bwd_h_kernel(const T *__restrict__ dy, int64_t N, int Tt, int64_t FC8, const uint8_t *__restrict__ mask,
+                                        T *__restrict__ dx)
 {
     const int To = Tt / 2;
     const int64_t total = N * To * FC8;
@@ -488,7 +496,12 @@ __global__ void avgpool_t2_bwd_h_kernel(const T *__restrict__ dy, int64_t N, int
         const int64_t fc = i % FC8, r = i / FC8;
         const int64_t t = r % To, n = r / To;
         float a[8];
-        ld8(dy, i * 8, a);
+        if (mask && mask[r]) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = 0.f;
+        } else {
+            ld8(dy, i * 8, a);
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) a[k] *= 0.5f;
         st8(dx, ((n * Tt + 2 * t) * FC8 + fc) * 8, a);
@@ -498,8 +511,9 @@ __global__ void avgpool_t2_bwd_h_kernel(const T *__restrict__ dy, int64_t N, int
 // out (N, 2T, F, C1 + C2) = cat(upsample2(x (N,T,F,C1)), skip (N,2T,F,C2)); one thread = 8 channels of one output pixel
 template <typename T>
 __global__ void upcat_fwd_h_kernel(const T *__restrict__ x, const T *__restrict__ skip, int64_t N, int Tt, int F, int C1,
-                                   int C2, T *__restrict__ out)
+                                   int C2, const uint8_t *__restrict__ mask, T *__restrict__ out)
 {
+    // mask (N, 2 Tt), nonzero = padded frame of the OUTPUT: written as zeros
     const int Co8 = (C1 + C2) / 8, C18 = C1 / 8;
     const int64_t total = N * 2 * Tt * F * Co8;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -508,15 +522,21 @@ __global__ void upcat_fwd_h_kernel(const T *__restrict__ x, const T *__restrict_
         const int64_t f = r % F, r2 = r / F;
         const int64_t t2 = r2 % (2 * Tt), n = r2 / (2 * Tt);
         float v[8];
-        if (c8 < C18) ld8(x, ((n * Tt + (t2 >> 1)) * F + f) * C1 + c8 * 8, v);
-        else ld8(skip, r * C2 + (c8 - C18) * 8, v);
+        if (mask && mask[r2]) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = 0.f;
+        } else if (c8 < C18) {
+            ld8(x, ((n * Tt + (t2 >> 1)) * F + f) * C1 + c8 * 8, v);
+        } else {
+            ld8(skip, r * C2 + (c8 - C18) * 8, v);
+        }
         st8(out, i * 8, v);
     }
 }
 // dx (N,T,F,C1) = sum of the two upsampled rows; dskip (N,2T,F,C2) = copy
 template <typename T>
-__global__ void upcat_bwd_h_kernel(const T *__restrict__ dout, int64_t N, int Tt, int F, int C1, int C2, T *__restrict__ dx,
-                                   T *__restrict__ dskip)
+__global__ void upcat_bwd_h_kernel(const T *__restrict__ dout, int64_t N, int Tt, int F, int C1, int C2,
+                                   const uint8_t *__restrict__ mask, T *__restrict__ dx, T *__restrict__ dskip)
 {
     const int Co = C1 + C2, Co8 = Co / 8, C18 = C1 / 8;
     const int64_t total = N * Tt * F * Co8;          // one thread: 8 channels of an INPUT-resolution pixel (both output rows)
@@ -526,20 +546,22 @@ __global__ void upcat_bwd_h_kernel(const T *__restrict__ dout, int64_t N, int Tt
         const int64_t f = r % F, r2 = r / F;
         const int64_t t = r2 % Tt, n = r2 / Tt;
         const int64_t o0 = ((n * 2 * Tt + 2 * t) * F + f), o1 = o0 + F;
+        const bool p0 = mask && mask[n * 2 * Tt + 2 * t], p1 = mask && mask[n * 2 * Tt + 2 * t + 1];
+        float a[8], b[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = b[k] = 0.f;
         if (c8 < C18) {
-            float a[8], b[8];
-            ld8(dout, o0 * Co + c8 * 8, a);
-            ld8(dout, o1 * Co + c8 * 8, b);
+            if (!p0) ld8(dout, o0 * Co + c8 * 8, a);
+            if (!p1) ld8(dout, o1 * Co + c8 * 8, b);
 #pragma unroll
             for (int k = 0; k < 8; ++k) a[k] += b[k];
             st8(dx, r * C1 + c8 * 8, a);
         } else {
             const int cs = (c8 - C18) * 8;
-            float a[8];
-            ld8(dout, o0 * Co + C1 + cs, a);
+            if (!p0) ld8(dout, o0 * Co + C1 + cs, a);
+            if (!p1) ld8(dout, o1 * Co + C1 + cs, b);
             st8(dskip, o0 * C2 + cs, a);
-            ld8(dout, o1 * Co + C1 + cs, a);
-            st8(dskip, o1 * C2 + cs, a);
+            st8(dskip, o1 * C2 + cs, b);
         }
     }
 }
@@ -619,50 +641,58 @@ extern "C" int mq_mask_upsample2(const uint8_t *in, int B, int Tin, uint8_t *out
     return 0;
 }
 
-extern "C" int mq_avgpool_t2_fwd(const float *x, int N, int T, int F, int C, float *y, mqStream stream)
+extern "C" int mq_avgpool_t2_fwd(const float *x, int N, int T, int F, int C, const uint8_t *mask, float *y, mqStream stream)
 {
     MQ_REQUIRE(x && y && N > 0 && T > 0 && T % 2 == 0 && F > 0 && C > 0, "mq_avgpool_t2_fwd: bad arguments (T must be even)");
+    MQ_REQUIRE(!mask || (C % 8 == 0 && al16(x) && al16(y)), "mq_avgpool_t2_fwd: the fused output mask needs C %% 8 == 0 (C=%d)", C);
     const int64_t FC = (int64_t)F * C;
     if (C % 8 == 0 && al16(x) && al16(y))
         hipLaunchKernelGGL((avgpool_t2_fwd_h_kernel<float>), dim3(ew_grid((int64_t)N * (T / 2) * (FC / 8), 256)), dim3(256), 0, S(stream), x,
-                           (int64_t)N, T, FC / 8, y);
+                           (int64_t)N, T, FC / 8, mask, y);
     else
         hipLaunchKernelGGL(avgpool_t2_fwd_kernel, dim3(ew_grid((int64_t)N * (T / 2) * FC, 256)), dim3(256), 0, S(stream), x, (int64_t)N,
                            T, FC, y);
     MQ_LAUNCH_CHECK("mq_avgpool_t2_fwd");
     return 0;
 }
-extern "C" int mq_avgpool_t2_bwd(const float *dy, int N, int T, int F, int C, float *dx, mqStream stream)
+extern "C" int mq_avgpool_t2_bwd(const float *dy, int N, int T, int F, int C, const uint8_t *mask, float *dx, mqStream stream)
 {
     MQ_REQUIRE(dy && dx && N > 0 && T > 0 && T % 2 == 0 && F > 0 && C > 0, "mq_avgpool_t2_bwd: bad arguments (T must be even)");
+    MQ_REQUIRE(!mask || (C % 8 == 0 && al16(dy) && al16(dx)), "mq_avgpool_t2_bwd: the fused output mask needs C %% 8 == 0 (C=%d)", C);
     const int64_t FC = (int64_t)F * C;
     if (C % 8 == 0 && al16(dy) && al16(dx))
         hipLaunchKernelGGL((avgpool_t2_bwd_h_kernel<float>), dim3(ew_grid((int64_t)N * (T / 2) * (FC / 8), 256)), dim3(256), 0, S(stream), dy,
-                           (int64_t)N, T, FC / 8, dx);
+                           (int64_t)N, T, FC / 8, mask, dx);
     else
         hipLaunchKernelGGL(avgpool_t2_bwd_kernel, dim3(ew_grid((int64_t)N * T * FC, 256)), dim3(256), 0, S(stream), dy, (int64_t)N, T, FC,
                            dx);
     MQ_LAUNCH_CHECK("mq_avgpool_t2_bwd");
     return 0;
 }
-extern "C" int mq_upcat_fwd(const float *x, const float *skip, int N, int T, int F, int C1, int C2, float *out, mqStream stream)
+extern "C" int mq_upcat_fwd(const float *x, const float *skip, int N, int T, int F, int C1, int C2, const uint8_t *mask, float *out,
+                            mqStream stream)
 {
     MQ_REQUIRE(x && skip && out && N > 0 && T > 0 && F > 0 && C1 > 0 && C2 > 0, "mq_upcat_fwd: bad arguments");
+    MQ_REQUIRE(!mask || (C1 % 8 == 0 && C2 % 8 == 0 && al16(x) && al16(skip) && al16(out)),
+               "mq_upcat_fwd: the fused output mask needs C1, C2 multiples of 8 (%d, %d)", C1, C2);
     if (C1 % 8 == 0 && C2 % 8 == 0 && al16(x) && al16(skip) && al16(out))
         hipLaunchKernelGGL((upcat_fwd_h_kernel<float>), dim3(ew_grid((int64_t)N * 2 * T * F * ((C1 + C2) / 8), 256)), dim3(256), 0, S(stream), x,
-                           skip, (int64_t)N, T, F, C1, C2, out);
+                           skip, (int64_t)N, T, F, C1, C2, mask, out);
     else
         hipLaunchKernelGGL(upcat_fwd_kernel, dim3(ew_grid((int64_t)N * 2 * T * F * (C1 + C2), 256)), dim3(256), 0, S(stream), x, skip,
                            (int64_t)N, T, F, C1, C2, out);
     MQ_LAUNCH_CHECK("mq_upcat_fwd");
     return 0;
 }
-extern "C" int mq_upcat_bwd(const float *dout, int N, int T, int F, int C1, int C2, float *dx, float *dskip, mqStream stream)
+extern "C" int mq_upcat_bwd(const float *dout, int N, int T, int F, int C1, int C2, const uint8_t *mask, float *dx, float *dskip,
+                            mqStream stream)
 {
     MQ_REQUIRE(dout && dx && dskip && N > 0 && T > 0 && F > 0 && C1 > 0 && C2 > 0, "mq_upcat_bwd: bad arguments");
+    MQ_REQUIRE(!mask || (C1 % 8 == 0 && C2 % 8 == 0 && al16(dout) && al16(dx) && al16(dskip)),
+               "mq_upcat_bwd: the fused output mask needs C1, C2 multiples of 8 (%d, %d)", C1, C2);
     if (C1 % 8 == 0 && C2 % 8 == 0 && al16(dout) && al16(dx) && al16(dskip)) {
         hipLaunchKernelGGL((upcat_bwd_h_kernel<float>), dim3(ew_grid((int64_t)N * T * F * ((C1 + C2) / 8), 256)), dim3(256), 0, S(stream), dout,
-                           (int64_t)N, T, F, C1, C2, dx, dskip);
+                           (int64_t)N, T, F, C1, C2, mask, dx, dskip);
     } else {
         hipLaunchKernelGGL(upcat_bwd_x_kernel, dim3(ew_grid((int64_t)N * T * F * C1, 256)), dim3(256), 0, S(stream), dout, (int64_t)N, T,
                            F, C1, C2, dx);
@@ -794,41 +824,43 @@ extern "C" int mq_pointwise_bwd_h(const mqPointwiseDesc *d, const uint16_t *dout
     return 0;
 }
 
-extern "C" int mq_avgpool_t2_fwd_h(const uint16_t *x, int N, int T, int F, int C, uint16_t *y, mqStream stream)
+extern "C" int mq_avgpool_t2_fwd_h(const uint16_t *x, int N, int T, int F, int C, const uint8_t *mask, uint16_t *y, mqStream stream)
 {
     MQ_REQUIRE(x && y && N > 0 && T > 0 && T % 2 == 0 && F > 0 && C > 0 && C % 8 == 0 && al16(x) && al16(y),
                "mq_avgpool_t2_fwd_h: bad arguments (T even, C %% 8 == 0, 16-byte alignment)");
     const int64_t FC8 = (int64_t)F * C / 8;
     hipLaunchKernelGGL((avgpool_t2_fwd_h_kernel<bf16_t>), dim3(ew_grid((int64_t)N * (T / 2) * FC8, 256)), dim3(256), 0, S(stream), x, (int64_t)N,
-                       T, FC8, y);
+                       T, FC8, mask, y);
     MQ_LAUNCH_CHECK("mq_avgpool_t2_fwd_h");
     return 0;
 }
-extern "C" int mq_avgpool_t2_bwd_h(const uint16_t *dy, int N, int T, int F, int C, uint16_t *dx, mqStream stream)
+extern "C" int mq_avgpool_t2_bwd_h(const uint16_t *dy, int N, int T, int F, int C, const uint8_t *mask, uint16_t *dx, mqStream stream)
 {
     MQ_REQUIRE(dy && dx && N > 0 && T > 0 && T % 2 == 0 && F > 0 && C > 0 && C % 8 == 0 && al16(dy) && al16(dx),
                "mq_avgpool_t2_bwd_h: bad arguments (T even, C %% 8 == 0, 16-byte alignment)");
     const int64_t FC8 = (int64_t)F * C / 8;
     hipLaunchKernelGGL((avgpool_t2_bwd_h_kernel<bf16_t>), dim3(ew_grid((int64_t)N * (T / 2) * FC8, 256)), dim3(256), 0, S(stream), dy, (int64_t)N,
-                       T, FC8, dx);
+                       T, FC8, mask, dx);
     MQ_LAUNCH_CHECK("mq_avgpool_t2_bwd_h");
     return 0;
 }
-extern "C" int mq_upcat_fwd_h(const uint16_t *x, const uint16_t *skip, int N, int T, int F, int C1, int C2, uint16_t *out, mqStream stream)
+extern "C" int mq_upcat_fwd_h(const uint16_t *x, const uint16_t *skip, int N, int T, int F, int C1, int C2, const uint8_t *mask,
+                              uint16_t *out, mqStream stream)
 {
     MQ_REQUIRE(x && skip && out && N > 0 && T > 0 && F > 0 && C1 > 0 && C2 > 0 && C1 % 8 == 0 && C2 % 8 == 0 && al16(x) && al16(skip) && al16(out),
                "mq_upcat_fwd_h: bad arguments (C1, C2 multiples of 8, 16-byte alignment)");
     hipLaunchKernelGGL((upcat_fwd_h_kernel<bf16_t>), dim3(ew_grid((int64_t)N * 2 * T * F * ((C1 + C2) / 8), 256)), dim3(256), 0, S(stream), x, skip,
-                       (int64_t)N, T, F, C1, C2, out);
+                       (int64_t)N, T, F, C1, C2, mask, out);
     MQ_LAUNCH_CHECK("mq_upcat_fwd_h");
     return 0;
 }
-extern "C" int mq_upcat_bwd_h(const uint16_t *dout, int N, int T, int F, int C1, int C2, uint16_t *dx, uint16_t *dskip, mqStream stream)
+extern "C" int mq_upcat_bwd_h(const uint16_t *dout, int N, int T, int F, int C1, int C2, const uint8_t *mask, uint16_t *dx,
+                              uint16_t *dskip, mqStream stream)
 {
     MQ_REQUIRE(dout && dx && dskip && N > 0 && T > 0 && F > 0 && C1 > 0 && C2 > 0 && C1 % 8 == 0 && C2 % 8 == 0 && al16(dout) && al16(dx) && al16(dskip),
                "mq_upcat_bwd_h: bad arguments (C1, C2 multiples of 8, 16-byte alignment)");
     hipLaunchKernelGGL((upcat_bwd_h_kernel<bf16_t>), dim3(ew_grid((int64_t)N * T * F * ((C1 + C2) / 8), 256)), dim3(256), 0, S(stream), dout,
-                       (int64_t)N, T, F, C1, C2, dx, dskip);
+                       (int64_t)N, T, F, C1, C2, mask, dx, dskip);
     MQ_LAUNCH_CHECK("mq_upcat_bwd_h");
     return 0;
 }

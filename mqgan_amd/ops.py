@@ -795,16 +795,31 @@ def mask_upsample2(mask: torch.Tensor) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------- UNet data movement
+def _frame_mask(mask, N, T, what):
+    """uint8 (N, T) mask of an op's OUTPUT frames (nonzero = padded), or None."""
+    if mask is None:
+        return None
+    if mask.dtype != torch.uint8 or tuple(mask.shape) != (N, T):
+        raise _lib.MqganHipError(f"{what}: output mask must be uint8 {(N, T)}, got {mask.dtype} {tuple(mask.shape)}")
+    return mask.contiguous()
+
+
 class AvgPoolT2Fn(torch.autograd.Function):
+    """Time-only average pool / 2.  ``mask`` (N, T/2): padded output frames are written as zeros and pass no gradient -
+    the entry masked_fill of the block that consumes the pooled map (preencoder.py:93), in the same pass."""
+
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, mask=None):
         N, T, Fq, Cc = x.shape
+        mask = _frame_mask(mask, N, T // 2, "avgpool_t2")
         y = _empty((N, T // 2, Fq, Cc), x, x.dtype)
         if x.dtype == BF16:
-            check(L().mq_avgpool_t2_fwd_h(ptr(x, BF16), N, T, Fq, Cc, ptr(y, BF16), stream()), "mq_avgpool_t2_fwd_h")
+            check(L().mq_avgpool_t2_fwd_h(ptr(x, BF16), N, T, Fq, Cc, ptr(mask, torch.uint8, True), ptr(y, BF16), stream()),
+                  "mq_avgpool_t2_fwd_h")
         else:
-            check(L().mq_avgpool_t2_fwd(fptr(x), N, T, Fq, Cc, fptr(y), stream()), "mq_avgpool_t2_fwd")
+            check(L().mq_avgpool_t2_fwd(fptr(x), N, T, Fq, Cc, ptr(mask, torch.uint8, True), fptr(y), stream()), "mq_avgpool_t2_fwd")
         ctx.shape = (N, T, Fq, Cc)
+        ctx.mask = mask
         return y
 
     @staticmethod
@@ -812,28 +827,34 @@ class AvgPoolT2Fn(torch.autograd.Function):
         N, T, Fq, Cc = ctx.shape
         dy = dy.contiguous()
         dx = _empty(ctx.shape, dy, dy.dtype)
+        m = ptr(ctx.mask, torch.uint8, True)
         if dy.dtype == BF16:
-            check(L().mq_avgpool_t2_bwd_h(ptr(dy, BF16), N, T, Fq, Cc, ptr(dx, BF16), stream()), "mq_avgpool_t2_bwd_h")
+            check(L().mq_avgpool_t2_bwd_h(ptr(dy, BF16), N, T, Fq, Cc, m, ptr(dx, BF16), stream()), "mq_avgpool_t2_bwd_h")
         else:
-            check(L().mq_avgpool_t2_bwd(fptr(dy), N, T, Fq, Cc, fptr(dx), stream()), "mq_avgpool_t2_bwd")
-        return dx
+            check(L().mq_avgpool_t2_bwd(fptr(dy), N, T, Fq, Cc, m, fptr(dx), stream()), "mq_avgpool_t2_bwd")
+        return dx, None
 
 
 class UpCatFn(torch.autograd.Function):
+    """cat(nearest-upsample x2 in time of x, skip) along channels.  ``mask`` (N, 2T): as in AvgPoolT2Fn."""
+
     @staticmethod
-    def forward(ctx, x, skip):
+    def forward(ctx, x, skip, mask=None):
         N, T, Fq, C1 = x.shape
         C2 = skip.shape[-1]
         if tuple(skip.shape[:3]) != (N, 2 * T, Fq):
             raise _lib.MqganHipError(f"upcat: skip {tuple(skip.shape)} does not match upsampled {(N, 2 * T, Fq)}")
         if x.dtype != skip.dtype:
             raise _lib.MqganHipError(f"upcat: dtype mismatch {x.dtype} vs {skip.dtype}")
+        mask = _frame_mask(mask, N, 2 * T, "upcat")
+        m = ptr(mask, torch.uint8, True)
         out = _empty((N, 2 * T, Fq, C1 + C2), x, x.dtype)
         if x.dtype == BF16:
-            check(L().mq_upcat_fwd_h(ptr(x, BF16), ptr(skip, BF16), N, T, Fq, C1, C2, ptr(out, BF16), stream()), "mq_upcat_fwd_h")
+            check(L().mq_upcat_fwd_h(ptr(x, BF16), ptr(skip, BF16), N, T, Fq, C1, C2, m, ptr(out, BF16), stream()), "mq_upcat_fwd_h")
         else:
-            check(L().mq_upcat_fwd(fptr(x), fptr(skip), N, T, Fq, C1, C2, fptr(out), stream()), "mq_upcat_fwd")
+            check(L().mq_upcat_fwd(fptr(x), fptr(skip), N, T, Fq, C1, C2, m, fptr(out), stream()), "mq_upcat_fwd")
         ctx.dims = (N, T, Fq, C1, C2)
+        ctx.mask = mask
         return out
 
     @staticmethod
@@ -842,11 +863,17 @@ class UpCatFn(torch.autograd.Function):
         dout = dout.contiguous()
         dx = _empty((N, T, Fq, C1), dout, dout.dtype)
         ds = _empty((N, 2 * T, Fq, C2), dout, dout.dtype)
+        m = ptr(ctx.mask, torch.uint8, True)
         if dout.dtype == BF16:
-            check(L().mq_upcat_bwd_h(ptr(dout, BF16), N, T, Fq, C1, C2, ptr(dx, BF16), ptr(ds, BF16), stream()), "mq_upcat_bwd_h")
+            check(L().mq_upcat_bwd_h(ptr(dout, BF16), N, T, Fq, C1, C2, m, ptr(dx, BF16), ptr(ds, BF16), stream()), "mq_upcat_bwd_h")
         else:
-            check(L().mq_upcat_bwd(fptr(dout), N, T, Fq, C1, C2, fptr(dx), fptr(ds), stream()), "mq_upcat_bwd")
-        return dx, ds
+            check(L().mq_upcat_bwd(fptr(dout), N, T, Fq, C1, C2, m, fptr(dx), fptr(ds), stream()), "mq_upcat_bwd")
+        return dx, ds, None
+
+
+def mask_fusable(*channels):
+    """The pool / upsample-concat kernels take the consumer's frame mask only on their vectorised path."""
+    return all(c % 8 == 0 for c in channels)
 
 
 class BandSplitFn(torch.autograd.Function):

@@ -64,9 +64,10 @@ class DownBlock(nn.Module):
         self.conv = ConvBlock(c_in, c_out)
 
     def forward(self, x, mask):
-        x = ops.AvgPoolT2Fn.apply(x)                               # time / 2 (preencoder.py:108)
         m = ops.mask_pool(mask, 2, ceil_mode=False)                # padding stays padded (:63-65)
-        return self.conv(x, m), m
+        fused = ops.mask_fusable(x.shape[-1])                      # the block's entry masked_fill rides on the pooling pass
+        x = ops.AvgPoolT2Fn.apply(x, m if fused else None)         # time / 2 (preencoder.py:108)
+        return self.conv(x, m, input_is_masked=fused), m
 
 
 class UpBlock(nn.Module):
@@ -80,8 +81,9 @@ class UpBlock(nn.Module):
         dt = skip.shape[1] - t_up
         if dt > 0:                                                 # crop_to_match (:73-82); never hit when T % 2^depth == 0
             skip = skip[:, dt // 2: dt // 2 + t_up].contiguous()
-        x = ops.UpCatFn.apply(x, skip)                             # nearest x2 in time + channel concat (:124-129)
-        return self.conv(x, m), m
+        fused = ops.mask_fusable(x.shape[-1], skip.shape[-1])
+        x = ops.UpCatFn.apply(x, skip, m if fused else None)       # nearest x2 in time + channel concat (:124-129), masked
+        return self.conv(x, m, input_is_masked=fused), m
 
 
 class UNetRefiner(nn.Module):

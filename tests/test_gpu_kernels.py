@@ -622,6 +622,46 @@ def test_pool_upcat_bandsplit(env):
     np.testing.assert_array_equal(ops.mask_upsample2(m).cpu().numpy(), np.repeat(m.cpu().numpy(), 2, axis=1))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pool_upcat_with_consumer_mask(env, dtype):
+    """The ConvBlock's entry masked_fill (reference preencoder.py:93) fused into the pooling / upsample-concat pass:
+    identical, forward and backward, to the op followed by the stand-alone mask pass."""
+    ops = env
+    torch.manual_seed(16)
+    N, T, Fq, C1, C2 = 3, 12, 5, 16, 24
+    lens = torch.tensor([12, 7, 0], device=DEV)
+    x = torch.randn(N, T, Fq, C1, device=DEV).to(dtype)
+    m_half = ops.sequence_mask((lens // 2).to(torch.int32), T // 2)
+    outs = []
+    for fused in (True, False):
+        xx = x.clone().requires_grad_(True)
+        y = ops.AvgPoolT2Fn.apply(xx, m_half if fused else None)
+        if not fused:
+            y = ops.pointwise(y, mask=m_half, mask_post=True, dmap=(Fq, 1, 1))
+        g = torch.randn(y.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3)).to(dtype)
+        y.backward(g)
+        outs.append((y.detach(), xx.grad))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert bool((outs[0][0][1, 3:] == 0).all()) and bool((outs[0][0][2] == 0).all())
+    m_full = ops.sequence_mask(lens.to(torch.int32) + torch.tensor([0, 1, 3], device=DEV, dtype=torch.int32), 2 * (T // 2))
+    a = torch.randn(N, T // 2, Fq, C1, device=DEV).to(dtype)
+    sk = torch.randn(N, T, Fq, C2, device=DEV).to(dtype)
+    outs = []
+    for fused in (True, False):
+        aa, ss = a.clone().requires_grad_(True), sk.clone().requires_grad_(True)
+        y = ops.UpCatFn.apply(aa, ss, m_full if fused else None)
+        if not fused:
+            y = ops.pointwise(y, mask=m_full, mask_post=True, dmap=(Fq, 1, 1))
+        g = torch.randn(y.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(4)).to(dtype)
+        y.backward(g)
+        outs.append((y.detach(), aa.grad, ss.grad))
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
+    with pytest.raises(Exception, match="multiples of 8|C % 8|C %% 8"):
+        ops.UpCatFn.apply(torch.randn(1, 2, 2, 6, device=DEV), torch.randn(1, 4, 2, 3, device=DEV),
+                          torch.zeros(1, 4, dtype=torch.uint8, device=DEV))
+
+
 # ----------------------------------------------------------------------------------------- optimiser
 def test_sumsq_and_adam_match_torch(env):
     ops = env
