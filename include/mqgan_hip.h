@@ -149,11 +149,21 @@ int mq_conv_fprop_h2(const mqConvDesc *desc_host, const uint16_t *x, const uint1
                      mqStream stream);
 int mq_conv_dgrad_h2(const mqConvDesc *desc_host, const uint16_t *dy, const uint16_t *wt_h2, int out_f32, void *dx,
                      mqStream stream);
+/* mq_conv_dgrad_h2 for a conv whose bf16 input x came out of a LeakyReLU(slope) + masked_fill layer (discriminators.py:219,
+ * 232): dx is returned with respect to that layer's PRE-activation, dx * (x > 0 ? 1 : slope), zero on its padded frames
+ * (mask index of input pixel m = (n*H + h)*W + w: (m / d1) * d2 + m % d3) - the producer's activation backward without a
+ * pass of its own.  bf16 results are bit-identical to mq_conv_dgrad_h2 followed by mq_pointwise_bwd_h. */
+int mq_conv_dgrad_h2_gated(const mqConvDesc *desc_host, const uint16_t *dy, const uint16_t *wt_h2, const uint16_t *x,
+                           const uint8_t *mask, int64_t d1, int64_t d2, int64_t d3, float slope, int out_f32, void *dx,
+                           mqStream stream);
 size_t mq_conv_wgrad_h2_workspace(const mqConvDesc *desc_host);
 int mq_conv_wgrad_h2(const mqConvDesc *desc_host, const uint16_t *x, const uint16_t *dy, float *dw_krsc, float *dbias,
                      void *workspace, size_t workspace_bytes, mqStream stream);
 /* dx (N,H,W,C) = conv_transpose(dy (N,P,Q,K)); weights given as (groups, C, R, S, K) */
 int mq_conv_dgrad(const mqConvDesc *desc_host, const float *dy, const float *w_crsk, float *dx, mqStream stream);
+/* the f32-tensor counterpart of mq_conv_dgrad_h2_gated (all f32-tensor engines; same summation order as mq_conv_dgrad) */
+int mq_conv_dgrad_gated(const mqConvDesc *desc_host, const float *dy, const float *w_crsk, const float *x, const uint8_t *mask,
+                        int64_t d1, int64_t d2, int64_t d3, float slope, float *dx, mqStream stream);
 /* dw (groups, K, R, S, C); split-K over pixels with a deterministic slab reduction.
  * workspace: mq_conv_wgrad_workspace() bytes (may be 0 -> pass NULL). */
 size_t mq_conv_wgrad_workspace(const mqConvDesc *desc_host);
@@ -373,8 +383,10 @@ int mq_lsgan_g_bwd(const float *fake, const uint8_t *padded, int mask_mode, int 
  * count]; loss = mq_ratio_final(sums2, 1e-8).  workspace: 512 floats. */
 int mq_masked_mae_sums(const float *pred, const float *target, const uint8_t *padded, int B, int H, int W, int C,
                        float *sums2, float *workspace, mqStream stream);
+/* leaky_slope: 1 for the plain gradient; s != 1 when pred = LeakyReLU_s(h) of a layer that takes its gradient with respect
+ * to h (mq_conv_dgrad_gated below): dpred *= pred > 0 ? 1 : s. */
 int mq_masked_mae_bwd(const float *pred, const float *target, const uint8_t *padded, int B, int H, int W, int C,
-                      const float *sums2, const float *gout, float *dpred, mqStream stream);
+                      const float *sums2, const float *gout, float leaky_slope, float *dpred, mqStream stream);
 
 /* ------------------------------------------------------------------ optimiser
  * clip_grad_norm_ + Adam on flat arenas (train.py:401-407,485-492; torch.optim.Adam

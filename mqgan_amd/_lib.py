@@ -56,6 +56,7 @@ SIGNATURES = {
     "mq_codebook_ema_update": (_I, [_P, _P, _L, _I, _I, _F, _F, _P, _P, _P, _P, _Z, _P]),
     "mq_conv_fprop": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "mq_conv_dgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
+    "mq_conv_dgrad_gated": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _L, _L, _L, _F, _P, _P]),
     "mq_conv_fprop_leaky": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _L, _L, _L, _F, _P, _P]),
     "mq_cast_bf16": (_I, [_P, _P, _L, _P]),
     "mq_conv_fprop_h": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
@@ -66,6 +67,7 @@ SIGNATURES = {
     "mq_h2_weight_image": (_I, [C.POINTER(ConvDesc), _I, _P, _P, _P]),
     "mq_conv_fprop_h2": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _L, _L, _L, _I, _F, _I, _P, _P]),
     "mq_conv_dgrad_h2": (_I, [C.POINTER(ConvDesc), _P, _P, _I, _P, _P]),
+    "mq_conv_dgrad_h2_gated": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _L, _L, _L, _F, _I, _P, _P]),
     "mq_conv_wgrad_h2_workspace": (_Z, [C.POINTER(ConvDesc)]),
     "mq_conv_wgrad_h2": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _Z, _P]),
     "mq_conv_wgrad_workspace": (_Z, [C.POINTER(ConvDesc)]),
@@ -131,7 +133,7 @@ SIGNATURES = {
     "mq_ratio_final": (_I, [_P, _F, _P, _P]),
     "mq_lsgan_g_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "mq_masked_mae_sums": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
-    "mq_masked_mae_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "mq_masked_mae_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _F, _P, _P]),
     "mq_sumsq": (_I, [_P, _L, _P, _P, _P]),
     "mq_adam_step": (_I, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _I, _P, _F, _F, _P]),
 }

@@ -41,11 +41,16 @@ struct ConvGeom {
 // Optional fused epilogue of the fprop kernels: y = padded(row) ? 0 : leaky(conv + bias), i.e. the discriminators'
 // conv -> LeakyReLU -> masked_fill (discriminators.py:219,232) without a second pass over the output.  The frame mask
 // index of output row m is (m / d1) * d2 + (m % d3), as in the pointwise kernels.
+//
+// act 3 is the matching dgrad epilogue: the conv's INPUT x was produced by such a layer (x = padded ? 0 : leaky(h)), and the
+// gradient the kernel hands back is the one with respect to h: dx * (x > 0 ? 1 : slope), zero on padded frames - the
+// producer's LeakyReLU / mask backward without a pass of its own.  `gate` is x, laid out like the output dx.
 struct NtEpi {
     const uint8_t *mask;       // nullptr: no masking
     int d1, d2, d3;
     float slope;
-    int act;                   // 0: plain store, 2: LeakyReLU(slope) (+ mask)
+    int act;                   // 0: plain store, 2: LeakyReLU(slope) (+ mask), 3 (dgrad): LeakyReLU'(gate) (+ mask)
+    const float *gate;
 };
 
 // ------------------------------------------------------------------------------------------ loaders
@@ -331,8 +336,10 @@ __device__ __forceinline__ void conv_nt_body(const float *__restrict__ act, cons
     // fused activation: the padded flag of each of the tile's 128 rows is looked up once (LDS is free after the main
     // loop's last barrier)
     unsigned char *padf = reinterpret_cast<unsigned char *>(smem);
-    const bool fused = !DGRAD && epi.act != 0;
-    if (fused) {
+    const bool fused = !DGRAD && epi.act == 2;
+    const bool gated = DGRAD && epi.act == 3;
+    const float *gt = gated ? epi.gate + (size_t)grp * g.Mtot * g.Ncols : nullptr;
+    if (fused || gated) {
         if (threadIdx.x < GEMM_BM) {
             const int m = m0 + threadIdx.x;
             unsigned char pd = 0;
@@ -358,6 +365,10 @@ __device__ __forceinline__ void conv_nt_body(const float *__restrict__ act, cons
                 float v = acc[tm][tn][r] + bv;
                 if (fused) {
                     v = v > 0.f ? v : epi.slope * v;
+                    v = padf[row] ? 0.f : v;
+                }
+                if (gated && m < g.Mtot) {
+                    v = gt[(size_t)m * g.Ncols + n] > 0.f ? v : epi.slope * v;
                     v = padf[row] ? 0.f : v;
                 }
                 if (m < g.Mtot) o[(size_t)m * g.Ncols + n] = v;
@@ -483,7 +494,8 @@ struct ParityBLoader {     // filter bank [Ncols][R*S*IC] (channel-blocked), col
 template <class E, int BN, int WRAPS_>
 __device__ __forceinline__ void conv_dgrad_parity_body(const float *__restrict__ dy, const float *__restrict__ wgt,
                                                        float *__restrict__ dx, const ConvGeom &g, const ParityInfo &pi,
-                                                       size_t act_group_stride, size_t w_group_stride, int ng, float *smem)
+                                                       size_t act_group_stride, size_t w_group_stride, int ng, float *smem,
+                                                       const NtEpi &epi)
 {
     using Cfg = GemmCfg<BN, E>;
     constexpr bool UNI = WRAPS_ == 0;
@@ -531,21 +543,50 @@ __device__ __forceinline__ void conv_dgrad_parity_body(const float *__restrict__
     zero_acc<BN>(acc);
     nt_gemm_run<E, BN>(la, lb, (Kdim + E::BK - 1) / E::BK, smem, acc);
 
-    float *o = dx + (size_t)grp * ng * g.OH * g.OW * g.Ncols;
+    const size_t gbase = (size_t)grp * ng * g.OH * g.OW;             // first pixel of the group
+    float *o = dx + gbase * g.Ncols;
+    const bool gated = epi.act == 3;                                 // LeakyReLU' / mask of the layer that produced the input
+    const float *gt = gated ? epi.gate + gbase * g.Ncols : nullptr;
+    auto pixel_of = [&](int m) -> size_t {                           // class row -> pixel of the group
+        const int iwq = m % Wb;
+        const int t = m / Wb;
+        const int ihq = t % Ha, n = t / Ha;
+        return ((size_t)n * g.OH + ihq * g.sh + a) * g.OW + iwq * g.sw + b;
+    };
+    // padded flag of the tile's 128 rows, looked up once (LDS is free after the main loop's last barrier)
+    unsigned char *padf = reinterpret_cast<unsigned char *>(smem);
+    if (gated) {
+        if (threadIdx.x < GEMM_BM) {
+            const int m = m0 + threadIdx.x;
+            unsigned char pd = 0;
+            if (epi.mask != nullptr && m < Mc) {
+                const int64_t mg = (int64_t)(gbase + pixel_of(m));
+                pd = epi.mask[(mg / epi.d1) * epi.d2 + (mg % epi.d3)] != 0;
+            }
+            padf[threadIdx.x] = pd;
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int tm = 0; tm < Cfg::TM; ++tm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = m0 + acc_row<BN>(tm, r);
+            const int row = acc_row<BN>(tm, r);
+            const int m = m0 + row;
             if (m >= Mc) continue;
-            const int iwq = m % Wb;
-            const int t = m / Wb;
-            const int ihq = t % Ha, n = t / Ha;
-            const size_t base = (((size_t)n * g.OH + ihq * g.sh + a) * g.OW + iwq * g.sw + b) * g.Ncols;
+            const size_t base = pixel_of(m) * g.Ncols;
+            const bool pd = gated && padf[row] != 0;
 #pragma unroll
             for (int tn = 0; tn < Cfg::TN; ++tn) {
                 const int col = n0 + acc_col<BN>(tn);
-                if (col < g.Ncols) o[base + col] = acc[tm][tn][r];
+                if (col < g.Ncols) {
+                    float v = acc[tm][tn][r];
+                    if (gated) {
+                        v = gt[base + col] > 0.f ? v : epi.slope * v;
+                        v = pd ? 0.f : v;
+                    }
+                    o[base + col] = v;
+                }
             }
         }
 }
@@ -553,36 +594,36 @@ __device__ __forceinline__ void conv_dgrad_parity_body(const float *__restrict__
 template <int BN, int WRAPS>
 __global__ __launch_bounds__(256, MQ_NT_OCC) void conv_dgrad_parity_kernel(const float *__restrict__ dy, const float *__restrict__ wgt,
                                                                 float *__restrict__ dx, ConvGeom g, ParityInfo pi,
-                                                                size_t act_group_stride, size_t w_group_stride, int ng)
+                                                                size_t act_group_stride, size_t w_group_stride, int ng, NtEpi epi)
 {
     __shared__ __attribute__((aligned(16))) float smem[GemmCfg<BN, EngF32>::LDS_FLOATS];
-    conv_dgrad_parity_body<EngF32, BN, WRAPS>(dy, wgt, dx, g, pi, act_group_stride, w_group_stride, ng, smem);
+    conv_dgrad_parity_body<EngF32, BN, WRAPS>(dy, wgt, dx, g, pi, act_group_stride, w_group_stride, ng, smem, epi);
 }
 template <int BN, int WRAPS>
 __global__ __launch_bounds__(256, 3) void conv_dgrad_parity_x3_kernel(const float *__restrict__ dy, const float *__restrict__ wgt,
                                                                    float *__restrict__ dx, ConvGeom g, ParityInfo pi,
-                                                                   size_t act_group_stride, size_t w_group_stride, int ng)
+                                                                   size_t act_group_stride, size_t w_group_stride, int ng, NtEpi epi)
 {
     __shared__ __attribute__((aligned(16))) float smem[GemmCfg<BN, EngSplit>::LDS_FLOATS];
-    conv_dgrad_parity_body<EngSplit, BN, WRAPS>(dy, wgt, dx, g, pi, act_group_stride, w_group_stride, ng, smem);
+    conv_dgrad_parity_body<EngSplit, BN, WRAPS>(dy, wgt, dx, g, pi, act_group_stride, w_group_stride, ng, smem, epi);
 }
 template <int BN>
 __global__ __launch_bounds__(256, (BN == 128 ? 3 : 4)) void conv_dgrad_parity_h_kernel(const float *__restrict__ dy,
                                                                   const float *__restrict__ wgt, float *__restrict__ dx,
                                                                   ConvGeom g, ParityInfo pi, size_t act_group_stride,
-                                                                  size_t w_group_stride, int ng)
+                                                                  size_t w_group_stride, int ng, NtEpi epi)
 {
     __shared__ __attribute__((aligned(16))) float smem[GemmCfg<BN, EngBF16H>::LDS_FLOATS];
-    conv_dgrad_parity_body<EngBF16H, BN, 2>(dy, wgt, dx, g, pi, act_group_stride, w_group_stride, ng, smem);
+    conv_dgrad_parity_body<EngBF16H, BN, 2>(dy, wgt, dx, g, pi, act_group_stride, w_group_stride, ng, smem, epi);
 }
 template <int BN, int WRAPS>
 __global__ __launch_bounds__(256, (BN == 128 ? 3 : 4)) void conv_dgrad_parity_bf16_kernel(const float *__restrict__ dy,
                                                                      const float *__restrict__ wgt, float *__restrict__ dx,
                                                                      ConvGeom g, ParityInfo pi, size_t act_group_stride,
-                                                                     size_t w_group_stride, int ng)
+                                                                     size_t w_group_stride, int ng, NtEpi epi)
 {
     __shared__ __attribute__((aligned(16))) float smem[GemmCfg<BN, EngBF16>::LDS_FLOATS];
-    conv_dgrad_parity_body<EngBF16, BN, WRAPS>(dy, wgt, dx, g, pi, act_group_stride, w_group_stride, ng, smem);
+    conv_dgrad_parity_body<EngBF16, BN, WRAPS>(dy, wgt, dx, g, pi, act_group_stride, w_group_stride, ng, smem, epi);
 }
 
 // ------------------------------------------------------------------------------------------ wgrad
@@ -1125,12 +1166,12 @@ static int check_desc(const mqConvDesc *d, const char *who)
 // hmode: act and w are bf16 arrays (mq_cast_bf16 copies of the f32 tensors), passed as float* in disguise
 template <bool DGRAD>
 static int launch_nt(const mqConvDesc *d, const float *act, const float *w, const float *bias, float *out, hipStream_t st,
-                     bool hmode = false, NtEpi epi = NtEpi{nullptr, 1, 0, 1, 0.f, 0})
+                     bool hmode = false, NtEpi epi = NtEpi{nullptr, 1, 0, 1, 0.f, 0, nullptr})
 {
     const bool want_bf16 = d->precision == MQ_PRECISION_BF16 && !hmode;
     const bool want_x3 = d->precision == MQ_PRECISION_F32X3;
-    if (use_d32() && d->precision == MQ_PRECISION_F32 && !hmode && ((uintptr_t)act % 16 == 0) && ((uintptr_t)w % 16 == 0) &&
-        d32_nt_ok(d, DGRAD))
+    if (use_d32() && epi.act != 3 && d->precision == MQ_PRECISION_F32 && !hmode && ((uintptr_t)act % 16 == 0) &&
+        ((uintptr_t)w % 16 == 0) && d32_nt_ok(d, DGRAD))
         return d32_nt_launch(d, DGRAD, act, w, bias, epi.mask, epi.d1, epi.d2, epi.d3, epi.act, epi.slope, out, st);
     ConvGeom g;
     const int ng = d->N / d->groups;
@@ -1209,14 +1250,14 @@ static int launch_nt(const mqConvDesc *d, const float *act, const float *w, cons
             }
         pi.tile0[pi.ncls] = t0;
         dim3 pgrid(t0 * g.nNt, d->groups);
-#define MQ_PAR(BN_, W_) hipLaunchKernelGGL((conv_dgrad_parity_kernel<BN_, W_>), pgrid, dim3(256), 0, st, act, w, out, g, pi, act_gs, w_gs, ng)
-#define MQ_PARH(BN_, W_) hipLaunchKernelGGL((conv_dgrad_parity_bf16_kernel<BN_, W_>), pgrid, dim3(256), 0, st, act, w, out, g, pi, act_gs, w_gs, ng)
+#define MQ_PAR(BN_, W_) hipLaunchKernelGGL((conv_dgrad_parity_kernel<BN_, W_>), pgrid, dim3(256), 0, st, act, w, out, g, pi, act_gs, w_gs, ng, epi)
+#define MQ_PARH(BN_, W_) hipLaunchKernelGGL((conv_dgrad_parity_bf16_kernel<BN_, W_>), pgrid, dim3(256), 0, st, act, w, out, g, pi, act_gs, w_gs, ng, epi)
         if (hmode) {
-#define MQ_PARHH(BN_) hipLaunchKernelGGL((conv_dgrad_parity_h_kernel<BN_>), pgrid, dim3(256), 0, st, act, w, out, g, pi, act_gs, w_gs, ng)
+#define MQ_PARHH(BN_) hipLaunchKernelGGL((conv_dgrad_parity_h_kernel<BN_>), pgrid, dim3(256), 0, st, act, w, out, g, pi, act_gs, w_gs, ng, epi)
             if (BN == 128) MQ_PARHH(128); else if (BN == 64) MQ_PARHH(64); else MQ_PARHH(32);
 #undef MQ_PARHH
         } else if (x3) {
-#define MQ_PARX(BN_, W_) hipLaunchKernelGGL((conv_dgrad_parity_x3_kernel<BN_, W_>), pgrid, dim3(256), 0, st, act, w, out, g, pi, act_gs, w_gs, ng)
+#define MQ_PARX(BN_, W_) hipLaunchKernelGGL((conv_dgrad_parity_x3_kernel<BN_, W_>), pgrid, dim3(256), 0, st, act, w, out, g, pi, act_gs, w_gs, ng, epi)
             const int wr = g.IC % 16 == 0 ? 0 : (wide ? 1 : 4);
             if (BN == 128) { if (wr == 0) MQ_PARX(128, 0); else if (wr == 1) MQ_PARX(128, 1); else MQ_PARX(128, 4); }
             else if (BN == 64) { if (wr == 0) MQ_PARX(64, 0); else if (wr == 1) MQ_PARX(64, 1); else MQ_PARX(64, 4); }
@@ -1331,7 +1372,7 @@ extern "C" int mq_conv_fprop_leaky(const mqConvDesc *d, const float *x, const fl
     MQ_REQUIRE(d->C % 4 == 0, "mq_conv_fprop_leaky: the fused epilogue exists on the vector path only (C %% 4 == 0, got %d)", d->C);
     MQ_REQUIRE(mask == nullptr || (d1 > 0 && d3 > 0 && d2 >= 0 && d1 < INT32_MAX && d2 < INT32_MAX && d3 < INT32_MAX),
                "mq_conv_fprop_leaky: bad mask map");
-    NtEpi epi{mask, (int)(mask ? d1 : 1), (int)(mask ? d2 : 0), (int)(mask ? d3 : 1), slope, 2};
+    NtEpi epi{mask, (int)(mask ? d1 : 1), (int)(mask ? d2 : 0), (int)(mask ? d3 : 1), slope, 2, nullptr};
     return launch_nt<false>(d, x, w, bias, y, S(stream), false, epi);
 }
 
@@ -1356,6 +1397,20 @@ extern "C" int mq_conv_dgrad(const mqConvDesc *d, const float *dy, const float *
     if (check_desc(d, "mq_conv_dgrad")) return 1;
     MQ_REQUIRE(dy && w_crsk && dx, "mq_conv_dgrad: null pointer");
     return launch_nt<true>(d, dy, w_crsk, nullptr, dx, S(stream));
+}
+
+// dgrad of a conv whose input x came out of a LeakyReLU + masked_fill layer, returning the gradient with respect to that
+// layer's PRE-activation: dx * (x > 0 ? 1 : slope), zero on the producer's padded frames (mask index of input pixel m:
+// (m / d1) * d2 + m % d3, m = (n * H + h) * W + w).  Same engines and summation order as mq_conv_dgrad.
+extern "C" int mq_conv_dgrad_gated(const mqConvDesc *d, const float *dy, const float *w_crsk, const float *x, const uint8_t *mask,
+                                   int64_t d1, int64_t d2, int64_t d3, float slope, float *dx, mqStream stream)
+{
+    if (check_desc(d, "mq_conv_dgrad_gated")) return 1;
+    MQ_REQUIRE(dy && w_crsk && x && dx, "mq_conv_dgrad_gated: null pointer");
+    MQ_REQUIRE(!mask || (d1 > 0 && d3 > 0 && d1 < INT32_MAX && d2 < INT32_MAX && d3 < INT32_MAX && d2 >= 0),
+               "mq_conv_dgrad_gated: bad mask map");
+    NtEpi epi{mask, (int)(mask ? d1 : 1), (int)(mask ? d2 : 0), (int)(mask ? d3 : 1), slope, 3, x};
+    return launch_nt<true>(d, dy, w_crsk, nullptr, dx, S(stream), false, epi);
 }
 
 static int colsum_launch(const float *x, int64_t rows, int cols, float *out, float *workspace, hipStream_t st);

@@ -56,9 +56,11 @@ struct H2Epi {
     const float *bias;         // [groups * Ncols] or null
     const uint8_t *mask;       // frame mask (1 = padded) or null; index of output row m: (m / d1) * d2 + m % d3
     int d1, d2, d3;
-    int act;                   // 0: none, 2: LeakyReLU(slope) then masked_fill
+    int act;                   // 0: none, 2: LeakyReLU(slope) then masked_fill, 3 (dgrad): LeakyReLU'(gate), masked
     float slope;
     int out_f32;               // 1: f32 output, 0: bf16
+    const unsigned short *gate;   // act 3: the conv's bf16 input x = padded ? 0 : leaky(h), laid out like the output dx;
+                                  // the kernel returns the gradient with respect to h: dx * (x > 0 ? 1 : slope), masked
 };
 
 __device__ __forceinline__ unsigned short f2bf(float v)
@@ -450,19 +452,7 @@ __device__ __forceinline__ void conv_h2_body(const void *__restrict__ act_v, con
     constexpr int STG_ROWB = 64 * TN;                             // bytes of one staged bf16 row: 32 * TN columns
     constexpr int STG_WAVE = 32 * STG_ROWB;                       // one wave stages 32 rows (one tm) at a time
     unsigned char *padf = reinterpret_cast<unsigned char *>(smem) + 8 * STG_WAVE;
-    const bool fused = epi.act != 0;
-    if (fused) {
-        if (tid < H2_BM) {
-            const int m = m0 + tid;
-            unsigned char pd = 0;
-            if (epi.mask != nullptr && m < Mc) {
-                const int64_t mg = (int64_t)grp * Mc + m;
-                pd = epi.mask[(mg / epi.d1) * epi.d2 + (mg % epi.d3)] != 0;
-            }
-            padf[tid] = pd;
-        }
-        __syncthreads();
-    }
+    const bool fused = epi.act == 2, gated = epi.act == 3;
     auto out_index = [&](int m) -> size_t {                       // element offset of column 0 of output row m
         if constexpr (PARITY) {
             const int iwq = m % OWc, t2 = m / OWc;
@@ -472,6 +462,19 @@ __device__ __forceinline__ void conv_h2_body(const void *__restrict__ act_v, con
             return ((size_t)grp * Mc + m) * g.Ncols;
         }
     };
+    if (fused || gated) {
+        if (tid < H2_BM) {
+            const int m = m0 + tid;
+            unsigned char pd = 0;
+            if (epi.mask != nullptr && m < Mc) {
+                const int64_t mg = (int64_t)(out_index(m) / (size_t)g.Ncols);    // output pixel, counted over all groups
+                pd = epi.mask[(mg / epi.d1) * epi.d2 + (mg % epi.d3)] != 0;
+            }
+            padf[tid] = pd;
+        }
+        __syncthreads();
+    }
+    auto bf2f = [](unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); };
     // visit the accumulator elements of one 32-row half of the wave tile: fn(row in half, column in wave tile, value)
     auto for_half = [&](auto half_tag, auto &&fn) {
         constexpr int half = decltype(half_tag)::value;
@@ -513,6 +516,10 @@ __device__ __forceinline__ void conv_h2_body(const void *__restrict__ act_v, con
                         v = v > 0.f ? v : epi.slope * v;
                         v = padf[row] ? 0.f : v;
                     }
+                    if (gated) {
+                        v = bf2f(epi.gate[out_index(m) + n]) > 0.f ? v : epi.slope * v;
+                        v = padf[row] ? 0.f : v;
+                    }
                     of[out_index(m) + n] = v;
                 }
             });
@@ -528,6 +535,22 @@ __device__ __forceinline__ void conv_h2_body(const void *__restrict__ act_v, con
     char *stg = smem + wave * STG_WAVE;
     auto stage_half = [&](auto half_tag) {
         constexpr int half = decltype(half_tag)::value;
+        constexpr int CPR = 4 * TN;                                   // 16-byte chunks per row
+        constexpr int NIT = (32 * CPR + 63) / 64;
+        // gated store: this lane's chunks of the gate tensor are requested before the tile is staged, so their latency
+        // hides behind the LDS transpose instead of sitting in front of every store
+        uint4 gq[NIT];
+        if (gated) {
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int q = i * 64 + lane;
+                const int rl = q / CPR, c16 = q - rl * CPR;
+                const int m = m0 + wm * 64 + half * 32 + rl;
+                const int n = n0 + wn * 32 * TN + c16 * 8;
+                gq[i] = make_uint4(0, 0, 0, 0);
+                if (rl < 32 && m < Mc && n < g.Ncols) gq[i] = *reinterpret_cast<const uint4 *>(epi.gate + out_index(m) + n);
+            }
+        }
         for_half(half_tag, [&](int rl, int cl, float a) {
             float v = a + bias_of(cl);
             if (fused) {
@@ -537,15 +560,31 @@ __device__ __forceinline__ void conv_h2_body(const void *__restrict__ act_v, con
             *reinterpret_cast<unsigned short *>(stg + rl * STG_ROWB + cl * 2) = f2bf(v);
         });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // own writes (the patch is private to the wave)
-        constexpr int CPR = 4 * TN;                                   // 16-byte chunks per row
 #pragma unroll
-        for (int i = 0; i < (32 * CPR + 63) / 64; ++i) {
+        for (int i = 0; i < NIT; ++i) {
             const int q = i * 64 + lane;
             const int rl = q / CPR, c16 = q - rl * CPR;
             const int m = m0 + wm * 64 + half * 32 + rl;
             const int n = n0 + wn * 32 * TN + c16 * 8;
             if (rl < 32 && m < Mc && n < g.Ncols) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(stg + rl * STG_ROWB + c16 * 16);
+                uint4 v = *reinterpret_cast<const uint4 *>(stg + rl * STG_ROWB + c16 * 16);
+                if (gated) {
+                    // the staged values are the bf16 gradient an ungated launch would have stored; gate them as the
+                    // stand-alone pointwise backward does (f32 product, one more rounding): bit-identical to the two passes
+                    const bool pd = padf[wm * 64 + half * 32 + rl] != 0;
+                    const unsigned vw[4] = {v.x, v.y, v.z, v.w}, gw[4] = {gq[i].x, gq[i].y, gq[i].z, gq[i].w};
+                    unsigned ow[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float lo = bf2f((unsigned short)(vw[e] & 0xFFFFu)), hi = bf2f((unsigned short)(vw[e] >> 16));
+                        lo = bf2f((unsigned short)(gw[e] & 0xFFFFu)) > 0.f ? lo : epi.slope * lo;
+                        hi = bf2f((unsigned short)(gw[e] >> 16)) > 0.f ? hi : epi.slope * hi;
+                        lo = pd ? 0.f : lo;
+                        hi = pd ? 0.f : hi;
+                        ow[e] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+                    }
+                    v = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                }
                 *reinterpret_cast<uint4 *>(oh_ + out_index(m) + n) = v;
             }
         }
@@ -1124,7 +1163,7 @@ extern "C" int mq_conv_fprop_h2(const mqConvDesc *d, const uint16_t *x, const ui
     MQ_REQUIRE(act == 0 || act == 2, "mq_conv_fprop_h2: act must be 0 (none) or 2 (LeakyReLU + mask)");
     MQ_REQUIRE(mask == nullptr || (d1 > 0 && d3 > 0 && d2 >= 0 && d1 < INT32_MAX && d2 < INT32_MAX && d3 < INT32_MAX),
                "mq_conv_fprop_h2: bad mask map");
-    H2Epi epi{bias, act ? mask : nullptr, (int)(mask ? d1 : 1), (int)(mask ? d2 : 0), (int)(mask ? d3 : 1), act, slope, out_f32};
+    H2Epi epi{bias, act ? mask : nullptr, (int)(mask ? d1 : 1), (int)(mask ? d2 : 0), (int)(mask ? d3 : 1), act, slope, out_f32, nullptr};
     return launch_h2<ElemBF16, false>(d, x, w_h2, y, epi, S(stream), "mq_conv_fprop_h2");
 }
 
@@ -1132,8 +1171,24 @@ extern "C" int mq_conv_dgrad_h2(const mqConvDesc *d, const uint16_t *dy, const u
 {
     if (h2_check(d, "mq_conv_dgrad_h2")) return 1;
     MQ_REQUIRE(dy && wt_h2 && dx, "mq_conv_dgrad_h2: null pointer");
-    H2Epi epi{nullptr, nullptr, 1, 0, 1, 0, 0.f, out_f32};
+    H2Epi epi{nullptr, nullptr, 1, 0, 1, 0, 0.f, out_f32, nullptr};
     return launch_h2<ElemBF16, true>(d, dy, wt_h2, dx, epi, S(stream), "mq_conv_dgrad_h2");
+}
+
+// mq_conv_dgrad_h2 for a conv whose bf16 input x came out of a LeakyReLU + masked_fill layer: returns the gradient with
+// respect to that layer's pre-activation (see mq_conv_dgrad_gated); bf16 results are bit-identical to mq_conv_dgrad_h2
+// followed by the pointwise LeakyReLU backward.
+extern "C" int mq_conv_dgrad_h2_gated(const mqConvDesc *d, const uint16_t *dy, const uint16_t *wt_h2, const uint16_t *x,
+                                      const uint8_t *mask, int64_t d1, int64_t d2, int64_t d3, float slope, int out_f32, void *dx,
+                                      mqStream stream)
+{
+    if (h2_check(d, "mq_conv_dgrad_h2_gated")) return 1;
+    MQ_REQUIRE(dy && wt_h2 && x && dx, "mq_conv_dgrad_h2_gated: null pointer");
+    MQ_REQUIRE((uintptr_t)x % 16 == 0, "mq_conv_dgrad_h2_gated: x must be 16-byte aligned");
+    MQ_REQUIRE(mask == nullptr || (d1 > 0 && d3 > 0 && d2 >= 0 && d1 < INT32_MAX && d2 < INT32_MAX && d3 < INT32_MAX),
+               "mq_conv_dgrad_h2_gated: bad mask map");
+    H2Epi epi{nullptr, mask, (int)(mask ? d1 : 1), (int)(mask ? d2 : 0), (int)(mask ? d3 : 1), 3, slope, out_f32, x};
+    return launch_h2<ElemBF16, true>(d, dy, wt_h2, dx, epi, S(stream), "mq_conv_dgrad_h2_gated");
 }
 
 namespace mq {

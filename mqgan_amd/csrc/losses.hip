@@ -288,8 +288,10 @@ __global__ void mae_sums_kernel(const float *__restrict__ part, int nb, float *_
     sums2[1] = v;
 }
 __global__ void mae_bwd_kernel(const float *__restrict__ p, const float *__restrict__ t, const uint8_t *__restrict__ padded, int B, int H,
-                               int W, int C, const float *__restrict__ sums2, const float *__restrict__ gout, float *__restrict__ dp)
+                               int W, int C, const float *__restrict__ sums2, const float *__restrict__ gout, float leaky_slope,
+                               float *__restrict__ dp)
 {
+    // leaky_slope != 1: p = leaky(h) of a layer that takes its gradient with respect to h (mq_conv_dgrad_gated): d *= leaky'(p)
     const int64_t n = (int64_t)B * H * W * C;
     const float k = gout[0] / (sums2[1] + 1e-8f);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -298,8 +300,10 @@ __global__ void mae_bwd_kernel(const float *__restrict__ p, const float *__restr
         const int64_t b = pix / ((int64_t)H * W);
         float d = 0.f;
         if (!padded[b * W + w]) {
-            const float e = p[i] - t[i];
+            const float pv = p[i];
+            const float e = pv - t[i];
             d = e > 0.f ? k : (e < 0.f ? -k : 0.f);
+            d = pv > 0.f ? d : leaky_slope * d;
         }
         dp[i] = d;
     }
@@ -427,11 +431,11 @@ extern "C" int mq_masked_mae_sums(const float *pred, const float *target, const 
     return 0;
 }
 extern "C" int mq_masked_mae_bwd(const float *pred, const float *target, const uint8_t *padded, int B, int H, int W, int C, const float *sums2,
-                                 const float *gout, float *dpred, mqStream stream)
+                                 const float *gout, float leaky_slope, float *dpred, mqStream stream)
 {
     MQ_REQUIRE(pred && target && padded && sums2 && gout && dpred && B > 0 && H > 0 && W > 0 && C > 0, "mq_masked_mae_bwd: bad arguments");
     hipLaunchKernelGGL(mae_bwd_kernel, dim3(ew_grid((int64_t)B * H * W * C, 256)), dim3(256), 0, S(stream), pred, target, padded, B, H, W, C,
-                       sums2, gout, dpred);
+                       sums2, gout, leaky_slope, dpred);
     MQ_LAUNCH_CHECK("mq_masked_mae_bwd");
     return 0;
 }

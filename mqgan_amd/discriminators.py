@@ -120,15 +120,18 @@ def _stack_now(bands, get, need_crsk, power_iteration, detach):
 
 
 def run_discriminators(bands: List[MelSpectrogramPatchDiscriminator2D], x, x_lengths, return_features=False,
-                       need_input_grad=None, detach_params=False):
+                       need_input_grad=None, detach_params=False, pregate=False):
     """Shared forward.  x (B, T, F) -> logits (G*B, H, W, 1) channels-last, padded mask uint8 (G*B, W) and
     [(feature (G*B, H, W, C), padded mask (G*B, W))].  G = len(bands); band j owns rows [jB, (j+1)B).
-    ``detach_params``: treat the weights as constants (generator step: no discriminator weight gradients)."""
+    ``detach_params``: treat the weights as constants (generator step: no discriminator weight gradients).
+    ``pregate`` (the trainer's mode): the LeakyReLU / mask backward of a hidden layer rides on the store of the next conv's
+    input-gradient kernel (ops.conv_leaky); features then come back as (feature, mask, leaky_slope or None) and whoever
+    differentiates through a feature with a slope has to gate the gradient (losses.masked_mae(leaky_slope=...))."""
     with ops.act_storage(ops.ACT_BF16_REQUESTED):                  # bf16 feature maps inside, f32 logits / features out
-        return _run_discriminators(bands, x, x_lengths, return_features, need_input_grad, detach_params)
+        return _run_discriminators(bands, x, x_lengths, return_features, need_input_grad, detach_params, pregate)
 
 
-def _run_discriminators(bands, x, x_lengths, return_features, need_input_grad, detach_params):
+def _run_discriminators(bands, x, x_lengths, return_features, need_input_grad, detach_params, pregate=False):
     G = len(bands)
     d0 = bands[0]
     B, T, Fq = x.shape
@@ -140,6 +143,7 @@ def _run_discriminators(bands, x, x_lengths, return_features, need_input_grad, d
     out = ops.BandSplitFn.apply(x.contiguous(), G)                            # (G*B, F/G, T, 1)  (:211, :298)
     feats = []
     n = len(d0.convs)
+    gate = None                                                               # (mask, dmap, slope) of a pregated `out`
     for i in range(n):
         N, H, W, Cin = out.shape
         if i == n - 1:                                                        # masked SE before the logits conv (:216-217)
@@ -164,7 +168,17 @@ def _run_discriminators(bands, x, x_lengths, return_features, need_input_grad, d
             mask = ops.mask_pool(mask, sw, ceil_mode=True)
         # conv -> LeakyReLU(0.2) -> masked_fill (:219, :232), fused into the conv's store where the kernel allows it
         # (the layer in front of the squeeze-excite block and the logits conv hand f32 tensors on)
-        out = ops.conv_leaky(out, wk, wc, bias, desc, mask, (desc.P * desc.Q, desc.Q, desc.Q), out_f32=(i >= n - 2))
-        if return_features and d0.ret_features_map[i]:
-            feats.append((ops.to_f32(out), mask))
+        dmap = (desc.P * desc.Q, desc.Q, desc.Q)
+        if pregate:
+            # layers whose output feeds the next conv (not the squeeze-excite block / the logits) may hand their activation
+            # backward to that conv's dgrad store
+            out, honoured = ops.conv_leaky(out, wk, wc, bias, desc, mask, dmap, out_f32=(i >= n - 2), in_gate=gate,
+                                           pregate=(i < n - 2), chain=True)
+            gate = (mask, dmap, 0.2) if honoured else None
+            if return_features and d0.ret_features_map[i]:
+                feats.append((ops.to_f32(out), mask, 0.2 if honoured else None))
+        else:
+            out = ops.conv_leaky(out, wk, wc, bias, desc, mask, dmap, out_f32=(i >= n - 2))
+            if return_features and d0.ret_features_map[i]:
+                feats.append((ops.to_f32(out), mask))
     return ops.to_f32(out), mask, feats

@@ -114,6 +114,7 @@ def recon_loss(x, y, lengths, group_size=16, group_weight=0.25, comm: Comm = Non
                                float(group_weight), comm)
 
 
-def masked_mae(pred, target, mask, eps: float = 1e-8, comm: Comm = None):
-    """train.py:38-45 on channels-last features (B, H, W, C) with a uint8 padded mask (B, W)."""
-    return ops.MaskedMaeFn.apply(ops.to_f32(pred).contiguous(), ops.to_f32(target).contiguous(), mask, comm)
+def masked_mae(pred, target, mask, eps: float = 1e-8, comm: Comm = None, leaky_slope=None):
+    """train.py:38-45 on channels-last features (B, H, W, C) with a uint8 padded mask (B, W).  ``leaky_slope``: pred is a
+    feature map of a discriminator run with ``pregate=True`` (the LeakyReLU backward of its layer rides on this gradient)."""
+    return ops.MaskedMaeFn.apply(ops.to_f32(pred).contiguous(), ops.to_f32(target).contiguous(), mask, comm, leaky_slope)

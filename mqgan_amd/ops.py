@@ -310,12 +310,22 @@ def conv_fprop_h2(d: ConvDesc, x, w_h2, bias=None, mask=None, dmap=(1, 0, 1), ac
     return y
 
 
-def conv_dgrad_h2(d: ConvDesc, dy, wt_h2, out_dtype=None):
+def conv_dgrad_h2(d: ConvDesc, dy, wt_h2, out_dtype=None, gate=None):
+    """``gate`` = (x bf16, mask, dmap, slope): x came out of a LeakyReLU + masked_fill layer and dx is returned with respect
+    to that layer's pre-activation (mq_conv_dgrad_h2_gated)."""
     out_dtype = BF16 if out_dtype is None else out_dtype
     dx = torch.empty((d.N, d.H, d.W, d.C), dtype=out_dtype, device=dy.device)
-    _timed(_conv_tag("dgrad", d, h2=True), _conv_flops(d), lambda: check(
-        L().mq_conv_dgrad_h2(C.byref(d), ptr(dy, BF16), ptr(wt_h2, BF16), int(out_dtype == F32), ptr(dx, out_dtype), stream()),
-        "mq_conv_dgrad_h2"), _desc_key(d))
+    if gate is None:
+        _timed(_conv_tag("dgrad", d, h2=True), _conv_flops(d), lambda: check(
+            L().mq_conv_dgrad_h2(C.byref(d), ptr(dy, BF16), ptr(wt_h2, BF16), int(out_dtype == F32), ptr(dx, out_dtype), stream()),
+            "mq_conv_dgrad_h2"), _desc_key(d))
+    else:
+        gx, gmask, gmap, gslope = gate
+        gmap = gmap if gmask is not None else (1, 0, 1)
+        _timed(_conv_tag("dgrad", d, h2=True), _conv_flops(d), lambda: check(
+            L().mq_conv_dgrad_h2_gated(C.byref(d), ptr(dy, BF16), ptr(wt_h2, BF16), ptr(gx, BF16), ptr(gmask, torch.uint8, True),
+                                       gmap[0], gmap[1], gmap[2], float(gslope), int(out_dtype == F32), ptr(dx, out_dtype),
+                                       stream()), "mq_conv_dgrad_h2_gated"), _desc_key(d))
     return dx
 
 
@@ -333,10 +343,10 @@ def conv_wgrad_h2(d: ConvDesc, x, dy, w_shape, want_bias: bool):
 class ConvH2Fn(torch.autograd.Function):
     """Convolution on the bf16-storage kernels: x bf16, y bf16 (or f32), effective weights f32 (``w_krsc`` carries the
     gradient).  ``epi`` = None, or (mask, dmap, slope): LeakyReLU + masked_fill fused into the store (the backward pass
-    reads LeakyReLU's derivative off the sign of y)."""
+    reads LeakyReLU's derivative off the sign of y).  ``in_gate`` / ``pregated``: see conv_leaky."""
 
     @staticmethod
-    def forward(ctx, x, w_krsc, w_crsk, bias, key, epi, out_f32):
+    def forward(ctx, x, w_krsc, w_crsk, bias, key, epi, out_f32, in_gate=None, pregated=False):
         d = _desc_from_key(key)
         w_h2 = h2_weight_image(d, w_krsc, False)
         if epi is None:
@@ -349,15 +359,20 @@ class ConvH2Fn(torch.autograd.Function):
         ctx.w_shape = tuple(w_krsc.shape)
         ctx.has_bias = bias is not None
         ctx.have_crsk = w_crsk is not None
-        ctx.save_for_backward(x, w_crsk if w_crsk is not None else w_krsc, y if epi is not None else None, mask)
+        ctx.pregated = bool(pregated) and epi is not None
+        ctx.in_gate_cfg = None if in_gate is None else (in_gate[1], in_gate[2])
+        ctx.save_for_backward(x, w_crsk if w_crsk is not None else w_krsc, y if (epi is not None and not ctx.pregated) else None, mask,
+                              None if in_gate is None else in_gate[0])
         return y
 
     @staticmethod
     def backward(ctx, dout):
-        x, w_crsk, y, mask = ctx.saved_tensors
+        x, w_crsk, y, mask, gate_mask = ctx.saved_tensors
         d = _desc_from_key(ctx.key)
         dout = dout.contiguous()
-        if ctx.epi_cfg is not None:
+        if ctx.pregated:                # every consumer handed back the gradient with respect to the pre-activation
+            dy = dout
+        elif ctx.epi_cfg is not None:
             dmap, slope = ctx.epi_cfg
             if slope != 0.2:
                 raise _lib.MqganHipError("the pointwise backward kernel implements LeakyReLU(0.2) only")
@@ -371,7 +386,8 @@ class ConvH2Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if not ctx.have_crsk:
                 raise _lib.MqganHipError("conv backward wrt the input needs the CRSK weights")
-            dx = conv_dgrad_h2(d, dy, h2_weight_image(d, w_crsk, True), out_dtype=x.dtype)
+            gate = None if ctx.in_gate_cfg is None else (x, gate_mask, ctx.in_gate_cfg[0], ctx.in_gate_cfg[1])
+            dx = conv_dgrad_h2(d, dy, h2_weight_image(d, w_crsk, True), out_dtype=x.dtype, gate=gate)
         want_db = ctx.has_bias and ctx.needs_input_grad[3]
         if ctx.needs_input_grad[1]:
             if h2_wgrad_supported(d):
@@ -380,7 +396,7 @@ class ConvH2Fn(torch.autograd.Function):
                 _, dw, db = _conv_backward_f32(d, ctx.key, cast_f32(x), None, cast_f32(dy), ctx.w_shape, False, True, want_db)
         elif want_db:
             db = _bias_grad(d, cast_f32(dy))
-        return dx, dw, None, db, None, None, None
+        return dx, dw, None, db, None, None, None, None, None
 
 
 class ConvFn(torch.autograd.Function):
@@ -427,10 +443,12 @@ def _conv_backward(ctx, x, w_crsk, dy):
         raise _lib.MqganHipError("conv backward wrt the input needs the CRSK weights")
     d = _desc_from_key(ctx.key)
     return _conv_backward_f32(d, ctx.key, x, w_crsk, dy, ctx.w_shape, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                              ctx.has_bias and ctx.needs_input_grad[3])
+                              ctx.has_bias and ctx.needs_input_grad[3], in_gate=getattr(ctx, "in_gate", None))
 
 
-def _conv_backward_f32(d, key, x, w_crsk, dy, w_shape, want_dx, want_dw, want_db):
+def _conv_backward_f32(d, key, x, w_crsk, dy, w_shape, want_dx, want_dw, want_db, in_gate=None):
+    """``in_gate`` = (mask, dmap, slope): x came out of a LeakyReLU + masked_fill layer that expects its gradient with respect
+    to the pre-activation - fused into the dgrad store where the engine has the epilogue, one pointwise pass otherwise."""
     class _C:       # the body below was written against an autograd ctx
         pass
     ctx = _C()
@@ -445,6 +463,14 @@ def _conv_backward_f32(d, key, x, w_crsk, dy, w_shape, want_dx, want_dw, want_db
             _timed(_conv_tag("dgrad", d), _conv_flops(d), lambda: check(
                 L().mq_conv_dgrad_h(C.byref(d), ptr(dy_h, BF16), ptr(wc_h, BF16), fptr(dx), stream()), "mq_conv_dgrad_h"),
                 ctx.key)
+            if in_gate is not None:
+                dx = pointwise_bwd_raw(dx, x, act=ACT_LEAKY, mask=in_gate[0], mask_post=in_gate[0] is not None, dmap=in_gate[1])
+        elif in_gate is not None:
+            gmask, gmap, gslope = in_gate
+            gmap = gmap if gmask is not None else (1, 0, 1)
+            _timed(_conv_tag("dgrad", d), _conv_flops(d), lambda: check(
+                L().mq_conv_dgrad_gated(C.byref(d), fptr(dy), fptr(w_crsk), fptr(x), ptr(gmask, torch.uint8, True), gmap[0], gmap[1],
+                                        gmap[2], float(gslope), fptr(dx), stream()), "mq_conv_dgrad_gated"), ctx.key)
         else:
             _timed(_conv_tag("dgrad", d), _conv_flops(d), lambda: check(
                 L().mq_conv_dgrad(C.byref(d), fptr(dy), fptr(w_crsk), fptr(dx), stream()), "mq_conv_dgrad"), ctx.key)
@@ -472,10 +498,10 @@ def _conv_backward_f32(d, key, x, w_crsk, dy, w_shape, want_dx, want_dw, want_db
 class ConvLeakyFn(torch.autograd.Function):
     """y = padded ? 0 : LeakyReLU(conv(x, w) + bias), activation and mask fused into the conv's store
     (mq_conv_fprop_leaky).  The pre-activation is never written: the backward pass reads LeakyReLU's derivative off
-    the sign of y."""
+    the sign of y.  ``in_gate`` / ``pregated``: see conv_leaky."""
 
     @staticmethod
-    def forward(ctx, x, w_krsc, w_crsk, bias, mask, key, dmap, slope):
+    def forward(ctx, x, w_krsc, w_crsk, bias, mask, key, dmap, slope, in_gate=None, pregated=False):
         d = _desc_from_key(key)
         y = _empty((d.N, d.P, d.Q, d.K), x)
         _timed(_conv_tag("fprop", d), _conv_flops(d), lambda: check(
@@ -485,7 +511,9 @@ class ConvLeakyFn(torch.autograd.Function):
         ctx.w_shape = tuple(w_krsc.shape)
         ctx.has_bias = bias is not None
         ctx.have_crsk = w_crsk is not None
-        ctx.save_for_backward(x, w_crsk if w_crsk is not None else w_krsc, y, mask)
+        ctx.pregated = bool(pregated)
+        ctx.in_gate = None if in_gate is None else (in_gate[0], in_gate[1], in_gate[2])
+        ctx.save_for_backward(x, w_crsk if w_crsk is not None else w_krsc, None if ctx.pregated else y, mask)
         return y
 
     @staticmethod
@@ -493,14 +521,36 @@ class ConvLeakyFn(torch.autograd.Function):
         x, w_crsk, y, mask = ctx.saved_tensors
         if ctx.slope != 0.2:
             raise _lib.MqganHipError("the pointwise backward kernel implements LeakyReLU(0.2) only")
-        Cc = y.shape[-1]
-        pd = PointwiseDesc(rows=y.numel() // Cc, C=Cc, act=ACT_LEAKY, mask_pre=0, mask_post=int(mask is not None),
-                           d1=ctx.dmap[0], d2=ctx.dmap[1], d3=ctx.dmap[2], p_drop=0.0, seed=0)
-        dy = torch.empty_like(y)
-        check(L().mq_pointwise_bwd(C.byref(pd), fptr(dout.contiguous()), fptr(y), None, ptr(mask, torch.uint8, True), None,
-                                   None, fptr(dy), None, None, None, None, stream()), "mq_pointwise_bwd")
+        if ctx.pregated:                # every consumer handed back the gradient with respect to the pre-activation
+            dy = dout.contiguous()
+        else:
+            Cc = y.shape[-1]
+            pd = PointwiseDesc(rows=y.numel() // Cc, C=Cc, act=ACT_LEAKY, mask_pre=0, mask_post=int(mask is not None),
+                               d1=ctx.dmap[0], d2=ctx.dmap[1], d3=ctx.dmap[2], p_drop=0.0, seed=0)
+            dy = torch.empty_like(y)
+            check(L().mq_pointwise_bwd(C.byref(pd), fptr(dout.contiguous()), fptr(y), None, ptr(mask, torch.uint8, True), None,
+                                       None, fptr(dy), None, None, None, None, stream()), "mq_pointwise_bwd")
         dx, dw, db = _conv_backward(ctx, x, w_crsk, dy)
-        return dx, dw, None, db, None, None, None, None
+        return dx, dw, None, db, None, None, None, None, None, None
+
+
+class LeakyGateFn(torch.autograd.Function):
+    """Identity on a tensor that came out of a ``pregated`` LeakyReLU layer, for a consumer without a gated backward of its
+    own: the gradient passing through is multiplied by LeakyReLU'(x) and zeroed on padded frames (one pointwise pass)."""
+
+    @staticmethod
+    def forward(ctx, x, mask, dmap):
+        ctx.dmap = dmap
+        ctx.save_for_backward(x, mask)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, mask = ctx.saved_tensors
+        dout = dout.contiguous()
+        if dout.dtype != x.dtype:
+            dout = cast_bf16(dout) if x.dtype == BF16 else cast_f32(dout)
+        return pointwise_bwd_raw(dout, x, act=ACT_LEAKY, mask=mask, mask_post=mask is not None, dmap=ctx.dmap), None, None
 
 
 class TapsGatherFn(torch.autograd.Function):
@@ -545,7 +595,7 @@ class TapsReduceFn(torch.autograd.Function):
         return du, db, None, None
 
 
-def _thin_conv(x, w_krsc, w_crsk, bias, desc: ConvDesc, leaky=None, out_f32=True):
+def _thin_conv(x, w_krsc, w_crsk, bias, desc: ConvDesc, leaky=None, out_f32=True, pregate=False, chain=False):
     """C = 1 or K = 1 with more than one tap (csrc/taps.hip): tap gather / fold around a 1x1 GEMM.  With bf16 activation
     storage the tap axis is padded to a multiple of 32 so that the 1x1 GEMM (the only pass over the wide tensor) runs on
     the bf16-storage kernels and the wide tensor is a bf16 tensor from the start."""
@@ -561,13 +611,15 @@ def _thin_conv(x, w_krsc, w_crsk, bias, desc: ConvDesc, leaky=None, out_f32=True
         d1 = conv_desc(desc.N, desc.P, desc.Q, T, K, 1, 1, groups=G, precision=desc.precision)
         if _use_h2(d1):
             epi = None if leaky is None else (leaky[0], leaky[1], leaky[2])
-            return ConvH2Fn.apply(to_bf16(cols), wk, wc, bias, _desc_key(d1), epi, False)
+            y = ConvH2Fn.apply(to_bf16(cols), wk, wc, bias, _desc_key(d1), epi, False, None, pregate and epi is not None)
+            return (y, pregate and epi is not None) if chain else y
         if leaky is not None and not _h_ok(d1, T):          # same output rows (n, p, q): the fused activation applies
-            return ConvLeakyFn.apply(cols, wk, wc, bias, leaky[0], _desc_key(d1), leaky[1], leaky[2])
+            y = ConvLeakyFn.apply(cols, wk, wc, bias, leaky[0], _desc_key(d1), leaky[1], leaky[2], None, pregate)
+            return (y, bool(pregate)) if chain else y
         y = ConvFn.apply(cols, wk, wc, bias, _desc_key(d1))
         if leaky is not None:
             y = pointwise(y, act=ACT_LEAKY, mask=leaky[0], mask_post=leaky[0] is not None, dmap=leaky[1])
-        return y
+        return (y, False) if chain else y
     # K = 1: w_krsc is (G, RS, C) in the channel-blocked order [C/CB][RS][CB] -> rows = taps, plain channels
     CB = 16 if Cin % 16 == 0 else Cin
     wt = w_krsc.view(G, Cin // CB, RS, CB).permute(0, 2, 1, 3).contiguous().view(G, RS, Cin)
@@ -590,19 +642,38 @@ def _is_thin(desc: ConvDesc) -> bool:
     return desc.R * desc.S > 1 and ((desc.C == 1) != (desc.K == 1)) and (desc.C % 4 == 0 or desc.K % 4 == 0)
 
 
-def conv_leaky(x, w_krsc, w_crsk, bias, desc: ConvDesc, mask, dmap, slope: float = 0.2, out_f32: bool = False):
-    """LeakyReLU(conv) with padded frames zeroed - one kernel where the fused epilogue applies, conv + pointwise otherwise."""
+def conv_leaky(x, w_krsc, w_crsk, bias, desc: ConvDesc, mask, dmap, slope: float = 0.2, out_f32: bool = False, in_gate=None,
+               pregate: bool = False, chain: bool = False):
+    """LeakyReLU(conv) with padded frames zeroed - one kernel where the fused epilogue applies, conv + pointwise otherwise.
+
+    Chains of such layers (the discriminators) can drop the stand-alone LeakyReLU backward passes:
+    ``pregate=True`` asks for an output whose incoming gradient is taken to be the one with respect to the layer's
+    PRE-activation - every consumer of that tensor then has to apply LeakyReLU'(y) and the mask itself.  With ``chain=True``
+    the call returns (y, honoured); when honoured, pass ``in_gate=(mask, dmap, slope)`` of this layer to the conv_leaky that
+    consumes y (its dgrad kernel applies the gate in its store), give ``leaky_slope`` to masked_mae, or wrap y in LeakyGateFn."""
+    if pregate and not chain:
+        raise _lib.MqganHipError("conv_leaky(pregate=True) needs chain=True: the caller must know whether the gate was honoured")
+
+    def ret(y, honoured=False):
+        return (y, bool(honoured)) if chain else y
     if _use_h2(desc):
-        return ConvH2Fn.apply(to_bf16(x), w_krsc, w_crsk, bias, _desc_key(desc), (mask, tuple(dmap), slope), out_f32)
+        return ret(ConvH2Fn.apply(to_bf16(x), w_krsc, w_crsk, bias, _desc_key(desc), (mask, tuple(dmap), slope), out_f32, in_gate,
+                                  pregate), pregate)
     thin = _is_thin(desc)
+    if in_gate is not None and (thin or desc.C % 4 != 0 or _h_ok(desc, desc.C)):
+        x = LeakyGateFn.apply(x, in_gate[0], tuple(in_gate[1]))         # no gated dgrad on these paths: one pointwise pass
+        in_gate = None
     if thin and desc.C == 1:
-        return _thin_conv(to_f32(x), w_krsc, w_crsk, bias, desc, leaky=(mask, tuple(dmap), slope))
+        return _thin_conv(to_f32(x), w_krsc, w_crsk, bias, desc, leaky=(mask, tuple(dmap), slope), pregate=pregate, chain=chain)
     if thin:
-        return pointwise(_thin_conv(x, w_krsc, w_crsk, bias, desc), act=ACT_LEAKY, mask=mask, mask_post=mask is not None, dmap=dmap)
+        return ret(pointwise(_thin_conv(x, w_krsc, w_crsk, bias, desc), act=ACT_LEAKY, mask=mask, mask_post=mask is not None, dmap=dmap))
+    if x.dtype != F32 and in_gate is not None:
+        x = LeakyGateFn.apply(x, in_gate[0], tuple(in_gate[1]))         # the gate tensor of the f32 kernels is the f32 input itself
+        in_gate = None
     x = to_f32(x)
     if desc.C % 4 != 0 or _h_ok(desc, desc.C):
-        return pointwise(conv(x, w_krsc, w_crsk, bias, desc), act=ACT_LEAKY, mask=mask, mask_post=mask is not None, dmap=dmap)
-    return ConvLeakyFn.apply(x, w_krsc, w_crsk, bias, mask, _desc_key(desc), tuple(dmap), slope)
+        return ret(pointwise(conv(x, w_krsc, w_crsk, bias, desc), act=ACT_LEAKY, mask=mask, mask_post=mask is not None, dmap=dmap))
+    return ret(ConvLeakyFn.apply(x, w_krsc, w_crsk, bias, mask, _desc_key(desc), tuple(dmap), slope, in_gate, pregate), pregate)
 
 
 def conv(x, w_krsc, w_crsk, bias, desc: ConvDesc, out_f32: bool = False):
@@ -1270,8 +1341,11 @@ class LsganGFn(torch.autograd.Function):
 
 
 class MaskedMaeFn(torch.autograd.Function):
+    """``leaky_slope``: pred is the output of a ``pregated`` LeakyReLU layer (conv_leaky): the gradient handed back is the one
+    with respect to that layer's pre-activation."""
+
     @staticmethod
-    def forward(ctx, pred, target, padded, comm):
+    def forward(ctx, pred, target, padded, comm, leaky_slope=None):
         B, H, W, Cc = pred.shape
         sums2, ws, out = _empty((2,), pred), _empty((512,), pred), _empty((1,), pred)
         check(L().mq_masked_mae_sums(fptr(pred), fptr(target), ptr(padded, torch.uint8), B, H, W, Cc, fptr(sums2), fptr(ws), stream()),
@@ -1279,6 +1353,7 @@ class MaskedMaeFn(torch.autograd.Function):
         _reduce(comm, sums2)
         check(L().mq_ratio_final(fptr(sums2), 1e-8, fptr(out), stream()), "mq_ratio_final")
         ctx.save_for_backward(pred, target, padded, sums2)
+        ctx.leaky_slope = 1.0 if leaky_slope is None else float(leaky_slope)
         return out.view(())
 
     @staticmethod
@@ -1287,8 +1362,8 @@ class MaskedMaeFn(torch.autograd.Function):
         B, H, W, Cc = pred.shape
         dp = torch.empty_like(pred)
         check(L().mq_masked_mae_bwd(fptr(pred), fptr(target), ptr(padded, torch.uint8), B, H, W, Cc, fptr(sums2),
-                                    fptr(gout.contiguous().view(1)), fptr(dp), stream()), "mq_masked_mae_bwd")
-        return dp, None, None, None
+                                    fptr(gout.contiguous().view(1)), ctx.leaky_slope, fptr(dp), stream()), "mq_masked_mae_bwd")
+        return dp, None, None, None, None
 
 
 # ----------------------------------------------------------------------------- optimiser

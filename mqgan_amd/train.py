@@ -321,10 +321,11 @@ class Trainer:
 
     # -- discriminator passes -------------------------------------------------------------------
     def _d1(self, x, lens, feats=False, detach_params=False):
-        return run_discriminators([self.patch_discriminator], x, lens, feats, detach_params=detach_params)
+        return run_discriminators([self.patch_discriminator], x, lens, feats, detach_params=detach_params, pregate=True)
 
     def _d2(self, x, lens, feats=False, detach_params=False):
-        return run_discriminators(list(self.multibin_discriminator.discriminators), x, lens, feats, detach_params=detach_params)
+        return run_discriminators(list(self.multibin_discriminator.discriminators), x, lens, feats, detach_params=detach_params,
+                                  pregate=True)
 
     def _bands(self, t):
         G = self.multibin_discriminator.n_bins
@@ -408,16 +409,17 @@ class Trainer:
             lam_g, lam_fm = t["loss_weights"]["Gloss_lambda"], t["loss_weights"]["fm_lambda"]
             if use_fm:
                 f1 = None
-                for (r, m), (f, _) in zip(rf, gf):
-                    l = masked_mae(f, r, m, comm=self.comm)
+                for (r, m, _), (f, _, gs) in zip(rf, gf):       # gs: the feature's layer takes a pre-activation gradient
+                    l = masked_mae(f, r, m, comm=self.comm, leaky_slope=gs)
                     f1 = l if f1 is None else ops.add(f1, l)
                 f1 = ops.scale(f1, 1.0 / len(rf))
                 f2 = None
                 nf = len(rf2)
                 for j in range(G):                       # train.py:466-472: cumulative division inside the bin loop
-                    for (r, m), (f, _) in zip(rf2, gf2):
+                    for (r, m, _), (f, _, gs) in zip(rf2, gf2):
                         Bn = r.shape[0] // G
-                        l = masked_mae(f[j * Bn:(j + 1) * Bn], r[j * Bn:(j + 1) * Bn], m[:Bn].contiguous(), comm=self.comm)
+                        l = masked_mae(f[j * Bn:(j + 1) * Bn], r[j * Bn:(j + 1) * Bn], m[:Bn].contiguous(), comm=self.comm,
+                                       leaky_slope=gs)
                         f2 = l if f2 is None else ops.add(f2, l)
                     f2 = ops.scale(f2, 1.0 / nf)
                 f2 = ops.scale(f2, 1.0 / G)

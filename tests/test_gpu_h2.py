@@ -127,6 +127,42 @@ def test_h2_leaky_mask_epilogue(env):
     assert float(y[1, :, 13:].abs().max()) == 0.0
 
 
+GATE_CASES = [
+    dict(N=4, H=6, W=40, C=64, K=96, R=3, S=3, pad=(1, 1)),                                   # stride 1
+    dict(N=2, H=16, W=20, C=64, K=128, R=5, S=5, stride=(2, 2), pad=(2, 2)),                  # parity classes
+    dict(N=16, H=2, W=40, C=32, K=64, R=3, S=5, stride=(1, 2), pad=(1, 2), groups=8),         # 8 groups, stride (1,2)
+]
+
+
+@pytest.mark.parametrize("c", GATE_CASES, ids=_ids)
+@pytest.mark.parametrize("out_f32", [False, True])
+def test_h2_gated_dgrad_is_dgrad_then_leaky_backward(env, c, out_f32):
+    """mq_conv_dgrad_h2_gated: the producer layer's LeakyReLU / mask backward in the dgrad store, bit-for-bit the two
+    passes it replaces (dgrad, then the pointwise LeakyReLU backward on the conv's input)."""
+    ops = env
+    x, w, b, desc, wk, wc = _setup(ops, c)
+    G = c.get("groups", 1)
+    torch.manual_seed(5)
+    xin = F.leaky_relu(torch.randn(c["N"], c["H"], c["W"], G * c["C"] // G, device=DEV), 0.2)
+    mask = torch.zeros(c["N"], c["W"], dtype=torch.uint8, device=DEV)
+    mask[1, c["W"] // 3:] = 1
+    mask[-1, 2:] = 1
+    xin = (xin * (1 - mask[:, None, :, None].float())).to(BF16)                 # what a leaky + masked_fill layer hands on
+    dy = torch.randn(c["N"], desc.P, desc.Q, c["K"], device=DEV).to(BF16)
+    wt = ops.h2_weight_image(desc, wc, True)
+    dmap = (c["H"] * c["W"], c["W"], c["W"])
+    od = torch.float32 if out_f32 else BF16
+    plain = ops.conv_dgrad_h2(desc, dy, wt, out_dtype=od)
+    want = ops.pointwise_bwd_raw(plain if not out_f32 else plain, xin if not out_f32 else xin.float(), act=ops.ACT_LEAKY, mask=mask,
+                                 mask_post=True, dmap=dmap)
+    got = ops.conv_dgrad_h2(desc, dy, wt, out_dtype=od, gate=(xin, mask, dmap, 0.2))
+    assert torch.equal(got, want)
+    assert float(got[1, :, c["W"] // 3:].abs().max()) == 0.0
+    nomask = ops.conv_dgrad_h2(desc, dy, wt, out_dtype=od, gate=(xin, None, dmap, 0.2))
+    want2 = ops.pointwise_bwd_raw(plain, xin if not out_f32 else xin.float(), act=ops.ACT_LEAKY)
+    assert torch.equal(nomask, want2)
+
+
 def test_h2_full_size_refiner_layer_and_addressing(env):
     """C3's deepest refiner level at full size (16 x 128 x 144 pixels, 768 -> 768 channels): the H2 kernels against the
     f32-tensor bf16 engine of igemm.hip on the same bf16-representable operands (both have exact products and f32

@@ -622,6 +622,56 @@ def test_pool_upcat_bandsplit(env):
     np.testing.assert_array_equal(ops.mask_upsample2(m).cpu().numpy(), np.repeat(m.cpu().numpy(), 2, axis=1))
 
 
+@pytest.mark.parametrize("prec", ["f32", "f32x3", "bf16"])
+@pytest.mark.parametrize("c", [dict(N=3, H=7, W=33, C=32, K=48, R=3, S=3, pad=(1, 1)),
+                               dict(N=2, H=16, W=21, C=16, K=32, R=5, S=5, stride=(2, 2), pad=(2, 2)),
+                               dict(N=8, H=3, W=30, C=8, K=16, R=3, S=5, stride=(1, 2), pad=(1, 2), groups=4),
+                               dict(N=2, H=9, W=10, C=6, K=8, R=3, S=3, stride=(3, 1), pad=(1, 1))],
+                         ids=["s1", "s2x2", "groups_s1x2", "scalar_s3"])
+def test_gated_dgrad_is_dgrad_then_leaky_backward(env, c, prec):
+    """mq_conv_dgrad_gated (the discriminators' LeakyReLU / mask backward in the next conv's dgrad store) equals
+    mq_conv_dgrad followed by the pointwise LeakyReLU backward, bit for bit, on every f32-tensor engine."""
+    ops = env
+    torch.manual_seed(9)
+    G = c.get("groups", 1)
+    desc = ops.conv_desc(c["N"], c["H"], c["W"], c["C"], c["K"], c["R"], c["S"], stride=c.get("stride", (1, 1)),
+                         pad=c.get("pad", (0, 0)), groups=G, precision=prec)
+    w = torch.randn(G * c["K"], c["C"], c["R"], c["S"], device=DEV) * 0.2
+    ks, cs = [], []
+    for gi in range(G):
+        a, bb = ops.weight_prep(w[gi * c["K"]:(gi + 1) * c["K"]].contiguous(), None, True)
+        ks.append(a); cs.append(bb)
+    wk, wc = torch.cat(ks, 0), torch.cat(cs, 0)
+    mask = torch.zeros(c["N"], c["W"], dtype=torch.uint8, device=DEV)
+    mask[1, c["W"] // 2:] = 1
+    mask[-1, 1:] = 1
+    x = F.leaky_relu(torch.randn(c["N"], c["H"], c["W"], c["C"], device=DEV), 0.2) * (1 - mask[:, None, :, None].float())
+    dy = torch.randn(c["N"], desc.P, desc.Q, c["K"], device=DEV)
+    dmap = (c["H"] * c["W"], c["W"], c["W"])
+    key = ops._desc_key(desc)
+    plain, _, _ = ops._conv_backward_f32(desc, key, x, wc, dy, tuple(wk.shape), True, False, False)
+    want = ops.pointwise_bwd_raw(plain, x, act=ops.ACT_LEAKY, mask=mask, mask_post=True, dmap=dmap)
+    got, _, _ = ops._conv_backward_f32(desc, key, x, wc, dy, tuple(wk.shape), True, False, False, in_gate=(mask, dmap, 0.2))
+    assert torch.equal(got, want)
+    assert float(got[1, :, c["W"] // 2:].abs().max()) == 0.0
+
+
+def test_masked_mae_leaky_gate(env):
+    ops = env
+    torch.manual_seed(10)
+    B, H, W, Cc = 3, 4, 11, 8
+    mask = ops.sequence_mask(torch.tensor([11, 6, 0], device=DEV, dtype=torch.int32), W)
+    f = F.leaky_relu(torch.randn(B, H, W, Cc, device=DEV), 0.2)
+    r = torch.randn(B, H, W, Cc, device=DEV)
+    grads = []
+    for slope in (None, 0.2):
+        ff = f.clone().requires_grad_(True)
+        ops.MaskedMaeFn.apply(ff, r, mask, None, slope).backward()
+        grads.append(ff.grad)
+    want = ops.pointwise_bwd_raw(grads[0], f, act=ops.ACT_LEAKY)
+    assert torch.equal(grads[1], want)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_pool_upcat_with_consumer_mask(env, dtype):
     """The ConvBlock's entry masked_fill (reference preencoder.py:93) fused into the pooling / upsample-concat pass:
