@@ -399,6 +399,10 @@ int mq_sumsq(const float *g, int64_t n, float *out, float *workspace, mqStream s
 int mq_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, double lr, double beta1,
                  double beta2, double eps, int step_host, const float *sumsq, float max_norm, float grad_scale,
                  mqStream stream);
+/* Fill of a flat gradient arena from per-parameter gradient tensors in one launch.  table (device, int64 [n_tensors][4]):
+ * {source address or 0 (zeros), destination element offset (multiple of 4), elements, first block}, rows ordered by
+ * first block; a block covers 2048 elements; total_blocks = sum over rows of ceil(elements / 2048). */
+int mq_multi_gather(const int64_t *table_dev, int n_tensors, int64_t total_blocks, float *dst, mqStream stream);
 
 #ifdef __cplusplus
 }

@@ -54,9 +54,49 @@ __global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, 
     }
 }
 
+// Gradient arena fill.  Autograd leaves every parameter's gradient in a tensor of its own; one launch copies them all
+// into the flat arena the clip / Adam kernels and the bucketed all-reduce read (instead of one small add per parameter
+// into pre-zeroed views).  Table rows: {source address (0: no gradient this step -> zeros), arena offset, elements,
+// first block}; a block covers MG_CHUNK elements of one tensor and finds its row by bisection.
+constexpr int MG_CHUNK = 2048;
+__global__ __launch_bounds__(256) void multi_gather_kernel(const int64_t *__restrict__ tab, int nt, float *__restrict__ dst)
+{
+    const int64_t b = blockIdx.x;
+    int lo = 0, hi = nt - 1;
+    while (lo < hi) {                                   // last row whose first block is <= b
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[4 * mid + 3] <= b) lo = mid; else hi = mid - 1;
+    }
+    const float *src = reinterpret_cast<const float *>(tab[4 * lo]);
+    float *d = dst + tab[4 * lo + 1];
+    const int64_t n = tab[4 * lo + 2];
+    const int64_t base = (b - tab[4 * lo + 3]) * MG_CHUNK;
+    const bool vec = (reinterpret_cast<uintptr_t>(src) & 15) == 0;      // arena slices are 16-byte aligned by construction
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int64_t e = base + h * 1024 + threadIdx.x * 4;
+        if (e + 4 <= n && vec) {
+            const float4 v = src ? *reinterpret_cast<const float4 *>(src + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(d + e) = v;
+        } else {
+            for (int k = 0; k < 4; ++k)
+                if (e + k < n) d[e + k] = src ? src[e + k] : 0.f;
+        }
+    }
+}
+
 }  // namespace mq
 
 using namespace mq;
+
+extern "C" int mq_multi_gather(const int64_t *table_dev, int n_tensors, int64_t total_blocks, float *dst, mqStream stream)
+{
+    MQ_REQUIRE(table_dev && dst && n_tensors > 0 && total_blocks > 0 && total_blocks < INT32_MAX, "mq_multi_gather: bad arguments");
+    MQ_REQUIRE((uintptr_t)dst % 16 == 0, "mq_multi_gather: dst must be 16-byte aligned");
+    hipLaunchKernelGGL(multi_gather_kernel, dim3((unsigned)total_blocks), dim3(256), 0, S(stream), table_dev, n_tensors, dst);
+    MQ_LAUNCH_CHECK("mq_multi_gather");
+    return 0;
+}
 
 extern "C" int mq_sumsq(const float *g, int64_t n, float *out, float *workspace, mqStream stream)
 {

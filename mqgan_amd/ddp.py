@@ -22,9 +22,15 @@ import torch.distributed as dist
 
 class FlatArena:
     """Re-homes the parameters of ``modules`` into one flat buffer and gives every parameter a
-    gradient view into a second flat buffer (zeroed, never None)."""
+    gradient view into a second flat buffer (zeroed, never None).
 
-    def __init__(self, modules: Iterable[torch.nn.Module], align: int = 4):
+    ``gather=True`` (the trainer's mode): ``.grad`` is None between steps, autograd leaves each gradient in the tensor its
+    backward kernel wrote (no per-parameter accumulation launch into a zeroed view), and ``gather()`` fills the gradient arena
+    from all of them with ONE kernel (zeros where a parameter got no gradient) - per bucket when a GradReducer drives it."""
+
+    MG_CHUNK = 2048                # elements per block of mq_multi_gather
+
+    def __init__(self, modules: Iterable[torch.nn.Module], align: int = 4, gather: bool = False):
         self.params: List[torch.nn.Parameter] = []
         seen = set()
         for m in modules:
@@ -42,18 +48,83 @@ class FlatArena:
         self.numel = n
         self.flat_param = torch.zeros(n, dtype=dt, device=dev)
         self.flat_grad = torch.zeros(n, dtype=dt, device=dev)
+        self.gather_mode = bool(gather)
         with torch.no_grad():
             for p, o in zip(self.params, self.offsets):
                 view = self.flat_param[o:o + p.numel()].view_as(p)
                 view.copy_(p)
                 p.data = view
-                p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+                p.grad = None if self.gather_mode else self.flat_grad[o:o + p.numel()].view_as(p)
+        self._gathered = [False] * len(self.params)
+        self._ring = None              # (pinned int64 table ring, device ring, rows, cursor) of the gather launches
 
     def zero_grad(self):
+        if self.gather_mode:
+            for p in self.params:
+                p.grad = None
+            self._gathered = [False] * len(self.params)
+            return
         self.flat_grad.zero_()
         for p, o in zip(self.params, self.offsets):               # re-attach if something reset .grad to None
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
                 p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+
+    def gather(self, indices=None):
+        """Gradient arena <- the parameters' gradient tensors (``indices``: positions in ``params``, default all that were
+        not gathered since the last zero_grad).  No-op outside gather mode."""
+        if not self.gather_mode:
+            return
+        todo = [i for i in (range(len(self.params)) if indices is None else indices) if not self._gathered[i]]
+        if not todo:
+            return
+        for i in todo:
+            self._gathered[i] = True
+        if self.flat_grad.is_cuda:
+            self._gather_hip(todo)
+        else:                      # CPU arenas exist for the gloo tests of the reducer logic only
+            with torch.no_grad():
+                for i in todo:
+                    p, o = self.params[i], self.offsets[i]
+                    if p.grad is None:
+                        self.flat_grad[o:o + p.numel()].zero_()
+                    else:
+                        self.flat_grad[o:o + p.numel()].copy_(p.grad.reshape(-1))
+
+    def _gather_hip(self, todo):
+        from . import _lib
+        from .ops import L, check, ptr, stream
+        n = len(todo)
+        if self._ring is None:
+            rows = 4 * len(self.params)
+            self._ring = [torch.empty((rows, 4), dtype=torch.int64).pin_memory(),
+                          torch.empty((rows, 4), dtype=torch.int64, device=self.flat_grad.device), rows, 0]
+        host, dev, rows, cur = self._ring
+        if cur + n > rows:
+            cur = 0
+        base = self.flat_grad.data_ptr()
+        table, blocks = [], 0
+        for i in todo:
+            p, o = self.params[i], self.offsets[i]
+            g = p.grad
+            src = 0
+            if g is not None:
+                if g.dtype != self.flat_grad.dtype or g.device != self.flat_grad.device:
+                    raise _lib.MqganHipError(f"FlatArena.gather: gradient of parameter {i} is {g.dtype} on {g.device}")
+                if not g.is_contiguous():
+                    g = g.contiguous()
+                    p.grad = g                                  # keeps the copy alive until the kernel has run
+                src = g.data_ptr()
+            if src == base + 4 * o:                             # already an arena view (legacy holders): nothing to move
+                continue
+            table.append((src, o, p.numel(), blocks))
+            blocks += (p.numel() + self.MG_CHUNK - 1) // self.MG_CHUNK
+        if not table:
+            return
+        k = len(table)
+        host[cur:cur + k] = torch.tensor(table, dtype=torch.int64)
+        dev[cur:cur + k].copy_(host[cur:cur + k], non_blocking=True)
+        check(L().mq_multi_gather(ptr(dev[cur:cur + k]), k, blocks, ptr(self.flat_grad), stream()), "mq_multi_gather")
+        self._ring[3] = cur + k
 
     def rebind(self):
         """After load_state_dict / .to(): make sure parameters still alias the arena."""
@@ -75,10 +146,13 @@ class GradReducer:
         self.world = self.comm.world if self.comm is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
         self.average = average
         self.buckets = []                      # (start, end) element ranges of flat_grad, reverse order
+        self.bucket_members = []               # positions in arena.params, per bucket
         self.param_bucket = {}
         cap = max(1, bucket_bytes // 4)
         end = arena.numel
         cur_start, members = end, []
+        index_of = {id(p): i for i, p in enumerate(arena.params)}
+        self._index_of = index_of
         for p, o in reversed(list(zip(arena.params, arena.offsets))):
             cur_start = o
             members.append(p)
@@ -100,6 +174,7 @@ class GradReducer:
     def _add_bucket(self, start, end, members):
         b = len(self.buckets)
         self.buckets.append((start, end, len(members)))
+        self.bucket_members.append([self._index_of[id(p)] for p in members])
         for p in members:
             self.param_bucket[id(p)] = b
 
@@ -112,6 +187,7 @@ class GradReducer:
     def _launch(self, b):
         s, e, _ = self.buckets[b]
         self._launched[b] = True
+        self.arena.gather(self.bucket_members[b])      # gather mode: the bucket's gradients move into the arena now
         self._handles.append(dist.all_reduce(self.arena.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def _on_grad(self, p):
@@ -127,11 +203,13 @@ class GradReducer:
         wait for every collective.  The arena then holds SUMS over ranks; the 1 / world factor is
         applied inside the clip / Adam kernel (``grad_scale``) unless ``average`` asks for it here."""
         if self.comm is not None:
+            self.arena.gather()
             self.comm.all_reduce_sum(self.arena.flat_grad)
             if self.average:
                 self.arena.flat_grad.mul_(1.0 / self.world)
             return
         if not self.enabled:
+            self.arena.gather()
             return
         for b in range(len(self.buckets)):
             if not self._launched[b]:

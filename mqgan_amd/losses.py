@@ -114,6 +114,14 @@ def recon_loss(x, y, lengths, group_size=16, group_weight=0.25, comm: Comm = Non
                                float(group_weight), comm)
 
 
+def masked_mae_bands(pred, target, mask, n_bands: int, comm: Comm = None, leaky_slope=None):
+    """masked_mae of each of the ``n_bands`` row blocks of a multi-band feature map -> (n_bands,) losses (one autograd node)."""
+    if pred.shape[0] % n_bands != 0 or tuple(mask.shape) != (pred.shape[0] // n_bands, pred.shape[2]):
+        raise ValueError(f"masked_mae_bands: pred {tuple(pred.shape)}, mask {tuple(mask.shape)}, bands {n_bands}")
+    return ops.MaskedMaeBandsFn.apply(ops.to_f32(pred).contiguous(), ops.to_f32(target).contiguous(), mask.contiguous(), n_bands, comm,
+                                      leaky_slope)
+
+
 def masked_mae(pred, target, mask, eps: float = 1e-8, comm: Comm = None, leaky_slope=None):
     """train.py:38-45 on channels-last features (B, H, W, C) with a uint8 padded mask (B, W).  ``leaky_slope``: pred is a
     feature map of a discriminator run with ``pregate=True`` (the LeakyReLU backward of its layer rides on this gradient)."""

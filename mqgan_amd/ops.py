@@ -702,12 +702,15 @@ class WeightPrepFn(torch.autograd.Function):
                                  stream()), "mq_weight_prep")
         ctx.mode, ctx.dims = mode, (K, Cin, RS)
         ctx.save_for_backward(v, g, inv)
+        ctx.set_materialize_grads(False)       # no zero tensor for the CRSK copy's (absent) gradient
         if w_crsk is not None:
             ctx.mark_non_differentiable(w_crsk)
         return w_krsc, w_crsk
 
     @staticmethod
     def backward(ctx, dw_krsc, _unused):
+        if dw_krsc is None:
+            return None, None, None
         v, g, inv = ctx.saved_tensors
         K, Cin, RS = ctx.dims
         dv = torch.empty_like(v)
@@ -738,12 +741,15 @@ class SpectralPrepFn(torch.autograd.Function):
         ctx.dims = (K, Cin, RS)
         # u, v as used for sigma (after the power iteration); clone so later iterations do not disturb backward
         ctx.save_for_backward(w_orig, u.clone() if power_iteration else u, v.clone() if power_iteration else v, sigma)
+        ctx.set_materialize_grads(False)       # no zero tensor for the CRSK copy's (absent) gradient
         if w_crsk is not None:
             ctx.mark_non_differentiable(w_crsk)
         return w_krsc, w_crsk
 
     @staticmethod
     def backward(ctx, dw_krsc, _unused):
+        if dw_krsc is None:
+            return None, None, None, None, None
         w_orig, u, v, sigma = ctx.saved_tensors
         K, Cin, RS = ctx.dims
         dw = torch.empty_like(w_orig)
@@ -1364,6 +1370,43 @@ class MaskedMaeFn(torch.autograd.Function):
         check(L().mq_masked_mae_bwd(fptr(pred), fptr(target), ptr(padded, torch.uint8), B, H, W, Cc, fptr(sums2),
                                     fptr(gout.contiguous().view(1)), ctx.leaky_slope, fptr(dp), stream()), "mq_masked_mae_bwd")
         return dp, None, None, None, None
+
+
+class MaskedMaeBandsFn(torch.autograd.Function):
+    """masked_mae of every band of a multi-band feature map in one autograd node: pred / target (G*Bn, H, W, C) with band j
+    in rows [j*Bn, (j+1)*Bn), one padded mask (Bn, W) for all bands (the reference uses bin 0's) -> (G,) losses.
+    The backward writes each band's slice of ONE gradient tensor (slicing the feature per band instead costs a zero-filled
+    full-size tensor and an accumulation per band); the G normalisers travel in one all-reduce."""
+
+    @staticmethod
+    def forward(ctx, pred, target, padded, G, comm, leaky_slope=None):
+        GB, H, W, Cc = pred.shape
+        Bn = GB // G
+        sums2, ws, out = _empty((G, 2), pred), _empty((512,), pred), _empty((G,), pred)
+        for j in range(G):
+            check(L().mq_masked_mae_sums(fptr(pred[j * Bn:(j + 1) * Bn]), fptr(target[j * Bn:(j + 1) * Bn]), ptr(padded, torch.uint8),
+                                         Bn, H, W, Cc, fptr(sums2[j]), fptr(ws), stream()), "mq_masked_mae_sums")
+        _reduce(comm, sums2)
+        for j in range(G):
+            check(L().mq_ratio_final(fptr(sums2[j]), 1e-8, fptr(out[j:j + 1]), stream()), "mq_ratio_final")
+        ctx.save_for_backward(pred, target, padded, sums2)
+        ctx.G = G
+        ctx.leaky_slope = 1.0 if leaky_slope is None else float(leaky_slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        pred, target, padded, sums2 = ctx.saved_tensors
+        GB, H, W, Cc = pred.shape
+        G = ctx.G
+        Bn = GB // G
+        gout = gout.contiguous()
+        dp = torch.empty_like(pred)
+        for j in range(G):
+            check(L().mq_masked_mae_bwd(fptr(pred[j * Bn:(j + 1) * Bn]), fptr(target[j * Bn:(j + 1) * Bn]), ptr(padded, torch.uint8),
+                                        Bn, H, W, Cc, fptr(sums2[j]), fptr(gout[j:j + 1]), ctx.leaky_slope,
+                                        fptr(dp[j * Bn:(j + 1) * Bn]), stream()), "mq_masked_mae_bwd")
+        return dp, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------- optimiser

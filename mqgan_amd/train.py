@@ -28,7 +28,7 @@ from . import ops
 from .comm import Comm, default_comm
 from .ddp import FlatArena, GradReducer, broadcast_arena
 from .discriminators import MelSpectrogramPatchDiscriminator2D, MultiBinDiscriminator, run_discriminators
-from .losses import LSGANLoss, masked_mae, recon_loss
+from .losses import masked_mae_bands, LSGANLoss, masked_mae, recon_loss
 from .nn_base import share_effective_weights
 from .preencoder import PreEncoder
 
@@ -117,6 +117,7 @@ class FlatAdam:
 
     def step(self, max_norm=0.0, grad_scale=1.0):
         self.step_count += 1
+        self.arena.gather()                    # gather-mode arenas: whatever the reducer has not moved yet
         if max_norm:
             ops.sumsq(self.arena.flat_grad, self.sumsq)
         ops.adam_step(self.arena.flat_param, self.arena.flat_grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0],
@@ -183,8 +184,10 @@ class Trainer:
         if build_data:
             self.train_loader, self.eval_dataset = self._get_dataloaders()
         self.generator, self.patch_discriminator, self.multibin_discriminator = self._init_models()
-        self.arena_g = FlatArena([self.generator])
-        self.arena_d = FlatArena([self.patch_discriminator, self.multibin_discriminator])
+        # gradients stay where the backward kernels wrote them; one launch per step (per all-reduce bucket) moves them
+        # into the arenas instead of ~350 small accumulation kernels
+        self.arena_g = FlatArena([self.generator], gather=True)
+        self.arena_d = FlatArena([self.patch_discriminator, self.multibin_discriminator], gather=True)
         broadcast_arena(self.arena_g)
         broadcast_arena(self.arena_d)
         self.optimizer_g, self.optimizer_d = self._init_optimizers()
@@ -413,16 +416,19 @@ class Trainer:
                     l = masked_mae(f, r, m, comm=self.comm, leaky_slope=gs)
                     f1 = l if f1 is None else ops.add(f1, l)
                 f1 = ops.scale(f1, 1.0 / len(rf))
-                f2 = None
+                # multi-bin features: per band j the sum over the feature layers, then the reference's cumulative division
+                # inside the bin loop (train.py:466-472): f2 = sum_j S_j / nf^(G-j) / G.  One loss node per layer covers
+                # all bands (one gradient tensor per feature instead of a zero-filled slice gradient per band).
                 nf = len(rf2)
-                for j in range(G):                       # train.py:466-472: cumulative division inside the bin loop
-                    for (r, m, _), (f, _, gs) in zip(rf2, gf2):
-                        Bn = r.shape[0] // G
-                        l = masked_mae(f[j * Bn:(j + 1) * Bn], r[j * Bn:(j + 1) * Bn], m[:Bn].contiguous(), comm=self.comm,
-                                       leaky_slope=gs)
-                        f2 = l if f2 is None else ops.add(f2, l)
-                    f2 = ops.scale(f2, 1.0 / nf)
-                f2 = ops.scale(f2, 1.0 / G)
+                S = None
+                for (r, m, _), (f, _, gs) in zip(rf2, gf2):
+                    Bn = r.shape[0] // G
+                    lb = masked_mae_bands(f, r, m[:Bn].contiguous(), G, comm=self.comm, leaky_slope=gs)
+                    S = lb if S is None else S + lb
+                if getattr(self, "_fm_band_w", None) is None or self._fm_band_w[0] != (nf, G):
+                    self._fm_band_w = ((nf, G), torch.tensor([1.0 / (float(nf) ** (G - j)) / G for j in range(G)],
+                                                             dtype=torch.float32, device=self.device))
+                f2 = (S * self._fm_band_w[1]).sum()
                 loss_fm = ops.add(f1, f2, 0.5, 0.5)
         w = t["loss_weights"]
         total = ops.add(loss_pre, loss_post, w.get("recon_lambda_pre", 1.0), w.get("recon_lambda_post", 2.0))

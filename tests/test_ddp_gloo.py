@@ -32,14 +32,14 @@ class Net(torch.nn.Module):
         return self.c(torch.tanh(self.b(torch.relu(self.a(x))))) * self.scale
 
 
-def _worker(rank, world, port, out_q):
+def _worker(rank, world, port, out_q, gather=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from mqgan_amd.ddp import FlatArena, GradReducer, broadcast_arena
         torch.manual_seed(100 + rank)                # different init per rank: broadcast must fix that
         net = Net()
-        arena = FlatArena([net])
+        arena = FlatArena([net], gather=gather)
         broadcast_arena(arena)
         red = GradReducer(arena, bucket_bytes=1024)  # several buckets
         assert len(red.buckets) >= 3
@@ -56,21 +56,24 @@ def _worker(rank, world, port, out_q):
             n_hook = len(launched_during_backward)
             red.finish()
             results.append((arena.flat_grad.clone(), n_hook))
-        # every parameter still aliases the arena and .grad views were filled in place
+        # every parameter still aliases the arena and .grad views were filled in place (gather mode: the gradients stay in
+        # autograd's own tensors and were copied into the arena bucket by bucket)
         for p, o in zip(arena.params, arena.offsets):
             assert p.data_ptr() == arena.flat_param.data_ptr() + 4 * o
-            assert p.grad.data_ptr() == arena.flat_grad.data_ptr() + 4 * o
+            if not gather:
+                assert p.grad.data_ptr() == arena.flat_grad.data_ptr() + 4 * o
         out_q.put((rank, arena.flat_param.clone(), [r[0] for r in results], [r[1] for r in results]))
     finally:
         dist.destroy_process_group()
 
 
-def test_bucketed_allreduce_world2():
+@pytest.mark.parametrize("gather", [False, True])
+def test_bucketed_allreduce_world2(gather):
     world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, gather)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=60) for _ in range(world)]

@@ -712,6 +712,51 @@ def test_pool_upcat_with_consumer_mask(env, dtype):
                           torch.zeros(1, 4, dtype=torch.uint8, device=DEV))
 
 
+def test_arena_gather_one_launch(env):
+    """FlatArena(gather=True): gradients left in their own tensors, copied into the arena by mq_multi_gather - aligned and
+    misaligned sources, a 0-d parameter, a parameter without gradient (zeros), tails that are not multiples of 4."""
+    from mqgan_amd.ddp import FlatArena
+    torch.manual_seed(21)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Parameter(torch.randn(5000, 3))
+            self.s = torch.nn.Parameter(torch.tensor(2.0))
+            self.unused = torch.nn.Parameter(torch.randn(7))
+            self.b = torch.nn.Parameter(torch.randn(2049))
+            self.c = torch.nn.Parameter(torch.randn(33, 5))
+    net = Net().to(DEV)
+    arena = FlatArena([net], gather=True)
+    assert all(p.grad is None for p in arena.params)
+    arena.flat_grad.fill_(123.0)                                        # stale content must not survive
+    pad = torch.ones_like(arena.flat_grad, dtype=torch.bool)
+    for p, o in zip(arena.params, arena.offsets):
+        pad[o:o + p.numel()] = False
+    arena.flat_grad[pad] = 0.0                                          # alignment gaps are zero from construction
+    big = torch.randn(1 + 2049, device=DEV)
+    net.a.grad = torch.randn(5000, 3, device=DEV)
+    net.s.grad = torch.tensor(-3.0, device=DEV)
+    net.b.grad = big[1:]                                                # 4-byte aligned only: the scalar path
+    net.c.grad = torch.randn(5, 33, device=DEV).t()                     # not contiguous
+    want_c = net.c.grad.clone()
+    arena.gather()
+    for p, o, want in [(net.a, arena.offsets[0], net.a.grad), (net.s, arena.offsets[1], net.s.grad),
+                       (net.b, arena.offsets[3], big[1:]), (net.c, arena.offsets[4], want_c)]:
+        assert torch.equal(arena.flat_grad[o:o + p.numel()], want.reshape(-1))
+    o = arena.offsets[2]
+    assert float(arena.flat_grad[o:o + 7].abs().max()) == 0.0
+    assert float(arena.flat_grad[pad].abs().max()) == 0.0
+    before = arena.flat_grad.clone()
+    net.a.grad = torch.zeros_like(net.a)
+    arena.gather()                                                      # already gathered this step: nothing moves
+    assert torch.equal(arena.flat_grad, before)
+    arena.zero_grad()
+    assert all(p.grad is None for p in arena.params)
+    arena.gather()
+    assert float(arena.flat_grad.abs().max()) == 0.0
+
+
 # ----------------------------------------------------------------------------------------- optimiser
 def test_sumsq_and_adam_match_torch(env):
     ops = env
