@@ -21,6 +21,9 @@ __device__ __forceinline__ uint64_t cb_group(int64_t pixel, int k, int groups_pe
     return (uint64_t)pixel * (uint64_t)groups_per_pixel + (uint64_t)(k >> 3);
 }
 
+// Forward.  Block tile CB_FT time steps x CB_TC channels; thread = channel c, CB_FP consecutive time steps, so the three MLP
+// weights of a hidden unit are read from LDS once for CB_FP pixels and the per-pixel chains are independent (packed f32 math).
+constexpr int CB_FT = 32, CB_FP = 8;
 __global__ __launch_bounds__(256) void cb2d_fwd_kernel(const float *__restrict__ x, const uint8_t *__restrict__ mask,
                                                        const float *__restrict__ wdw, const float *__restrict__ bdw,
                                                        const float *__restrict__ w1, const float *__restrict__ b1,
@@ -30,56 +33,68 @@ __global__ __launch_bounds__(256) void cb2d_fwd_kernel(const float *__restrict__
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float *sw1 = sm, *sb1 = sm + C0, *sw2 = sm + 2 * C0;
-    float *xt = sm + 3 * C0;                       // [(CB_TT+4)][(CB_TC+4)]
+    float *xt = sm + 3 * C0;                       // [(CB_FT+4)][(CB_TC+4)]
     __shared__ float swd[25];
     const int tid = threadIdx.x;
-    const int b = blockIdx.z, t0 = blockIdx.y * CB_TT, c0 = blockIdx.x * CB_TC;
+    const int b = blockIdx.z, t0 = blockIdx.y * CB_FT, c0 = blockIdx.x * CB_TC;
     for (int i = tid; i < C0; i += 256) {
         sw1[i] = w1[i];
         sb1[i] = b1[i];
         sw2[i] = w2[i];
     }
     if (tid < 25) swd[tid] = wdw[tid];
-    for (int i = tid; i < (CB_TT + 4) * (CB_TC + 4); i += 256) {
+    for (int i = tid; i < (CB_FT + 4) * (CB_TC + 4); i += 256) {
         const int tt = i / (CB_TC + 4), cc = i - tt * (CB_TC + 4);
         const int t = t0 + tt - 2, c = c0 + cc - 2;
         xt[i] = (t >= 0 && t < T && c >= 0 && c < C0) ? x[((size_t)b * T + t) * C0 + c] : 0.f;
     }
     __syncthreads();
-    const int tt = tid >> 6, tc = tid & 63;
-    const int t = t0 + tt, c = c0 + tc;
-    if (t >= T || c >= C0) return;
-    const int64_t pixel = ((int64_t)b * T + t) * C0 + c;
-    const bool padded = mask[(size_t)b * T + t] != 0;
-    const float bias2 = b2[0];
-    if (padded) {
-        y[pixel] = bias2;
-        if (v_save) v_save[pixel] = 0.f;
-        return;
+    const int tq = tid >> 6, tc = tid & 63;
+    const int c = c0 + tc;
+    if (c >= C0) return;
+    const float bias2 = b2[0], bias_dw = bdw[0];
+    float v[CB_FP], acc[CB_FP];
+    bool inb[CB_FP], on[CB_FP];
+    int64_t pix[CB_FP];
+#pragma unroll
+    for (int p = 0; p < CB_FP; ++p) {
+        const int tt = tq * CB_FP + p, t = t0 + tt;
+        inb[p] = t < T;
+        pix[p] = inb[p] ? ((int64_t)b * T + t) * C0 + c : 0;
+        on[p] = inb[p] && mask[(size_t)b * T + t] == 0;
+        float vv = bias_dw;
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) vv = fmaf(swd[i * 5 + j], xt[(tt + j) * (CB_TC + 4) + tc + i], vv);
+        v[p] = on[p] ? vv : 0.f;
+        if (v_save && inb[p]) v_save[pix[p]] = v[p];
+        acc[p] = bias2;
     }
-    float v = bdw[0];
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-#pragma unroll
-        for (int j = 0; j < 5; ++j) v = fmaf(swd[i * 5 + j], xt[(tt + j) * (CB_TC + 4) + tc + i], v);
-    if (v_save) v_save[pixel] = v;
     const int gpp = (C0 + 7) >> 3;
-    float acc = bias2;
     for (int k0 = 0; k0 < C0; k0 += 8) {
-        Drop8 rng;
-        if (thresh16) rng = Drop8(seed, cb_group(pixel, k0, gpp));
+        Drop8 rng[CB_FP];
+        if (thresh16) {
+#pragma unroll
+            for (int p = 0; p < CB_FP; ++p) rng[p] = Drop8(seed, cb_group(pix[p], k0, gpp));
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int k = k0 + e;
-            if (k < C0) {
-                const float h = fmaf(sw1[k], v, sb1[k]);
+            if (k >= C0) break;
+            const float wk1 = sw1[k], bk1 = sb1[k], wk2 = sw2[k];
+#pragma unroll
+            for (int p = 0; p < CB_FP; ++p) {
+                const float h = fmaf(wk1, v[p], bk1);
                 float a = aptx_s(h) * 0.5f * h;
-                if (thresh16) a = rng.keep(e, thresh16) ? a * scale : 0.f;
-                acc = fmaf(sw2[k], a, acc);
+                if (thresh16) a = rng[p].keep(e, thresh16) ? a * scale : 0.f;
+                acc[p] = fmaf(wk2, a, acc[p]);
             }
         }
     }
-    y[pixel] = acc;
+#pragma unroll
+    for (int p = 0; p < CB_FP; ++p)
+        if (inb[p]) y[pix[p]] = on[p] ? acc[p] : bias2;
 }
 
 // Backward pass 1: per-pixel MLP backward.  Thread = channel c, CB_TM consecutive time steps.
@@ -297,8 +312,8 @@ extern "C" int mq_convblock2d_fwd(const mqCb2dWeights *w, const float *x, const 
 {
     if (cb_check(w, B, T, C0, p_drop, "mq_convblock2d_fwd")) return 1;
     MQ_REQUIRE(x && mask && y, "mq_convblock2d_fwd: null pointer");
-    const size_t shm = (size_t)(3 * C0 + (CB_TT + 4) * (CB_TC + 4)) * sizeof(float);
-    dim3 grid((unsigned)cdiv(C0, CB_TC), (unsigned)cdiv(T, CB_TT), B);
+    const size_t shm = (size_t)(3 * C0 + (CB_FT + 4) * (CB_TC + 4)) * sizeof(float);
+    dim3 grid((unsigned)cdiv(C0, CB_TC), (unsigned)cdiv(T, CB_FT), B);
     hipLaunchKernelGGL(cb2d_fwd_kernel, grid, dim3(256), shm, S(stream), x, mask, w->wdw, w->bdw, w->w1, w->b1, w->w2, w->b2, B, T,
                        C0, p_drop > 0.f ? drop_thresh16(p_drop) : 0u, p_drop > 0.f ? drop_scale(p_drop) : 1.0f, seed, y, v_save);
     MQ_LAUNCH_CHECK("mq_convblock2d_fwd");
