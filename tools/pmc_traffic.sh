@@ -1,12 +1,14 @@
 #!/bin/bash
 # HBM traffic per kernel (FETCH_SIZE / WRITE_SIZE in separate passes) for `bench.py`; writes profiles-style JSON
+# usage: bash tools/pmc_traffic.sh [tag [extra bench.py args]]    e.g.  pmc_traffic.sh c3 --config hifimusic --precision bf16
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/pmc_traffic
+TAG=${1:-}; [ $# -gt 0 ] && shift
+OUT=$R/gpurun_out/pmc_traffic${TAG:+_$TAG}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   echo "pmc_traffic: pass $C $(date +%T)" | tee -a $OUT/progress.log
-  timeout -k 10 500 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vq --no-alt --no-configs > $OUT/$C.log 2>&1 || { echo "pass $C failed"; tail -5 $OUT/$C.log; exit 1; }
+  timeout -k 10 500 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vq --no-alt --no-configs "$@" > $OUT/$C.log 2>&1 || { echo "pass $C failed"; tail -5 $OUT/$C.log; exit 1; }
 done
 python3 - <<PY
 import csv, glob, collections, json, sys
