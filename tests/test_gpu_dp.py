@@ -156,3 +156,89 @@ def test_two_ragged_shards_equal_the_global_batch(use_fm):
         # replicas stay bit-identical to each other
         assert torch.equal(got[0][s][3], got[1][s][3])
         assert torch.equal(got[0][s][1], got[1][s][1]) and torch.equal(got[0][s][2], got[1][s][2])
+
+
+# ----------------------------------------------------------------------------------------- the torch.distributed path
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _dist_rank(rank, world, port, use_fm, q):
+    """One rank of a real process group (gloo here; the production run differs only in backend = RCCL): TorchComm for the loss
+    sums, GradReducer's post-accumulate hooks + per-bucket arena fill + asynchronous bucket all-reduces for the gradients."""
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import __graft_entry__ as ge
+        ge.build()
+        from mqgan_amd.train import synthetic_mel
+        from mqgan_amd import ddp
+        g = load_golden("g7_trainstep.npz")
+        T, mel = 40, 16
+        xs = torch.from_numpy(np.stack([synthetic_mel(T, mel, 300 + b) for b in range(5)])).to(DEV)
+        lens_all = torch.tensor([40, 23, 31, 40, 17], dtype=torch.int32, device=DEV)
+        for b in range(5):
+            xs[b, int(lens_all[b]):] = 0.0
+        sl = slice(0, 2) if rank == 0 else slice(2, 5)
+        tr = _trainer(g, use_fm)
+        assert tr.world == 2 and tr.rank == rank and tr.reducer_g.enabled and tr.arena_g.gather_mode
+        tr.reducer_g = ddp.GradReducer(tr.arena_g, bucket_bytes=64 << 10)       # several buckets on the tiny model
+        tr.reducer_d = ddp.GradReducer(tr.arena_d, bucket_bytes=64 << 10)
+        launched = []
+        for red in (tr.reducer_g, tr.reducer_d):
+            orig = red._launch
+            red._launch = (lambda o: (lambda b: (launched.append(b), o(b))[1]))(orig)
+        res = []
+        for _ in range(2):
+            out = tr.train_step(xs[sl].contiguous(), lens_all[sl].contiguous())
+            res.append(({k: float(v) for k, v in out.items()}, tr.arena_g.flat_grad.cpu().numpy(), tr.arena_d.flat_grad.cpu().numpy(),
+                        tr.gan_loss._state.cpu().numpy(), tr.arena_g.flat_param.cpu().numpy(), tr.arena_d.flat_param.cpu().numpy()))
+        q.put((rank, res, len(launched), len(tr.reducer_g.buckets) + len(tr.reducer_d.buckets)))     # numpy: pickled by value
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_fm", [True])
+def test_two_processes_over_torch_distributed_equal_the_global_batch(use_fm):
+    import torch.multiprocessing as mp
+    from mqgan_amd.train import synthetic_mel
+    g = load_golden("g7_trainstep.npz")
+    T, mel = 40, 16
+    xs = torch.from_numpy(np.stack([synthetic_mel(T, mel, 300 + b) for b in range(5)])).to(DEV)
+    lens_all = torch.tensor([40, 23, 31, 40, 17], dtype=torch.int32, device=DEV)
+    for b in range(5):
+        xs[b, int(lens_all[b]):] = 0.0
+    ref = _trainer(g, use_fm)
+    ref_out = []
+    for _ in range(2):
+        out = ref.train_step(xs, lens_all)
+        ref_out.append(({k: float(v) for k, v in out.items()}, ref.arena_g.flat_grad.cpu(), ref.arena_d.flat_grad.cpu(),
+                        ref.gan_loss._state.cpu(), ref.arena_g.flat_param.cpu(), ref.arena_d.flat_param.cpu()))
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dist_rank, args=(r, 2, port, use_fm, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=240) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    got = [(r, [(st[0],) + tuple(torch.from_numpy(a) for a in st[1:]) for st in res], nl, nb) for r, res, nl, nb in got]
+    for rank, res, n_launched, n_buckets in got:
+        assert n_buckets >= 4 and n_launched == 2 * n_buckets          # every bucket, every step
+        for s in range(2):
+            want, have = ref_out[s], res[s]
+            for k in ("loss_d", "loss_g_total", "loss_recon_pre", "loss_recon_post", "loss_gan", "loss_fm"):
+                np.testing.assert_allclose(have[0][k], want[0][k], rtol=2e-5, atol=1e-7, err_msg=f"step {s} rank {rank} {k}")
+            assert rel_err(have[1], want[1]) < 2e-5 and rel_err(have[2], want[2]) < 2e-5, f"step {s} rank {rank}: gradients"
+            np.testing.assert_allclose(have[3].numpy(), want[3].numpy(), rtol=1e-5, atol=1e-7, err_msg="LeCam EMA state")
+            assert rel_err(have[4], want[4]) < 1e-6 and rel_err(have[5], want[5]) < 1e-6, "updated weights"
+    for s in range(2):                                                  # replicas bit-identical to each other
+        for i in (1, 2, 3, 4, 5):
+            assert torch.equal(got[0][1][s][i], got[1][1][s][i])
