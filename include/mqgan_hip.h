@@ -388,6 +388,24 @@ int mq_masked_mae_sums(const float *pred, const float *target, const uint8_t *pa
 int mq_masked_mae_bwd(const float *pred, const float *target, const uint8_t *padded, int B, int H, int W, int C,
                       const float *sums2, const float *gout, float leaky_slope, float *dpred, mqStream stream);
 
+/* ------------------------------------------------------------------ Winograd F(2x2, 3x3)
+ * The refiner's 3x3 / stride 1 / pad 1 convolutions (preencoder.py:86-102) as 16 batch-grouped GEMMs around HBM-bound
+ * transforms (csrc/winograd.hip): 16 multiplications per 4 outputs instead of 36, f32 products and accumulation as in
+ * mq_conv_fprop.  tiles = N * ceil(H/2) * ceil(W/2); every tensor f32, channels-last, channel counts multiples of 4.
+ *   forward : V = input_transform(x) (16, tiles, C); U = weight_transform(w_krsc, flip 0) (16, K, C);
+ *             M = mq_conv_fprop(desc{N = 16 * N * ceil(H/2), H = 1, W = ceil(W/2), C, K, R = S = 1, groups = 16}, V, U)
+ *             (16, tiles, K);
+ *             y = output_transform(M, bias)
+ *   dgrad   : the same with dy in place of x and weight_transform(w_krsc, flip 1) (16, C, K) (the filter rotated by 180
+ *             degrees and transposed)
+ *   wgrad   : V as above; Z = dy_transform(dy) (16, tiles, K); P = mq_conv_wgrad(that desc, V, Z) (16, K, C);
+ *             dw_krsc = wgrad_inverse(P) */
+int mq_wino_input_transform(const float *x, int N, int H, int W, int C, float *V, mqStream stream);
+int mq_wino_dy_transform(const float *dy, int N, int H, int W, int K, float *Z, mqStream stream);
+int mq_wino_output_transform(const float *M, const float *bias, int N, int H, int W, int K, float *y, mqStream stream);
+int mq_wino_weight_transform(const float *w_krsc, int K, int C, int flip_transpose, float *U, mqStream stream);
+int mq_wino_wgrad_inverse(const float *P, int K, int C, float *dw_krsc, mqStream stream);
+
 /* ------------------------------------------------------------------ optimiser
  * clip_grad_norm_ + Adam on flat arenas (train.py:401-407,485-492; torch.optim.Adam
  * defaults eps=1e-8, no weight decay, no amsgrad).

@@ -134,6 +134,11 @@ SIGNATURES = {
     "mq_lsgan_g_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "mq_masked_mae_sums": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "mq_masked_mae_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _F, _P, _P]),
+    "mq_wino_input_transform": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "mq_wino_dy_transform": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "mq_wino_output_transform": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "mq_wino_weight_transform": (_I, [_P, _I, _I, _I, _P, _P]),
+    "mq_wino_wgrad_inverse": (_I, [_P, _I, _I, _P, _P]),
     "mq_sumsq": (_I, [_P, _L, _P, _P, _P]),
     "mq_multi_gather": (_I, [_P, _I, _L, _P, _P]),
     "mq_adam_step": (_I, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _I, _P, _F, _F, _P]),

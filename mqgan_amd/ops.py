@@ -7,6 +7,7 @@ frame masks are uint8 (B, T) with 1 = padded.
 """
 import ctypes as C
 import itertools
+import os
 from typing import Optional
 
 import torch
@@ -429,6 +430,90 @@ class ConvFn(torch.autograd.Function):
         return dx, dw, None, db, None
 
 
+# ----------------------------------------------------------------------------- Winograd F(2x2, 3x3) (csrc/winograd.hip)
+WINO_MIN_CHANNELS = int(os.environ.get("MQGAN_WINO_MINC", "128"))      # 0 switches the path off (A/B runs)
+
+
+def _wino_ok(d: ConvDesc) -> bool:
+    """3x3, stride 1, pad 1, no dilation, one group, f32 tensors on an f32-result engine, channel counts that fill the GEMM."""
+    return (WINO_MIN_CHANNELS > 0 and d.R == 3 and d.S == 3 and d.stride_h == 1 and d.stride_w == 1 and d.pad_h == 1 and d.pad_w == 1
+            and d.dil_h == 1 and d.dil_w == 1 and d.groups == 1 and d.P == d.H and d.Q == d.W
+            and d.precision in (PRECISIONS["f32"], PRECISIONS["f32x3"])
+            and d.C % 16 == 0 and d.K % 16 == 0 and min(d.C, d.K) >= WINO_MIN_CHANNELS)
+
+
+def _wino_tiles(d: ConvDesc) -> int:
+    return d.N * ((d.H + 1) // 2) * ((d.W + 1) // 2)
+
+
+def _wino_gemm_desc(d: ConvDesc, cin: int, cout: int) -> ConvDesc:
+    """The 16 transform positions as 16 groups of one-row "images" (one per tile row: small images keep the kernels' 32-bit
+    image-relative offsets far from their limits) with batch-grouped 1x1 filters."""
+    return conv_desc(16 * d.N * ((d.H + 1) // 2), 1, (d.W + 1) // 2, cin, cout, 1, 1, groups=16, precision=d.precision)
+
+
+def _wino_in(t, d: ConvDesc, channels: int, dy_side: bool = False):
+    out = _empty((16 * _wino_tiles(d), 1, 1, channels), t)
+    fn = L().mq_wino_dy_transform if dy_side else L().mq_wino_input_transform
+    check(fn(fptr(t), d.N, d.H, d.W, channels, fptr(out), stream()), "mq_wino_dy_transform" if dy_side else "mq_wino_input_transform")
+    return out
+
+
+def _wino_conv(d: ConvDesc, x, w_krsc, bias, cin: int, cout: int, flip: bool, key):
+    """'same' 3x3 convolution of x (N, H, W, cin) with the KRSC weights (forward: flip False; input gradient: flip True)."""
+    V = _wino_in(x, d, cin)
+    U = _empty((16 * cout, 1, cin), x)
+    check(L().mq_wino_weight_transform(fptr(w_krsc), d.K, d.C, int(flip), fptr(U), stream()), "mq_wino_weight_transform")
+    dg = _wino_gemm_desc(d, cin, cout)
+    M = _empty((16 * _wino_tiles(d), 1, 1, cout), x)
+    _timed(_conv_tag("fprop", dg), _conv_flops(dg), lambda: check(
+        L().mq_conv_fprop(C.byref(dg), fptr(V), fptr(U), None, fptr(M), stream()), "mq_conv_fprop"), key)
+    del V
+    y = _empty((d.N, d.H, d.W, cout), x)
+    check(L().mq_wino_output_transform(fptr(M), fptr(bias, True), d.N, d.H, d.W, cout, fptr(y), stream()), "mq_wino_output_transform")
+    return y
+
+
+class ConvWinoFn(torch.autograd.Function):
+    """ConvFn for 3x3 / stride-1 / pad-1 layers by Winograd F(2x2, 3x3): 2.25x fewer multiplications, run as one
+    batch-grouped (16 groups) 1x1 convolution on the same f32 GEMM kernels between HBM-bound transforms.  Same arguments and
+    gradients as ConvFn; the CRSK weights are not needed (the input gradient transforms the KRSC filter rotated)."""
+
+    @staticmethod
+    def forward(ctx, x, w_krsc, w_crsk, bias, key):
+        d = _desc_from_key(key)
+        y = _wino_conv(d, x, w_krsc, bias, d.C, d.K, False, key)
+        ctx.key = key
+        ctx.w_shape = tuple(w_krsc.shape)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, w_krsc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w_krsc = ctx.saved_tensors
+        d = _desc_from_key(ctx.key)
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _wino_conv(d, dy, w_krsc, None, d.K, d.C, True, ctx.key)
+        if ctx.needs_input_grad[1]:
+            V = _wino_in(x, d, d.C)
+            Z = _wino_in(dy, d, d.K, dy_side=True)
+            dg = _wino_gemm_desc(d, d.C, d.K)
+            P = _empty((16 * d.K, 1, d.C), x)
+            nbytes = L().mq_conv_wgrad_workspace(C.byref(dg))
+            ws = _ws_bytes(nbytes, x)
+            _timed(_conv_tag("wgrad", dg), _conv_flops(dg), lambda: check(
+                L().mq_conv_wgrad(C.byref(dg), fptr(V), fptr(Z), fptr(P), ptr(ws), nbytes, stream()), "mq_conv_wgrad"), ctx.key)
+            del V, Z
+            dw = _empty(ctx.w_shape, x)
+            check(L().mq_wino_wgrad_inverse(fptr(P), d.K, d.C, fptr(dw), stream()), "mq_wino_wgrad_inverse")
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            db = _bias_grad(d, dy)
+        return dx, dw, None, db, None
+
+
 def _bias_grad(d, dy):
     rows_per_group = (d.N // d.groups) * d.P * d.Q
     if d.groups == 1:
@@ -683,6 +768,8 @@ def conv(x, w_krsc, w_crsk, bias, desc: ConvDesc, out_f32: bool = False):
         return ConvH2Fn.apply(to_bf16(x), w_krsc, w_crsk, bias, _desc_key(desc), None, out_f32)
     if _is_thin(desc):
         return _thin_conv(x if desc.K == 1 else to_f32(x), w_krsc, w_crsk, bias, desc)
+    if _wino_ok(desc):
+        return ConvWinoFn.apply(to_f32(x), w_krsc, w_crsk, bias, _desc_key(desc))
     return ConvFn.apply(to_f32(x), w_krsc, w_crsk, bias, _desc_key(desc))
 
 

@@ -308,6 +308,50 @@ def test_conv_fprop_dgrad_wgrad(env, c, precision):
     assert_rel(bd.grad, b.grad, 2e-5, "bias grad")
 
 
+WINO_CASES = [
+    dict(N=2, H=8, W=10, C=128, K=128, R=3, S=3, pad=(1, 1)),
+    dict(N=1, H=7, W=9, C=144, K=128, R=3, S=3, pad=(1, 1)),          # odd height and width: half-used edge tiles
+    dict(N=3, H=1, W=5, C=128, K=256, R=3, S=3, pad=(1, 1)),          # single row
+    dict(N=1, H=12, W=6, C=384, K=128, R=3, S=3, pad=(1, 1)),         # the up-blocks' concatenated input
+]
+
+
+@pytest.mark.parametrize("precision", ["f32", "f32x3"])
+@pytest.mark.parametrize("c", WINO_CASES, ids=lambda c: "N{N}H{H}W{W}C{C}K{K}".format(**c))
+def test_winograd_conv_fprop_dgrad_wgrad(env, c, precision):
+    """3x3 / stride 1 / pad 1 layers with >= 128 channels run as Winograd F(2x2, 3x3) (ops.ConvWinoFn): forward, input,
+    weight and bias gradients against the float64 direct convolution.  The transforms add a few roundings to the direct
+    kernels' error, so the bound is 4e-5 of the output scale instead of 2e-5."""
+    ops = env
+    torch.manual_seed(0)
+    x = torch.randn(c["N"], c["H"], c["W"], c["C"], dtype=torch.float64)
+    w = torch.randn(c["K"], c["C"], 3, 3, dtype=torch.float64) * 0.2
+    b = torch.randn(c["K"], dtype=torch.float64)
+    x.requires_grad_(True); w.requires_grad_(True); b.requires_grad_(True)
+    y_ref = _torch_conv(x, w, b, c)
+    r = torch.randn_like(y_ref)
+    (y_ref * r).sum().backward()
+    xd = x.detach().float().to(DEV).requires_grad_(True)
+    wd = w.detach().float().to(DEV).requires_grad_(True)
+    bd = b.detach().float().to(DEV).requires_grad_(True)
+    wk, wc = ops.weight_prep(wd, None, True)
+    desc = ops.conv_desc(c["N"], c["H"], c["W"], c["C"], c["K"], 3, 3, pad=(1, 1), precision=precision)
+    assert ops._wino_ok(desc)
+    y = ops.conv(xd, wk, wc, bd, desc)
+    assert y.grad_fn.__class__.__name__.startswith("ConvWinoFn")
+    assert_rel(y, y_ref, 4e-5, "fprop")
+    (y * r.float().to(DEV)).sum().backward()
+    assert_rel(xd.grad, x.grad, 4e-5, "dgrad")
+    assert_rel(wd.grad, w.grad, 4e-5, "wgrad")
+    assert_rel(bd.grad, b.grad, 2e-5, "bias grad")
+    # layers the path does not take stay on the direct kernels
+    for cc in (dict(c, C=64, K=64), ):
+        d2 = ops.conv_desc(cc["N"], cc["H"], cc["W"], cc["C"], cc["K"], 3, 3, pad=(1, 1), precision=precision)
+        assert not ops._wino_ok(d2)
+    assert not ops._wino_ok(ops.conv_desc(1, 8, 8, 128, 128, 3, 3, stride=(2, 2), pad=(1, 1), precision=precision))
+    assert not ops._wino_ok(ops.conv_desc(1, 8, 8, 128, 128, 3, 3, pad=(1, 1), precision="bf16"))
+
+
 @pytest.mark.parametrize("precision", ["f32", "bf16", "f32x3"])
 def test_conv_large_split_k_and_tiles(env, precision):
     """A refiner-sized layer: many M tiles, split-K wgrad with the slab reduction."""
