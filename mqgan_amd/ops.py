@@ -432,6 +432,8 @@ class ConvFn(torch.autograd.Function):
 
 # ----------------------------------------------------------------------------- Winograd F(2x2, 3x3) (csrc/winograd.hip)
 WINO_MIN_CHANNELS = int(os.environ.get("MQGAN_WINO_MINC", "128"))      # 0 switches the path off (A/B runs)
+# the transformed input V (4x the input) is kept for the weight gradient when it is at most this many MiB, else recomputed
+WINO_KEEP_V_MIB = int(os.environ.get("MQGAN_WINO_KEEP_MIB", "6144"))
 
 
 def _wino_ok(d: ConvDesc) -> bool:
@@ -459,9 +461,12 @@ def _wino_in(t, d: ConvDesc, channels: int, dy_side: bool = False):
     return out
 
 
-def _wino_conv(d: ConvDesc, x, w_krsc, bias, cin: int, cout: int, flip: bool, key):
-    """'same' 3x3 convolution of x (N, H, W, cin) with the KRSC weights (forward: flip False; input gradient: flip True)."""
+def _wino_conv(d: ConvDesc, x, w_krsc, bias, cin: int, cout: int, flip: bool, key, keep=None):
+    """'same' 3x3 convolution of x (N, H, W, cin) with the KRSC weights (forward: flip False; input gradient: flip True).
+    ``keep``: a list that receives the transformed input V."""
     V = _wino_in(x, d, cin)
+    if keep is not None:
+        keep.append(V)
     U = _empty((16 * cout, 1, cin), x)
     check(L().mq_wino_weight_transform(fptr(w_krsc), d.K, d.C, int(flip), fptr(U), stream()), "mq_wino_weight_transform")
     dg = _wino_gemm_desc(d, cin, cout)
@@ -482,11 +487,14 @@ class ConvWinoFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_krsc, w_crsk, bias, key):
         d = _desc_from_key(key)
-        y = _wino_conv(d, x, w_krsc, bias, d.C, d.K, False, key)
+        keep_v = w_krsc.requires_grad and 64 * _wino_tiles(d) * d.C <= WINO_KEEP_V_MIB << 20
+        kept = [] if keep_v else None
+        y = _wino_conv(d, x, w_krsc, bias, d.C, d.K, False, key, keep=kept)
         ctx.key = key
         ctx.w_shape = tuple(w_krsc.shape)
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(x, w_krsc)
+        ctx.kept_v = keep_v
+        ctx.save_for_backward(kept[0] if keep_v else x, w_krsc)       # V stands in for x in the weight gradient
         return y
 
     @staticmethod
@@ -498,7 +506,7 @@ class ConvWinoFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _wino_conv(d, dy, w_krsc, None, d.K, d.C, True, ctx.key)
         if ctx.needs_input_grad[1]:
-            V = _wino_in(x, d, d.C)
+            V = x if ctx.kept_v else _wino_in(x, d, d.C)
             Z = _wino_in(dy, d, d.K, dy_side=True)
             dg = _wino_gemm_desc(d, d.C, d.K)
             P = _empty((16 * d.K, 1, d.C), x)

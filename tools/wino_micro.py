@@ -59,7 +59,7 @@ for name, N, H, W, Cc, K in CASES:
     class Ctx:
         pass
     ctx = Ctx()
-    ctx.key, ctx.w_shape, ctx.has_bias, ctx.needs_input_grad, ctx.saved_tensors = key, tuple(wk.shape), True, (True, True, False, True, False), (x, wk)
+    ctx.key, ctx.w_shape, ctx.has_bias, ctx.needs_input_grad, ctx.saved_tensors, ctx.kept_v = key, tuple(wk.shape), True, (True, True, False, True, False), (x, wk), False
     res["wino bwd"] = tm(lambda: ops.ConvWinoFn.backward(ctx, dy))
     dsum, wsum = res["direct fprop"] + res["direct bwd"], res["wino fprop"] + res["wino bwd"]
     print(f"{name:24s} direct {res['direct fprop']:7.3f} + {res['direct bwd']:7.3f} = {dsum:7.3f} ms ({3 * flops / dsum / 1e9:6.1f} TF/s)   "
