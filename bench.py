@@ -50,7 +50,7 @@ def kernel_build_id():
     """Hash of the conv kernel sources: ties a PMC traffic file to the build it was measured on."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("gemm_core.h", "igemm.hip", "igemm_h2.hip", "common.h"):
+    for f in ("gemm_core.h", "igemm.hip", "igemm_h2.hip", "winograd.hip", "common.h"):
         with open(os.path.join(ROOT, "mqgan_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -202,7 +202,9 @@ def quick_engine(cfg, precision, device, batches, lens, B, T, steps=4, warmup=1)
            "arithmetic": {"fp32x3": "f32 operands split exactly into 3 bf16 terms in-kernel, 6 cross products on the bf16 MFMA, "
                                     "f32 accumulate; passes the reference fixtures at the f32 tolerances",
                           "bf16": "bf16 MFMA operands, f32 accumulate; refiner / discriminator activations stored as bf16 tensors "
-                                  "(reference autocast mode), elsewhere f32 tensors rounded in-kernel"}[precision]}
+                                  "(reference autocast mode), elsewhere f32 tensors rounded in-kernel",
+                          "fp32": "exact f32 products on the f32 MFMA, every conv on the direct implicit-GEMM kernels "
+                                  "(Winograd switched off for this run)"}[precision]}
     del tr
     torch.cuda.empty_cache()
     return out
@@ -359,13 +361,23 @@ def main():
                 "config": {"workload": f"{args.config} PreEncoder VQ-GAN train step (G fwd + D step + G step + clip/Adam), "
                                        f"{mel} mels x {T} frames, batch {B}/GPU, FSQ {cfg['model']['generator']['fsq_levels']}, "
                                        "D active, FM off, train-mode dropout", "global_batch": world * B, "frames": T,
-                           "parallelism": f"dp{world}"},
+                           "parallelism": f"dp{world}",
+                           "conv_algorithm": ("implicit GEMM; 3x3 / stride-1 layers with >= 128 channels as Winograd F(2x2,3x3): "
+                                              "f32 transforms, products on the same MFMA engine, f32 accumulation "
+                                              "(MQGAN_WINO_MINC=0 switches it off)") if args.precision != "bf16"
+                           else "implicit GEMM on bf16-storage kernels"},
                 "losses_finite": bool(finite), "roofline": roof}
         del tr
         torch.cuda.empty_cache()
         if world == 1 and not args.no_alt and args.precision == "fp32":
             # secondary figures, same workload, opt-in engines (never `value`): see DESIGN.md section 3
             line["other_engines"] = {p: quick_engine(cfg, p, device, batches, lens, B, T) for p in ("fp32x3", "bf16")}
+            from mqgan_amd import ops as _ops
+            keep, _ops.WINO_MIN_CHANNELS = _ops.WINO_MIN_CHANNELS, 0          # every layer on the direct kernels (A/B, same box)
+            try:
+                line["other_engines"]["fp32_direct"] = quick_engine(cfg, "fp32", device, batches, lens, B, T)
+            finally:
+                _ops.WINO_MIN_CHANNELS = keep
         if world == 1 and not args.no_configs and args.config == "hifispeech" and args.precision == "fp32":
             del batches
             torch.cuda.empty_cache()
