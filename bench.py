@@ -101,8 +101,9 @@ def bench_vq(device):
     out["fsq"] = {"n": n, "ms": ms, "achieved_GBps": gb / (ms / 1e3), "peak_GBps": PEAK_HBM_GBS,
                   "frac": gb / (ms / 1e3) / PEAK_HBM_GBS, "bound": "hbm", "bytes_per_vector": 36}
     del z
-    rows = 16384
-    for k, d in ((1024, 256), (2048, 512), (8192, 512)):
+    # 16384 rows = one config-2 batch (32 x 512 frames): 768 blocks, a single round on 256 CUs - ramp and tail are a third of
+    # these 0.1-1.3 ms launches; the last entry shows the same kernel on four batches' worth of rows
+    for rows, k, d in ((16384, 1024, 256), (16384, 2048, 512), (16384, 8192, 512), (65536, 8192, 512)):
         g = torch.Generator(device="cpu").manual_seed(7)
         x = torch.randn(rows, d, generator=g).to(device)
         g = torch.Generator(device="cpu").manual_seed(11)
@@ -113,7 +114,7 @@ def bench_vq(device):
         ms = time_events(lambda: ops.l2_argmin(x, cb, cn, workspace=ws), 10)
         flops = 2.0 * rows * k * d
         byts = 4.0 * (rows * d + k * d + rows)
-        out[f"l2_argmin_{k}x{d}"] = {"n": rows, "ms": ms, "achieved_TFLOPs": flops / (ms / 1e3) / 1e12,
+        out[f"l2_argmin_{k}x{d}" + ("" if rows == 16384 else f"_rows{rows}")] = {"n": rows, "ms": ms, "achieved_TFLOPs": flops / (ms / 1e3) / 1e12,
                                      "peak_TFLOPs": PEAK_F32_MFMA_TFLOPS, "frac": flops / (ms / 1e3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                      "bound": "mfma", "algorithmic_GBps": byts / (ms / 1e3) / 1e9}
     return out

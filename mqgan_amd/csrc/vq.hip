@@ -155,9 +155,13 @@ __device__ __forceinline__ unsigned long long pack_dist_idx(float dist, int idx)
     return ((unsigned long long)u << 32) | (unsigned)idx;
 }
 
-// distances of a finished code tile -> running minimum; clears the accumulators
+// distances of a finished code tile -> running minimum; clears the accumulators.
+// IDX16: the running indices are kept as 16-bit halves (two per register; codebooks of at most 65535 codes), which brings
+// the kernel under the register budget of three blocks per CU.
+template <bool IDX16>
 __device__ __forceinline__ void argmin_fold(f32x16 (&acc)[GemmCfg<128>::TM][GemmCfg<128>::TN], float (&best)[GemmCfg<128>::TM][16],
-                                            int (&bidx)[GemmCfg<128>::TM][16], int tile, int k, const float *__restrict__ cn)
+                                            unsigned (&bidx)[GemmCfg<128>::TM][IDX16 ? 8 : 16], int tile, int k,
+                                            const float *__restrict__ cn)
 {
     using Cfg = GemmCfg<128>;
 #pragma unroll
@@ -174,7 +178,13 @@ __device__ __forceinline__ void argmin_fold(f32x16 (&acc)[GemmCfg<128>::TM][Gemm
                 dist = dist != dist ? -INFINITY : dist;      // NaN counts as -inf: the first NaN column wins
                 const bool take = cv && dist < best[tm][r];  // strict: lowest index wins ties inside a lane
                 best[tm][r] = take ? dist : best[tm][r];
-                bidx[tm][r] = take ? col : bidx[tm][r];
+                if constexpr (IDX16) {
+                    unsigned &b = bidx[tm][r >> 1];
+                    const unsigned repl = (r & 1) ? ((b & 0x0000ffffu) | ((unsigned)col << 16)) : ((b & 0xffff0000u) | (unsigned)col);
+                    b = take ? repl : b;
+                } else {
+                    bidx[tm][r] = take ? (unsigned)col : bidx[tm][r];
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = 0.f;
@@ -189,7 +199,8 @@ __device__ __forceinline__ void argmin_fold(f32x16 (&acc)[GemmCfg<128>::TM][Gemm
 // tile).  Measured: the same 88-103 TFLOP/s as before - the kernel is bound by its register footprint (64 accumulators +
 // 64 running (distance, index) registers: 2 blocks per CU), not by the restarts.  The accumulation order inside a tile is
 // unchanged (k in natural order, see gemm_core.h), so indices and distances stay bit-exact against oracle/vq_ref.c.
-__global__ __launch_bounds__(256, 2) void l2_argmin_kernel(const float *__restrict__ x, const float *__restrict__ cb,
+template <bool IDX16>
+__global__ __launch_bounds__(256, IDX16 ? 3 : 2) void l2_argmin_kernel(const float *__restrict__ x, const float *__restrict__ cb,
                                                         const float *__restrict__ cn, int64_t n, int k, int d,
                                                         int tiles_per_split, unsigned long long *__restrict__ packed)
 {
@@ -203,14 +214,14 @@ __global__ __launch_bounds__(256, 2) void l2_argmin_kernel(const float *__restri
     const int nk = (d + GEMM_BK - 1) / GEMM_BK;
 
     float best[Cfg::TM][16];
-    int bidx[Cfg::TM][16];
+    unsigned bidx[Cfg::TM][IDX16 ? 8 : 16];
 #pragma unroll
-    for (int a = 0; a < Cfg::TM; ++a)
+    for (int a = 0; a < Cfg::TM; ++a) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            best[a][r] = INFINITY;
-            bidx[a][r] = 0x7fffffff;
-        }
+        for (int r = 0; r < 16; ++r) best[a][r] = INFINITY;
+#pragma unroll
+        for (int r = 0; r < (IDX16 ? 8 : 16); ++r) bidx[a][r] = IDX16 ? 0xffffffffu : 0x7fffffffu;
+    }
     f32x16 acc[Cfg::TM][Cfg::TN];
 #pragma unroll
     for (int a = 0; a < Cfg::TM; ++a)
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void l2_argmin_kernel(const float *__restri
         }
         __syncthreads();
         if (++kin == nk) {                               // wave-uniform
-            argmin_fold(acc, best, bidx, tile, k, cn);
+            argmin_fold<IDX16>(acc, best, bidx, tile, k, cn);
             kin = 0;
             ++tile;
         }
@@ -302,7 +313,14 @@ __global__ __launch_bounds__(256, 2) void l2_argmin_kernel(const float *__restri
     for (int tm = 0; tm < Cfg::TM; ++tm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            unsigned long long p = pack_dist_idx(best[tm][r], bidx[tm][r]);
+            int bi;
+            if constexpr (IDX16) {
+                const unsigned h = (r & 1) ? (bidx[tm][r >> 1] >> 16) : (bidx[tm][r >> 1] & 0xffffu);
+                bi = h == 0xffffu ? 0x7fffffff : (int)h;          // 0xffff: this lane never saw a valid column (k <= 65535)
+            } else {
+                bi = (int)bidx[tm][r];
+            }
+            unsigned long long p = pack_dist_idx(best[tm][r], bi);
 #pragma unroll
             for (int off = 1; off < 32; off <<= 1) {
                 const unsigned long long o = __shfl_xor(p, off, 64);
@@ -497,8 +515,12 @@ extern "C" int mq_l2_argmin(const float *x, const float *codebook, const float *
     if (splits < 1) splits = 1;
     const int tps = (int)cdiv(ntiles, splits);
     splits = (int)cdiv(ntiles, tps);
-    hipLaunchKernelGGL(l2_argmin_kernel, dim3(row_tiles, splits), dim3(256), 0, S(stream), x, codebook, cnorm, n, k, d, tps,
-                       reinterpret_cast<unsigned long long *>(workspace));
+    if (k <= 65535)
+        hipLaunchKernelGGL(l2_argmin_kernel<true>, dim3(row_tiles, splits), dim3(256), 0, S(stream), x, codebook, cnorm, n, k, d, tps,
+                           reinterpret_cast<unsigned long long *>(workspace));
+    else
+        hipLaunchKernelGGL(l2_argmin_kernel<false>, dim3(row_tiles, splits), dim3(256), 0, S(stream), x, codebook, cnorm, n, k, d, tps,
+                           reinterpret_cast<unsigned long long *>(workspace));
     hipLaunchKernelGGL(l2_unpack_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S(stream),
                        reinterpret_cast<const unsigned long long *>(workspace), n, idx, best_dist);
     MQ_LAUNCH_CHECK("mq_l2_argmin");

@@ -29,7 +29,7 @@ for f in glob.glob("$OUT/p1/*/*kernel_trace.csv"):
         dur[r["Kernel_Name"]].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
 out = {}
 for k, cs in agg.items():
-    if "conv" not in k: continue
+    if "conv" not in k and "l2_argmin" not in k: continue
     name = k.split("(")[0].replace("void ", "").replace("mq::", "")
     a = {c: sum(v) / len(v) for c, v in cs.items()}
     e = {"launches": len(next(iter(cs.values()))), "avg_ns_under_pmc": (sum(dur[k]) / len(dur[k])) if dur.get(k) else None}
