@@ -207,6 +207,17 @@ int mq_spectral_prep(const float *w_orig, float *u, float *v, int K, int C, int 
 /* dW_orig = dW/sigma - (sum(dW * W_orig) / sigma^2) * u v^T ; scratch: 1 + 256 floats */
 int mq_spectral_prep_bwd(const float *dw_krsc, const float *w_orig, const float *u, const float *v,
                          const float *sigma, int K, int C, int RS, float *dw_orig, float *scratch, mqStream stream);
+/* The same layer of up to MQ_SN_MAX_BANDS band discriminators (discriminators.py:252-300: eight identical networks) in one
+ * launch per stage, without power iteration (eval-mode discriminators).  w_orig / u / v / dw_orig are HOST arrays of
+ * `bands` device pointers; band g fills rows [g*K, (g+1)*K) of the stacked KRSC filter (and [g*C, (g+1)*C) of the CRSK
+ * one), sigma_out[g].  scratch: bands * K floats (forward), bands * 256 floats (backward).  Per band the arithmetic and
+ * its order are those of mq_spectral_prep / mq_spectral_prep_bwd. */
+#define MQ_SN_MAX_BANDS 16
+int mq_spectral_prep_bands(const float *const *w_orig, const float *const *u, const float *const *v, int bands, int K, int C,
+                           int RS, float *w_krsc, float *w_crsk, float *sigma_out, float *scratch, mqStream stream);
+int mq_spectral_prep_bands_bwd(const float *dw_krsc, const float *const *w_orig, const float *const *u, const float *const *v,
+                               const float *sigma, int bands, int K, int C, int RS, float *const *dw_orig, float *scratch,
+                               mqStream stream);
 
 /* ------------------------------------------------------------------ fused ConvBlock2D
  * preencoder.py:277-301 as instantiated at :322,:351: 1-channel C0 x T image ->

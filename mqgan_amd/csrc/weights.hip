@@ -1,6 +1,7 @@
 // Effective-weight preparation for the implicit GEMM: layout change (reference (K, C, R*S) ->
 // KRSC and CRSK) fused with weight norm / spectral norm, plus the matching backward passes.
 #include "common.h"
+#include <cstring>
 
 namespace mq {
 
@@ -153,9 +154,151 @@ __global__ void sn_bwd_apply_kernel(const float *__restrict__ dw_krsc, const flo
     }
 }
 
+// ---- the same layer of up to MQ_SN_MAX_BANDS band discriminators in one launch each (no power iteration: eval-mode
+// discriminators, i.e. every step after the first generator step of an epoch).  Band g reads its own weight_orig / u / v
+// and writes rows [g*K, (g+1)*K) of the stacked KRSC (and [g*C, (g+1)*C) of the stacked CRSK) filters.
+struct SnBands {
+    const float *w[MQ_SN_MAX_BANDS];
+    const float *u[MQ_SN_MAX_BANDS];
+    const float *v[MQ_SN_MAX_BANDS];
+};
+struct SnBandsOut {
+    float *dw[MQ_SN_MAX_BANDS];
+};
+// s[g][k] = sum_j W_g[k][j] * v_g[j]      grid (K, G)
+__global__ void sn_w_v_bands_kernel(SnBands b, int K, int fan, float *__restrict__ s)
+{
+    __shared__ float red[4];
+    const int k = blockIdx.x, g = blockIdx.y;
+    const float *W = b.w[g], *v = b.v[g];
+    float a = 0.f;
+    for (int j = threadIdx.x; j < fan; j += 256) a += W[(size_t)k * fan + j] * v[j];
+    a = block_sum<256>(a, red);
+    if (threadIdx.x == 0) s[(size_t)g * K + k] = a;
+}
+// sigma_g = dot(u_g, s_g) recomputed by every block (K <= a few hundred values), then the scaled KRSC / CRSK filters
+__global__ __launch_bounds__(256) void sn_scale_bands_kernel(SnBands b, const float *__restrict__ s, int K, int C, int RS,
+                                                             float *__restrict__ w_krsc, float *__restrict__ w_crsk,
+                                                             float *__restrict__ sigma_out)
+{
+    __shared__ float red[4];
+    const int g = blockIdx.y;
+    const float *W = b.w[g], *u = b.u[g];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < K; i += 256) a += u[i] * s[(size_t)g * K + i];
+    a = block_sum<256>(a, red);
+    __shared__ float sig;
+    if (threadIdx.x == 0) sig = a;
+    __syncthreads();
+    const float sigma = sig;
+    if (blockIdx.x == 0 && threadIdx.x == 0) sigma_out[g] = sigma;
+    const float inv = 1.0f / sigma;
+    const int fan = C * RS;
+    const int64_t n = (int64_t)K * fan;
+    const int cbc = chan_block(C), cbk = chan_block(K);
+    float *ok = w_krsc ? w_krsc + (size_t)g * n : nullptr;
+    float *oc = w_crsk ? w_crsk + (size_t)g * n : nullptr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i / fan), r = (int)(i - (int64_t)k * fan);
+        const int c = r / RS, rs = r - c * RS;
+        const float w = W[i] * inv;
+        if (ok) ok[(size_t)k * fan + kidx(rs, c, RS, cbc)] = w;
+        if (oc) oc[(size_t)c * RS * K + kidx(rs, k, RS, cbk)] = w;
+    }
+}
+// partial[g][b] = sum over a slice of dW_g (stacked KRSC) * W_g (KCRS)      grid (nparts, G)
+__global__ void sn_bwd_dot_bands_kernel(const float *__restrict__ dw_krsc, SnBands b, int K, int C, int RS, float *__restrict__ partial)
+{
+    __shared__ float red[4];
+    const int g = blockIdx.y;
+    const int fan = C * RS;
+    const int64_t n = (int64_t)K * fan;
+    const float *dw = dw_krsc + (size_t)g * n, *W = b.w[g];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int k = (int)(i / fan), r = (int)(i - (int64_t)k * fan);
+        const int c = r / RS, rs = r - c * RS;
+        s += dw[(size_t)k * fan + kidx(rs, c, RS, chan_block(C))] * W[i];
+    }
+    s = block_sum<256>(s, red);
+    if (threadIdx.x == 0) partial[(size_t)g * gridDim.x + blockIdx.x] = s;
+}
+__global__ void sn_bwd_apply_bands_kernel(const float *__restrict__ dw_krsc, SnBands b, const float *__restrict__ sigma,
+                                          const float *__restrict__ partial, int nparts, int K, int C, int RS, SnBandsOut o)
+{
+    const int g = blockIdx.y;
+    const int fan = C * RS;
+    const int64_t n = (int64_t)K * fan;
+    const float *dw = dw_krsc + (size_t)g * n, *u = b.u[g], *v = b.v[g];
+    float *dW = o.dw[g];
+    float dot = 0.f;
+    for (int i = 0; i < nparts; ++i) dot += partial[(size_t)g * nparts + i];
+    const float inv = 1.0f / sigma[g];
+    const float coef = dot * inv * inv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i / fan), r = (int)(i - (int64_t)k * fan);
+        const int c = r / RS, rs = r - c * RS;
+        dW[i] = dw[(size_t)k * fan + kidx(rs, c, RS, chan_block(C))] * inv - coef * u[k] * v[r];
+    }
+}
+
 }  // namespace mq
 
 using namespace mq;
+
+static int sn_bands_nparts(int K, int C, int RS)
+{
+    int nparts = (int)cdiv((int64_t)K * C * RS, 256 * 16);
+    return nparts > 256 ? 256 : (nparts < 1 ? 1 : nparts);
+}
+
+extern "C" int mq_spectral_prep_bands(const float *const *w_orig, const float *const *u, const float *const *v, int bands, int K,
+                                      int C, int RS, float *w_krsc, float *w_crsk, float *sigma_out, float *scratch,
+                                      mqStream stream)
+{
+    MQ_REQUIRE(w_orig && u && v && sigma_out && scratch && (w_krsc || w_crsk) && K > 0 && C > 0 && RS > 0,
+               "mq_spectral_prep_bands: bad arguments");
+    MQ_REQUIRE(bands > 0 && bands <= MQ_SN_MAX_BANDS, "mq_spectral_prep_bands: 1 .. %d bands, got %d", MQ_SN_MAX_BANDS, bands);
+    SnBands b;
+    memset(&b, 0, sizeof(b));
+    for (int g = 0; g < bands; ++g) {
+        MQ_REQUIRE(w_orig[g] && u[g] && v[g], "mq_spectral_prep_bands: null pointer for band %d", g);
+        b.w[g] = w_orig[g]; b.u[g] = u[g]; b.v[g] = v[g];
+    }
+    const int fan = C * RS;
+    hipStream_t st = S(stream);
+    hipLaunchKernelGGL(sn_w_v_bands_kernel, dim3(K, bands), dim3(256), 0, st, b, K, fan, scratch);
+    int gx = ew_grid((int64_t)K * fan, 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(sn_scale_bands_kernel, dim3(gx, bands), dim3(256), 0, st, b, scratch, K, C, RS, w_krsc, w_crsk, sigma_out);
+    MQ_LAUNCH_CHECK("mq_spectral_prep_bands");
+    return 0;
+}
+
+extern "C" int mq_spectral_prep_bands_bwd(const float *dw_krsc, const float *const *w_orig, const float *const *u,
+                                          const float *const *v, const float *sigma, int bands, int K, int C, int RS,
+                                          float *const *dw_orig, float *scratch, mqStream stream)
+{
+    MQ_REQUIRE(dw_krsc && w_orig && u && v && sigma && dw_orig && scratch && K > 0 && C > 0 && RS > 0,
+               "mq_spectral_prep_bands_bwd: bad arguments");
+    MQ_REQUIRE(bands > 0 && bands <= MQ_SN_MAX_BANDS, "mq_spectral_prep_bands_bwd: 1 .. %d bands, got %d", MQ_SN_MAX_BANDS, bands);
+    SnBands b;
+    SnBandsOut o;
+    memset(&b, 0, sizeof(b));
+    memset(&o, 0, sizeof(o));
+    for (int g = 0; g < bands; ++g) {
+        MQ_REQUIRE(w_orig[g] && u[g] && v[g] && dw_orig[g], "mq_spectral_prep_bands_bwd: null pointer for band %d", g);
+        b.w[g] = w_orig[g]; b.u[g] = u[g]; b.v[g] = v[g]; o.dw[g] = dw_orig[g];
+    }
+    const int nparts = sn_bands_nparts(K, C, RS);
+    int gx = ew_grid((int64_t)K * C * RS, 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(sn_bwd_dot_bands_kernel, dim3(nparts, bands), dim3(256), 0, S(stream), dw_krsc, b, K, C, RS, scratch);
+    hipLaunchKernelGGL(sn_bwd_apply_bands_kernel, dim3(gx, bands), dim3(256), 0, S(stream), dw_krsc, b, sigma, scratch, nparts, K, C,
+                       RS, o);
+    MQ_LAUNCH_CHECK("mq_spectral_prep_bands_bwd");
+    return 0;
+}
 
 extern "C" int mq_weight_prep(int mode, const float *v, const float *g, int K, int C, int RS, float *w_krsc, float *w_crsk,
                               float *inv_norm, mqStream stream)

@@ -106,14 +106,25 @@ def _stacked(bands, get, need_crsk=True, power_iteration=False, detach=False):
 
 
 def _stack_now(bands, get, need_crsk, power_iteration, detach):
-    ws = [get(b).effective(need_crsk=need_crsk, power_iteration=power_iteration) for b in bands]
+    mods = [get(b) for b in bands]
+    if (1 < len(mods) <= ops.SN_MAX_BANDS and not power_iteration and all(m.flavour == "sn" for m in mods)
+            and not any(getattr(m, "_frozen", False) for m in mods) and mods[0].weight_orig.is_cuda
+            and all(tuple(m.weight_orig.shape) == tuple(mods[0].weight_orig.shape) for m in mods)):
+        # eval-mode band discriminators: spectral norm of the same layer of all bands in two launches, written stacked
+        w_krsc, w_crsk = ops.spectral_prep_bands([m.weight_orig for m in mods], [m.weight_u for m in mods],
+                                                 [m.weight_v for m in mods], need_crsk)
+        bias = torch.cat([m.bias for m in mods], dim=0)
+        if detach:
+            w_krsc, bias = w_krsc.detach(), bias.detach()
+        return w_krsc, w_crsk, bias
+    ws = [m.effective(need_crsk=need_crsk, power_iteration=power_iteration) for m in mods]
     if len(ws) == 1:
         w_krsc, w_crsk = ws[0]
-        bias = get(bands[0]).bias
+        bias = mods[0].bias
     else:
         w_krsc = torch.cat([w[0] for w in ws], dim=0)
         w_crsk = torch.cat([w[1] for w in ws], dim=0) if need_crsk else None
-        bias = torch.cat([get(b).bias for b in bands], dim=0)
+        bias = torch.cat([m.bias for m in mods], dim=0)
     if detach:
         w_krsc, bias = w_krsc.detach(), bias.detach()
     return w_krsc, w_crsk, bias

@@ -489,6 +489,7 @@ class ConvWinoFn(torch.autograd.Function):
         d = _desc_from_key(key)
         keep_v = w_krsc.requires_grad and 64 * _wino_tiles(d) * d.C <= WINO_KEEP_V_MIB << 20
         kept = [] if keep_v else None
+        x, w_krsc = x.contiguous(), w_krsc.contiguous()
         y = _wino_conv(d, x, w_krsc, bias, d.C, d.K, False, key, keep=kept)
         ctx.key = key
         ctx.w_shape = tuple(w_krsc.shape)
@@ -856,6 +857,61 @@ class SpectralPrepFn(torch.autograd.Function):
 
 def spectral_prep(w_orig, u, v, power_iteration, need_crsk=True):
     return SpectralPrepFn.apply(w_orig, u, v, power_iteration, need_crsk)
+
+
+SN_MAX_BANDS = 16
+
+
+def _ptr_array(tensors):
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+class SpectralPrepBandsFn(torch.autograd.Function):
+    """SpectralPrepFn (no power iteration) for the same layer of G band discriminators at once: G weight_orig tensors ->
+    stacked (G*K, RS, C) / (G*C, RS, K) filters with two launches instead of 3 G (and no concatenation), backward with two
+    instead of 2 G."""
+
+    @staticmethod
+    def forward(ctx, need_crsk, us, vs, *w_origs):
+        G = len(w_origs)
+        w0 = w_origs[0]
+        K, Cin = w0.shape[0], w0.shape[1]
+        RS = w0.numel() // (K * Cin)
+        for t in tuple(w_origs) + tuple(us) + tuple(vs):
+            if t.dtype != F32 or not t.is_contiguous() or t.device != w0.device:
+                raise _lib.MqganHipError("spectral_prep_bands: f32 contiguous tensors on one device expected")
+        if any(tuple(w.shape) != tuple(w0.shape) for w in w_origs):
+            raise _lib.MqganHipError("spectral_prep_bands: the bands' weights differ in shape")
+        w_krsc = _empty((G * K, RS, Cin), w0)
+        w_crsk = _empty((G * Cin, RS, K), w0) if need_crsk else None
+        sigma = _empty((G,), w0)
+        scratch = _empty((G * max(K, 256),), w0)
+        check(L().mq_spectral_prep_bands(_ptr_array(w_origs), _ptr_array(us), _ptr_array(vs), G, K, Cin, RS, fptr(w_krsc),
+                                         fptr(w_crsk, True), fptr(sigma), fptr(scratch), stream()), "mq_spectral_prep_bands")
+        ctx.dims = (G, K, Cin, RS)
+        ctx.uv = (tuple(us), tuple(vs))                 # buffers: untouched without power iteration
+        ctx.save_for_backward(sigma, *w_origs)
+        ctx.set_materialize_grads(False)
+        if w_crsk is not None:
+            ctx.mark_non_differentiable(w_crsk)
+        return w_krsc, w_crsk
+
+    @staticmethod
+    def backward(ctx, dw_krsc, _unused):
+        G, K, Cin, RS = ctx.dims
+        if dw_krsc is None:
+            return (None,) * (3 + G)
+        sigma, *w_origs = ctx.saved_tensors
+        us, vs = ctx.uv
+        dws = [torch.empty_like(w) for w in w_origs]
+        scratch = _empty((G * 256,), sigma)
+        check(L().mq_spectral_prep_bands_bwd(fptr(dw_krsc.contiguous()), _ptr_array(w_origs), _ptr_array(us), _ptr_array(vs), fptr(sigma),
+                                             G, K, Cin, RS, _ptr_array(dws), fptr(scratch), stream()), "mq_spectral_prep_bands_bwd")
+        return (None, None, None) + tuple(dws)
+
+
+def spectral_prep_bands(w_origs, us, vs, need_crsk=True):
+    return SpectralPrepBandsFn.apply(need_crsk, tuple(us), tuple(vs), *w_origs)
 
 
 # ----------------------------------------------------------------------------- pointwise

@@ -756,6 +756,35 @@ def test_pool_upcat_with_consumer_mask(env, dtype):
                           torch.zeros(1, 4, dtype=torch.uint8, device=DEV))
 
 
+@pytest.mark.parametrize("shape", [(32, 16, 3, 5), (48, 1, 3, 3), (1, 64, 3, 3)])
+def test_spectral_prep_bands_equals_per_band(env, shape):
+    """The eight band discriminators' spectral norm in two launches: stacked filters, sigma and weight gradients equal the
+    per-band preparation (only sigma's summation order differs: one 256-thread block instead of 1024)."""
+    ops = env
+    torch.manual_seed(17)
+    G = 8
+    K, Cin = shape[0], shape[1]
+    ws = [torch.randn(*shape, device=DEV).requires_grad_(True) for _ in range(G)]
+    us = [F.normalize(torch.randn(K, device=DEV), dim=0) for _ in range(G)]
+    vs = [F.normalize(torch.randn(Cin * shape[2] * shape[3], device=DEV), dim=0) for _ in range(G)]
+    ref = [ops.spectral_prep(w, u, v, False, True) for w, u, v in zip(ws, us, vs)]
+    wk_ref, wc_ref = torch.cat([r[0] for r in ref], 0), torch.cat([r[1] for r in ref], 0)
+    g = torch.randn_like(wk_ref)
+    (wk_ref * g).sum().backward()
+    want = [w.grad.clone() for w in ws]
+    for w in ws:
+        w.grad = None
+    wk, wc = ops.spectral_prep_bands(ws, us, vs, True)
+    assert tuple(wk.shape) == tuple(wk_ref.shape) and tuple(wc.shape) == tuple(wc_ref.shape)
+    close(wk, wk_ref, rtol=2e-6, atol=1e-7)
+    close(wc, wc_ref, rtol=2e-6, atol=1e-7)
+    (wk * g).sum().backward()
+    for w, gw in zip(ws, want):
+        close(w.grad, gw, rtol=2e-5, atol=2e-6)
+    wk2, wc2 = ops.spectral_prep_bands(ws, us, vs, False)
+    assert wc2 is None and torch.equal(wk2, wk)
+
+
 def test_arena_gather_one_launch(env):
     """FlatArena(gather=True): gradients left in their own tensors, copied into the arena by mq_multi_gather - aligned and
     misaligned sources, a 0-d parameter, a parameter without gradient (zeros), tails that are not multiples of 4."""
