@@ -81,3 +81,33 @@ def test_pad_collate_drops_failed_loads_and_pads_to_the_batch_crop():
     assert pad_collate_fn([None, None], crop_lens=32) == (None, None, None)
     x, lens, _ = pad_collate_fn(items, crop_lens=None)
     assert x.shape == (2, 50, 4) and lens.tolist() == [50, 20]
+
+
+def test_winograd_f2x2_3x3_identities():
+    """The algebra csrc/winograd.hip implements, in float64: forward Y = A^T[(G g G^T) . (B^T d B)]A equals the direct 3x3
+    correlation of a 4x4 tile; the weight gradient is G^T[(B^T d B) . (A dY A^T)]G; the input gradient is the same forward
+    form applied to dy with the filter rotated by 180 degrees (a 'same' convolution)."""
+    rng = np.random.default_rng(3)
+    Bt = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], float)
+    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], float)
+    At = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], float)
+    d, g, dY = rng.standard_normal((4, 4)), rng.standard_normal((3, 3)), rng.standard_normal((2, 2))
+    direct = np.array([[(d[a:a + 3, b:b + 3] * g).sum() for b in range(2)] for a in range(2)])
+    V, U = Bt @ d @ Bt.T, G @ g @ G.T
+    np.testing.assert_allclose(At @ (U * V) @ At.T, direct, rtol=1e-12, atol=1e-12)
+    # d(sum(Y * dY)) / dg
+    want_dg = np.array([[(d[r:r + 2, s:s + 2] * dY).sum() for s in range(3)] for r in range(3)])
+    Z = At.T @ dY @ At
+    np.testing.assert_allclose(G.T @ (V * Z) @ G, want_dg, rtol=1e-12, atol=1e-12)
+    # input gradient of a padded 'same' convolution = 'same' convolution of dy with the rotated filter
+    H = W = 6
+    x, w, gy = rng.standard_normal((H, W)), rng.standard_normal((3, 3)), rng.standard_normal((H, W))
+    xp = np.pad(x, 1)
+    dx = np.zeros_like(xp)
+    for h in range(H):
+        for ww in range(W):
+            dx[h:h + 3, ww:ww + 3] += gy[h, ww] * w
+    gp = np.pad(gy, 1)
+    rot = w[::-1, ::-1]
+    same = np.array([[(gp[h:h + 3, ww:ww + 3] * rot).sum() for ww in range(W)] for h in range(H)])
+    np.testing.assert_allclose(dx[1:-1, 1:-1], same, rtol=1e-12, atol=1e-12)
