@@ -242,6 +242,12 @@ def roofline_of(timer, steps, elapsed, step_peak):
             "conv_share_of_step_time": total_conv_ms / 1e3 / elapsed}
 
 
+def _trace(rank, msg):
+    """MQGAN_BENCH_TRACE=1: progress lines on stderr (where does a multi-rank run stop?)."""
+    if os.environ.get("MQGAN_BENCH_TRACE") == "1":
+        print(f"[bench rank {rank}] {time.strftime('%H:%M:%S')} {msg}", file=sys.stderr, flush=True)
+
+
 def timed_run(cfg, precision, B, T, steps, warmup, device, world, rank):
     """W untimed + K timed optimisation steps of one configuration; returns the trainer, inputs, kernel timer, wall
     seconds of the timed region (max over ranks) and the last step's losses."""
@@ -251,6 +257,7 @@ def timed_run(cfg, precision, B, T, steps, warmup, device, world, rank):
     cfg = copy.deepcopy(cfg)
     cfg["training"]["precision"] = precision
     mel = cfg["model"]["mel_channels"]
+    _trace(rank, "building the trainer")
     tr = Trainer(cfg, device=device, build_data=False)
     tr.generator.train()
     tr.patch_discriminator.train()
@@ -259,7 +266,11 @@ def timed_run(cfg, precision, B, T, steps, warmup, device, world, rank):
     batches = synthetic_batches(B, T, mel, 4, device, rank)
     lens = torch.full((B,), T, dtype=torch.int32, device=device)
     for i in range(warmup):
+        _trace(rank, f"warm-up step {i}")
         tr.train_step(batches[i % len(batches)], lens)
+        if os.environ.get("MQGAN_BENCH_TRACE") == "1":
+            torch.cuda.synchronize()
+    _trace(rank, "warm-up done")
     timer = ops.KernelTimer()
     ops.TIMER = timer
     torch.cuda.synchronize()
@@ -319,6 +330,9 @@ def main():
     args = ap.parse_args()
 
     import __graft_entry__ as ge
+    if os.environ.get("MQGAN_BENCH_TRACE") == "1":       # a stuck rank prints the Python stacks of all its threads
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get("MQGAN_BENCH_TRACE_AFTER", "150")), repeat=False, file=sys.stderr)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

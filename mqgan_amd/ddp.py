@@ -16,8 +16,13 @@ Design (MI355X-first, not a port of torch DDP):
 """
 from typing import Iterable, List
 
+import os
+
 import torch
 import torch.distributed as dist
+
+_TRACE = os.environ.get("MQGAN_DDP_TRACE") == "1"      # one stderr line per bucket all-reduce (which rank launches what, when)
+_BLOCKING = os.environ.get("MQGAN_DDP_BLOCKING") == "1"  # debugging: blocking bucket all-reduces instead of asynchronous ones
 
 
 class FlatArena:
@@ -166,6 +171,10 @@ class GradReducer:
         self._handles = []
         self._hooks = []
         self.enabled = self.world > 1 and self.comm is None
+        # gloo with device tensors (the one-GPU rehearsal of the multi-rank path) hangs with several asynchronous all-reduces
+        # of device tensors in flight on four ranks (two are fine; launch order verified identical on all ranks): there the
+        # buckets go out blocking, from the same hooks.  RCCL ("nccl") and gloo on host tensors keep the asynchronous path.
+        self._blocking = _BLOCKING or (self.enabled and arena.flat_grad.is_cuda and dist.get_backend(process_group) == "gloo")
         if self.enabled:
             for p in arena.params:
                 if p.requires_grad:
@@ -187,7 +196,14 @@ class GradReducer:
     def _launch(self, b):
         s, e, _ = self.buckets[b]
         self._launched[b] = True
+        if _TRACE:
+            import sys, threading
+            print(f"[ddp rank {dist.get_rank(self.pg)}] launch bucket {b} of {len(self.buckets)} [{s}:{e}) from "
+                  f"{threading.current_thread().name}", file=sys.stderr, flush=True)
         self.arena.gather(self.bucket_members[b])      # gather mode: the bucket's gradients move into the arena now
+        if self._blocking:
+            dist.all_reduce(self.arena.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.pg)
+            return
         self._handles.append(dist.all_reduce(self.arena.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def _on_grad(self, p):
@@ -214,8 +230,11 @@ class GradReducer:
         for b in range(len(self.buckets)):
             if not self._launched[b]:
                 self._launch(b)
-        for h in self._handles:
+        for i, h in enumerate(self._handles):
             h.wait()
+            if _TRACE:
+                import sys
+                print(f"[ddp rank {dist.get_rank(self.pg)}] handle {i} of {len(self._handles)} done", file=sys.stderr, flush=True)
         self._handles = []
         if self.average:
             self.arena.flat_grad.mul_(1.0 / self.world)
