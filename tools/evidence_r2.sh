@@ -8,8 +8,21 @@ cd /tmp && export TMPDIR=/tmp
 echo "== kernel stats, config 2 f32"; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c2 -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-vq --no-alt --no-configs > $O/c2_under_rocprof.json 2> $O/c2.err || { echo FAILED c2; tail -3 $O/c2.err; exit 1; }
 echo "== kernel stats, config 3 bf16"; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3 -- python3 $R/bench.py --config hifimusic --precision bf16 --steps 3 --warmup 2 --no-cpu-baseline --no-vq --no-alt > $O/c3_under_rocprof.json 2> $O/c3.err || { echo FAILED c3; tail -3 $O/c3.err; exit 1; }
 echo "== pmc traffic"; bash $R/tools/pmc_traffic.sh 2>&1 | tee $O/pmc_traffic.log || { echo FAILED traffic; tail -5 $O/pmc_traffic.log; exit 1; }
-cp $R/gpurun_out/pmc_traffic/traffic.json $O/pmc_traffic.json
+echo "== pmc traffic, config 3 bf16"; bash $R/tools/pmc_traffic.sh c3 --config hifimusic --precision bf16 2>&1 | tee $O/pmc_traffic_c3.log || { echo FAILED traffic c3; exit 1; }
+# one file for bench.py: config-2 entries as they are, config-3 kernels added with a "run" tag (profiles/r2_pmc_traffic.json)
+python3 - <<PY
+import json
+a = json.load(open("$R/gpurun_out/pmc_traffic/traffic.json"))
+b = json.load(open("$R/gpurun_out/pmc_traffic_c3/traffic.json"))
+assert a["_build"] == b["_build"]
+for k, v in b.items():
+    if not k.startswith("_") and k not in a:
+        a[k] = dict(v, run="config 3 (hifimusic, bf16)")
+a["_note"] = "per-launch averages; kernels without 'run' were measured in the config-2 f32 bench, those with 'run' in the named pass"
+json.dump(a, open("$O/pmc_traffic.json", "w"), indent=1, sort_keys=True)
+PY
 echo "== counters"; bash $R/tools/pmc_h2.sh h2 h2_micro.py "c2 mid" "c3 mid" --old 2>&1 | tee $O/counters_h2.log && bash $R/tools/pmc_h2.sh f32 f32_micro.py 2>&1 | tee $O/counters_f32.log || { echo FAILED counters; tail -5 $O/counters_h2.log $O/counters_f32.log; exit 1; }
 cp $R/gpurun_out/pmc_h2.json $R/gpurun_out/pmc_f32.json $O/
-tail -4 $O/counters_h2.log $O/counters_f32.log
+echo "== single-layer timings"; cd $R && python3 tools/h2_micro.py --old > $O/h2_micro.txt 2>&1 && python3 tools/f32_micro.py > $O/f32_micro.txt 2>&1 && python3 tools/wino_micro.py > $O/wino_micro.txt 2>&1 && python3 tools/gate_micro.py > $O/gate_micro.txt 2>&1 || { echo FAILED micro; exit 1; }
+tail -n 4 $O/counters_h2.log $O/counters_f32.log
 echo DONE
