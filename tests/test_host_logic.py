@@ -111,3 +111,28 @@ def test_winograd_f2x2_3x3_identities():
     rot = w[::-1, ::-1]
     same = np.array([[(gp[h:h + 3, ww:ww + 3] * rot).sum() for ww in range(W)] for h in range(H)])
     np.testing.assert_allclose(dx[1:-1, 1:-1], same, rtol=1e-12, atol=1e-12)
+
+
+def test_bench_traffic_lookup_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
+    """bench.pmc_traffic: bytes per launch only from a PMC pass taken on the kernel sources that are being run (hash of the
+    conv kernel files); another build reads as None with the file named as stale; unknown kernels read as None."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    bid = bench.kernel_build_id()
+    assert len(bid) == 16 and bid == bench.kernel_build_id()
+    (tmp_path / "profiles").mkdir()
+    f = tmp_path / "profiles" / "r9_pmc_traffic.json"
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_build_id", lambda: bid)
+    f.write_text(json.dumps({"_build": bid, "k<1>": {"fetch_bytes_per_launch": 10.0, "write_bytes_per_launch": 5.0, "launches": 3}}))
+    assert bench.pmc_traffic("k<1>") == (15.0, os.path.join("profiles", "r9_pmc_traffic.json"))
+    assert bench.pmc_traffic("other") == (None, None)
+    f.write_text(json.dumps({"_build": "0" * 16, "k<1>": {"fetch_bytes_per_launch": 10.0, "write_bytes_per_launch": 5.0, "launches": 3}}))
+    t, src = bench.pmc_traffic("k<1>")
+    assert t is None and "stale" in src
+    assert bench.peak_of("conv_h2_kernel<3, 2, 64, false, true>") == bench.PEAK_BF16_MFMA_TFLOPS
+    assert bench.peak_of("conv_nt_kernel<128, false, 3>") == bench.PEAK_F32_MFMA_TFLOPS
