@@ -248,7 +248,32 @@ def _trace(rank, msg):
         print(f"[bench rank {rank}] {time.strftime('%H:%M:%S')} {msg}", file=sys.stderr, flush=True)
 
 
-def timed_run(cfg, precision, B, T, steps, warmup, device, world, rank):
+def host_ms_per_step(tr, batches, lens, samples=3):
+    """CPU time the host needs to ISSUE one optimisation step (Python + ctypes launches + hooks + collectives), measured from
+    an idle stream to the return of train_step with the stream left unsynchronised: as long as this stays below the GPU's
+    ms_per_step the stream never runs dry.  Median of `samples`; the steps run after the timed region."""
+    out = []
+    for i in range(samples):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tr.train_step(batches[i % len(batches)], lens)
+        out.append((time.perf_counter() - t0) * 1e3)
+        torch.cuda.synchronize()
+    return sorted(out)[len(out) // 2]
+
+
+def collectives_of(tr, world, forced):
+    """What the step exchanged (rank 0's view)."""
+    if not (world > 1 or forced):
+        return None
+    return {"backend": dist.get_backend(), "ranks_counted_by_all_reduce": world, "forced_on_one_rank": bool(forced and world == 1),
+            "gradient_buckets_per_step": len(tr.reducer_g.buckets) + len(tr.reducer_d.buckets),
+            "bucket_MiB": [round((e - s) * 4 / 2**20, 1) for red in (tr.reducer_d, tr.reducer_g) for (s, e, _) in red.buckets],
+            "asynchronous": not tr.reducer_g._blocking, "host_drains_stream_before_gloo_device_collective": tr.reducer_g._drain_first,
+            "loss_sum_all_reduces_total": getattr(tr.comm, "calls", None)}
+
+
+def timed_run(cfg, precision, B, T, steps, warmup, device, world, rank, force=False):
     """W untimed + K timed optimisation steps of one configuration; returns the trainer, inputs, kernel timer, wall
     seconds of the timed region (max over ranks) and the last step's losses."""
     import copy
@@ -258,7 +283,7 @@ def timed_run(cfg, precision, B, T, steps, warmup, device, world, rank):
     cfg["training"]["precision"] = precision
     mel = cfg["model"]["mel_channels"]
     _trace(rank, "building the trainer")
-    tr = Trainer(cfg, device=device, build_data=False)
+    tr = Trainer(cfg, device=device, build_data=False, force_collectives=force)
     tr.generator.train()
     tr.patch_discriminator.train()
     tr.multibin_discriminator.train()
@@ -312,6 +337,26 @@ def config3_line(device):
     return out
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher in the environment: start the N ranks ourselves (one process per GPU,
+    torch.distributed.run on 127.0.0.1) as a CHILD of this process - which has made no GPU call - pass rank 0's JSON line
+    through on stdout and exit with the child's code."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MQGAN_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -327,31 +372,107 @@ def main():
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary fp32x3 / bf16 engine timings")
     ap.add_argument("--no-configs", action="store_true", help="skip the 3-step BASELINE config-3 (hifimusic, bf16) line")
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="issue every data-parallel collective (gradient buckets on RCCL's side stream, loss sums) even with one "
+                         "rank: the N = 1 cost of the N > 1 code path")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous rehearsal: start the ranks, count them with an all-reduce, print the line with "
+                         "value null - no kernels (runs on a box without GPUs when MQGAN_BENCH_BACKEND=gloo)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    launched = all(k in os.environ for k in ("RANK", "WORLD_SIZE"))
+    if not launched and args.gpus > 1:
+        # no launcher: this process becomes one (before anything here touches a GPU) and relays the ranks' output
+        backend = os.environ.get("MQGAN_BENCH_BACKEND", "nccl")
+        if backend == "nccl" and os.environ.get("MQGAN_BENCH_SHARE_GPU") != "1" and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} HIP device(s) are visible")
+        raise SystemExit(self_launch(args.gpus))
 
     import __graft_entry__ as ge
-    if os.environ.get("MQGAN_BENCH_TRACE") == "1":       # a stuck rank prints the Python stacks of all its threads
+    if os.environ.get("MQGAN_BENCH_TRACE") == "1":
+        # a stuck rank leaves the Python stacks of all its threads and the state / kernel wait channel of every OS thread
+        # (the collective library's workers have no Python frames) in MQGAN_BENCH_TRACE_DIR
         import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ.get("MQGAN_BENCH_TRACE_AFTER", "150")), repeat=False, file=sys.stderr)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+        import threading
+        after = int(os.environ.get("MQGAN_BENCH_TRACE_AFTER", "150"))
+        faulthandler.dump_traceback_later(after, repeat=False, file=sys.stderr)
+
+        def _dump():
+            time.sleep(after)
+            d = os.environ.get("MQGAN_BENCH_TRACE_DIR", os.path.join(ROOT, "gpurun_out"))
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, f"stuck_rank{os.environ.get('RANK', '0')}.txt"), "w") as f:
+                f.write(f"bench.py still running after {after} s\n== OS threads ==\n")
+                for tid in sorted(os.listdir("/proc/self/task"), key=int):
+                    def rd(n):
+                        try:
+                            with open(f"/proc/self/task/{tid}/{n}") as fh:
+                                return fh.read().strip()
+                        except OSError:
+                            return "?"
+                    st = rd("stat")
+                    f.write(f"tid {tid} {rd('comm'):<18} state {st.rsplit(')', 1)[-1].split()[0] if ')' in st else '?'} wchan {rd('wchan')}\n")
+                f.write("== Python stacks ==\n")
+                f.flush()
+                faulthandler.dump_traceback(file=f, all_threads=True)
+        threading.Thread(target=_dump, daemon=True, name="bench-trace").start()
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if rank == 0:
-        ge.build()
+    if world_env != args.gpus:
+        # never a silent run on another number of GPUs than the one asked for
+        raise SystemExit(f"--gpus {args.gpus} but the launcher set WORLD_SIZE={world_env}")
     # MQGAN_BENCH_SHARE_GPU=1 (rehearsal only): all ranks on device 0 with the gloo backend, to exercise the N > 1
     # code path on a one-GPU box; RCCL needs one device per rank.
     share = os.environ.get("MQGAN_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("MQGAN_BENCH_BACKEND", "gloo" if share else "nccl")
     if share:
         local = 0
+    use_pg = world_env > 1 or args.force_collectives
+    if use_pg and not launched:                      # one forced rank without a launcher: rendezvous with ourselves
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    if args.dry_run:
+        # rendezvous + rank count only: what the driver's `--gpus N` command has to get right before any kernel runs
+        world = 1
+        if use_pg:
+            if backend == "nccl":
+                torch.cuda.set_device(local)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+                ones = torch.ones(1, device=torch.device("cuda", local))
+            else:
+                dist.init_process_group(backend)
+                ones = torch.ones(1)
+            dist.all_reduce(ones)
+            world = int(ones.item())
+            if world != dist.get_world_size():
+                raise SystemExit(f"all-reduce of ones counted {world} ranks, the process group says {dist.get_world_size()}")
+        if rank == 0:
+            print(json.dumps({"metric": METRIC, "value": None, "unit": "mel-frames/s", "n_gpus": world, "steps": 0, "warmup": 0,
+                              "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                              "dry_run": True, "backend": backend if use_pg else None,
+                              "self_launched": os.environ.get("MQGAN_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+        if use_pg:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    if rank == 0:
+        ge.build()
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
-        if share:
-            dist.init_process_group("gloo")
-        else:
+    world = 1
+    if use_pg:
+        if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+        # the rank count the line reports is the one the collective library saw, not the flag
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)
+        world = int(ones.item())
+        if world != dist.get_world_size() or world != args.gpus:
+            raise SystemExit(f"all-reduce of ones counted {world} ranks; process group {dist.get_world_size()}, --gpus {args.gpus}")
         dist.barrier()
     from mqgan_amd import _lib, ops
     from mqgan_amd.train import Trainer
@@ -361,7 +482,9 @@ def main():
     B = args.batch or cfg["data"]["batch_size"]
     T = args.frames or cfg["data"]["crop_len"]
     mel = cfg["model"]["mel_channels"]
-    tr, batches, lens, timer, elapsed, last = timed_run(cfg, args.precision, B, T, args.steps, args.warmup, device, world, rank)
+    tr, batches, lens, timer, elapsed, last = timed_run(cfg, args.precision, B, T, args.steps, args.warmup, device, world, rank,
+                                                        force=args.force_collectives)
+    host_ms = host_ms_per_step(tr, batches, lens)
     finite = all(np.isfinite(float(v)) for v in last.values())
 
     if rank == 0:
@@ -381,7 +504,8 @@ def main():
                                               "f32 transforms, products on the same MFMA engine, f32 accumulation "
                                               "(MQGAN_WINO_MINC=0 switches it off)") if args.precision != "bf16"
                            else "implicit GEMM on bf16-storage kernels"},
-                "losses_finite": bool(finite), "roofline": roof}
+                "losses_finite": bool(finite), "roofline": roof,
+                "host_ms_per_step": host_ms, "collectives": collectives_of(tr, world, args.force_collectives)}
         del tr
         torch.cuda.empty_cache()
         if world == 1 and not args.no_alt and args.precision == "fp32":
@@ -402,7 +526,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

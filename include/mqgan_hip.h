@@ -432,6 +432,11 @@ int mq_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg
  * {source address or 0 (zeros), destination element offset (multiple of 4), elements, first block}, rows ordered by
  * first block; a block covers 2048 elements; total_blocks = sum over rows of ceil(elements / 2048). */
 int mq_multi_gather(const int64_t *table_dev, int n_tensors, int64_t total_blocks, float *dst, mqStream stream);
+/* The same fill from a HOST table, int64 [n_tensors][3 used of 4]: {source address or 0, destination element offset
+ * (multiple of 4), elements > 0, ignored}.  The rows travel by value in the kernel arguments (120 per launch), so the
+ * table is consumed before the call returns: the caller may rewrite it immediately, however far the host runs ahead of
+ * the stream (what the data-parallel gradient exchange uses; train.py:140-197 makes shapes, hence addresses, vary per step). */
+int mq_multi_gather_args(const int64_t *table_host, int n_tensors, float *dst, mqStream stream);
 
 #ifdef __cplusplus
 }

@@ -143,6 +143,7 @@ SIGNATURES = {
     "mq_wino_wgrad_inverse": (_I, [_P, _I, _I, _P, _P]),
     "mq_sumsq": (_I, [_P, _L, _P, _P, _P]),
     "mq_multi_gather": (_I, [_P, _I, _L, _P, _P]),
+    "mq_multi_gather_args": (_I, [_P, _I, _P, _P]),
     "mq_adam_step": (_I, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _I, _P, _F, _F, _P]),
 }
 

@@ -85,9 +85,69 @@ __global__ __launch_bounds__(256) void multi_gather_kernel(const int64_t *__rest
     }
 }
 
+// The same fill with the table passed BY VALUE in the kernel arguments: the launch captures the rows, so the caller's host
+// table may be reused the moment the call returns (no staging buffer whose reuse would have to be ordered against the
+// stream).  A launch carries up to MG_ARG_ROWS rows; the block -> row search runs on scalar loads from the kernarg segment.
+constexpr int MG_ARG_ROWS = 120;                        // 120 rows x 32 B + dst + count < the 4 KiB kernarg limit
+struct MgArgTable {
+    int64_t row[MG_ARG_ROWS][4];
+};
+__global__ __launch_bounds__(256) void multi_gather_args_kernel(const MgArgTable tab, int nt, float *__restrict__ dst)
+{
+    const int64_t b = blockIdx.x;
+    int lo = 0, hi = nt - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab.row[mid][3] <= b) lo = mid; else hi = mid - 1;
+    }
+    const float *src = reinterpret_cast<const float *>(tab.row[lo][0]);
+    float *d = dst + tab.row[lo][1];
+    const int64_t n = tab.row[lo][2];
+    const int64_t base = (b - tab.row[lo][3]) * MG_CHUNK;
+    const bool vec = (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int64_t e = base + h * 1024 + threadIdx.x * 4;
+        if (e + 4 <= n && vec) {
+            const float4 v = src ? *reinterpret_cast<const float4 *>(src + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(d + e) = v;
+        } else {
+            for (int k = 0; k < 4; ++k)
+                if (e + k < n) d[e + k] = src ? src[e + k] : 0.f;
+        }
+    }
+}
+
 }  // namespace mq
 
 using namespace mq;
+
+extern "C" int mq_multi_gather_args(const int64_t *table_host, int n_tensors, float *dst, mqStream stream)
+{
+    MQ_REQUIRE(table_host && dst && n_tensors > 0, "mq_multi_gather_args: bad arguments");
+    MQ_REQUIRE((uintptr_t)dst % 16 == 0, "mq_multi_gather_args: dst must be 16-byte aligned");
+    for (int i = 0; i < n_tensors; ++i) {
+        const int64_t *r = table_host + 4 * i;
+        MQ_REQUIRE(r[1] >= 0 && (r[1] & 3) == 0 && r[2] > 0, "mq_multi_gather_args: row with a negative / unaligned offset or no elements");
+    }
+    for (int first = 0; first < n_tensors; first += MG_ARG_ROWS) {
+        const int nt = n_tensors - first < MG_ARG_ROWS ? n_tensors - first : MG_ARG_ROWS;
+        MgArgTable t;
+        int64_t blocks = 0;
+        for (int i = 0; i < nt; ++i) {
+            const int64_t *r = table_host + 4 * (first + i);
+            t.row[i][0] = r[0];
+            t.row[i][1] = r[1];
+            t.row[i][2] = r[2];
+            t.row[i][3] = blocks;                      // first block of the row inside THIS launch
+            blocks += (r[2] + MG_CHUNK - 1) / MG_CHUNK;
+        }
+        MQ_REQUIRE(blocks < INT32_MAX, "mq_multi_gather_args: too many elements for one launch");
+        hipLaunchKernelGGL(multi_gather_args_kernel, dim3((unsigned)blocks), dim3(256), 0, S(stream), t, nt, dst);
+    }
+    MQ_LAUNCH_CHECK("mq_multi_gather_args");
+    return 0;
+}
 
 extern "C" int mq_multi_gather(const int64_t *table_dev, int n_tensors, int64_t total_blocks, float *dst, mqStream stream)
 {

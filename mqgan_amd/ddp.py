@@ -16,6 +16,7 @@ Design (MI355X-first, not a port of torch DDP):
 """
 from typing import Iterable, List
 
+import ctypes as C
 import os
 
 import torch
@@ -23,6 +24,7 @@ import torch.distributed as dist
 
 _TRACE = os.environ.get("MQGAN_DDP_TRACE") == "1"      # one stderr line per bucket all-reduce (which rank launches what, when)
 _BLOCKING = os.environ.get("MQGAN_DDP_BLOCKING") == "1"  # debugging: blocking bucket all-reduces instead of asynchronous ones
+_ASYNC = os.environ.get("MQGAN_DDP_ASYNC") == "1"        # debugging: no host drain in front of gloo device collectives (reproduces the r2 hang)
 
 
 class FlatArena:
@@ -61,7 +63,6 @@ class FlatArena:
                 p.data = view
                 p.grad = None if self.gather_mode else self.flat_grad[o:o + p.numel()].view_as(p)
         self._gathered = [False] * len(self.params)
-        self._ring = None              # (pinned int64 table ring, device ring, rows, cursor) of the gather launches
 
     def zero_grad(self):
         if self.gather_mode:
@@ -95,19 +96,11 @@ class FlatArena:
                     else:
                         self.flat_grad[o:o + p.numel()].copy_(p.grad.reshape(-1))
 
-    def _gather_hip(self, todo):
+    def _gather_table(self, todo):
+        """Host rows {source address or 0, arena offset, elements, 0} of the gradients to move (pure host logic)."""
         from . import _lib
-        from .ops import L, check, ptr, stream
-        n = len(todo)
-        if self._ring is None:
-            rows = 4 * len(self.params)
-            self._ring = [torch.empty((rows, 4), dtype=torch.int64).pin_memory(),
-                          torch.empty((rows, 4), dtype=torch.int64, device=self.flat_grad.device), rows, 0]
-        host, dev, rows, cur = self._ring
-        if cur + n > rows:
-            cur = 0
         base = self.flat_grad.data_ptr()
-        table, blocks = [], 0
+        table = []
         for i in todo:
             p, o = self.params[i], self.offsets[i]
             g = p.grad
@@ -121,15 +114,20 @@ class FlatArena:
                 src = g.data_ptr()
             if src == base + 4 * o:                             # already an arena view (legacy holders): nothing to move
                 continue
-            table.append((src, o, p.numel(), blocks))
-            blocks += (p.numel() + self.MG_CHUNK - 1) // self.MG_CHUNK
+            table.append((src, o, p.numel(), 0))
+        return table
+
+    def _gather_hip(self, todo):
+        # The rows go to the kernel BY VALUE (mq_multi_gather_args copies them into the launch's arguments before it
+        # returns), so nothing the host does later - however many steps it runs ahead of the stream, whatever addresses
+        # the allocator hands out for the next step's gradients - can change what an enqueued launch reads.  (r2 staged
+        # the table in a pinned ring that the host could wrap before the copy had executed.)
+        from .ops import L, check, ptr, stream
+        table = self._gather_table(todo)
         if not table:
             return
-        k = len(table)
-        host[cur:cur + k] = torch.tensor(table, dtype=torch.int64)
-        dev[cur:cur + k].copy_(host[cur:cur + k], non_blocking=True)
-        check(L().mq_multi_gather(ptr(dev[cur:cur + k]), k, blocks, ptr(self.flat_grad), stream()), "mq_multi_gather")
-        self._ring[3] = cur + k
+        rows = (C.c_int64 * (4 * len(table)))(*[v for r in table for v in r])
+        check(L().mq_multi_gather_args(rows, len(table), ptr(self.flat_grad), stream()), "mq_multi_gather_args")
 
     def rebind(self):
         """After load_state_dict / .to(): make sure parameters still alias the arena."""
@@ -142,7 +140,10 @@ class FlatArena:
 
 
 class GradReducer:
-    def __init__(self, arena: FlatArena, process_group=None, bucket_bytes: int = 32 << 20, average: bool = False, comm=None):
+    def __init__(self, arena: FlatArena, process_group=None, bucket_bytes: int = 32 << 20, average: bool = False, comm=None,
+                 force: bool = False):
+        """``force``: hooks, per-bucket arena fill and asynchronous all-reduces even in a process group of ONE rank (the sum
+        is then the identity) - lets a one-GPU box execute the production RCCL path end to end."""
         self.arena = arena
         self.pg = process_group
         # ``comm``: a non-torch.distributed communicator (mqgan_amd.comm.Comm with world > 1, e.g. a test double): the whole
@@ -170,11 +171,16 @@ class GradReducer:
         self._launched = [False] * len(self.buckets)
         self._handles = []
         self._hooks = []
-        self.enabled = self.world > 1 and self.comm is None
-        # gloo with device tensors (the one-GPU rehearsal of the multi-rank path) hangs with several asynchronous all-reduces
-        # of device tensors in flight on four ranks (two are fine; launch order verified identical on all ranks): there the
-        # buckets go out blocking, from the same hooks.  RCCL ("nccl") and gloo on host tensors keep the asynchronous path.
-        self._blocking = _BLOCKING or (self.enabled and arena.flat_grad.is_cuda and dist.get_backend(process_group) == "gloo")
+        self.enabled = (self.world > 1 or (force and dist.is_initialized())) and self.comm is None
+        # gloo with DEVICE tensors (only the one-GPU rehearsal of the multi-rank path uses it): ProcessGroupGloo stages every
+        # collective through a private HIGH-PRIORITY stream that waits ON THE DEVICE for the compute stream.  With several
+        # ranks sharing one GPU those waiting high-priority queues starve the normal-priority compute queues they wait for
+        # (stuck-rank dumps in profiles/r3_dp4_hang/, tools/gloo_async_probe.py).  There the host drains
+        # the compute stream before it hands a bucket to gloo, so no queue ever waits on the device; the collectives stay
+        # asynchronous, issued from the hooks and waited in finish() exactly as under RCCL (whose stream has normal priority
+        # and whose ranks own their GPU).
+        self._drain_first = (not _ASYNC and self.enabled and arena.flat_grad.is_cuda and dist.get_backend(process_group) == "gloo")
+        self._blocking = _BLOCKING
         if self.enabled:
             for p in arena.params:
                 if p.requires_grad:
@@ -201,6 +207,8 @@ class GradReducer:
             print(f"[ddp rank {dist.get_rank(self.pg)}] launch bucket {b} of {len(self.buckets)} [{s}:{e}) from "
                   f"{threading.current_thread().name}", file=sys.stderr, flush=True)
         self.arena.gather(self.bucket_members[b])      # gather mode: the bucket's gradients move into the arena now
+        if self._drain_first:
+            torch.cuda.current_stream().synchronize()
         if self._blocking:
             dist.all_reduce(self.arena.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.pg)
             return

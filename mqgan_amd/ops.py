@@ -1398,7 +1398,7 @@ def codebook_ema_update(x, idx, cluster_size, embed_sum, codebook, decay=0.99, e
 # kernels leave numerators and counts in a small device buffer, ``comm.all_reduce_sum`` (identity for one process) sums it
 # over the ranks, and the *_final / backward kernels work from the reduced buffer (see include/mqgan_hip.h).
 def _reduce(comm, buf):
-    if comm is not None and comm.world > 1:
+    if comm is not None and comm.active:
         comm.all_reduce_sum(buf)
     return buf
 

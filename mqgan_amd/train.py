@@ -167,9 +167,16 @@ class WarmupLR:
 
 # ----------------------------------------------------------------------------- trainer
 class Trainer:
-    def __init__(self, config, device=None, build_data=True, log_fn=None, comm: Comm = None):
+    def __init__(self, config, device=None, build_data=True, log_fn=None, comm: Comm = None, force_collectives: bool = False):
         self.config = config
-        # data-parallel communicator: torch.distributed when a process group is up, else the single-process identity
+        # data-parallel communicator: torch.distributed when a process group is up, else the single-process identity.
+        # force_collectives (needs an initialised process group): every collective of the data-parallel step is issued
+        # even with one rank - the gradient hooks, bucket all-reduces on the group's side stream and the loss-sum
+        # all-reduces then run exactly as with eight ranks (tests/test_gpu_rccl.py, bench.py --force-collectives)
+        if force_collectives and comm is None:
+            from .comm import TorchComm
+            comm = TorchComm(force=True)
+        self.force_collectives = bool(force_collectives)
         self.comm = comm if comm is not None else default_comm()
         self.rank, self.world = self.comm.rank, self.comm.world
         self.device = torch.device(device) if device is not None else self._get_device()
@@ -192,8 +199,8 @@ class Trainer:
         broadcast_arena(self.arena_d)
         self.optimizer_g, self.optimizer_d = self._init_optimizers()
         self.scheduler_g = WarmupLR(self.optimizer_g, config["training"]["warmup_steps"])
-        self.reducer_g = GradReducer(self.arena_g, comm=self.comm)
-        self.reducer_d = GradReducer(self.arena_d, comm=self.comm)
+        self.reducer_g = GradReducer(self.arena_g, comm=self.comm, force=self.force_collectives)
+        self.reducer_d = GradReducer(self.arena_d, comm=self.comm, force=self.force_collectives)
         self.gan_loss = LSGANLoss(comm=self.comm).to(self.device)   # ONE instance for all nine discriminators (train.py:216)
         # The reference picks bf16 autocast whenever the GPU supports it (train.py:220, 523); here the engine is an
         # explicit knob: training.precision = "fp32" (default; the 1e-4 parity path, BASELINE config 2), "fp32x3" or "bf16"

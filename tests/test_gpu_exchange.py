@@ -1,0 +1,198 @@
+"""-m gpu: the gradient exchange as it runs in production, as far as ONE GPU can execute it.
+
+  * the RCCL path itself (backend "nccl", a group of one rank, every collective force-issued): post-accumulate hooks ->
+    per-bucket mq_multi_gather_args -> asynchronous all-reduce on the process group's side stream -> wait -> clip / Adam,
+    plus the loss-sum all-reduces - bit-identical to the step without any collective;
+  * the gradient-arena fill with the host running far ahead of the stream (the r2 race: a pinned staging ring the host could
+    wrap before the device had read it; now the rows travel by value in the kernel arguments);
+  * twelve unsynchronised optimisation steps with a different crop length per step (reference train.py:140-197: the
+    allocator hands out different gradient addresses every step) against the same steps synchronised one by one.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import DEV, npz_state_dict  # noqa: E402
+from test_oracle_trainstep import TINY_CFG  # noqa: E402
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    import __graft_entry__ as g
+    g.build()
+    assert torch.cuda.is_available()
+
+
+def _trainer(g, **kw):
+    from mqgan_amd.train import Trainer
+    cfg = {"model": TINY_CFG["model"], "training": dict(TINY_CFG["training"], use_fm_loss=True, pretrained=None, precision="fp32")}
+    tr = Trainer(cfg, device=DEV, build_data=False, **kw)
+    tr.generator.load_state_dict(npz_state_dict(g, "g0/"), strict=True)
+    tr.patch_discriminator.load_state_dict(npz_state_dict(g, "p0/"), strict=True)
+    tr.multibin_discriminator.load_state_dict(npz_state_dict(g, "m0/"), strict=True)
+    tr.arena_g.rebind()
+    tr.arena_d.rebind()
+    tr.generator.eval()                       # no dropout: the step is a deterministic function of the batch
+    tr.patch_discriminator.train()
+    tr.multibin_discriminator.train()
+    tr.epoch = 1
+    return tr
+
+
+def _batch(T, first, B=3, mel=16):
+    from mqgan_amd.train import synthetic_mel
+    x = torch.from_numpy(np.stack([synthetic_mel(T, mel, first + b) for b in range(B)])).to(DEV)
+    lens = torch.tensor([T, max(8, T - 9), max(8, T // 2 + 1)][:B], dtype=torch.int32, device=DEV)
+    for b in range(B):
+        x[b, int(lens[b]):] = 0.0
+    return x, lens
+
+
+# ----------------------------------------------------------------------------------------- RCCL, one rank
+def _rccl_rank(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        import __graft_entry__ as ge
+        ge.build()
+        from mqgan_amd import ddp
+        from mqgan_amd.comm import TorchComm
+        g = load_golden("g7_trainstep.npz")
+        ones = torch.ones(4, device=DEV)
+        dist.all_reduce(ones)
+        assert dist.get_backend() == "nccl" and float(ones.sum()) == 4.0
+        Ts = [40, 24, 48, 32]
+        batches = [_batch(T, 700 + 10 * i) for i, T in enumerate(Ts)]
+
+        def run(force):
+            tr = _trainer(g, force_collectives=force)
+            launched = []
+            if force:
+                assert isinstance(tr.comm, TorchComm) and tr.comm.active and tr.world == 1
+                tr.reducer_g.remove()
+                tr.reducer_d.remove()
+                tr.reducer_g = ddp.GradReducer(tr.arena_g, bucket_bytes=64 << 10, force=True)     # several buckets on the tiny model
+                tr.reducer_d = ddp.GradReducer(tr.arena_d, bucket_bytes=64 << 10, force=True)
+                for red in (tr.reducer_g, tr.reducer_d):
+                    assert red.enabled and not red._blocking and len(red.buckets) >= 2
+                    orig = red._launch
+                    red._launch = (lambda o: (lambda b: (launched.append(b), o(b))[1]))(orig)
+            else:
+                assert not tr.reducer_g.enabled and not tr.comm.active
+            res = []
+            for x, lens in batches:             # no host synchronisation between the steps
+                out = tr.train_step(x, lens)
+                res.append((out, tr.arena_g.flat_grad.clone(), tr.arena_d.flat_grad.clone()))
+            torch.cuda.synchronize()
+            res = [({k: float(v) for k, v in o.items()}, a.cpu().numpy(), b.cpu().numpy()) for o, a, b in res]
+            n_buckets = len(tr.reducer_g.buckets) + len(tr.reducer_d.buckets)
+            calls = tr.comm.calls if force else 0
+            return res, tr.arena_g.flat_param.cpu().numpy(), tr.arena_d.flat_param.cpu().numpy(), tr.gan_loss._state.cpu().numpy(), len(launched), n_buckets, calls
+
+        plain = run(False)
+        forced = run(True)
+        q.put(("ok", plain, forced))
+    except BaseException as e:                 # noqa: BLE001 - reported by the parent
+        import traceback
+        q.put(("error", repr(e), traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_single_rank_step_is_bit_identical_to_no_collectives():
+    """Backend "nccl" (= RCCL on ROCm) with one rank and every collective forced: the hooks fire during backward, each bucket's
+    gradients are moved by mq_multi_gather_args and all-reduced asynchronously on RCCL's stream, finish() waits, clip + Adam
+    read the arena; the loss sums go through TorchComm.  A sum over one rank is the identity, so losses, both gradient arenas,
+    LeCam state and weights after four unsynchronised steps (four crop lengths) must equal the plain single-process step BIT
+    FOR BIT - any mis-ordering between the compute stream and RCCL's stream shows up as a difference."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_rank, args=(port, q))
+    p.start()
+    msg = q.get(timeout=420)
+    p.join(timeout=120)
+    assert msg[0] == "ok", msg[1:]
+    assert p.exitcode == 0
+    _, plain, forced = msg
+    n_steps = len(plain[0])
+    assert forced[4] == n_steps * forced[5] and forced[5] >= 4        # every bucket, every step, launched through _launch
+    assert forced[6] >= n_steps * 3                                   # loss-sum all-reduces went through the process group
+    for s in range(n_steps):
+        assert plain[0][s][0] == forced[0][s][0], f"step {s}: losses differ"
+        assert np.array_equal(plain[0][s][1], forced[0][s][1]), f"step {s}: generator gradient arena"
+        assert np.array_equal(plain[0][s][2], forced[0][s][2]), f"step {s}: discriminator gradient arena"
+    for i, what in ((1, "generator weights"), (2, "discriminator weights"), (3, "LeCam state")):
+        assert np.array_equal(plain[i], forced[i]), what
+
+
+# ----------------------------------------------------------------------------------------- host far ahead of the stream
+def test_arena_fill_rows_are_captured_at_launch():
+    """Stall the stream, then enqueue 40 arena fills (each with freshly allocated gradient tensors, > 120 rows so that one fill
+    is several launches) before the first one can have started.  Every fill must see ITS OWN table."""
+    from mqgan_amd.ddp import FlatArena
+    torch.manual_seed(5)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.ps = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(1 + (7 * i) % 300)) for i in range(260)])
+    net = Net().to(DEV)
+    arena = FlatArena([net], gather=True)
+    rounds = 40
+    keep, snaps = [], []
+    grads = [[torch.randn_like(p) for p in net.ps] for _ in range(rounds)]       # distinct addresses per round
+    torch.cuda.synchronize()
+    torch.cuda._sleep(400_000_000)            # the stream is busy while the host enqueues everything below
+    done = torch.cuda.Event()
+    for r in range(rounds):
+        arena.zero_grad()
+        for p, gr in zip(net.ps, grads[r]):
+            p.grad = gr
+        arena.gather()
+        snaps.append(arena.flat_grad.clone())
+    done.record()
+    ran_ahead = not done.query()
+    torch.cuda.synchronize()
+    for r in range(rounds):
+        for p, o, gr in zip(arena.params, arena.offsets, grads[r]):
+            assert torch.equal(snaps[r][o:o + p.numel()], gr.reshape(-1)), f"round {r}"
+    assert ran_ahead, "the host did not get ahead of the stream: the stall was too short to test anything"
+
+
+def test_unsynchronised_steps_with_varying_crop_length():
+    """Twelve optimisation steps, a different T per step, issued back to back behind a stalled stream, against the same twelve
+    steps with a synchronize() after each: final weights, moments and LeCam state identical bit for bit."""
+    g = load_golden("g7_trainstep.npz")
+    Ts = [40, 24, 48, 32, 56, 72, 40, 64, 24, 48, 32, 40]
+    batches = [_batch(T, 900 + 10 * i) for i, T in enumerate(Ts)]
+
+    def run(sync):
+        tr = _trainer(g)
+        torch.cuda.synchronize()
+        if not sync:
+            torch.cuda._sleep(400_000_000)
+        for x, lens in batches:
+            tr.train_step(x, lens)
+            if sync:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        return [t.clone() for t in (tr.arena_g.flat_param, tr.arena_d.flat_param, tr.optimizer_g.exp_avg, tr.optimizer_d.exp_avg_sq,
+                                    tr.gan_loss._state)]
+
+    a = run(True)
+    b = run(False)
+    for x, y, what in zip(a, b, ("generator weights", "discriminator weights", "generator exp_avg", "discriminator exp_avg_sq", "LeCam")):
+        assert torch.equal(x, y), what

@@ -136,3 +136,43 @@ def test_bench_traffic_lookup_is_tied_to_the_kernel_sources(tmp_path, monkeypatc
     assert t is None and "stale" in src
     assert bench.peak_of("conv_h2_kernel<3, 2, 64, false, true>") == bench.PEAK_BF16_MFMA_TFLOPS
     assert bench.peak_of("conv_nt_kernel<128, false, 3>") == bench.PEAK_F32_MFMA_TFLOPS
+
+
+def test_gather_table_is_plain_host_data_per_call():
+    """FlatArena._gather_table: the rows handed to mq_multi_gather_args are built from scratch on every call (no staging
+    buffer survives a call, so nothing can be overwritten while a launch is in flight - the r2 pinned-ring race), one row per
+    parameter with a source (0 = zeros), skipping gradients that already alias the arena."""
+    import torch
+    from mqgan_amd.ddp import FlatArena
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Parameter(torch.randn(5, 3))
+            self.s = torch.nn.Parameter(torch.tensor(2.0))
+            self.b = torch.nn.Parameter(torch.randn(9))
+    net = Net()
+    arena = FlatArena([net], gather=True)
+    assert not hasattr(arena, "_ring")
+    ga, gb = torch.randn(5, 3), torch.randn(9)
+    net.a.grad, net.b.grad = ga, gb
+    t1 = arena._gather_table([0, 1, 2])
+    assert t1 == [(ga.data_ptr(), 0, 15, 0), (0, 16, 1, 0), (gb.data_ptr(), 20, 9, 0)]
+    ga2 = torch.randn(5, 3)
+    net.a.grad = ga2
+    t2 = arena._gather_table([0, 1, 2])
+    assert t2[0][0] == ga2.data_ptr() and t1[0][0] == ga.data_ptr() and t1 is not t2      # the first table is untouched
+    net.b.grad = arena.flat_grad[20:29]                         # already an arena view: nothing to move
+    assert [r[1] for r in arena._gather_table([0, 1, 2])] == [0, 16]
+    nc = torch.randn(3, 5).t()
+    net.a.grad = nc                                             # made contiguous, and the copy is kept alive on the parameter
+    row = arena._gather_table([0])[0]
+    assert net.a.grad.is_contiguous() and row[0] == net.a.grad.data_ptr() and torch.equal(net.a.grad, nc)
+
+
+def test_comm_active_flag():
+    from mqgan_amd.comm import Comm
+
+    class Two(Comm):
+        world = 2
+    assert not Comm().active and Two().active
