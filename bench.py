@@ -357,6 +357,44 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+def reencode_line(n_files=128):
+    """SURVEY 8f N2 on this GPU: the bulk re-encoding job (ScriptedPreEncoder encode -> decode of a .npy tree, hifispeech
+    architecture, random weights, fp32, lengths U(200, 1200), batch 32) under the reference's batching ('order', the default)
+    and the length-sorted policy.  File I/O included (that is the job); never `value`."""
+    import contextlib
+    import io
+    import tempfile
+    from mqgan_amd.export import export
+    from mqgan_amd.preencoder import PreEncoder
+    from mqgan_amd.reencode_spectrograms import reencode_spectrograms
+    from mqgan_amd.train import synthetic_mel
+    cfg = load_config("hifispeech")
+    m, g = cfg["model"], cfg["model"]["generator"]
+    out = {"workload": f"re-encode {n_files} synthetic .npy files of 200-1200 frames x {m['mel_channels']} mels, hifispeech PreEncoder "
+                       "(export -> ScriptedPreEncoder.encode -> .decode), fp32, batch 32, file I/O included", "unit": "mel-frames/s"}
+    with tempfile.TemporaryDirectory() as tmp, contextlib.redirect_stdout(io.StringIO()):
+        torch.manual_seed(0)
+        model = PreEncoder(m["mel_channels"], g["channels"], g["kernel_sizes"], fsq_levels=g["fsq_levels"], dropout=0.0,
+                           refiner_base_channels=g["refiner_base_channels"], refiner_depth=g["refiner_depth"])
+        ck, cf = os.path.join(tmp, "ck.pth"), os.path.join(tmp, "cfg.yaml")
+        torch.save({"model_state_dict": model.state_dict()}, ck)
+        with open(cf, "w") as f:
+            yaml.safe_dump(cfg, f)
+        mdir = export(ck, cf, os.path.join(tmp, "model"))
+        src = os.path.join(tmp, "in")
+        os.makedirs(src)
+        rng = np.random.default_rng(0)
+        for i in range(n_files):
+            np.save(os.path.join(src, f"{i:05d}.npy"), synthetic_mel(int(rng.integers(200, 1201)), m["mel_channels"], i))
+        for tag, bucket in (("warm", "sorted"), ("order", "order"), ("sorted", "sorted")):      # first pass: allocator / kernels warm
+            st = {}
+            reencode_spectrograms(mdir, src, os.path.join(tmp, "out_" + tag), "cuda", 32, bucket=bucket, stats=st)
+            if tag != "warm":
+                out[tag] = {"value": st["frames_per_s"], "files": st["files"], "frames": st["frames"],
+                            "padding_fraction": st["pad_fraction"], "seconds": st["seconds"]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -521,6 +559,8 @@ def main():
             del batches
             torch.cuda.empty_cache()
             line["configs"] = {"config3_hifimusic_bf16": config3_line(device)}
+            torch.cuda.empty_cache()
+            line["configs"]["reencode_n2_hifispeech_fp32"] = reencode_line()
         if not args.no_vq:
             line["vq"] = bench_vq(device)
         if world == 1 and not args.no_cpu_baseline:

@@ -30,6 +30,10 @@ typedef void *mqStream; /* hipStream_t */
 
 int mq_abi_version(void);
 const char *mq_last_error(void);
+/* Name of the kernel instantiation the last mq_conv_* / mq_gemm-type call on this thread launched, spelled as rocprofv3
+ * prints it (e.g. "conv_nt_kernel<128, false, 3>"); "" before the first such call.  For labelling timings: the dispatch
+ * decides the kernel, callers ask. */
+const char *mq_last_kernel(void);
 
 /* ------------------------------------------------------------------ quantiser
  * FSQ (reference quantizer.py:109-114 bound, :128-140 quantize, :39-42 round_ste,

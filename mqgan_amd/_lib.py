@@ -46,6 +46,7 @@ _P, _I, _L, _F, _D, _Z, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_do
 SIGNATURES = {
     "mq_abi_version": (C.c_int, []),
     "mq_last_error": (C.c_char_p, []),
+    "mq_last_kernel": (C.c_char_p, []),
     "mq_fsq_forward": (_I, [C.POINTER(FsqDesc), _P, _L, _P, _P, _P]),
     "mq_fsq_backward": (_I, [C.POINTER(FsqDesc), _P, _P, _L, _P, _P]),
     "mq_fsq_decode": (_I, [C.POINTER(FsqDesc), _P, _L, _P, _P]),

@@ -18,6 +18,19 @@ class Comm:
         """In-place sum over the ranks; returns ``t``."""
         return t
 
+    def all_reduce_sum_host(self, t: torch.Tensor) -> torch.Tensor:
+        """The same for a HOST tensor, without touching the device stream (control decisions: no stream synchronisation)."""
+        return self.all_reduce_sum(t)
+
+    def any_rank(self, flag: bool) -> bool:
+        """True on every rank if ``flag`` is true on any.  Host-side agreement: the device stream is not synchronised, so the
+        host keeps running ahead of the GPU (the per-step skip decision of the training loop)."""
+        if not self.active:
+            return bool(flag)
+        t = torch.tensor([1.0 if flag else 0.0])
+        self.all_reduce_sum_host(t)
+        return bool(t[0] > 0)
+
 
 class TorchComm(Comm):
     """``force``: issue the collectives even in a group of one rank (a one-GPU box can then execute the whole RCCL path:
@@ -31,6 +44,7 @@ class TorchComm(Comm):
         self.rank = dist.get_rank(group)
         self.force = bool(force)
         self.calls = 0
+        self._host_group = None
 
     @property
     def active(self) -> bool:
@@ -40,6 +54,19 @@ class TorchComm(Comm):
         if self.active:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
             self.calls += 1
+        return t
+
+
+    def all_reduce_sum_host(self, t):
+        if not self.active:
+            return t
+        if dist.get_backend(self.group) == "gloo":
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            return t
+        if self._host_group is None:               # RCCL moves device memory only: host decisions travel over a gloo twin
+            ranks = dist.get_process_group_ranks(self.group) if self.group is not None else None
+            self._host_group = dist.new_group(ranks=ranks, backend="gloo")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self._host_group)
         return t
 
 

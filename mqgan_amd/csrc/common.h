@@ -23,6 +23,19 @@ inline int fail(const char *fmt, ...)
     return 1;
 }
 
+// Name of the conv / GEMM kernel instantiation the last mq_conv_* call on this thread launched (mq_last_kernel()): the
+// dispatch decides it, so whoever labels timings asks instead of re-deriving the decision.
+extern thread_local char g_kernel[128];
+inline void kname(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+inline void kname(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+    va_end(ap);
+}
+inline const char *tf(bool b) { return b ? "true" : "false"; }
+
 #define MQ_REQUIRE(cond, ...)                      \
     do {                                           \
         if (!(cond)) return ::mq::fail(__VA_ARGS__); \

@@ -1250,14 +1250,14 @@ static int launch_nt(const mqConvDesc *d, const float *act, const float *w, cons
             }
         pi.tile0[pi.ncls] = t0;
         dim3 pgrid(t0 * g.nNt, d->groups);
-#define MQ_PAR(BN_, W_) hipLaunchKernelGGL((conv_dgrad_parity_kernel<BN_, W_>), pgrid, dim3(256), 0, st, act, w, out, g, pi, act_gs, w_gs, ng, epi)
-#define MQ_PARH(BN_, W_) hipLaunchKernelGGL((conv_dgrad_parity_bf16_kernel<BN_, W_>), pgrid, dim3(256), 0, st, act, w, out, g, pi, act_gs, w_gs, ng, epi)
+#define MQ_PAR(BN_, W_) do { kname("conv_dgrad_parity_kernel<%d, %d>", BN_, W_); hipLaunchKernelGGL((conv_dgrad_parity_kernel<BN_, W_>), pgrid, dim3(256), 0, st, act, w, out, g, pi, act_gs, w_gs, ng, epi); } while (0)
+#define MQ_PARH(BN_, W_) do { kname("conv_dgrad_parity_bf16_kernel<%d, %d>", BN_, W_); hipLaunchKernelGGL((conv_dgrad_parity_bf16_kernel<BN_, W_>), pgrid, dim3(256), 0, st, act, w, out, g, pi, act_gs, w_gs, ng, epi); } while (0)
         if (hmode) {
-#define MQ_PARHH(BN_) hipLaunchKernelGGL((conv_dgrad_parity_h_kernel<BN_>), pgrid, dim3(256), 0, st, act, w, out, g, pi, act_gs, w_gs, ng, epi)
+#define MQ_PARHH(BN_) do { kname("conv_dgrad_parity_h_kernel<%d>", BN_); hipLaunchKernelGGL((conv_dgrad_parity_h_kernel<BN_>), pgrid, dim3(256), 0, st, act, w, out, g, pi, act_gs, w_gs, ng, epi); } while (0)
             if (BN == 128) MQ_PARHH(128); else if (BN == 64) MQ_PARHH(64); else MQ_PARHH(32);
 #undef MQ_PARHH
         } else if (x3) {
-#define MQ_PARX(BN_, W_) hipLaunchKernelGGL((conv_dgrad_parity_x3_kernel<BN_, W_>), pgrid, dim3(256), 0, st, act, w, out, g, pi, act_gs, w_gs, ng, epi)
+#define MQ_PARX(BN_, W_) do { kname("conv_dgrad_parity_x3_kernel<%d, %d>", BN_, W_); hipLaunchKernelGGL((conv_dgrad_parity_x3_kernel<BN_, W_>), pgrid, dim3(256), 0, st, act, w, out, g, pi, act_gs, w_gs, ng, epi); } while (0)
             const int wr = g.IC % 16 == 0 ? 0 : (wide ? 1 : 4);
             if (BN == 128) { if (wr == 0) MQ_PARX(128, 0); else if (wr == 1) MQ_PARX(128, 1); else MQ_PARX(128, 4); }
             else if (BN == 64) { if (wr == 0) MQ_PARX(64, 0); else if (wr == 1) MQ_PARX(64, 1); else MQ_PARX(64, 4); }
@@ -1284,10 +1284,10 @@ static int launch_nt(const mqConvDesc *d, const float *act, const float *w, cons
     wg.CB = cb; wg.nchunks = g.IC / cb;
     const int mode = vec ? (wide ? ((g.IC % 16 == 0 && !bf16) ? 3 : 2) : 1) : 0;
     dim3 grid(g.nMt * g.nNt, d->groups), block(256);
-#define MQ_NT(BN_, M_) hipLaunchKernelGGL((conv_nt_kernel<BN_, DGRAD, M_>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs, epi)
-#define MQ_NTH(BN_, M_) hipLaunchKernelGGL((conv_nt_bf16_kernel<BN_, DGRAD, M_>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs, epi)
-#define MQ_NTX(BN_, M_) hipLaunchKernelGGL((conv_nt_x3_kernel<BN_, DGRAD, M_>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs, epi)
-#define MQ_NTHH(BN_) hipLaunchKernelGGL((conv_nt_h_kernel<BN_, DGRAD>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs, epi)
+#define MQ_NT(BN_, M_) do { kname("conv_nt_kernel<%d, %s, %d>", BN_, tf(DGRAD), M_); hipLaunchKernelGGL((conv_nt_kernel<BN_, DGRAD, M_>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs, epi); } while (0)
+#define MQ_NTH(BN_, M_) do { kname("conv_nt_bf16_kernel<%d, %s, %d>", BN_, tf(DGRAD), M_); hipLaunchKernelGGL((conv_nt_bf16_kernel<BN_, DGRAD, M_>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs, epi); } while (0)
+#define MQ_NTX(BN_, M_) do { kname("conv_nt_x3_kernel<%d, %s, %d>", BN_, tf(DGRAD), M_); hipLaunchKernelGGL((conv_nt_x3_kernel<BN_, DGRAD, M_>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs, epi); } while (0)
+#define MQ_NTHH(BN_) do { kname("conv_nt_h_kernel<%d, %s>", BN_, tf(DGRAD)); hipLaunchKernelGGL((conv_nt_h_kernel<BN_, DGRAD>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs, epi); } while (0)
 #define MQ_NT3(BN_) do { if (hmode) MQ_NTHH(BN_); else if (x3) { if (mode == 3) MQ_NTX(BN_, 3); else if (mode == 2) MQ_NTX(BN_, 2); else MQ_NTX(BN_, 1); } \
                          else if (bf16) { if (mode == 2) MQ_NTH(BN_, 2); else MQ_NTH(BN_, 1); } \
                          else if (mode == 3) MQ_NT(BN_, 3); else if (mode == 2) MQ_NT(BN_, 2); else if (mode == 1) MQ_NT(BN_, 1); \
@@ -1465,9 +1465,9 @@ static int wgrad_impl(const mqConvDesc *d, const float *x, const float *dy, floa
     MQ_REQUIRE(!(bf16 || x3) || vec, "%s: bf16 engines need 16-byte aligned tensors below the 2 GB-per-split span", who);
     // fused bias partials: vector path only; one split writes straight into dbias
     float *bias_target = (dbias && mode > 0) ? (g.splits > 1 ? bias_ws : dbias) : nullptr;
-#define MQ_WG(A_, B_, M_) hipLaunchKernelGGL((conv_wgrad_kernel<A_, B_, M_>), grid, block, 0, st, x, dy, target, bias_target, g, d->groups)
-#define MQ_WGH(A_, B_, M_) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<A_, B_, M_>), grid, block, 0, st, x, dy, target, bias_target, g, d->groups)
-#define MQ_WGX(A_, B_, M_) hipLaunchKernelGGL((conv_wgrad_x3_kernel<A_, B_, M_>), grid, block, 0, st, x, dy, target, bias_target, g, d->groups)
+#define MQ_WG(A_, B_, M_) do { kname("conv_wgrad_kernel<%d, %d, %d>", A_, B_, M_); hipLaunchKernelGGL((conv_wgrad_kernel<A_, B_, M_>), grid, block, 0, st, x, dy, target, bias_target, g, d->groups); } while (0)
+#define MQ_WGH(A_, B_, M_) do { kname("conv_wgrad_bf16_kernel<%d, %d, %d>", A_, B_, M_); hipLaunchKernelGGL((conv_wgrad_bf16_kernel<A_, B_, M_>), grid, block, 0, st, x, dy, target, bias_target, g, d->groups); } while (0)
+#define MQ_WGX(A_, B_, M_) do { kname("conv_wgrad_x3_kernel<%d, %d, %d>", A_, B_, M_); hipLaunchKernelGGL((conv_wgrad_x3_kernel<A_, B_, M_>), grid, block, 0, st, x, dy, target, bias_target, g, d->groups); } while (0)
 #define MQ_WG3(A_, B_) do { if (x3) { if (mode == 3) MQ_WGX(A_, B_, 3); else MQ_WGX(A_, B_, 1); } \
                             else if (bf16) { if (mode == 3) MQ_WGH(A_, B_, 3); else if (mode == 2) MQ_WGH(A_, B_, 2); else MQ_WGH(A_, B_, 1); } \
                             else if (mode == 3) MQ_WG(A_, B_, 3); else if (mode == 1) MQ_WG(A_, B_, 1); else MQ_WG(A_, B_, 0); } while (0)

@@ -1093,12 +1093,12 @@ static int launch_h2(const mqConvDesc *d, const void *act, const void *w, void *
         pi.tile0[pi.ncls] = t0;
         grid = dim3((unsigned)(t0 * g.nNt), d->groups);
     }
-#define MQ_H2(TN_, NS_, CB_, PAR_) do { if (mf16) hipLaunchKernelGGL((conv_h2_kernel<TN_, NS_, CB_, PAR_, true>), grid, block, 0, st, reinterpret_cast<const unsigned short *>(act), \
+#define MQ_H2(TN_, NS_, CB_, PAR_) do { kname("conv_h2_kernel<%d, %d, %d, %s, %s>", TN_, NS_, CB_, tf(PAR_), tf(mf16)); if (mf16) hipLaunchKernelGGL((conv_h2_kernel<TN_, NS_, CB_, PAR_, true>), grid, block, 0, st, reinterpret_cast<const unsigned short *>(act), \
                                                       reinterpret_cast<const unsigned short *>(w), out, g, pi, epi, act_gs); \
                                         else hipLaunchKernelGGL((conv_h2_kernel<TN_, NS_, CB_, PAR_, false>), grid, block, 0, st, reinterpret_cast<const unsigned short *>(act), \
                                                       reinterpret_cast<const unsigned short *>(w), out, g, pi, epi, act_gs); } while (0)
-#define MQ_D32(TN_, NS_, PAR_) hipLaunchKernelGGL((conv_d32_kernel<TN_, NS_, PAR_>), grid, block, 0, st, reinterpret_cast<const float *>(act), \
-                                                  reinterpret_cast<const float *>(w), reinterpret_cast<float *>(out), g, pi, epi, act_gs)
+#define MQ_D32(TN_, NS_, PAR_) do { kname("conv_d32_kernel<%d, %d, %s>", TN_, NS_, tf(PAR_)); hipLaunchKernelGGL((conv_d32_kernel<TN_, NS_, PAR_>), grid, block, 0, st, reinterpret_cast<const float *>(act), \
+                                                  reinterpret_cast<const float *>(w), reinterpret_cast<float *>(out), g, pi, epi, act_gs); } while (0)
 #define MQ_H2_CB(TN_, NS_, PAR_) do { if constexpr (ET::F32) MQ_D32(TN_, NS_, PAR_); else if (g.CB == 64) MQ_H2(TN_, NS_, 64, PAR_); else MQ_H2(TN_, NS_, 32, PAR_); } while (0)
 #define MQ_H2_TN(PAR_) do { if (TN == 4) MQ_H2_CB(4, 2, PAR_); else if (TN == 3) MQ_H2_CB(3, 2, PAR_); \
                             else if (TN == 2) MQ_H2_CB(2, 3, PAR_); else MQ_H2_CB(1, 2, PAR_); } while (0)
@@ -1278,7 +1278,7 @@ extern "C" int mq_conv_wgrad_h2(const mqConvDesc *d, const uint16_t *x, const ui
     // the weight gradient stays on 32x32x16: its 16x16x32 instantiation (conflict-free too) measured 3-5 % slower
     // (twice the transposed LDS reads per flop); MQGAN_H2_WG16=1 selects it for A/B runs
     static const bool mf16 = getenv("MQGAN_H2_WG16") != nullptr;
-#define MQ_WH2(WM_, TM_, WR_) do { if (mf16) hipLaunchKernelGGL((conv_wgrad_h2_kernel<WM_, TM_, WR_, true>), grid, block, 0, st, x, dy, target, g, d->groups); \
+#define MQ_WH2(WM_, TM_, WR_) do { kname("conv_wgrad_h2_kernel<%d, %d, %d, %s>", WM_, TM_, WR_, tf(mf16)); if (mf16) hipLaunchKernelGGL((conv_wgrad_h2_kernel<WM_, TM_, WR_, true>), grid, block, 0, st, x, dy, target, g, d->groups); \
                                    else hipLaunchKernelGGL((conv_wgrad_h2_kernel<WM_, TM_, WR_, false>), grid, block, 0, st, x, dy, target, g, d->groups); } while (0)
 #define MQ_WH(WM_, TM_) do { if (wraps == 1) MQ_WH2(WM_, TM_, 1); else MQ_WH2(WM_, TM_, 4); } while (0)
     if (wm == 4) MQ_WH(4, 2);

@@ -3,6 +3,7 @@
 
 namespace mq {
 thread_local char g_err[512] = "";
+thread_local char g_kernel[128] = "";
 }
 
 // 2: mqConvDesc gained `precision`; mq_conv_wgrad_bias, mq_taps_*, mq_cast_bf16, mq_conv_*_h added
@@ -10,3 +11,4 @@ thread_local char g_err[512] = "";
 //    parallelism, per-element masks); deterministic codebook EMA with its own workspace query
 extern "C" int mq_abi_version(void) { return 4; }
 extern "C" const char *mq_last_error(void) { return mq::g_err; }
+extern "C" const char *mq_last_kernel(void) { return mq::g_kernel; }

@@ -147,10 +147,14 @@ class KernelTimer:
         self.details = []
 
     def run(self, tag, flops, fn, detail=None):
+        """``tag`` None: the name of the kernel instantiation the C dispatch launched inside ``fn`` (mq_last_kernel: the
+        library says what it ran, nothing here mirrors its choice)."""
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         fn()
         e.record()
+        if tag is None:
+            tag = L().mq_last_kernel().decode()
         self.records.append((tag, flops, s, e))
         self.details.append(detail)
 
@@ -173,43 +177,6 @@ def _timed(tag, flops, fn, detail=None):
         fn()
     else:
         TIMER.run(tag, flops, fn, detail)
-
-
-def _h2_tn(ncols):
-    return min((4, 3, 2, 1), key=lambda t: (-(-ncols // (64 * t)) * 64 * t / {4: 1.0, 3: 0.93, 2: 0.85, 1: 0.65}[t], -t))
-
-
-def _conv_tag(kind, d: ConvDesc, h2=False):
-    """Name of the kernel instantiation the C side picks (igemm.hip: launch_nt / mq_conv_wgrad; igemm_h2.hip)."""
-    if h2:
-        if kind == "wgrad":
-            wmtm = "4, 2" if (d.K % 256 == 0 or (d.K > 256 and d.K % 192 != 0)) else ("2, 3" if d.K % 192 == 0 else "2, 2")
-            return f"conv_wgrad_h2_kernel<{wmtm}, {1 if d.Q >= 64 else 4}, false>"
-        ncols, ic = (d.K, d.C) if kind == "fprop" else (d.C, d.K)
-        tn = _h2_tn(ncols)
-        par = kind == "dgrad" and (d.stride_h > 1 or d.stride_w > 1)
-        return f"conv_h2_kernel<{tn}, {3 if tn == 2 else 2}, {64 if ic % 64 == 0 else 32}, {str(par).lower()}, true>"
-    eng = {0: "", 1: "bf16_", 2: "x3_"}[d.precision]
-    if kind == "wgrad":
-        vec = d.C % 4 == 0 and d.K % 4 == 0
-        mode = (3 if d.Q >= (32 if eng == "bf16_" else 16) else (2 if d.Q >= 16 else 1)) if vec else 0
-        return f"conv_wgrad_{eng if vec else ''}kernel<{'64, 256' if d.K <= 64 else '128, 128'}, {mode}>"
-    ncols, ic = (d.K, d.C) if kind == "fprop" else (d.C, d.K)
-    bn = min((128, 64, 32), key=lambda b: (-(-ncols // b) * b / {128: 1.0, 64: 0.9, 32: 0.75}[b], -b))
-    strided = d.stride_h > 1 or d.stride_w > 1
-    e = eng if ic % 4 == 0 else ""
-    if BF16_STORAGE and e == "bf16_" and ic % 16 == 0 and d.stride_h <= 2 and d.stride_w <= 2:   # bf16-storage kernels
-        if kind == "dgrad" and strided:
-            return f"conv_dgrad_parity_h_kernel<{bn}>"
-        return f"conv_nt_h_kernel<{bn}, {str(kind == 'dgrad').lower()}>"
-    bf = e == "bf16_"
-    if kind == "dgrad" and strided:
-        if ic % 4 == 0 and d.stride_h <= 2 and d.stride_w <= 2:
-            wraps = (2 if ic % 16 == 0 else 8) if bf else (0 if ic % 16 == 0 else (1 if ic >= 16 else 4))
-            return f"conv_dgrad_parity_{e}kernel<{bn}, {wraps}>"
-        return f"conv_nt_kernel<{bn}, true, 0>"
-    mode = (2 if bf else 3) if ic % 16 == 0 else ((2 if ic >= 16 else 1) if ic % 4 == 0 else 0)
-    return f"conv_nt_{e}kernel<{bn}, {str(kind == 'dgrad').lower()}, {mode}>"
 
 
 def _conv_flops(d: ConvDesc):
@@ -304,7 +271,7 @@ def h2_weight_image(d: ConvDesc, w: torch.Tensor, dgrad: bool) -> torch.Tensor:
 def conv_fprop_h2(d: ConvDesc, x, w_h2, bias=None, mask=None, dmap=(1, 0, 1), act=0, slope=0.2, out_dtype=None):
     out_dtype = BF16 if out_dtype is None else out_dtype
     y = torch.empty((d.N, d.P, d.Q, d.K), dtype=out_dtype, device=x.device)
-    _timed(_conv_tag("fprop", d, h2=True), _conv_flops(d), lambda: check(
+    _timed(None, _conv_flops(d), lambda: check(
         L().mq_conv_fprop_h2(C.byref(d), ptr(x, BF16), ptr(w_h2, BF16), fptr(bias, True), ptr(mask, torch.uint8, True), dmap[0],
                              dmap[1], dmap[2], int(act), float(slope), int(out_dtype == F32), ptr(y, out_dtype), stream()),
         "mq_conv_fprop_h2"), _desc_key(d))
@@ -317,13 +284,13 @@ def conv_dgrad_h2(d: ConvDesc, dy, wt_h2, out_dtype=None, gate=None):
     out_dtype = BF16 if out_dtype is None else out_dtype
     dx = torch.empty((d.N, d.H, d.W, d.C), dtype=out_dtype, device=dy.device)
     if gate is None:
-        _timed(_conv_tag("dgrad", d, h2=True), _conv_flops(d), lambda: check(
+        _timed(None, _conv_flops(d), lambda: check(
             L().mq_conv_dgrad_h2(C.byref(d), ptr(dy, BF16), ptr(wt_h2, BF16), int(out_dtype == F32), ptr(dx, out_dtype), stream()),
             "mq_conv_dgrad_h2"), _desc_key(d))
     else:
         gx, gmask, gmap, gslope = gate
         gmap = gmap if gmask is not None else (1, 0, 1)
-        _timed(_conv_tag("dgrad", d, h2=True), _conv_flops(d), lambda: check(
+        _timed(None, _conv_flops(d), lambda: check(
             L().mq_conv_dgrad_h2_gated(C.byref(d), ptr(dy, BF16), ptr(wt_h2, BF16), ptr(gx, BF16), ptr(gmask, torch.uint8, True),
                                        gmap[0], gmap[1], gmap[2], float(gslope), int(out_dtype == F32), ptr(dx, out_dtype),
                                        stream()), "mq_conv_dgrad_h2_gated"), _desc_key(d))
@@ -335,7 +302,7 @@ def conv_wgrad_h2(d: ConvDesc, x, dy, w_shape, want_bias: bool):
     db = torch.empty((d.groups * d.K,), dtype=F32, device=x.device) if want_bias else None
     nbytes = L().mq_conv_wgrad_h2_workspace(C.byref(d))
     ws = _ws_bytes(nbytes, x)
-    _timed(_conv_tag("wgrad", d, h2=True), _conv_flops(d), lambda: check(
+    _timed(None, _conv_flops(d), lambda: check(
         L().mq_conv_wgrad_h2(C.byref(d), ptr(x, BF16), ptr(dy, BF16), fptr(dw), fptr(db, True), ptr(ws), nbytes, stream()),
         "mq_conv_wgrad_h2"), _desc_key(d))
     return dw, db
@@ -410,11 +377,11 @@ class ConvFn(torch.autograd.Function):
         y = _empty((d.N, d.P, d.Q, d.K), x)
         if _h_ok(d, d.C):
             x_h, w_h = cast_bf16(x), cast_bf16(w_krsc)
-            _timed(_conv_tag("fprop", d), _conv_flops(d), lambda: check(
+            _timed(None, _conv_flops(d), lambda: check(
                 L().mq_conv_fprop_h(C.byref(d), ptr(x_h, BF16), ptr(w_h, BF16), fptr(bias, True), fptr(y), stream()),
                 "mq_conv_fprop_h"), key)
         else:
-            _timed(_conv_tag("fprop", d), _conv_flops(d), lambda: check(
+            _timed(None, _conv_flops(d), lambda: check(
                 L().mq_conv_fprop(C.byref(d), fptr(x), fptr(w_krsc), fptr(bias, True), fptr(y), stream()), "mq_conv_fprop"), key)
         ctx.key = key
         ctx.w_shape = tuple(w_krsc.shape)
@@ -471,7 +438,7 @@ def _wino_conv(d: ConvDesc, x, w_krsc, bias, cin: int, cout: int, flip: bool, ke
     check(L().mq_wino_weight_transform(fptr(w_krsc), d.K, d.C, int(flip), fptr(U), stream()), "mq_wino_weight_transform")
     dg = _wino_gemm_desc(d, cin, cout)
     M = _empty((16 * _wino_tiles(d), 1, 1, cout), x)
-    _timed(_conv_tag("fprop", dg), _conv_flops(dg), lambda: check(
+    _timed(None, _conv_flops(dg), lambda: check(
         L().mq_conv_fprop(C.byref(dg), fptr(V), fptr(U), None, fptr(M), stream()), "mq_conv_fprop"), key)
     del V
     y = _empty((d.N, d.H, d.W, cout), x)
@@ -513,7 +480,7 @@ class ConvWinoFn(torch.autograd.Function):
             P = _empty((16 * d.K, 1, d.C), x)
             nbytes = L().mq_conv_wgrad_workspace(C.byref(dg))
             ws = _ws_bytes(nbytes, x)
-            _timed(_conv_tag("wgrad", dg), _conv_flops(dg), lambda: check(
+            _timed(None, _conv_flops(dg), lambda: check(
                 L().mq_conv_wgrad(C.byref(dg), fptr(V), fptr(Z), fptr(P), ptr(ws), nbytes, stream()), "mq_conv_wgrad"), ctx.key)
             del V, Z
             dw = _empty(ctx.w_shape, x)
@@ -554,7 +521,7 @@ def _conv_backward_f32(d, key, x, w_crsk, dy, w_shape, want_dx, want_dw, want_db
         dx = torch.empty_like(x)
         if _h_ok(d, d.K):
             dy_h, wc_h = cast_bf16(dy), cast_bf16(w_crsk)
-            _timed(_conv_tag("dgrad", d), _conv_flops(d), lambda: check(
+            _timed(None, _conv_flops(d), lambda: check(
                 L().mq_conv_dgrad_h(C.byref(d), ptr(dy_h, BF16), ptr(wc_h, BF16), fptr(dx), stream()), "mq_conv_dgrad_h"),
                 ctx.key)
             if in_gate is not None:
@@ -562,11 +529,11 @@ def _conv_backward_f32(d, key, x, w_crsk, dy, w_shape, want_dx, want_dw, want_db
         elif in_gate is not None:
             gmask, gmap, gslope = in_gate
             gmap = gmap if gmask is not None else (1, 0, 1)
-            _timed(_conv_tag("dgrad", d), _conv_flops(d), lambda: check(
+            _timed(None, _conv_flops(d), lambda: check(
                 L().mq_conv_dgrad_gated(C.byref(d), fptr(dy), fptr(w_crsk), fptr(x), ptr(gmask, torch.uint8, True), gmap[0], gmap[1],
                                         gmap[2], float(gslope), fptr(dx), stream()), "mq_conv_dgrad_gated"), ctx.key)
         else:
-            _timed(_conv_tag("dgrad", d), _conv_flops(d), lambda: check(
+            _timed(None, _conv_flops(d), lambda: check(
                 L().mq_conv_dgrad(C.byref(d), fptr(dy), fptr(w_crsk), fptr(dx), stream()), "mq_conv_dgrad"), ctx.key)
     want_db = ctx.has_bias and ctx.needs_input_grad[3]
     if ctx.needs_input_grad[1]:
@@ -575,13 +542,13 @@ def _conv_backward_f32(d, key, x, w_crsk, dy, w_shape, want_dx, want_dw, want_db
             db = _empty((d.groups * d.K,), x)
             nbytes = L().mq_conv_wgrad_bias_workspace(C.byref(d))
             ws = _ws_bytes(nbytes, x)
-            _timed(_conv_tag("wgrad", d), _conv_flops(d), lambda: check(
+            _timed(None, _conv_flops(d), lambda: check(
                 L().mq_conv_wgrad_bias(C.byref(d), fptr(x), fptr(dy), fptr(dw), fptr(db), ptr(ws), nbytes, stream()),
                 "mq_conv_wgrad_bias"), ctx.key)
         else:
             nbytes = L().mq_conv_wgrad_workspace(C.byref(d))
             ws = _ws_bytes(nbytes, x)
-            _timed(_conv_tag("wgrad", d), _conv_flops(d), lambda: check(
+            _timed(None, _conv_flops(d), lambda: check(
                 L().mq_conv_wgrad(C.byref(d), fptr(x), fptr(dy), fptr(dw), ptr(ws), nbytes, stream()), "mq_conv_wgrad"),
                 ctx.key)
     elif want_db:
@@ -598,7 +565,7 @@ class ConvLeakyFn(torch.autograd.Function):
     def forward(ctx, x, w_krsc, w_crsk, bias, mask, key, dmap, slope, in_gate=None, pregated=False):
         d = _desc_from_key(key)
         y = _empty((d.N, d.P, d.Q, d.K), x)
-        _timed(_conv_tag("fprop", d), _conv_flops(d), lambda: check(
+        _timed(None, _conv_flops(d), lambda: check(
             L().mq_conv_fprop_leaky(C.byref(d), fptr(x), fptr(w_krsc), fptr(bias, True), ptr(mask, torch.uint8, True), dmap[0],
                                     dmap[1], dmap[2], float(slope), fptr(y), stream()), "mq_conv_fprop_leaky"), key)
         ctx.key, ctx.dmap, ctx.slope = key, dmap, slope

@@ -6,12 +6,14 @@ Batching.  The reference cuts the ``os.walk`` order into batch
 longest item and - because padded frames leak into valid ones in the reference's model (ConvBlock2D writes its output
 bias on padded frames, CBAM's max-pool and spatial gate are unmasked) - a file's result depends on
 which neighbours it happened to be batched with.  ``bucket`` selects the policy here:
-  * ``"sorted"`` (default): files are sorted by length and cut into batches of neighbours whose padding waste stays
+  * ``"sorted"``: files are sorted by length and cut into batches of neighbours whose padding waste stays
     under ``max_pad`` (fraction of the batch's frames).  Least padding work; results depend on padding exactly as the
     reference's do.
   * ``"exact"``: only files of identical length share a batch - no padding at all, so every file gets bit-for-bit the
     result of being processed alone, whatever else is in the tree.
-  * ``"order"``: the reference's loop (directory order), for side-by-side comparisons.
+  * ``"order"`` (default, as the reference-compatible entry points must behave): the reference's loop - directory order
+    cut into batches, so the same tree gives the same batches, hence the same outputs, as the reference's script.
+``sorted`` and ``exact`` are opt-in (``--bucket``): faster / padding-independent, but NOT the reference's batching.
 Outputs are always written to the mirrored path of their input, whatever the processing order."""
 import argparse
 import os
@@ -38,7 +40,7 @@ def _length_of(path):
         return None
 
 
-def plan_batches(files, lengths, batch_size, bucket="sorted", max_pad=0.1):
+def plan_batches(files, lengths, batch_size, bucket="order", max_pad=0.1):
     """List of batches (lists of paths).  Files whose length is unknown go one per batch at the end (their failure must
     not take readable files down with it)."""
     if bucket == "order":
@@ -61,7 +63,7 @@ def plan_batches(files, lengths, batch_size, bucket="sorted", max_pad=0.1):
     return batches
 
 
-def _run(encode_decode, input_dir, output_dir, batch_size, bucket="sorted", max_pad=0.1, stats=None):
+def _run(encode_decode, input_dir, output_dir, batch_size, bucket="order", max_pad=0.1, stats=None):
     files = _find_npy(input_dir)
     if not files:
         print("Warning: No .npy files were found.")
@@ -97,7 +99,7 @@ def _run(encode_decode, input_dir, output_dir, batch_size, bucket="sorted", max_
     return done
 
 
-def reencode_spectrograms(model_path, input_dir, output_dir, device, batch_size, bucket="sorted", max_pad=0.1, stats=None):
+def reencode_spectrograms(model_path, input_dir, output_dir, device, batch_size, bucket="order", max_pad=0.1, stats=None):
     """ScriptedPreEncoder variant (model directory)."""
     try:
         model = ScriptedPreEncoder(model_path, device=device)
@@ -108,7 +110,7 @@ def reencode_spectrograms(model_path, input_dir, output_dir, device, batch_size,
                 max_pad, stats)
 
 
-def reencode_spectrograms_from_checkpoint(checkpoint_path, config, input_dir, output_dir, device, batch_size, bucket="sorted",
+def reencode_spectrograms_from_checkpoint(checkpoint_path, config, input_dir, output_dir, device, batch_size, bucket="order",
                                           max_pad=0.1, stats=None):
     """Raw-checkpoint variant (get_pre_encoder(..., inference=True))."""
     try:
@@ -139,8 +141,8 @@ def main(argv=None):
     ap.add_argument("--output_dir", type=str, required=True)
     ap.add_argument("--device", type=str, default="cuda")
     ap.add_argument("--batch_size", type=int, default=32)
-    ap.add_argument("--bucket", type=str, default="sorted", choices=["sorted", "exact", "order"],
-                    help="batching policy: length-sorted neighbours (default), identical lengths only, or the reference's directory order")
+    ap.add_argument("--bucket", type=str, default="order", choices=["order", "sorted", "exact"],
+                    help="batching policy: the reference's directory order (default), length-sorted neighbours, or identical lengths only")
     ap.add_argument("--max_pad", type=float, default=0.1, help="'sorted': largest fraction of padded frames a batch may carry")
     a = ap.parse_args(argv)
     stats = {}

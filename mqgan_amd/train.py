@@ -476,11 +476,10 @@ class Trainer:
         from .data import PrefetchLoader
         for i, (real, lens, _) in enumerate(PrefetchLoader(self.train_loader, self.device, depth=2)):
             empty = real is None or real.size(0) == 0   # every file of the batch failed to load (train.py:512-514)
-            if self.world > 1:
-                # the step is full of collectives: either every rank takes it or none does
-                flag = torch.tensor([1.0 if empty else 0.0], device=self.device)
-                self.comm.all_reduce_sum(flag)
-                empty = float(flag.item()) > 0.0
+            if self.comm.active:
+                # the step is full of collectives: either every rank takes it or none does.  Agreed on the HOST (gloo twin
+                # of the RCCL group): no device synchronisation, the host keeps running ahead of the stream
+                empty = self.comm.any_rank(empty)
             if empty:
                 continue
             out = self.train_step(real, lens)

@@ -151,9 +151,9 @@ def _norm_worker(rank, world, port, out_q):
         local = ((y - 1.0) ** 2 * valid).sum() / sums[1]      # its own numerator over the global count
         local.backward()
         red.finish()                                          # SUM over ranks, no 1 / world factor
-        flag = torch.tensor([1.0 if rank == 1 else 0.0])      # "my batch failed to load" on one rank only ...
-        comm.all_reduce_sum(flag)
-        out_q.put((rank, float(loss_value), arena.flat_grad.clone(), float(flag)))
+        flag = comm.any_rank(rank == 1)                       # "my batch failed to load" on one rank only ...
+        assert comm.any_rank(False) is False
+        out_q.put((rank, float(loss_value), arena.flat_grad.clone(), 1.0 if flag else 0.0))
     finally:
         dist.destroy_process_group()
 

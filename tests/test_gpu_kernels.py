@@ -62,9 +62,18 @@ def test_fsq_large_vs_c_oracle_and_torch(env, levels):
     c_codes, c_idx = vq.fsq_forward(z, levels)
     np.testing.assert_array_equal(idx.cpu().numpy(), c_idx)            # bit-exact vs the C restatement
     np.testing.assert_array_equal(codes.cpu().numpy(), c_codes)
-    _, t_idx = O.fsq_forward(torch.from_numpy(z), levels)              # torch CPU (= the reference's arithmetic)
+    # Against torch-CPU's f32 tanh (what the reference runs on THIS host): the kernel's definition - tanh correctly rounded,
+    # like vq_ref.c - differs from it by one ulp at a few thresholds (tests/test_oracle_vq.py lists them), so an index
+    # differs only where z is exactly such a float: about 3e-8 per row for this distribution, 0.06 expected in 2^21 rows
+    # (1-2 in 2^26 were measured).  The count is recorded against that bound, not asserted to be zero.
+    _, t_idx = O.fsq_forward(torch.from_numpy(z), levels)
     flips = int((t_idx.numpy() != c_idx).sum())
-    assert flips == 0, f"{flips} index flips vs torch CPU tanh in {n} rows"
+    print(f"FSQ{levels}: {flips} index flips vs torch-CPU tanh in {n} rows (definition: correctly rounded tanh)")
+    assert flips <= 3, f"{flips} index flips vs torch CPU tanh in {n} rows: more than one-ulp threshold differences explain"
+    # tanh_impl="torch": thresholds bisected with this host's torch.tanh -> identical to torch CPU by construction
+    qt = FSQ(levels, tanh_impl="torch").to(DEV)
+    _, idx_t = qt(t(z))
+    np.testing.assert_array_equal(idx_t.cpu().numpy(), t_idx.numpy())
     # round trip: decode(encode) reproduces the codes exactly
     np.testing.assert_array_equal(q.indices_to_codes(idx.long()).cpu().numpy(), c_codes)
 
@@ -98,6 +107,37 @@ def test_fsq_at_the_thresholds(env, levels):
             assert at - below == basis[j], (levels, j, k, at, below)       # theta is the first z of level k + 1
             assert int(c_idx[r + 2]) == at
             r += 3
+
+
+@pytest.mark.parametrize("levels", [[8, 5, 5, 5], [8, 8, 5, 5, 5], [7, 3], [2, 9, 4]])
+def test_fsq_every_float_near_the_thresholds_both_definitions(env, levels):
+    """Every float within 64 ulps of every threshold of BOTH threshold sets (the adversarial inputs: all places where the two
+    tanh definitions can disagree): tanh_impl="exact" equals the C restatement on all of them, tanh_impl="torch" equals
+    torch CPU on all of them, and the two differ exactly where their thresholds do."""
+    from mqgan_amd.quantizer import FSQ, _f2o, _o2f
+    from oracle import nn as O
+    from oracle import vq
+    qe, qt = FSQ(levels).to(DEV), FSQ(levels, tanh_impl="torch").to(DEV)
+    rows = []
+    for q in (qe, qt):
+        for j, L in enumerate(levels):
+            for k in range(L - 1):
+                o = _f2o(np.float32(q._desc.thresh[j][k]))
+                for i in range(-64, 65):
+                    z = np.zeros(len(levels), np.float32)
+                    z[j] = _o2f(o + i)
+                    rows.append(z)
+    z = np.stack(rows)
+    _, ie = qe(t(z))
+    _, it = qt(t(z))
+    _, c_idx = vq.fsq_forward(z, levels)
+    _, t_idx = O.fsq_forward(torch.from_numpy(z), levels)
+    np.testing.assert_array_equal(ie.cpu().numpy(), c_idx)
+    np.testing.assert_array_equal(it.cpu().numpy(), t_idx.numpy())
+    n_thr_diff = sum(qe._desc.thresh[j][k] != qt._desc.thresh[j][k] for j, L in enumerate(levels) for k in range(L - 1))
+    differ = int((ie != it).sum())
+    assert (differ == 0) == (n_thr_diff == 0)
+    assert differ <= 2 * 2 * n_thr_diff                # each differing threshold appears in both window sets, <= 2 ulps apart
 
 
 def test_fsq_empty_and_odd_shapes(env):

@@ -176,3 +176,20 @@ def test_comm_active_flag():
     class Two(Comm):
         world = 2
     assert not Comm().active and Two().active
+
+
+def test_reencode_default_batching_is_the_reference_loop():
+    """reencode_spectrograms.py:36-47 (reference): os.walk order cut into consecutive batches.  That is the DEFAULT policy of
+    the drop-in entry points (a file's output depends on its batch neighbours, so another default would write other files
+    than the reference for the same tree); 'sorted' / 'exact' are opt-in."""
+    import inspect
+    from mqgan_amd import reencode_spectrograms as R
+    files = [f"f{i}.npy" for i in range(11)]
+    lengths = [50, 7, 31, 50, None, 12, 90, 7, 31, 64, 5]
+    ref = [files[i:i + 4] for i in range(0, len(files), 4)]
+    assert R.plan_batches(files, lengths, 4) == ref
+    assert R.plan_batches(files, lengths, 4, "order") == ref
+    for fn in (R.plan_batches, R._run, R.reencode_spectrograms, R.reencode_spectrograms_from_checkpoint):
+        assert inspect.signature(fn).parameters["bucket"].default == "order", fn.__name__
+    srt = R.plan_batches(files, lengths, 4, "sorted", 0.25)
+    assert srt != ref and sorted(f for b in srt for f in b) == sorted(files)

@@ -46,3 +46,33 @@ def test_l2_argmin_is_a_true_minimiser():
     np.testing.assert_array_equal(idx2, np.arange(5))
     # thread split does not change the answer
     np.testing.assert_array_equal(vq.l2_argmin(x, cb, threads=1), idx)
+
+
+def test_fsq_thresholds_exact_vs_host_torch_tanh():
+    """What 'bit-exact FSQ indices' is measured against.  The product's default thresholds come from tanh correctly rounded
+    (the definition vq_ref.c restates); the reference runs torch.tanh on f32 (quantizer.py:113).  On this host torch's f32
+    tanh is monotone within 64 ulps of every threshold (checked by make_fsq_desc(..., 'torch')) and the two threshold sets
+    agree except for a few entries ONE ulp apart - so the C oracle and torch CPU can differ only when z is exactly one of
+    those floats.  For levels [8,5,5,5] and z ~ N(0, 2^2) that is about 3e-8 per row."""
+    import math
+    from mqgan_amd.quantizer import _f2o, make_fsq_desc
+    for levels in ([8, 5, 5, 5], [8, 8, 5, 5, 5], [7, 3], [2, 9, 4]):
+        a, b = make_fsq_desc(levels), make_fsq_desc(levels, "torch")
+        p_row = 0.0
+        for j, L in enumerate(levels):
+            for k in range(L - 1):
+                ta, tb = np.float32(a.thresh[j][k]), np.float32(b.thresh[j][k])
+                gap = abs(_f2o(ta) - _f2o(tb))
+                assert gap <= 1, (levels, j, k, ta, tb)
+                if gap:
+                    ulp = float(np.spacing(np.abs(ta)))
+                    p_row += ulp * math.exp(-float(ta) ** 2 / 8.0) / (2.0 * math.sqrt(2 * math.pi))
+                    # the float between the thresholds is where the C oracle and torch CPU disagree
+                    z = np.zeros((16, len(levels)), np.float32)
+                    z[:, j] = min(ta, tb)
+                    _, ic = vq.fsq_forward(z, levels)
+                    _, it = O.fsq_forward(torch.from_numpy(z), levels)
+                    assert (ic != it.numpy()).all()
+        assert p_row < 1e-7, (levels, p_row)
+        if levels == [8, 5, 5, 5]:
+            assert 1e-8 < p_row < 6e-8                       # ~3e-8: 1-2 flips in 2^26 rows, as measured

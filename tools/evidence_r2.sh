@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-2 evidence on the GPU box: rocprofv3 kernel stats of the default bench (config 2, f32) and of config 3 (bf16),
 # PMC traffic of the default bench, MFMA / VALU / LDS counters per engine on single layers.  Outputs under gpurun_out/ev/.
+set -o pipefail        # `cmd | tee log || fail` must see cmd's status, not tee's
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/ev
 mkdir -p $O
