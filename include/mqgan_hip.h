@@ -69,6 +69,25 @@ int mq_l2_codebook_norms(const float *codebook, int k, int d, float *cnorm, mqSt
 size_t mq_l2_argmin_workspace(int64_t n);
 int mq_l2_argmin(const float *x, const float *codebook, const float *cnorm, int64_t n, int k, int d, int32_t *idx,
                  float *best_dist, void *workspace, mqStream stream);
+/* The same search, same results bit for bit (indices AND best distances), past the f32-MFMA roof (csrc/vq_screen.hip;
+ * SURVEY.md 8d "bf16 candidate scoring + exact fp32 re-rank"): every (row, code) pair is scored on the bf16 matrix pipe,
+ * pairs within a proven error bound of the row's minimum score become candidates, candidates get the exact k-ordered f32
+ * distance of the definition above; rows without a finite bound (NaN / inf / |x| |c| beyond 1e18) are searched exhaustively
+ * in exact arithmetic.  Needs d % 8 == 0 (mq_l2_screen_supported).
+ *   prepared : per-codebook blob of mq_l2_screen_codebook_bytes(k, d) bytes, 256-byte aligned, filled once per codebook by
+ *              mq_l2_screen_prepare (code norms, bf16 copy, max norm)
+ *   workspace: mq_l2_screen_workspace(n, k, d) bytes, 256-byte aligned (bf16 copy of x, 8 candidate slots per row and a
+ *              shared overflow list of 4 n + 4096 entries)
+ * mq_l2_screen_stats (synchronises `stream`): candidates appended by the last call on that workspace, in-row slots
+ * available, and the number of rows searched exhaustively because the overflow list ran over (0 or n; still exact). */
+int mq_l2_screen_supported(int64_t n, int k, int d);
+size_t mq_l2_screen_codebook_bytes(int k, int d);
+size_t mq_l2_screen_workspace(int64_t n, int k, int d);
+int mq_l2_screen_prepare(const float *codebook, int k, int d, void *prepared, mqStream stream);
+int mq_l2_argmin_screened(const float *x, const float *codebook, const void *prepared, int64_t n, int k, int d, int32_t *idx,
+                          float *best_dist, void *workspace, size_t workspace_bytes, mqStream stream);
+int mq_l2_screen_stats(const void *workspace, int64_t n, int k, int d, uint64_t *appended, uint64_t *slots, uint64_t *rows_over,
+                       mqStream stream);
 /* codebook EMA update (row Q3; no reference code - arithmetic AND summation order are defined in oracle/vq_ref.c
  * section 3, and the kernels are bit-exact against it, deterministic, no float atomics):
  *   cluster_size = decay*cluster_size + (1-decay)*count_k;  embed_sum = decay*embed_sum + (1-decay)*sum_{n: idx[n]==k} x[n];

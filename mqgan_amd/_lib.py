@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MQGAN_HIP_LIB: load another build of the same ABI (kernel experiments); the default is the in-tree library
 LIB_PATH = os.environ.get("MQGAN_HIP_LIB") or os.path.join(_HERE, "libmqgan_hip.so")
 _lib = None
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class MqganHipError(RuntimeError):
@@ -53,6 +53,12 @@ SIGNATURES = {
     "mq_l2_codebook_norms": (_I, [_P, _I, _I, _P, _P]),
     "mq_l2_argmin_workspace": (_Z, [_L]),
     "mq_l2_argmin": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _P]),
+    "mq_l2_screen_supported": (_I, [_L, _I, _I]),
+    "mq_l2_screen_codebook_bytes": (_Z, [_I, _I]),
+    "mq_l2_screen_workspace": (_Z, [_L, _I, _I]),
+    "mq_l2_screen_prepare": (_I, [_P, _I, _I, _P, _P]),
+    "mq_l2_argmin_screened": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _Z, _P]),
+    "mq_l2_screen_stats": (_I, [_P, _L, _I, _I, _P, _P, _P, _P]),
     "mq_codebook_ema_workspace": (_Z, [_L, _I, _I]),
     "mq_codebook_ema_update": (_I, [_P, _P, _L, _I, _I, _F, _F, _P, _P, _P, _P, _Z, _P]),
     "mq_conv_fprop": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),

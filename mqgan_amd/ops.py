@@ -1350,6 +1350,44 @@ def l2_argmin(x: torch.Tensor, codebook: torch.Tensor, cnorm: Optional[torch.Ten
     return (idx, dist) if return_dist else idx
 
 
+def l2_screen_supported(n, k, d) -> bool:
+    return bool(L().mq_l2_screen_supported(n, k, d))
+
+
+def l2_screen_prepare(codebook: torch.Tensor) -> torch.Tensor:
+    """Per-codebook data of the screened search (code norms, bf16 copy, largest norm): once per codebook version."""
+    k, d = codebook.shape
+    blob = _ws_bytes(L().mq_l2_screen_codebook_bytes(k, d), codebook)
+    check(L().mq_l2_screen_prepare(fptr(codebook), k, d, ptr(blob), stream()), "mq_l2_screen_prepare")
+    return blob
+
+
+def l2_argmin_screened(x: torch.Tensor, codebook: torch.Tensor, prepared: Optional[torch.Tensor] = None, return_dist=False,
+                       workspace: Optional[torch.Tensor] = None):
+    """mq_l2_argmin's results (bit for bit) from bf16 screening + exact f32 re-rank (csrc/vq_screen.hip)."""
+    n, d = x.shape
+    k = codebook.shape[0]
+    if prepared is None:
+        prepared = l2_screen_prepare(codebook)
+    idx = torch.empty((n,), dtype=torch.int32, device=x.device)
+    dist = _empty((n,), x) if return_dist else None
+    nbytes = L().mq_l2_screen_workspace(n, k, d)
+    if workspace is None:
+        workspace = _ws_bytes(nbytes, x)
+    check(L().mq_l2_argmin_screened(fptr(x), fptr(codebook), ptr(prepared), n, k, d, ptr(idx), fptr(dist, True), ptr(workspace),
+                                    workspace.numel() * workspace.element_size(), stream()), "mq_l2_argmin_screened")
+    return (idx, dist) if return_dist else idx
+
+
+def l2_screen_stats(workspace: torch.Tensor, n, k, d):
+    """(candidates appended, slots available, rows that overflowed their slots) of the last screened search on
+    ``workspace``; synchronises the stream."""
+    import ctypes as _C
+    a, sl, ov = _C.c_uint64(0), _C.c_uint64(0), _C.c_uint64(0)
+    check(L().mq_l2_screen_stats(ptr(workspace), n, k, d, _C.byref(a), _C.byref(sl), _C.byref(ov), stream()), "mq_l2_screen_stats")
+    return a.value, sl.value, ov.value
+
+
 def codebook_ema_update(x, idx, cluster_size, embed_sum, codebook, decay=0.99, eps=1e-5):
     """In-place EMA update of (cluster_size, embed_sum, codebook); deterministic, bit-exact against oracle/vq_ref.c."""
     n, d = x.shape

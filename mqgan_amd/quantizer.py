@@ -156,7 +156,14 @@ class L2Quantizer(nn.Module):
 
     @torch.no_grad()
     def indices(self, x: torch.Tensor) -> torch.Tensor:
+        """Nearest code per vector.  d % 8 == 0: bf16 screening + exact f32 re-rank (csrc/vq_screen.hip); otherwise the
+        f32-MFMA search.  Same result either way, bit for bit."""
         flat = x.reshape(-1, self.dim).contiguous()
+        if ops.l2_screen_supported(flat.shape[0], self.codebook_size, self.dim):
+            ver = (self.codebook.data_ptr(), self.codebook._version)
+            if getattr(self, "_prepared", None) is None or self._prepared[0] != ver:
+                self._prepared = (ver, ops.l2_screen_prepare(self.codebook))
+            return ops.l2_argmin_screened(flat, self.codebook, self._prepared[1]).view(x.shape[:-1])
         return ops.l2_argmin(flat, self.codebook).view(x.shape[:-1])
 
     def forward(self, x: torch.Tensor):
@@ -168,3 +175,4 @@ class L2Quantizer(nn.Module):
     def ema_update(self, x: torch.Tensor, idx: torch.Tensor):
         ops.codebook_ema_update(x.reshape(-1, self.dim).contiguous(), idx.reshape(-1).to(torch.int32).contiguous(),
                                 self.cluster_size, self.embed_sum, self.codebook, self.decay, self.eps)
+        self._prepared = None            # the kernel rewrote the codebook behind torch's version counter

@@ -203,6 +203,105 @@ def test_l2_argmin_nan_rows_give_a_valid_index(env):
     assert int(idx[0]) == 200
 
 
+# ----------------------------------------------------------------------------------------- L2 argmin, screened (bf16 scores + exact re-rank)
+@pytest.mark.parametrize("n,k,d", [(4096, 1000, 8), (2048, 1024, 256), (1000, 2048, 512), (777, 130, 24), (128, 8192, 64),
+                                   (1, 5, 8), (16384, 1024, 256), (2048, 8192, 512), (16384, 2048, 512)])
+def test_l2_argmin_screened_bit_exact_vs_c_oracle(env, n, k, d):
+    """The nine shapes of the f32 search (d % 8 == 0 variants of the two odd ones): the screened search returns the oracle's
+    indices AND best distances bit for bit, and equals mq_l2_argmin; no row overflowed its candidate slots (so every result
+    came through screening + re-rank, not through the exhaustive fallback)."""
+    from oracle import vq
+    ops = env
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    cb = rng.standard_normal((k, d)).astype(np.float32)
+    xd, cd = t(x), t(cb)
+    assert ops.l2_screen_supported(n, k, d)
+    ws = ops._ws_bytes(ops.L().mq_l2_screen_workspace(n, k, d), xd)
+    idx, dist = ops.l2_argmin_screened(xd, cd, return_dist=True, workspace=ws)
+    emitted, cap, over = ops.l2_screen_stats(ws, n, k, d)
+    want, wdist = vq.l2_argmin(x, cb, threads=8, return_dist=True)
+    np.testing.assert_array_equal(idx.cpu().numpy(), want)
+    np.testing.assert_array_equal(dist.cpu().numpy(), wdist)
+    i2, d2 = ops.l2_argmin(xd, cd, return_dist=True)
+    assert torch.equal(idx, i2) and torch.equal(dist, d2)
+    assert n <= emitted and over == 0, (emitted, cap, over)       # every row through screening + re-rank
+    print(f"screened ({n},{k},{d}): {emitted / n:.2f} candidates per row ({cap // n} slots)")
+
+
+def test_l2_argmin_screened_adversarial_near_ties(env):
+    """Near-ties the bf16 scores cannot order: codes that differ from each other by one f32 ulp in one coordinate, exact
+    duplicates (lowest index must win), codes at a common distance from every row (all scores equal up to rounding), and rows
+    that ARE codes.  Indices and distances must equal the oracle's."""
+    from oracle import vq
+    ops = env
+    rng = np.random.default_rng(17)
+    d, k0 = 64, 96
+    base = rng.standard_normal((k0, d)).astype(np.float32)
+    ulp = base.copy()
+    ulp[:, 5] = np.nextafter(ulp[:, 5], np.float32(np.inf))             # one ulp away in one coordinate
+    ulp2 = base.copy()
+    ulp2[:, 9] = np.nextafter(ulp2[:, 9], np.float32(-np.inf))
+    signs = rng.choice([-1.0, 1.0], size=(64, d)).astype(np.float32)     # +-1 codes: equal norms, many exact ties of the distance
+    cb = np.concatenate([ulp, base, base, ulp2, signs, signs[::-1]], 0).astype(np.float32)
+    x = np.concatenate([base + (rng.standard_normal(base.shape) * 1e-3).astype(np.float32), base, ulp,
+                        rng.choice([-1.0, 0.0, 1.0], size=(256, d)).astype(np.float32),
+                        np.zeros((8, d), np.float32)], 0)                # zero rows: every +-1 code at the same distance
+    idx, dist = ops.l2_argmin_screened(t(x), t(cb), return_dist=True)
+    want, wdist = vq.l2_argmin(x, cb, threads=4, return_dist=True)
+    np.testing.assert_array_equal(idx.cpu().numpy(), want)
+    np.testing.assert_array_equal(dist.cpu().numpy(), wdist)
+
+
+def test_l2_argmin_screened_rows_without_a_bound(env):
+    """NaN / inf / huge rows have no error bound: they take the exhaustive exact path and still match the oracle; a NaN code
+    or a huge codebook sends every row there.  (Rows that overflow their candidate slots take the same path: the zero rows of
+    the near-tie test, 128 codes at one distance.)"""
+    from oracle import vq
+    ops = env
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((300, 64)).astype(np.float32)
+    cb = rng.standard_normal((257, 64)).astype(np.float32)
+    x[7, 3] = np.nan
+    x[131, :] = np.nan
+    x[200, 10] = np.inf
+    x[201, :] = 3e19
+    x[202, 0] = -1e30
+    idx, dist = ops.l2_argmin_screened(t(x), t(cb), return_dist=True)
+    want, wdist = vq.l2_argmin(x, cb, threads=4, return_dist=True)
+    np.testing.assert_array_equal(idx.cpu().numpy(), want)
+    np.testing.assert_array_equal(dist.cpu().numpy(), wdist)
+    x = np.nan_to_num(x, nan=0.0, posinf=1.0, neginf=-1.0)
+    x[201:203] = 1.0
+    for bad in (np.nan, 1e25):
+        cb2 = cb.copy()
+        cb2[200, 5] = bad
+        idx, dist = ops.l2_argmin_screened(t(x), t(cb2), return_dist=True)
+        want, wdist = vq.l2_argmin(x, cb2, threads=4, return_dist=True)
+        np.testing.assert_array_equal(idx.cpu().numpy(), want)
+        np.testing.assert_array_equal(dist.cpu().numpy(), wdist)
+    # scaled data: the bound scales with |x| |c|, tiny and large magnitudes alike
+    for sx, sc in ((1e-12, 1e-9), (1e6, 1e9), (1e-20, 1e15)):
+        xs, cs = (x * np.float32(sx)).astype(np.float32), (cb * np.float32(sc)).astype(np.float32)
+        idx, dist = ops.l2_argmin_screened(t(xs), t(cs), return_dist=True)
+        want, wdist = vq.l2_argmin(xs, cs, threads=4, return_dist=True)
+        np.testing.assert_array_equal(idx.cpu().numpy(), want)
+        np.testing.assert_array_equal(dist.cpu().numpy(), wdist)
+
+
+def test_l2_quantizer_uses_the_screened_search(env):
+    from mqgan_amd.quantizer import L2Quantizer
+    ops = env
+    torch.manual_seed(3)
+    q = L2Quantizer(512, 64).to(DEV)
+    x = torch.randn(3, 50, 64, device=DEV)
+    idx = q.indices(x)
+    assert torch.equal(idx.reshape(-1), ops.l2_argmin(x.reshape(-1, 64).contiguous(), q.codebook))
+    q.ema_update(x, idx)                                      # the codebook changes: the prepared copy must follow
+    idx2 = q.indices(x)
+    assert torch.equal(idx2.reshape(-1), ops.l2_argmin(x.reshape(-1, 64).contiguous(), q.codebook))
+
+
 @pytest.mark.parametrize("n,k,d", [(5000, 64, 32), (16384, 1024, 256), (16384, 8192, 512), (100, 7, 1100)])
 def test_codebook_ema_bit_exact_vs_c_oracle(env, n, k, d):
     """EMA update against its definition in oracle/vq_ref.c (fixed summation order): cluster sizes, embedding sums and
