@@ -1100,8 +1100,9 @@ static int launch_h2(const mqConvDesc *d, const void *act, const void *w, void *
 #define MQ_D32(TN_, NS_, PAR_) do { kname("conv_d32_kernel<%d, %d, %s>", TN_, NS_, tf(PAR_)); hipLaunchKernelGGL((conv_d32_kernel<TN_, NS_, PAR_>), grid, block, 0, st, reinterpret_cast<const float *>(act), \
                                                   reinterpret_cast<const float *>(w), reinterpret_cast<float *>(out), g, pi, epi, act_gs); } while (0)
 #define MQ_H2_CB(TN_, NS_, PAR_) do { if constexpr (ET::F32) MQ_D32(TN_, NS_, PAR_); else if (g.CB == 64) MQ_H2(TN_, NS_, 64, PAR_); else MQ_H2(TN_, NS_, 32, PAR_); } while (0)
+    static const bool ns2 = getenv("MQGAN_H2_NS2") != nullptr;      // experiment: TN = 2 on a two-stage ring (A/B of the ring depth)
 #define MQ_H2_TN(PAR_) do { if (TN == 4) MQ_H2_CB(4, 2, PAR_); else if (TN == 3) MQ_H2_CB(3, 2, PAR_); \
-                            else if (TN == 2) MQ_H2_CB(2, 3, PAR_); else MQ_H2_CB(1, 2, PAR_); } while (0)
+                            else if (TN == 2) { if (ns2) MQ_H2_CB(2, 2, PAR_); else MQ_H2_CB(2, 3, PAR_); } else MQ_H2_CB(1, 2, PAR_); } while (0)
     if (parity) MQ_H2_TN(true);
     else MQ_H2_TN(false);
 #undef MQ_H2_TN
