@@ -437,6 +437,12 @@ int mq_masked_mae_bwd(const float *pred, const float *target, const uint8_t *pad
 int mq_wino_input_transform(const float *x, int N, int H, int W, int C, float *V, mqStream stream);
 int mq_wino_dy_transform(const float *dy, int N, int H, int W, int K, float *Z, mqStream stream);
 int mq_wino_output_transform(const float *M, const float *bias, int N, int H, int W, int K, float *y, mqStream stream);
+/* Backward of such a layer in ONE pass over dy: Z as mq_wino_dy_transform, Vd = mq_wino_input_transform(dy) (the input gradient's
+ * transformed operand) and deterministic per-block column sums for the bias gradient: bias_partial is
+ * [mq_wino_dy_fused_rows(N, H, W, K)][K] (0 rows: shape not supported, K > 1024), db[k] = sum over its rows (mq_colsum).  Z and
+ * Vd are bit-identical to the separate transforms; the column sums are deterministic in an order of their own. */
+int mq_wino_dy_fused_rows(int N, int H, int W, int K);
+int mq_wino_dy_fused(const float *dy, int N, int H, int W, int K, float *Z, float *Vd, float *bias_partial, mqStream stream);
 int mq_wino_weight_transform(const float *w_krsc, int K, int C, int flip_transpose, float *U, mqStream stream);
 int mq_wino_wgrad_inverse(const float *P, int K, int C, float *dw_krsc, mqStream stream);
 

@@ -146,6 +146,8 @@ SIGNATURES = {
     "mq_wino_input_transform": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "mq_wino_dy_transform": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "mq_wino_output_transform": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "mq_wino_dy_fused_rows": (_I, [_I, _I, _I, _I]),
+    "mq_wino_dy_fused": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "mq_wino_weight_transform": (_I, [_P, _I, _I, _I, _P, _P]),
     "mq_wino_wgrad_inverse": (_I, [_P, _I, _I, _P, _P]),
     "mq_sumsq": (_I, [_P, _L, _P, _P, _P]),

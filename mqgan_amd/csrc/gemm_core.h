@@ -6,8 +6,14 @@
 // global -> registers -> LDS (double buffered, one barrier per K-step); the global loads of step t+1
 // are issued before the MFMAs of step t.
 //
-// LDS image: rows of BK floats padded to LD = 18 (2 x odd: the 32 lanes of a ds_read_b64 then cover
-// all 64 banks).  Inside each aligned group of 4 k's the middle two are swapped when written,
+// LDS image: rows of BK floats padded to LD = 18 (2 x odd: the 32 lanes a ds_read_b64 serves per pass then
+// cover all 64 banks - the FRAGMENT READS are conflict-free: 18 li mod 64 takes 32 distinct even values).
+// The staging WRITES are not: a wave writes rows r .. r+15 at columns 4 kq (+2) as float2, and
+// (18 r + 4 kq) mod 64 collides between rows (row 0 / kq 2 with row 4 / kq 0, ...): that is where the
+// measured 25 % SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of these kernels comes from.  It costs nothing
+// measurable: writes are a fifth of the LDS instructions, the LDS is busy about half of the time and the
+// matrix pipe 98.5 % of the wave cycles in the main loop (profiles/r2_mfma_counters.json).
+// Inside each aligned group of 4 k's the middle two are swapped when written,
 // (k0,k2,k1,k3), so that lane half h reads ONE float2 at offset 4q+2h = (k = 4q+h, k = 4q+2+h): the
 // operands of MFMA steps 2q and 2q+1.  Every accumulator therefore sums k in natural order, which
 // the nearest-neighbour search relies on for bit-exactness against oracle/vq_ref.c.

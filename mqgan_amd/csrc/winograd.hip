@@ -108,6 +108,86 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float *__restrict__ 
     }
 }
 
+// Backward of a Winograd layer reads dy for three things: Z = A dY A^T (weight gradient), V' = B^T dy B (input gradient: the
+// "same" convolution of dy with the rotated filter) and the bias gradient (column sums).  One pass: the 4x4 window of a tile
+// holds its 2x2 outputs in the middle.  The column sums are deterministic: the launch is sized so that a thread keeps its
+// channel group over the whole grid-stride loop (threads % K4 == 0), sums it in registers, the block adds its threads' sums
+// in a fixed order and writes one row of partial[blocks][K]; the caller column-sums that small matrix.
+__global__ __launch_bounds__(256) void wino_dy_fused_kernel(const float *__restrict__ dy, int64_t N, int H, int W, int K4, int th, int tw,
+                                                            float *__restrict__ Z, float *__restrict__ V, float *__restrict__ partial)
+{
+    __shared__ float4 s_sum[256];
+    const int64_t tiles = N * th * tw;
+    const int64_t total = tiles * K4;
+    const float4 *y4 = reinterpret_cast<const float4 *>(dy);
+    float4 *Z4 = reinterpret_cast<float4 *>(Z);
+    float4 *V4 = reinterpret_cast<float4 *>(V);
+    float4 bsum = f4zero();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k4 = (int)(i % K4);
+        const int64_t tile = i / K4;
+        const int tj = (int)(tile % tw);
+        const int64_t r = tile / tw;
+        const int ti = (int)(r % th);
+        const int64_t n = r / th;
+        float4 d[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int h = 2 * ti - 1 + a;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int w = 2 * tj - 1 + b;
+                d[a][b] = (h >= 0 && h < H && w >= 0 && w < W) ? y4[((n * H + h) * W + w) * K4 + k4] : f4zero();
+            }
+        }
+        bsum = bsum + ((d[1][1] + d[1][2]) + (d[2][1] + d[2][2]));
+        {   // Z = A y A^T of the middle 2x2 (wino_dy_kernel)
+            float4 t[4][2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                t[0][b] = d[1][1 + b];
+                t[1][b] = d[1][1 + b] + d[2][1 + b];
+                t[2][b] = d[1][1 + b] - d[2][1 + b];
+                t[3][b] = -d[2][1 + b];
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                Z4[((int64_t)(4 * a + 0) * tiles + tile) * K4 + k4] = t[a][0];
+                Z4[((int64_t)(4 * a + 1) * tiles + tile) * K4 + k4] = t[a][0] + t[a][1];
+                Z4[((int64_t)(4 * a + 2) * tiles + tile) * K4 + k4] = t[a][0] - t[a][1];
+                Z4[((int64_t)(4 * a + 3) * tiles + tile) * K4 + k4] = -t[a][1];
+            }
+        }
+        {   // V' = B^T d B (wino_input_kernel)
+            float4 t[4][4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                t[0][b] = d[0][b] - d[2][b];
+                t[1][b] = d[1][b] + d[2][b];
+                t[2][b] = d[2][b] - d[1][b];
+                t[3][b] = d[1][b] - d[3][b];
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                V4[((int64_t)(4 * a + 0) * tiles + tile) * K4 + k4] = t[a][0] - t[a][2];
+                V4[((int64_t)(4 * a + 1) * tiles + tile) * K4 + k4] = t[a][1] + t[a][2];
+                V4[((int64_t)(4 * a + 2) * tiles + tile) * K4 + k4] = t[a][2] - t[a][1];
+                V4[((int64_t)(4 * a + 3) * tiles + tile) * K4 + k4] = t[a][1] - t[a][3];
+            }
+        }
+    }
+    // block sums per channel group: thread t owns group (blockIdx * 256 + t) % K4 for the whole loop
+    s_sum[threadIdx.x] = bsum;
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < K4) {                                   // first member of its group inside this block (K4 >= 256: every thread)
+        float4 acc = s_sum[t];
+        for (int j = t + K4; j < 256; j += K4) acc = acc + s_sum[j];
+        const int k4 = (int)(((int64_t)blockIdx.x * 256 + t) % K4);
+        reinterpret_cast<float4 *>(partial)[(int64_t)blockIdx.x * K4 + k4] = acc;
+    }
+}
+
 // y = A^T M A (+ bias),  A^T = [1 1 1 0; 0 1 -1 -1]
 __global__ __launch_bounds__(256) void wino_output_kernel(const float *__restrict__ M, const float *__restrict__ bias, int64_t N, int H,
                                                           int W, int K4, int th, int tw, float *__restrict__ y)
@@ -239,6 +319,35 @@ extern "C" int mq_wino_dy_transform(const float *dy, int N, int H, int W, int K,
     hipLaunchKernelGGL(wino_dy_kernel, dim3(ew_grid((int64_t)N * th * tw * (K / 4), 256)), dim3(256), 0, S(stream), dy, (int64_t)N, H, W,
                        K / 4, th, tw, Z);
     MQ_LAUNCH_CHECK("mq_wino_dy_transform");
+    return 0;
+}
+// blocks of mq_wino_dy_fused: enough to fill the chip, a multiple of K4 / gcd(K4, 256) so that (blocks * 256) % K4 == 0, and -
+// for K4 > 256 - at least K4 / 256 rounded up to that multiple (every channel group needs a thread)
+static int wino_fused_blocks(int64_t work_items, int K4)
+{
+    int g = 256, a = K4;
+    while (a) { const int t = g % a; g = a; a = t; }          // gcd(256, K4)
+    const int m = K4 / g;
+    int64_t want = ew_grid(work_items, 256);
+    want = (want / m) * m;
+    if (want < m) want = m;
+    return (int)want;
+}
+extern "C" int mq_wino_dy_fused_rows(int N, int H, int W, int K)
+{
+    if (N <= 0 || H <= 0 || W <= 0 || K <= 0 || K % 4 != 0 || K > 1024) return 0;
+    return wino_fused_blocks((int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (K / 4), K / 4);
+}
+extern "C" int mq_wino_dy_fused(const float *dy, int N, int H, int W, int K, float *Z, float *Vd, float *bias_partial, mqStream stream)
+{
+    if (wino_args(dy, Z, N, H, W, K, "mq_wino_dy_fused")) return 1;
+    MQ_REQUIRE(Vd && bias_partial && ((uintptr_t)Vd | (uintptr_t)bias_partial) % 16 == 0, "mq_wino_dy_fused: Vd / bias_partial null or unaligned");
+    MQ_REQUIRE(K <= 1024, "mq_wino_dy_fused: K <= 1024 (every block must cover every channel group; got %d)", K);
+    const int th = (H + 1) / 2, tw = (W + 1) / 2;
+    const int blocks = mq_wino_dy_fused_rows(N, H, W, K);
+    MQ_REQUIRE(blocks > 0 && ((int64_t)blocks * 256) % (K / 4) == 0, "mq_wino_dy_fused: launch plan");
+    hipLaunchKernelGGL(wino_dy_fused_kernel, dim3(blocks), dim3(256), 0, S(stream), dy, (int64_t)N, H, W, K / 4, th, tw, Z, Vd, bias_partial);
+    MQ_LAUNCH_CHECK("mq_wino_dy_fused");
     return 0;
 }
 extern "C" int mq_wino_output_transform(const float *M, const float *bias, int N, int H, int W, int K, float *y, mqStream stream)

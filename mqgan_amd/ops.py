@@ -428,22 +428,36 @@ def _wino_in(t, d: ConvDesc, channels: int, dy_side: bool = False):
     return out
 
 
-def _wino_conv(d: ConvDesc, x, w_krsc, bias, cin: int, cout: int, flip: bool, key, keep=None):
+def _wino_conv(d: ConvDesc, x, w_krsc, bias, cin: int, cout: int, flip: bool, key, keep=None, V=None):
     """'same' 3x3 convolution of x (N, H, W, cin) with the KRSC weights (forward: flip False; input gradient: flip True).
-    ``keep``: a list that receives the transformed input V."""
-    V = _wino_in(x, d, cin)
+    ``keep``: a list that receives the transformed input V.  ``V``: the already transformed input (x is then not read)."""
+    if V is None:
+        V = _wino_in(x, d, cin)
     if keep is not None:
         keep.append(V)
-    U = _empty((16 * cout, 1, cin), x)
+    U = _empty((16 * cout, 1, cin), V)
     check(L().mq_wino_weight_transform(fptr(w_krsc), d.K, d.C, int(flip), fptr(U), stream()), "mq_wino_weight_transform")
     dg = _wino_gemm_desc(d, cin, cout)
-    M = _empty((16 * _wino_tiles(d), 1, 1, cout), x)
+    M = _empty((16 * _wino_tiles(d), 1, 1, cout), V)
     _timed(None, _conv_flops(dg), lambda: check(
         L().mq_conv_fprop(C.byref(dg), fptr(V), fptr(U), None, fptr(M), stream()), "mq_conv_fprop"), key)
     del V
-    y = _empty((d.N, d.H, d.W, cout), x)
+    y = _empty((d.N, d.H, d.W, cout), M)
     check(L().mq_wino_output_transform(fptr(M), fptr(bias, True), d.N, d.H, d.W, cout, fptr(y), stream()), "mq_wino_output_transform")
     return y
+
+
+WINO_FUSED_DY = os.environ.get("MQGAN_WINO_FUSED_DY", "1") != "0"     # backward: dy read once for Z, the dgrad's V and the bias sums
+
+
+def _wino_dy_fused(dy, d: ConvDesc):
+    """(Z, V of dy, per-block column sums [rows][K]) in one pass over dy (mq_wino_dy_fused)."""
+    rows = L().mq_wino_dy_fused_rows(d.N, d.H, d.W, d.K)
+    Z = _empty((16 * _wino_tiles(d), 1, 1, d.K), dy)
+    Vd = _empty((16 * _wino_tiles(d), 1, 1, d.K), dy)
+    part = _empty((rows, d.K), dy)
+    check(L().mq_wino_dy_fused(fptr(dy), d.N, d.H, d.W, d.K, fptr(Z), fptr(Vd), fptr(part), stream()), "mq_wino_dy_fused")
+    return Z, Vd, part
 
 
 class ConvWinoFn(torch.autograd.Function):
@@ -471,11 +485,18 @@ class ConvWinoFn(torch.autograd.Function):
         d = _desc_from_key(ctx.key)
         dy = dy.contiguous()
         dx = dw = db = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[3]
+        Z = Vd = part = None
+        if (WINO_FUSED_DY and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
+                and L().mq_wino_dy_fused_rows(d.N, d.H, d.W, d.K) > 0):
+            Z, Vd, part = _wino_dy_fused(dy, d)
         if ctx.needs_input_grad[0]:
-            dx = _wino_conv(d, dy, w_krsc, None, d.K, d.C, True, ctx.key)
+            dx = _wino_conv(d, dy, w_krsc, None, d.K, d.C, True, ctx.key, V=Vd)
+            del Vd
         if ctx.needs_input_grad[1]:
             V = x if ctx.kept_v else _wino_in(x, d, d.C)
-            Z = _wino_in(dy, d, d.K, dy_side=True)
+            if Z is None:
+                Z = _wino_in(dy, d, d.K, dy_side=True)
             dg = _wino_gemm_desc(d, d.C, d.K)
             P = _empty((16 * d.K, 1, d.C), x)
             nbytes = L().mq_conv_wgrad_workspace(C.byref(dg))
@@ -485,8 +506,8 @@ class ConvWinoFn(torch.autograd.Function):
             del V, Z
             dw = _empty(ctx.w_shape, x)
             check(L().mq_wino_wgrad_inverse(fptr(P), d.K, d.C, fptr(dw), stream()), "mq_wino_wgrad_inverse")
-        if ctx.has_bias and ctx.needs_input_grad[3]:
-            db = _bias_grad(d, dy)
+        if want_db:
+            db = colsum(part) if part is not None else _bias_grad(d, dy)
         return dx, dw, None, db, None
 
 

@@ -1,6 +1,7 @@
 #!/bin/bash
 # MFMA / VALU / LDS counters of the conv kernels on single layers (tools/h2_micro.py), separate --pmc passes.
 # usage (on the GPU box): bash tools/pmc_h2.sh <tag> <script in tools/: h2_micro.py | f32_micro.py> <args...>     -> gpurun_out/pmc_<tag>.json
+set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=$1; shift
 SCRIPT=${1:-h2_micro.py}; shift
@@ -29,7 +30,7 @@ for f in glob.glob("$OUT/p1/*/*kernel_trace.csv"):
         dur[r["Kernel_Name"]].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
 out = {}
 for k, cs in agg.items():
-    if "conv" not in k and "l2_argmin" not in k: continue
+    if "conv" not in k and "l2_" not in k: continue
     name = k.split("(")[0].replace("void ", "").replace("mq::", "")
     a = {c: sum(v) / len(v) for c, v in cs.items()}
     e = {"launches": len(next(iter(cs.values()))), "avg_ns_under_pmc": (sum(dur[k]) / len(dur[k])) if dur.get(k) else None}

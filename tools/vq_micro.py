@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""The L2 codebook search alone (for tools/pmc_h2.sh counters): python tools/vq_micro.py [rows]"""
+"""The L2 codebook search alone - the f32-MFMA kernel and the bf16-screened search - for tools/pmc_h2.sh counters:
+python tools/vq_micro.py [rows]"""
 import os
 import sys
 
@@ -28,3 +29,15 @@ for k, d in ((8192, 512), (2048, 512), (1024, 256)):
     torch.cuda.synchronize()
     ms = s.elapsed_time(e) / 10
     print(f"l2_argmin rows {rows} codes {k} d {d}: {ms:.4f} ms  {2.0 * rows * k * d / ms / 1e9:.1f} TF/s", flush=True)
+    prep = ops.l2_screen_prepare(cb)
+    ws2 = ops._ws_bytes(ops.L().mq_l2_screen_workspace(rows, k, d), x)
+    for _ in range(3):
+        ops.l2_argmin_screened(x, cb, prep, workspace=ws2)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(10):
+        ops.l2_argmin_screened(x, cb, prep, workspace=ws2)
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / 10
+    print(f"l2_argmin_screened rows {rows} codes {k} d {d}: {ms:.4f} ms  {2.0 * rows * k * d / ms / 1e9:.1f} TF/s (algorithmic)", flush=True)
