@@ -196,3 +196,29 @@ def test_unsynchronised_steps_with_varying_crop_length():
     b = run(False)
     for x, y, what in zip(a, b, ("generator weights", "discriminator weights", "generator exp_avg", "discriminator exp_avg_sq", "LeCam")):
         assert torch.equal(x, y), what
+
+
+# ----------------------------------------------------------------------------------------- bench.py --gpus 2, end to end
+def test_bench_self_launches_two_ranks_on_this_gpu():
+    """`python bench.py --gpus 2` with no launcher in the environment: the parent starts two ranks, they rendezvous, count
+    themselves with an all-reduce, build trainers, exchange gradient buckets and loss sums every step, and rank 0 prints ONE
+    line with n_gpus = 2.  One GPU here, so the ranks share it over gloo (MQGAN_BENCH_SHARE_GPU=1, the rehearsal mode); the
+    code path - launcher, hooks, per-bucket arena fill, asynchronous bucket all-reduces, TorchComm - is the N > 1 path."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MQGAN_BENCH_SHARE_GPU="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+                          "--frames", "128", "--no-alt", "--no-configs", "--no-vq", "--no-cpu-baseline"], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (out.stdout, out.stderr[-2000:])
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["losses_finite"] is True and line["config"]["global_batch"] == 8
+    c = line["collectives"]
+    assert c["backend"] == "gloo" and c["ranks_counted_by_all_reduce"] == 2 and c["asynchronous"] is True
+    assert c["gradient_buckets_per_step"] >= 2 and c["loss_sum_all_reduces_total"] >= 3 * 3
+    assert line["value"] > 0 and line["ms_per_step"] > 0
