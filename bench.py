@@ -416,6 +416,37 @@ def reencode_line(n_files=128):
     return out
 
 
+def loader_line(device, n_files=288, file_frames=640):
+    """The same config-2 step fed by the real input pipeline instead of resident batches (the reference's loop
+    train.py:511-537): synthetic .npy files on disk -> DataLoader (num_workers 0, random 512-frame crops, collate) -> pinned
+    staging -> H2D on a side stream (PrefetchLoader) -> train_step.  Trainer._train_epoch itself is timed: one warm-up epoch,
+    one timed epoch.  The PCIe-inclusive rate - reported beside `value`, never as `value`."""
+    import copy
+    import tempfile
+    from mqgan_amd.train import Trainer, synthetic_mel
+    cfg = copy.deepcopy(load_config("hifispeech"))
+    B, T, mel = cfg["data"]["batch_size"], cfg["data"]["crop_len"], cfg["model"]["mel_channels"]
+    with tempfile.TemporaryDirectory() as tmp:
+        for i in range(n_files):
+            np.save(os.path.join(tmp, f"{i:05d}.npy"), synthetic_mel(file_frames, mel, 50000 + i))
+        cfg["data"]["data_dir"] = tmp
+        cfg["data"]["output_dir"] = None
+        cfg["data"]["validation_split"] = 0.0
+        tr = Trainer(cfg, device=device, build_data=True)
+        steps = len(tr.train_loader)
+        tr._train_epoch(1)                           # warm-up: allocator, kernels, page cache
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tr._train_epoch(1)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        del tr
+    torch.cuda.empty_cache()
+    return {"workload": f"hifispeech train step fed by DataLoader + PrefetchLoader: {n_files} .npy files of {file_frames} x {mel}, "
+                        f"random crops of {T}, batch {B}, num_workers 0 (as the reference), pinned staging, H2D on a side stream",
+            "value": steps * B * T / dt, "unit": "mel-frames/s", "ms_per_step": dt / steps * 1e3, "steps": steps}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -582,6 +613,8 @@ def main():
             line["configs"] = {"config3_hifimusic_bf16": config3_line(device)}
             torch.cuda.empty_cache()
             line["configs"]["reencode_n2_hifispeech_fp32"] = reencode_line()
+            torch.cuda.empty_cache()
+            line["configs"]["config2_through_the_loader"] = loader_line(device)
         if not args.no_vq:
             line["vq"] = bench_vq(device)
         if world == 1 and not args.no_cpu_baseline:
