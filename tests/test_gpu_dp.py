@@ -242,3 +242,62 @@ def test_two_processes_over_torch_distributed_equal_the_global_batch(use_fm):
     for s in range(2):                                                  # replicas bit-identical to each other
         for i in (1, 2, 3, 4, 5):
             assert torch.equal(got[0][1][s][i], got[1][1][s][i])
+
+
+# ----------------------------------------------------------------------------------------- the epoch loop under two ranks
+def _epoch_rank(rank, world, port, data_dir, q):
+    """Trainer._train_epoch under two real ranks (gloo, one GPU): DistributedSampler shards, per-rank random crop lengths
+    (different T on the two ranks in the same step), PrefetchLoader, the host-side skip agreement (Comm.any_rank) when ONE
+    rank's whole batch fails to load, gradient buckets + loss sums every step that is taken."""
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import __graft_entry__ as ge
+        ge.build()
+        from mqgan_amd.train import Trainer
+        cfg = {"data": {"data_dir": data_dir, "output_dir": None, "validation_split": 0.0, "crop_len": [32, 48], "batch_size": 1,
+                        "num_workers": 0},
+               "model": TINY_CFG["model"], "training": dict(TINY_CFG["training"], num_epochs=1, pretrained=None),
+               "logging": {"eval_interval": 1, "save_interval": 1, "log_interval": 1, "num_plot_examples": 1}}
+        logs = []
+        tr = Trainer(cfg, device=DEV, log_fn=logs.append)
+        assert tr.world == 2 and tr.comm.active
+        n_batches = len(tr.train_loader)
+        tr._train_epoch(1)
+        torch.cuda.synchronize()
+        q.put((rank, n_batches, tr.global_step, tr.arena_g.flat_param.cpu().numpy(), tr.arena_d.flat_param.cpu().numpy(),
+               tr.gan_loss._state.cpu().numpy(), [np.isfinite(r["loss_g_total"]) for r in logs]))
+    except BaseException as e:                 # noqa: BLE001
+        import traceback
+        q.put((rank, "error", repr(e), traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_epoch_loop_two_ranks_skip_agreement(tmp_path):
+    import torch.multiprocessing as mp
+    from mqgan_amd.train import synthetic_mel
+    data = tmp_path / "data"
+    data.mkdir()
+    for i, L in enumerate([64, 40, 96, 33, 70, 128, 50]):
+        np.save(data / f"u{i}.npy", synthetic_mel(L, 16, i))
+    np.save(data / "bad_rank1.npy", np.zeros(9, np.float32))              # not 2-D: dropped by the collate -> an EMPTY batch of 1
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_epoch_rank, args=(r, 2, port, str(data), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for g in got:
+        assert g[1] != "error", g[2:]
+    (_, nb0, steps0, g0, d0, s0, fin0), (_, nb1, steps1, g1, d1, s1, fin1) = got
+    assert nb0 == nb1 == 4                                                # 8 files over two ranks, batch 1
+    assert steps0 == steps1 == 3                                          # the step in which ONE rank drew the bad file was skipped by both
+    assert all(fin0) and all(fin1)
+    assert np.array_equal(g0, g1) and np.array_equal(d0, d1) and np.array_equal(s0, s1)   # replicas stay bit-identical

@@ -69,6 +69,8 @@ def _rccl_rank(port, q):
         ones = torch.ones(4, device=DEV)
         dist.all_reduce(ones)
         assert dist.get_backend() == "nccl" and float(ones.sum()) == 4.0
+        c = TorchComm(force=True)                                    # host-side decisions travel over a gloo twin of the RCCL group
+        assert c.any_rank(False) is False and c.any_rank(True) is True and c._host_group is not None
         Ts = [40, 24, 48, 32]
         batches = [_batch(T, 700 + 10 * i) for i, T in enumerate(Ts)]
 
