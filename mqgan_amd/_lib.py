@@ -150,6 +150,13 @@ SIGNATURES = {
     "mq_wino_dy_fused": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "mq_wino_weight_transform": (_I, [_P, _I, _I, _I, _P, _P]),
     "mq_wino_wgrad_inverse": (_I, [_P, _I, _I, _P, _P]),
+    "mq_wino1d_input_transform": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "mq_wino1d_weight_transform": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
+    "mq_wino1d_output_transform": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _L, _L, _L, _P, _P]),
+    "mq_wino1d_dy_rows": (_I, [_I, _I, _I, _I, _I]),
+    "mq_wino1d_dy_transform": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "mq_wino1d_dx_transform": (_I, [_P, _I, _I, _I, _I, _P, _F, _P, _L, _L, _L, _P, _P]),
+    "mq_wino1d_wgrad_inverse": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "mq_sumsq": (_I, [_P, _L, _P, _P, _P]),
     "mq_multi_gather": (_I, [_P, _I, _L, _P, _P]),
     "mq_multi_gather_args": (_I, [_P, _I, _P, _P]),

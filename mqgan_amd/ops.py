@@ -616,6 +616,114 @@ class ConvLeakyFn(torch.autograd.Function):
         return dx, dw, None, db, None, None, None, None, None, None
 
 
+# ----------------------------------------------------------------------------- 1-D Winograd F(2, 3) along the rows (csrc/wino1d.hip)
+WINO1D_MIN_CHANNELS = int(os.environ.get("MQGAN_WINO1D_MINC", "128"))     # 0 switches the path off (A/B runs)
+
+
+def _wino1d_ok(d: ConvDesc) -> bool:
+    """3 taps, stride 1, pad 1 along the rows (any taps, stride 1 or 2 along the columns): the multi-bin discriminator's
+    (3 x k) layers, on an f32-result engine, with channel counts that fill the GEMM."""
+    return (WINO1D_MIN_CHANNELS > 0 and d.R == 3 and d.stride_h == 1 and d.pad_h == 1 and d.dil_h == 1 and d.dil_w == 1 and d.P == d.H
+            and d.H >= 2 and d.stride_w in (1, 2) and d.precision in (PRECISIONS["f32"], PRECISIONS["f32x3"])
+            and d.C % 16 == 0 and d.K % 16 == 0 and d.K <= 1024 and min(d.C, d.K) >= WINO1D_MIN_CHANNELS
+            and d.N % d.groups == 0)
+
+
+def _wino1d_gemm_desc(d: ConvDesc) -> ConvDesc:
+    """The four transform positions as 4 x groups batch groups of one-row images (xi, n, row tile)."""
+    th = (d.H + 1) // 2
+    return conv_desc(4 * d.N * th, 1, d.W, d.C, d.K, 1, d.S, stride=(1, d.stride_w), pad=(0, d.pad_w), groups=4 * d.groups,
+                     precision=d.precision)
+
+
+class ConvWino1dLeakyFn(torch.autograd.Function):
+    """ConvLeakyFn for layers _wino1d_ok takes: y = padded ? 0 : LeakyReLU(conv(x, w) + bias) with the row taps as Winograd
+    F(2, 3) - two thirds of the multiplications, run as one batch-grouped (1 x S) convolution on the same f32 GEMM kernels
+    between HBM-bound transforms that also carry the epilogues (bias + LeakyReLU + mask forward; the producer's gate, the bias
+    sums backward).  Same arguments, contract (``in_gate`` / ``pregated``) and gradients as ConvLeakyFn."""
+
+    @staticmethod
+    def forward(ctx, x, w_krsc, bias, mask, key, dmap, slope, in_gate=None, pregated=False):
+        d = _desc_from_key(key)
+        th = (d.H + 1) // 2
+        G = d.groups
+        x, w_krsc = x.contiguous(), w_krsc.contiguous()
+        V = _empty((4 * d.N * th, 1, d.W, d.C), x)
+        check(L().mq_wino1d_input_transform(fptr(x), d.N, d.H, d.W, d.C, fptr(V), stream()), "mq_wino1d_input_transform")
+        U = _empty((4 * G * d.K, d.S, d.C), x)
+        Uc = _empty((4 * G * d.C, d.S, d.K), x)
+        check(L().mq_wino1d_weight_transform(fptr(w_krsc), G, d.K, d.C, d.S, fptr(U), fptr(Uc), stream()), "mq_wino1d_weight_transform")
+        dg = _wino1d_gemm_desc(d)
+        M = _empty((4 * d.N * th, 1, d.Q, d.K), x)
+        _timed(None, _conv_flops(dg), lambda: check(
+            L().mq_conv_fprop(C.byref(dg), fptr(V), fptr(U), None, fptr(M), stream()), "mq_conv_fprop"), key)
+        y = _empty((d.N, d.H, d.Q, d.K), x)
+        check(L().mq_wino1d_output_transform(fptr(M), fptr(bias, True), d.N, d.H, d.Q, d.K, G, 2, float(slope),
+                                             ptr(mask, torch.uint8, True), dmap[0], dmap[1], dmap[2], fptr(y), stream()),
+              "mq_wino1d_output_transform")
+        del M, U
+        ctx.key, ctx.dmap, ctx.slope = key, dmap, slope
+        ctx.w_shape = tuple(w_krsc.shape)
+        ctx.has_bias = bias is not None
+        ctx.pregated = bool(pregated)
+        ctx.in_gate = None if in_gate is None else (in_gate[1], in_gate[2])
+        keep_v = w_krsc.requires_grad
+        ctx.kept_v = keep_v
+        ctx.save_for_backward(V if keep_v else None, Uc, None if ctx.pregated else y, mask, x if in_gate is not None else None,
+                              None if in_gate is None else in_gate[0])
+        return y
+
+    @staticmethod
+    def backward(ctx, dout):
+        V, Uc, y, mask, x_gate, mask_in = ctx.saved_tensors
+        d = _desc_from_key(ctx.key)
+        th = (d.H + 1) // 2
+        G = d.groups
+        if ctx.slope != 0.2 and not ctx.pregated:
+            raise _lib.MqganHipError("the pointwise backward kernel implements LeakyReLU(0.2) only")
+        if ctx.pregated:
+            dy = dout.contiguous()
+        else:
+            Cc = y.shape[-1]
+            pd = PointwiseDesc(rows=y.numel() // Cc, C=Cc, act=ACT_LEAKY, mask_pre=0, mask_post=int(mask is not None),
+                               d1=ctx.dmap[0], d2=ctx.dmap[1], d3=ctx.dmap[2], p_drop=0.0, seed=0)
+            dy = torch.empty_like(y)
+            check(L().mq_pointwise_bwd(C.byref(pd), fptr(dout.contiguous()), fptr(y), None, ptr(mask, torch.uint8, True), None,
+                                       None, fptr(dy), None, None, None, None, stream()), "mq_pointwise_bwd")
+        want_dx, want_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        dx = dw = db = None
+        part = None
+        if want_db:
+            part = _empty((L().mq_wino1d_dy_rows(d.N, d.H, d.Q, d.K, G), G * d.K), dy)
+        Z = _empty((4 * d.N * th, 1, d.Q, d.K), dy)
+        check(L().mq_wino1d_dy_transform(fptr(dy), d.N, d.H, d.Q, d.K, G, fptr(Z), fptr(part, True), stream()), "mq_wino1d_dy_transform")
+        dg = _wino1d_gemm_desc(d)
+        if want_dx:
+            dV = _empty((4 * d.N * th, 1, d.W, d.C), dy)
+            _timed(None, _conv_flops(dg), lambda: check(
+                L().mq_conv_dgrad(C.byref(dg), fptr(Z), fptr(Uc), fptr(dV), stream()), "mq_conv_dgrad"), ctx.key)
+            dx = _empty((d.N, d.H, d.W, d.C), dy)
+            gd = ctx.in_gate[0] if ctx.in_gate is not None else (1, 0, 1)
+            gs = float(ctx.in_gate[1]) if ctx.in_gate is not None else 1.0
+            check(L().mq_wino1d_dx_transform(fptr(dV), d.N, d.H, d.W, d.C, fptr(x_gate, True), gs, ptr(mask_in, torch.uint8, True),
+                                             gd[0], gd[1], gd[2], fptr(dx), stream()), "mq_wino1d_dx_transform")
+            del dV
+        if want_dw:
+            if not ctx.kept_v:
+                raise _lib.MqganHipError("ConvWino1dLeakyFn: weight gradient asked for a layer whose weights did not require one")
+            dU = _empty((4 * G * d.K, d.S, d.C), dy)
+            nbytes = L().mq_conv_wgrad_workspace(C.byref(dg))
+            ws = _ws_bytes(nbytes, dy)
+            _timed(None, _conv_flops(dg), lambda: check(
+                L().mq_conv_wgrad(C.byref(dg), fptr(V), fptr(Z), fptr(dU), ptr(ws), nbytes, stream()), "mq_conv_wgrad"), ctx.key)
+            dw = _empty(ctx.w_shape, dy)
+            check(L().mq_wino1d_wgrad_inverse(fptr(dU), G, d.K, d.C, d.S, fptr(dw), stream()), "mq_wino1d_wgrad_inverse")
+        if want_db:
+            db = colsum(part)
+        return dx, dw, db, None, None, None, None, None, None
+
+
 class LeakyGateFn(torch.autograd.Function):
     """Identity on a tensor that came out of a ``pregated`` LeakyReLU layer, for a consumer without a gated backward of its
     own: the gradient passing through is multiplied by LeakyReLU'(x) and zeroed on padded frames (one pointwise pass)."""
@@ -755,6 +863,8 @@ def conv_leaky(x, w_krsc, w_crsk, bias, desc: ConvDesc, mask, dmap, slope: float
     x = to_f32(x)
     if desc.C % 4 != 0 or _h_ok(desc, desc.C):
         return ret(pointwise(conv(x, w_krsc, w_crsk, bias, desc), act=ACT_LEAKY, mask=mask, mask_post=mask is not None, dmap=dmap))
+    if _wino1d_ok(desc):
+        return ret(ConvWino1dLeakyFn.apply(x, w_krsc, bias, mask, _desc_key(desc), tuple(dmap), slope, in_gate, pregate), pregate)
     return ret(ConvLeakyFn.apply(x, w_krsc, w_crsk, bias, mask, _desc_key(desc), tuple(dmap), slope, in_gate, pregate), pregate)
 
 

@@ -839,6 +839,59 @@ def test_gated_dgrad_is_dgrad_then_leaky_backward(env, c, prec):
     assert float(got[1, :, c["W"] // 2:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("H,W,G,prec", [(10, 48, 8, "f32"), (9, 37, 2, "f32"), (10, 48, 8, "f32x3")])
+def test_wino1d_discriminator_chain_matches_direct_kernels(env, H, W, G, prec):
+    """Two (3 x k) multi-bin discriminator layers in a row - (3 x 5) stride (1, 1), then (3 x 3) stride (1, 2), batch-grouped
+    filters, frame masks, the first one pregated (its LeakyReLU / mask backward rides on the second one's input-gradient
+    transform) - on the 1-D Winograd path (csrc/wino1d.hip) against the direct implicit-GEMM kernels (ops.WINO1D_MIN_CHANNELS = 0):
+    outputs, input gradient, both weight gradients and both bias gradients.  Odd H exercises the half-used last row tile."""
+    ops = env
+    torch.manual_seed(31)
+    N, C0, C1, C2 = 2 * G, 128, 128, 256
+    x0 = torch.randn(N, H, W, C0, device=DEV)
+    w1 = torch.randn(G * C1, C0, 3, 5, device=DEV) * 0.05
+    w2 = torch.randn(G * C2, C1, 3, 3, device=DEV) * 0.05
+    b1, b2 = torch.randn(G * C1, device=DEV) * 0.1, torch.randn(G * C2, device=DEV) * 0.1
+    mask1 = torch.zeros(N, W, dtype=torch.uint8, device=DEV)
+    mask1[1, W // 2:] = 1
+    mask1[-1, 5:] = 1
+    mask2 = ops.mask_pool(mask1, 2, ceil_mode=True)
+
+    def prep(w, K):
+        ks, cs = [], []
+        for gi in range(G):
+            a, bb = ops.weight_prep(w[gi * K:(gi + 1) * K].contiguous(), None, True)
+            ks.append(a); cs.append(bb)
+        return torch.cat(ks, 0), torch.cat(cs, 0)
+
+    def run(minc):
+        keep = ops.WINO1D_MIN_CHANNELS
+        ops.WINO1D_MIN_CHANNELS = minc
+        try:
+            x = x0.clone().requires_grad_(True)
+            w1v, w2v = w1.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+            b1v, b2v = b1.clone().requires_grad_(True), b2.clone().requires_grad_(True)
+            k1, c1 = prep(w1v, C1)
+            k2, c2 = prep(w2v, C2)
+            d1 = ops.conv_desc(N, H, W, C0, C1, 3, 5, pad=(1, 2), groups=G, precision=prec)
+            d2 = ops.conv_desc(N, H, W, C1, C2, 3, 3, stride=(1, 2), pad=(1, 1), groups=G, precision=prec)
+            assert ops._wino1d_ok(d1) == (minc > 0) and ops._wino1d_ok(d2) == (minc > 0)
+            dm1, dm2 = (d1.P * d1.Q, d1.Q, d1.Q), (d2.P * d2.Q, d2.Q, d2.Q)
+            y1, hon = ops.conv_leaky(x, k1, c1, b1v, d1, mask1, dm1, pregate=True, chain=True)
+            assert hon and y1.grad_fn.__class__.__name__.startswith("ConvWino1dLeakyFn" if minc > 0 else "ConvLeakyFn")
+            y2 = ops.conv_leaky(y1, k2, c2, b2v, d2, mask2, dm2, in_gate=(mask1, dm1, 0.2))
+            r = torch.randn(y2.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+            (y2 * r).sum().backward()
+            return [t_.detach().clone() for t_ in (y1, y2, x.grad, w1v.grad, w2v.grad, b1v.grad, b2v.grad)]
+        finally:
+            ops.WINO1D_MIN_CHANNELS = keep
+
+    got, want = run(128), run(0)
+    for g_, w_, name in zip(got, want, ("y1", "y2", "dx", "dw1", "dw2", "db1", "db2")):
+        assert_rel(g_, w_, 4e-5, name)
+    assert float(got[1][1, :, (W // 2 + 1) // 2:].abs().max()) == 0.0          # padded output frames are exactly zero
+
+
 def test_masked_mae_leaky_gate(env):
     ops = env
     torch.manual_seed(10)
