@@ -50,7 +50,7 @@ def kernel_build_id():
     """Hash of the conv kernel sources: ties a PMC traffic file to the build it was measured on."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("gemm_core.h", "igemm.hip", "igemm_h2.hip", "winograd.hip", "wino1d.hip", "common.h"):
+    for f in ("gemm_core.h", "igemm.hip", "igemm_h2.hip", "winograd.hip", "winograd3.hip", "wino1d.hip", "common.h"):
         with open(os.path.join(ROOT, "mqgan_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -590,7 +590,7 @@ def main():
                                        f"{mel} mels x {T} frames, batch {B}/GPU, FSQ {cfg['model']['generator']['fsq_levels']}, "
                                        "D active, FM off, train-mode dropout", "global_batch": world * B, "frames": T,
                            "parallelism": f"dp{world}",
-                           "conv_algorithm": ("implicit GEMM; 3x3 / stride-1 layers with >= 128 channels as Winograd F(2x2,3x3), the "
+                           "conv_algorithm": ("implicit GEMM; 3x3 / stride-1 layers with >= 128 channels as Winograd F(3x3,3x3), the "
                                               "multi-bin discriminator's (3 x k) layers as one-dimensional Winograd F(2,3) along the "
                                               "bins: f32 transforms, products on the same MFMA engine, f32 accumulation "
                                               "(MQGAN_WINO_MINC=0 / MQGAN_WINO1D_MINC=0 switch them off)") if args.precision != "bf16"

@@ -446,6 +446,17 @@ int mq_wino_dy_fused(const float *dy, int N, int H, int W, int K, float *Z, floa
 int mq_wino_weight_transform(const float *w_krsc, int K, int C, int flip_transpose, float *U, mqStream stream);
 int mq_wino_wgrad_inverse(const float *P, int K, int C, float *dw_krsc, mqStream stream);
 
+/* The larger tile, F(3x3, 3x3) (csrc/winograd3.hip): 25 positions per 3x3 output tile (2.78 multiplications per output instead
+ * of 4; transformed tensors 2.78x the activation instead of 4x), one-layer error 2.7e-6 of the output rms against 1.5e-6.
+ * Same call sequence with tiles = N * ceil(H/3) * ceil(W/3) and groups = 25 in the GEMM descriptor
+ * (N = 25 * N * ceil(H/3), H = 1, W = ceil(W/3)); mq_wino3_dy_fused is mq_wino_dy_fused (Vd may be NULL: Z and sums only). */
+int mq_wino3_input_transform(const float *x, int N, int H, int W, int C, float *V, mqStream stream);
+int mq_wino3_output_transform(const float *M, const float *bias, int N, int H, int W, int K, float *y, mqStream stream);
+int mq_wino3_weight_transform(const float *w_krsc, int K, int C, int flip_transpose, float *U, mqStream stream);
+int mq_wino3_wgrad_inverse(const float *P, int K, int C, float *dw_krsc, mqStream stream);
+int mq_wino3_dy_fused_rows(int N, int H, int W, int K);
+int mq_wino3_dy_fused(const float *dy, int N, int H, int W, int K, float *Z, float *Vd, float *bias_partial, mqStream stream);
+
 /* ------------------------------------------------------------------ one-dimensional Winograd F(2, 3) along the rows
  * The multi-bin discriminator's (3 x k) layers (discriminators.py:251-290: 3 taps and stride 1 along the bins, k taps and
  * stride 1 or 2 along time): 4 row products per 2 output rows instead of 6 (csrc/wino1d.hip).  th = ceil(H / 2) row tiles;

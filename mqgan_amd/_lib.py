@@ -150,6 +150,12 @@ SIGNATURES = {
     "mq_wino_dy_fused": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "mq_wino_weight_transform": (_I, [_P, _I, _I, _I, _P, _P]),
     "mq_wino_wgrad_inverse": (_I, [_P, _I, _I, _P, _P]),
+    "mq_wino3_input_transform": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "mq_wino3_output_transform": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "mq_wino3_weight_transform": (_I, [_P, _I, _I, _I, _P, _P]),
+    "mq_wino3_wgrad_inverse": (_I, [_P, _I, _I, _P, _P]),
+    "mq_wino3_dy_fused_rows": (_I, [_I, _I, _I, _I]),
+    "mq_wino3_dy_fused": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "mq_wino1d_input_transform": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "mq_wino1d_weight_transform": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "mq_wino1d_output_transform": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _L, _L, _L, _P, _P]),

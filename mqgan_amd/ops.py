@@ -411,19 +411,43 @@ def _wino_ok(d: ConvDesc) -> bool:
             and d.C % 16 == 0 and d.K % 16 == 0 and min(d.C, d.K) >= WINO_MIN_CHANNELS)
 
 
+# output tile edge m of F(m x m, 3 x 3): 3 (default: 25 positions per 9 outputs, csrc/winograd3.hip) or 2 (16 per 4, winograd.hip)
+WINO_TILE = int(os.environ.get("MQGAN_WINO_TILE", "3"))
+
+
+def _wino_m() -> int:
+    if WINO_TILE not in (2, 3):
+        raise _lib.MqganHipError(f"MQGAN_WINO_TILE must be 2 or 3, got {WINO_TILE}")
+    return WINO_TILE
+
+
+def _wino_fn(name: str):
+    """Entry point of the active tile size: mq_wino_<name> (F(2x2,3x3)) or mq_wino3_<name> (F(3x3,3x3))."""
+    return getattr(L(), ("mq_wino3_" if _wino_m() == 3 else "mq_wino_") + name)
+
+
 def _wino_tiles(d: ConvDesc) -> int:
-    return d.N * ((d.H + 1) // 2) * ((d.W + 1) // 2)
+    m = _wino_m()
+    return d.N * ((d.H + m - 1) // m) * ((d.W + m - 1) // m)
+
+
+def _wino_np() -> int:
+    return (_wino_m() + 2) ** 2
 
 
 def _wino_gemm_desc(d: ConvDesc, cin: int, cout: int) -> ConvDesc:
-    """The 16 transform positions as 16 groups of one-row "images" (one per tile row: small images keep the kernels' 32-bit
+    """The transform positions as that many groups of one-row "images" (one per tile row: small images keep the kernels' 32-bit
     image-relative offsets far from their limits) with batch-grouped 1x1 filters."""
-    return conv_desc(16 * d.N * ((d.H + 1) // 2), 1, (d.W + 1) // 2, cin, cout, 1, 1, groups=16, precision=d.precision)
+    m, n_pos = _wino_m(), _wino_np()
+    return conv_desc(n_pos * d.N * ((d.H + m - 1) // m), 1, (d.W + m - 1) // m, cin, cout, 1, 1, groups=n_pos, precision=d.precision)
 
 
 def _wino_in(t, d: ConvDesc, channels: int, dy_side: bool = False):
-    out = _empty((16 * _wino_tiles(d), 1, 1, channels), t)
-    fn = L().mq_wino_dy_transform if dy_side else L().mq_wino_input_transform
+    out = _empty((_wino_np() * _wino_tiles(d), 1, 1, channels), t)
+    if dy_side and _wino_m() == 3:         # the larger tile has the fused pass only: Z without V and without column sums
+        check(L().mq_wino3_dy_fused(fptr(t), d.N, d.H, d.W, channels, fptr(out), None, None, stream()), "mq_wino3_dy_fused")
+        return out
+    fn = L().mq_wino_dy_transform if dy_side else _wino_fn("input_transform")
     check(fn(fptr(t), d.N, d.H, d.W, channels, fptr(out), stream()), "mq_wino_dy_transform" if dy_side else "mq_wino_input_transform")
     return out
 
@@ -435,15 +459,15 @@ def _wino_conv(d: ConvDesc, x, w_krsc, bias, cin: int, cout: int, flip: bool, ke
         V = _wino_in(x, d, cin)
     if keep is not None:
         keep.append(V)
-    U = _empty((16 * cout, 1, cin), V)
-    check(L().mq_wino_weight_transform(fptr(w_krsc), d.K, d.C, int(flip), fptr(U), stream()), "mq_wino_weight_transform")
+    U = _empty((_wino_np() * cout, 1, cin), V)
+    check(_wino_fn("weight_transform")(fptr(w_krsc), d.K, d.C, int(flip), fptr(U), stream()), "mq_wino_weight_transform")
     dg = _wino_gemm_desc(d, cin, cout)
-    M = _empty((16 * _wino_tiles(d), 1, 1, cout), V)
+    M = _empty((_wino_np() * _wino_tiles(d), 1, 1, cout), V)
     _timed(None, _conv_flops(dg), lambda: check(
         L().mq_conv_fprop(C.byref(dg), fptr(V), fptr(U), None, fptr(M), stream()), "mq_conv_fprop"), key)
     del V
     y = _empty((d.N, d.H, d.W, cout), M)
-    check(L().mq_wino_output_transform(fptr(M), fptr(bias, True), d.N, d.H, d.W, cout, fptr(y), stream()), "mq_wino_output_transform")
+    check(_wino_fn("output_transform")(fptr(M), fptr(bias, True), d.N, d.H, d.W, cout, fptr(y), stream()), "mq_wino_output_transform")
     return y
 
 
@@ -451,12 +475,12 @@ WINO_FUSED_DY = os.environ.get("MQGAN_WINO_FUSED_DY", "1") != "0"     # backward
 
 
 def _wino_dy_fused(dy, d: ConvDesc):
-    """(Z, V of dy, per-block column sums [rows][K]) in one pass over dy (mq_wino_dy_fused)."""
-    rows = L().mq_wino_dy_fused_rows(d.N, d.H, d.W, d.K)
-    Z = _empty((16 * _wino_tiles(d), 1, 1, d.K), dy)
-    Vd = _empty((16 * _wino_tiles(d), 1, 1, d.K), dy)
+    """(Z, V of dy, per-block column sums [rows][K]) in one pass over dy (mq_wino_dy_fused / mq_wino3_dy_fused)."""
+    rows = _wino_fn("dy_fused_rows")(d.N, d.H, d.W, d.K)
+    Z = _empty((_wino_np() * _wino_tiles(d), 1, 1, d.K), dy)
+    Vd = _empty((_wino_np() * _wino_tiles(d), 1, 1, d.K), dy)
     part = _empty((rows, d.K), dy)
-    check(L().mq_wino_dy_fused(fptr(dy), d.N, d.H, d.W, d.K, fptr(Z), fptr(Vd), fptr(part), stream()), "mq_wino_dy_fused")
+    check(_wino_fn("dy_fused")(fptr(dy), d.N, d.H, d.W, d.K, fptr(Z), fptr(Vd), fptr(part), stream()), "mq_wino_dy_fused")
     return Z, Vd, part
 
 
@@ -468,7 +492,7 @@ class ConvWinoFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_krsc, w_crsk, bias, key):
         d = _desc_from_key(key)
-        keep_v = w_krsc.requires_grad and 64 * _wino_tiles(d) * d.C <= WINO_KEEP_V_MIB << 20
+        keep_v = w_krsc.requires_grad and 4 * _wino_np() * _wino_tiles(d) * d.C <= WINO_KEEP_V_MIB << 20
         kept = [] if keep_v else None
         x, w_krsc = x.contiguous(), w_krsc.contiguous()
         y = _wino_conv(d, x, w_krsc, bias, d.C, d.K, False, key, keep=kept)
@@ -488,7 +512,7 @@ class ConvWinoFn(torch.autograd.Function):
         want_db = ctx.has_bias and ctx.needs_input_grad[3]
         Z = Vd = part = None
         if (WINO_FUSED_DY and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
-                and L().mq_wino_dy_fused_rows(d.N, d.H, d.W, d.K) > 0):
+                and _wino_fn("dy_fused_rows")(d.N, d.H, d.W, d.K) > 0):
             Z, Vd, part = _wino_dy_fused(dy, d)
         if ctx.needs_input_grad[0]:
             dx = _wino_conv(d, dy, w_krsc, None, d.K, d.C, True, ctx.key, V=Vd)
@@ -498,14 +522,14 @@ class ConvWinoFn(torch.autograd.Function):
             if Z is None:
                 Z = _wino_in(dy, d, d.K, dy_side=True)
             dg = _wino_gemm_desc(d, d.C, d.K)
-            P = _empty((16 * d.K, 1, d.C), x)
+            P = _empty((_wino_np() * d.K, 1, d.C), x)
             nbytes = L().mq_conv_wgrad_workspace(C.byref(dg))
             ws = _ws_bytes(nbytes, x)
             _timed(None, _conv_flops(dg), lambda: check(
                 L().mq_conv_wgrad(C.byref(dg), fptr(V), fptr(Z), fptr(P), ptr(ws), nbytes, stream()), "mq_conv_wgrad"), ctx.key)
             del V, Z
             dw = _empty(ctx.w_shape, x)
-            check(L().mq_wino_wgrad_inverse(fptr(P), d.K, d.C, fptr(dw), stream()), "mq_wino_wgrad_inverse")
+            check(_wino_fn("wgrad_inverse")(fptr(P), d.K, d.C, fptr(dw), stream()), "mq_wino_wgrad_inverse")
         if want_db:
             db = colsum(part) if part is not None else _bias_grad(d, dy)
         return dx, dw, None, db, None

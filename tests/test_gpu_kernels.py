@@ -455,12 +455,23 @@ WINO_CASES = [
 ]
 
 
+@pytest.fixture(params=[3, 2], ids=["F3x3", "F2x2"])
+def wino_tile(request):
+    """Both Winograd tile sizes: F(3x3, 3x3) (the default, csrc/winograd3.hip) and F(2x2, 3x3) (winograd.hip)."""
+    from mqgan_amd import ops
+    keep, ops.WINO_TILE = ops.WINO_TILE, request.param
+    yield request.param
+    ops.WINO_TILE = keep
+
+
 @pytest.mark.parametrize("precision", ["f32", "f32x3"])
-@pytest.mark.parametrize("c", WINO_CASES, ids=lambda c: "N{N}H{H}W{W}C{C}K{K}".format(**c))
-def test_winograd_conv_fprop_dgrad_wgrad(env, c, precision):
-    """3x3 / stride 1 / pad 1 layers with >= 128 channels run as Winograd F(2x2, 3x3) (ops.ConvWinoFn): forward, input,
-    weight and bias gradients against the float64 direct convolution.  The transforms add a few roundings to the direct
-    kernels' error, so the bound is 4e-5 of the output scale instead of 2e-5."""
+@pytest.mark.parametrize("c", WINO_CASES + [dict(N=2, H=9, W=90, C=128, K=192, R=3, S=3, pad=(1, 1)),      # whole 3x3 tiles
+                                            dict(N=1, H=10, W=11, C=256, K=128, R=3, S=3, pad=(1, 1))],    # one / two spare rows
+                         ids=lambda c: "N{N}H{H}W{W}C{C}K{K}".format(**c))
+def test_winograd_conv_fprop_dgrad_wgrad(env, c, precision, wino_tile):
+    """3x3 / stride 1 / pad 1 layers with >= 128 channels run as Winograd F(3x3, 3x3) or F(2x2, 3x3) (ops.ConvWinoFn):
+    forward, input, weight and bias gradients against the float64 direct convolution.  The transforms add a few roundings to
+    the direct kernels' error, so the bound is 4e-5 of the output scale instead of 2e-5."""
     ops = env
     torch.manual_seed(0)
     x = torch.randn(c["N"], c["H"], c["W"], c["C"], dtype=torch.float64)
