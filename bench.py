@@ -590,10 +590,11 @@ def main():
                                        f"{mel} mels x {T} frames, batch {B}/GPU, FSQ {cfg['model']['generator']['fsq_levels']}, "
                                        "D active, FM off, train-mode dropout", "global_batch": world * B, "frames": T,
                            "parallelism": f"dp{world}",
-                           "conv_algorithm": ("implicit GEMM; 3x3 / stride-1 layers with >= 128 channels as Winograd F(3x3,3x3), the "
-                                              "multi-bin discriminator's (3 x k) layers as one-dimensional Winograd F(2,3) along the "
-                                              "bins: f32 transforms, products on the same MFMA engine, f32 accumulation "
-                                              "(MQGAN_WINO_MINC=0 / MQGAN_WINO1D_MINC=0 switch them off)") if args.precision != "bf16"
+                           "conv_algorithm": ("implicit GEMM; 3x3 / stride-1 layers with >= 128 channels as Winograd F(3x3,3x3), the patch "
+                                              "discriminator's 5x5 / stride-2 layers as the same over the polyphase components of their "
+                                              "input, the multi-bin discriminator's (3 x k) layers as one-dimensional Winograd F(2,3) along "
+                                              "the bins: f32 transforms, products on the same MFMA engine, f32 accumulation "
+                                              "(MQGAN_WINO_MINC=0 / MQGAN_WINO_S2D_MINC=0 / MQGAN_WINO1D_MINC=0 switch them off)") if args.precision != "bf16"
                            else "implicit GEMM on bf16-storage kernels"},
                 "losses_finite": bool(finite), "roofline": roof,
                 "host_ms_per_step": host_ms, "collectives": collectives_of(tr, world, args.force_collectives)}
@@ -605,10 +606,11 @@ def main():
             from mqgan_amd import ops as _ops
             keep, _ops.WINO_MIN_CHANNELS = _ops.WINO_MIN_CHANNELS, 0          # every layer on the direct kernels (A/B, same box)
             keep1, _ops.WINO1D_MIN_CHANNELS = _ops.WINO1D_MIN_CHANNELS, 0
+            keep2, _ops.WINO_S2D_MIN_CHANNELS = _ops.WINO_S2D_MIN_CHANNELS, 0
             try:
                 line["other_engines"]["fp32_direct"] = quick_engine(cfg, "fp32", device, batches, lens, B, T)
             finally:
-                _ops.WINO_MIN_CHANNELS, _ops.WINO1D_MIN_CHANNELS = keep, keep1
+                _ops.WINO_MIN_CHANNELS, _ops.WINO1D_MIN_CHANNELS, _ops.WINO_S2D_MIN_CHANNELS = keep, keep1, keep2
         if world == 1 and not args.no_configs and args.config == "hifispeech" and args.precision == "fp32":
             del batches
             torch.cuda.empty_cache()

@@ -451,11 +451,29 @@ int mq_wino_wgrad_inverse(const float *P, int K, int C, float *dw_krsc, mqStream
  * Same call sequence with tiles = N * ceil(H/3) * ceil(W/3) and groups = 25 in the GEMM descriptor
  * (N = 25 * N * ceil(H/3), H = 1, W = ceil(W/3)); mq_wino3_dy_fused is mq_wino_dy_fused (Vd may be NULL: Z and sums only). */
 int mq_wino3_input_transform(const float *x, int N, int H, int W, int C, float *V, mqStream stream);
-int mq_wino3_output_transform(const float *M, const float *bias, int N, int H, int W, int K, float *y, mqStream stream);
+/* act 0: y = A^T M A + bias; act 2: LeakyReLU(slope) then zero where padded[(m / d1) * d2 + m % d3] (m = output pixel), as
+ * mq_conv_fprop_leaky */
+int mq_wino3_output_transform(const float *M, const float *bias, int N, int H, int W, int K, int act, float slope, const uint8_t *padded,
+                              int64_t d1, int64_t d2, int64_t d3, float *y, mqStream stream);
 int mq_wino3_weight_transform(const float *w_krsc, int K, int C, int flip_transpose, float *U, mqStream stream);
 int mq_wino3_wgrad_inverse(const float *P, int K, int C, float *dw_krsc, mqStream stream);
 int mq_wino3_dy_fused_rows(int N, int H, int W, int K);
 int mq_wino3_dy_fused(const float *dy, int N, int H, int W, int K, float *Z, float *Vd, float *bias_partial, mqStream stream);
+/* 5x5 / stride 2 / pad 2 layers (discriminators.py:86-173, the patch discriminator's widest) as F(3x3, 3x3) over the four
+ * polyphase components of the input (even H and W; x is (N, H, W, C), y (N, H/2, W/2, K)): X'[p][q][(rho, sigma, c)] =
+ * x[2p + rho][2q + sigma][c] convolved with g'[(rho, sigma, c)][a][b] = w[c][2a + rho][2b + sigma] - 11.1 products per output and
+ * channel pair instead of 25.  X' is never materialised: tiles = N * ceil(H/6) * ceil(W/6), GEMM descriptor with C' = 4C.
+ *   forward : V = input_transform_s2d(x) (25, tiles, 4C);  U = weight_transform_s2d(w_krsc (K, 25, C), flip 0) (25, K, 4C);
+ *             M = mq_conv_fprop(...);  y = mq_wino3_output_transform(M, bias, N, H/2, W/2, K, act, ...)
+ *   dgrad   : (Z, Vd, sums) = mq_wino3_dy_fused(dy, N, H/2, W/2, K);  U' = weight_transform_s2d(flip 1) (25, 4C, K);
+ *             M' = mq_conv_fprop(K -> 4C);  dx = output_transform_d2s(M'): written at full resolution, optionally gated by the
+ *             producer layer's LeakyReLU' and mask (mq_conv_dgrad_gated's contract)
+ *   wgrad   : P = mq_conv_wgrad(V, Z) (25, K, 4C);  dw_krsc (K, 25, C) = wgrad_inverse_s2d(P) */
+int mq_wino3_input_transform_s2d(const float *x, int N, int H, int W, int C, float *V, mqStream stream);
+int mq_wino3_weight_transform_s2d(const float *w_krsc, int K, int C, int flip_transpose, float *U, mqStream stream);
+int mq_wino3_output_transform_d2s(const float *M, int N, int H, int W, int C, const float *gate, float slope, const uint8_t *padded_in,
+                                  int64_t d1, int64_t d2, int64_t d3, float *dx, mqStream stream);
+int mq_wino3_wgrad_inverse_s2d(const float *P, int K, int C, float *dw_krsc, mqStream stream);
 
 /* ------------------------------------------------------------------ one-dimensional Winograd F(2, 3) along the rows
  * The multi-bin discriminator's (3 x k) layers (discriminators.py:251-290: 3 taps and stride 1 along the bins, k taps and

@@ -151,7 +151,11 @@ SIGNATURES = {
     "mq_wino_weight_transform": (_I, [_P, _I, _I, _I, _P, _P]),
     "mq_wino_wgrad_inverse": (_I, [_P, _I, _I, _P, _P]),
     "mq_wino3_input_transform": (_I, [_P, _I, _I, _I, _I, _P, _P]),
-    "mq_wino3_output_transform": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "mq_wino3_output_transform": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _P, _L, _L, _L, _P, _P]),
+    "mq_wino3_input_transform_s2d": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "mq_wino3_weight_transform_s2d": (_I, [_P, _I, _I, _I, _P, _P]),
+    "mq_wino3_output_transform_d2s": (_I, [_P, _I, _I, _I, _I, _P, _F, _P, _L, _L, _L, _P, _P]),
+    "mq_wino3_wgrad_inverse_s2d": (_I, [_P, _I, _I, _P, _P]),
     "mq_wino3_weight_transform": (_I, [_P, _I, _I, _I, _P, _P]),
     "mq_wino3_wgrad_inverse": (_I, [_P, _I, _I, _P, _P]),
     "mq_wino3_dy_fused_rows": (_I, [_I, _I, _I, _I]),

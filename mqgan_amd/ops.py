@@ -467,7 +467,11 @@ def _wino_conv(d: ConvDesc, x, w_krsc, bias, cin: int, cout: int, flip: bool, ke
         L().mq_conv_fprop(C.byref(dg), fptr(V), fptr(U), None, fptr(M), stream()), "mq_conv_fprop"), key)
     del V
     y = _empty((d.N, d.H, d.W, cout), M)
-    check(_wino_fn("output_transform")(fptr(M), fptr(bias, True), d.N, d.H, d.W, cout, fptr(y), stream()), "mq_wino_output_transform")
+    if _wino_m() == 3:
+        check(L().mq_wino3_output_transform(fptr(M), fptr(bias, True), d.N, d.H, d.W, cout, 0, 0.0, None, 1, 0, 1, fptr(y), stream()),
+              "mq_wino3_output_transform")
+    else:
+        check(L().mq_wino_output_transform(fptr(M), fptr(bias, True), d.N, d.H, d.W, cout, fptr(y), stream()), "mq_wino_output_transform")
     return y
 
 
@@ -748,6 +752,111 @@ class ConvWino1dLeakyFn(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None, None
 
 
+# ----------------------------------------------------------------------------- 5x5 / stride-2 layers: polyphase + F(3x3, 3x3)
+WINO_S2D_MIN_CHANNELS = int(os.environ.get("MQGAN_WINO_S2D_MINC", "128"))     # 0 switches the path off (A/B runs)
+
+
+def _wino_s2d_ok(d: ConvDesc) -> bool:
+    """5x5, stride 2, pad 2, one group, even image: the patch discriminator's wide layers as a 3x3 / stride-1 convolution over the
+    four polyphase components of the input, run as Winograd F(3x3, 3x3) (csrc/winograd3.hip)."""
+    return (WINO_S2D_MIN_CHANNELS > 0 and d.R == 5 and d.S == 5 and d.stride_h == 2 and d.stride_w == 2 and d.pad_h == 2 and d.pad_w == 2
+            and d.dil_h == 1 and d.dil_w == 1 and d.groups == 1 and d.H % 2 == 0 and d.W % 2 == 0 and d.P == d.H // 2 and d.Q == d.W // 2
+            and d.precision in (PRECISIONS["f32"], PRECISIONS["f32x3"]) and d.C % 16 == 0 and d.K % 16 == 0 and d.K <= 1024
+            and min(d.C, d.K) >= WINO_S2D_MIN_CHANNELS)
+
+
+def _s2d_tiles(d: ConvDesc) -> int:
+    return d.N * ((d.P + 2) // 3) * ((d.Q + 2) // 3)
+
+
+def _s2d_gemm_desc(d: ConvDesc, cin: int, cout: int) -> ConvDesc:
+    return conv_desc(25 * d.N * ((d.P + 2) // 3), 1, (d.Q + 2) // 3, cin, cout, 1, 1, groups=25, precision=d.precision)
+
+
+class ConvWinoS2dLeakyFn(torch.autograd.Function):
+    """ConvLeakyFn for layers _wino_s2d_ok takes (see csrc/winograd3.hip, the polyphase section): 11.1 instead of 25 products per
+    output and channel pair.  Same arguments, contract (``in_gate`` / ``pregated``) and gradients as ConvLeakyFn."""
+
+    @staticmethod
+    def forward(ctx, x, w_krsc, bias, mask, key, dmap, slope, in_gate=None, pregated=False):
+        d = _desc_from_key(key)
+        tiles = _s2d_tiles(d)
+        x, w_krsc = x.contiguous(), w_krsc.contiguous()
+        V = _empty((25 * tiles, 1, 1, 4 * d.C), x)
+        check(L().mq_wino3_input_transform_s2d(fptr(x), d.N, d.H, d.W, d.C, fptr(V), stream()), "mq_wino3_input_transform_s2d")
+        U = _empty((25 * d.K, 1, 4 * d.C), x)
+        check(L().mq_wino3_weight_transform_s2d(fptr(w_krsc), d.K, d.C, 0, fptr(U), stream()), "mq_wino3_weight_transform_s2d")
+        dg = _s2d_gemm_desc(d, 4 * d.C, d.K)
+        M = _empty((25 * tiles, 1, 1, d.K), x)
+        _timed(None, _conv_flops(dg), lambda: check(
+            L().mq_conv_fprop(C.byref(dg), fptr(V), fptr(U), None, fptr(M), stream()), "mq_conv_fprop"), key)
+        y = _empty((d.N, d.P, d.Q, d.K), x)
+        check(L().mq_wino3_output_transform(fptr(M), fptr(bias, True), d.N, d.P, d.Q, d.K, 2, float(slope), ptr(mask, torch.uint8, True),
+                                            dmap[0], dmap[1], dmap[2], fptr(y), stream()), "mq_wino3_output_transform")
+        del M, U
+        ctx.key, ctx.dmap, ctx.slope = key, dmap, slope
+        ctx.w_shape = tuple(w_krsc.shape)
+        ctx.has_bias = bias is not None
+        ctx.pregated = bool(pregated)
+        ctx.in_gate = None if in_gate is None else (in_gate[1], in_gate[2])
+        ctx.kept_v = w_krsc.requires_grad
+        ctx.save_for_backward(V if ctx.kept_v else None, w_krsc, None if ctx.pregated else y, mask, x if in_gate is not None else None,
+                              None if in_gate is None else in_gate[0])
+        return y
+
+    @staticmethod
+    def backward(ctx, dout):
+        V, w_krsc, y, mask, x_gate, mask_in = ctx.saved_tensors
+        d = _desc_from_key(ctx.key)
+        tiles = _s2d_tiles(d)
+        if ctx.slope != 0.2 and not ctx.pregated:
+            raise _lib.MqganHipError("the pointwise backward kernel implements LeakyReLU(0.2) only")
+        if ctx.pregated:
+            dy = dout.contiguous()
+        else:
+            Cc = y.shape[-1]
+            pd = PointwiseDesc(rows=y.numel() // Cc, C=Cc, act=ACT_LEAKY, mask_pre=0, mask_post=int(mask is not None),
+                               d1=ctx.dmap[0], d2=ctx.dmap[1], d3=ctx.dmap[2], p_drop=0.0, seed=0)
+            dy = torch.empty_like(y)
+            check(L().mq_pointwise_bwd(C.byref(pd), fptr(dout.contiguous()), fptr(y), None, ptr(mask, torch.uint8, True), None,
+                                       None, fptr(dy), None, None, None, None, stream()), "mq_pointwise_bwd")
+        want_dx, want_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        dx = dw = db = None
+        Z = _empty((25 * tiles, 1, 1, d.K), dy)
+        Vd = _empty((25 * tiles, 1, 1, d.K), dy) if want_dx else None
+        part = _empty((L().mq_wino3_dy_fused_rows(d.N, d.P, d.Q, d.K), d.K), dy) if want_db else None
+        check(L().mq_wino3_dy_fused(fptr(dy), d.N, d.P, d.Q, d.K, fptr(Z), fptr(Vd, True), fptr(part, True), stream()), "mq_wino3_dy_fused")
+        if want_dx:
+            Ut = _empty((25 * 4 * d.C, 1, d.K), dy)
+            check(L().mq_wino3_weight_transform_s2d(fptr(w_krsc), d.K, d.C, 1, fptr(Ut), stream()), "mq_wino3_weight_transform_s2d")
+            dgt = _s2d_gemm_desc(d, d.K, 4 * d.C)
+            Mt = _empty((25 * tiles, 1, 1, 4 * d.C), dy)
+            _timed(None, _conv_flops(dgt), lambda: check(
+                L().mq_conv_fprop(C.byref(dgt), fptr(Vd), fptr(Ut), None, fptr(Mt), stream()), "mq_conv_fprop"), ctx.key)
+            del Vd, Ut
+            dx = _empty((d.N, d.H, d.W, d.C), dy)
+            gd = ctx.in_gate[0] if ctx.in_gate is not None else (1, 0, 1)
+            gs = float(ctx.in_gate[1]) if ctx.in_gate is not None else 1.0
+            check(L().mq_wino3_output_transform_d2s(fptr(Mt), d.N, d.H, d.W, d.C, fptr(x_gate, True), gs, ptr(mask_in, torch.uint8, True),
+                                                    gd[0], gd[1], gd[2], fptr(dx), stream()), "mq_wino3_output_transform_d2s")
+            del Mt
+        if want_dw:
+            if not ctx.kept_v:
+                raise _lib.MqganHipError("ConvWinoS2dLeakyFn: weight gradient asked for a layer whose weights did not require one")
+            dg = _s2d_gemm_desc(d, 4 * d.C, d.K)
+            Pm = _empty((25 * d.K, 1, 4 * d.C), dy)
+            nbytes = L().mq_conv_wgrad_workspace(C.byref(dg))
+            ws = _ws_bytes(nbytes, dy)
+            _timed(None, _conv_flops(dg), lambda: check(
+                L().mq_conv_wgrad(C.byref(dg), fptr(V), fptr(Z), fptr(Pm), ptr(ws), nbytes, stream()), "mq_conv_wgrad"), ctx.key)
+            dw = _empty(ctx.w_shape, dy)
+            check(L().mq_wino3_wgrad_inverse_s2d(fptr(Pm), d.K, d.C, fptr(dw), stream()), "mq_wino3_wgrad_inverse_s2d")
+        if want_db:
+            db = colsum(part)
+        return dx, dw, db, None, None, None, None, None, None
+
+
 class LeakyGateFn(torch.autograd.Function):
     """Identity on a tensor that came out of a ``pregated`` LeakyReLU layer, for a consumer without a gated backward of its
     own: the gradient passing through is multiplied by LeakyReLU'(x) and zeroed on padded frames (one pointwise pass)."""
@@ -889,6 +998,8 @@ def conv_leaky(x, w_krsc, w_crsk, bias, desc: ConvDesc, mask, dmap, slope: float
         return ret(pointwise(conv(x, w_krsc, w_crsk, bias, desc), act=ACT_LEAKY, mask=mask, mask_post=mask is not None, dmap=dmap))
     if _wino1d_ok(desc):
         return ret(ConvWino1dLeakyFn.apply(x, w_krsc, bias, mask, _desc_key(desc), tuple(dmap), slope, in_gate, pregate), pregate)
+    if _wino_s2d_ok(desc):
+        return ret(ConvWinoS2dLeakyFn.apply(x, w_krsc, bias, mask, _desc_key(desc), tuple(dmap), slope, in_gate, pregate), pregate)
     return ret(ConvLeakyFn.apply(x, w_krsc, w_crsk, bias, mask, _desc_key(desc), tuple(dmap), slope, in_gate, pregate), pregate)
 
 

@@ -903,6 +903,52 @@ def test_wino1d_discriminator_chain_matches_direct_kernels(env, H, W, G, prec):
     assert float(got[1][1, :, (W // 2 + 1) // 2:].abs().max()) == 0.0          # padded output frames are exactly zero
 
 
+@pytest.mark.parametrize("H,W,prec", [(12, 20, "f32"), (16, 14, "f32"), (12, 20, "f32x3")])
+def test_polyphase_winograd_5x5_stride2_chain_matches_direct_kernels(env, H, W, prec):
+    """The patch discriminator's 5x5 / stride-2 layers as F(3x3, 3x3) over the polyphase components of the input
+    (ops.ConvWinoS2dLeakyFn) against the direct kernels (ops.WINO_S2D_MIN_CHANNELS = 0): two such layers in a row (the second
+    one's input gradient carries the first one's LeakyReLU' / mask), frame masks, ragged 3x3 tile edges: outputs, input gradient,
+    weight and bias gradients."""
+    ops = env
+    torch.manual_seed(33)
+    N, C0, C1, C2 = 3, 128, 128, 144
+    x0 = torch.randn(N, 2 * H, 2 * W, C0, device=DEV)
+    w1 = torch.randn(C1, C0, 5, 5, device=DEV) * 0.03
+    w2 = torch.randn(C2, C1, 5, 5, device=DEV) * 0.03
+    b1, b2 = torch.randn(C1, device=DEV) * 0.1, torch.randn(C2, device=DEV) * 0.1
+    mask0 = torch.zeros(N, 2 * W, dtype=torch.uint8, device=DEV)
+    mask0[1, W:] = 1
+    mask0[2, 5:] = 1
+    mask1 = ops.mask_pool(mask0, 2, ceil_mode=True)
+    mask2 = ops.mask_pool(mask1, 2, ceil_mode=True)
+
+    def run(minc):
+        keep = ops.WINO_S2D_MIN_CHANNELS
+        ops.WINO_S2D_MIN_CHANNELS = minc
+        try:
+            x = x0.clone().requires_grad_(True)
+            w1v, w2v = w1.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+            b1v, b2v = b1.clone().requires_grad_(True), b2.clone().requires_grad_(True)
+            k1, c1 = ops.weight_prep(w1v, None, True)
+            k2, c2 = ops.weight_prep(w2v, None, True)
+            d1 = ops.conv_desc(N, 2 * H, 2 * W, C0, C1, 5, 5, stride=(2, 2), pad=(2, 2), precision=prec)
+            d2 = ops.conv_desc(N, H, W, C1, C2, 5, 5, stride=(2, 2), pad=(2, 2), precision=prec)
+            assert ops._wino_s2d_ok(d1) == (minc > 0) and ops._wino_s2d_ok(d2) == (minc > 0)
+            dm1, dm2 = (d1.P * d1.Q, d1.Q, d1.Q), (d2.P * d2.Q, d2.Q, d2.Q)
+            y1, hon = ops.conv_leaky(x, k1, c1, b1v, d1, mask1, dm1, pregate=True, chain=True)
+            assert hon and y1.grad_fn.__class__.__name__.startswith("ConvWinoS2dLeakyFn" if minc > 0 else "ConvLeakyFn")
+            y2 = ops.conv_leaky(y1, k2, c2, b2v, d2, mask2, dm2, in_gate=(mask1, dm1, 0.2))
+            r = torch.randn(y2.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+            (y2 * r).sum().backward()
+            return [t_.detach().clone() for t_ in (y1, y2, x.grad, w1v.grad, w2v.grad, b1v.grad, b2v.grad)]
+        finally:
+            ops.WINO_S2D_MIN_CHANNELS = keep
+
+    got, want = run(128), run(0)
+    for g_, w_, name in zip(got, want, ("y1", "y2", "dx", "dw1", "dw2", "db1", "db2")):
+        assert_rel(g_, w_, 4e-5, name)
+
+
 def test_masked_mae_leaky_gate(env):
     ops = env
     torch.manual_seed(10)
