@@ -404,11 +404,17 @@ WINO_KEEP_V_MIB = int(os.environ.get("MQGAN_WINO_KEEP_MIB", "6144"))
 
 
 def _wino_ok(d: ConvDesc) -> bool:
-    """3x3, stride 1, pad 1, no dilation, one group, f32 tensors on an f32-result engine, channel counts that fill the GEMM."""
-    return (WINO_MIN_CHANNELS > 0 and d.R == 3 and d.S == 3 and d.stride_h == 1 and d.stride_w == 1 and d.pad_h == 1 and d.pad_w == 1
+    """3x3, stride 1, pad 1, no dilation, one group, f32 tensors on an f32-result engine, channel counts that fill the GEMM.
+    Worth it when the GEMM work saved (proportional to C K) outweighs the transforms (proportional to C + K): with the default
+    threshold that is C K / (C + K) >= 45 for F(3x3, 3x3) (192 -> 64 pays, x1.13; 64 -> 64 does not, x0.83: tools/wino_micro.py)
+    and min(C, K) >= 128 for F(2x2, 3x3); an explicit MQGAN_WINO_MINC is a plain minimum on min(C, K)."""
+    if not (WINO_MIN_CHANNELS > 0 and d.R == 3 and d.S == 3 and d.stride_h == 1 and d.stride_w == 1 and d.pad_h == 1 and d.pad_w == 1
             and d.dil_h == 1 and d.dil_w == 1 and d.groups == 1 and d.P == d.H and d.Q == d.W
-            and d.precision in (PRECISIONS["f32"], PRECISIONS["f32x3"])
-            and d.C % 16 == 0 and d.K % 16 == 0 and min(d.C, d.K) >= WINO_MIN_CHANNELS)
+            and d.precision in (PRECISIONS["f32"], PRECISIONS["f32x3"]) and d.C % 16 == 0 and d.K % 16 == 0):
+        return False
+    if WINO_TILE == 3 and WINO_MIN_CHANNELS == 128 and "MQGAN_WINO_MINC" not in os.environ:
+        return min(d.C, d.K) >= 64 and d.C * d.K >= 45 * (d.C + d.K)
+    return min(d.C, d.K) >= WINO_MIN_CHANNELS
 
 
 # output tile edge m of F(m x m, 3 x 3): 3 (default: 25 positions per 9 outputs, csrc/winograd3.hip) or 2 (16 per 4, winograd.hip)
