@@ -526,10 +526,12 @@ def test_conv_large_split_k_and_tiles(env, precision):
     assert_rel(w.grad, wr.grad, 5e-5, "wgrad")
 
 
-def test_f32x3_engine_has_the_error_of_the_f32_engine(env):
+def test_f32x3_engine_has_the_error_of_the_f32_engine(env, monkeypatch):
     """K-dim 4608 (the deepest reduction on the path): rms and max error against float64 of the split engine
-    (three bf16 terms, six products) vs the exact-product f32 MFMA engine - same order, well inside 2e-5."""
+    (three bf16 terms, six products) vs the exact-product f32 MFMA engine - same order, well inside 2e-5.  The
+    ENGINES are compared: the layer would otherwise take the Winograd route (its own error: the last assertion)."""
     ops = env
+    monkeypatch.setattr(ops, "WINO_MIN_CHANNELS", 0)
     torch.manual_seed(5)
     N, H, W, Cc, K = 1, 16, 24, 512, 128
     x = torch.randn(N, H, W, Cc, dtype=torch.float64)
@@ -546,6 +548,13 @@ def test_f32x3_engine_has_the_error_of_the_f32_engine(env):
     assert errs["f32"][0] < 2e-6 and errs["f32x3"][0] < 2e-6, errs
     assert errs["f32x3"][0] < 1.5 * errs["f32"][0] + 1e-8, errs
     assert errs["f32x3"][1] < 2.0 * errs["f32"][1] + 1e-7, errs
+    monkeypatch.undo()
+    assert ops._wino_ok(ops.conv_desc(N, H, W, Cc, K, 3, 3, pad=(1, 1)))
+    for tile, bound in ((2, 2.5e-6), (3, 4e-6)):
+        monkeypatch.setattr(ops, "WINO_TILE", tile)
+        d = ops.conv_desc(N, H, W, Cc, K, 3, 3, pad=(1, 1))
+        e = (ops.conv(x.float().to(DEV), wk, wc, None, d).double().cpu() - ref) / scale
+        assert float(e.pow(2).mean().sqrt()) < bound, (tile, float(e.pow(2).mean().sqrt()))
 
 
 def test_f32x3_error_bound_at_config2_depths(env):

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-launch conv timing of one train step at BASELINE config 2 (HIP events), grouped by shape."""
+"""Per-launch conv timing of one train step (HIP events), grouped by shape: `layer_profile.py [config] [precision]`
+(hifispeech fp32 = BASELINE config 2 by default; `hifimusic bf16` = config 3)."""
 import os, sys, collections
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,6 +9,8 @@ from mqgan_amd import ops
 from mqgan_amd.train import Trainer
 
 cfg = bench.load_config(sys.argv[1] if len(sys.argv) > 1 else "hifispeech")
+if len(sys.argv) > 2:
+    cfg["training"]["precision"] = sys.argv[2]
 dev = torch.device("cuda", 0)
 tr = Trainer(cfg, device=dev, build_data=False)
 tr.generator.train(); tr.patch_discriminator.train(); tr.multibin_discriminator.train(); tr.epoch = 1
