@@ -475,28 +475,31 @@ int mq_wino3_output_transform_d2s(const float *M, int N, int H, int W, int C, co
                                   int64_t d1, int64_t d2, int64_t d3, float *dx, mqStream stream);
 int mq_wino3_wgrad_inverse_s2d(const float *P, int K, int C, float *dw_krsc, mqStream stream);
 
-/* ------------------------------------------------------------------ one-dimensional Winograd F(2, 3) along the rows
+/* ------------------------------------------------------------------ one-dimensional Winograd F(m, 3) along the rows
  * The multi-bin discriminator's (3 x k) layers (discriminators.py:251-290: 3 taps and stride 1 along the bins, k taps and
- * stride 1 or 2 along time): 4 row products per 2 output rows instead of 6 (csrc/wino1d.hip).  th = ceil(H / 2) row tiles;
- * every tensor f32, channels-last, channel counts multiples of 4; `groups` = batch groups of the layer (N % groups == 0).
- *   forward : V = input_transform(x) (4, N, th, W, C);  U = weight_transform(w_krsc (groups * K, 3 * S, C));
- *             M = mq_conv_fprop(desc{N = 4 * N * th, H = 1, W, C, K, R = 1, S, stride (1, sw), pad (0, pw), groups = 4 * groups},
- *             V, U_krsc) (4, N, th, Q, K);  y = output_transform(M, bias): act 2 = LeakyReLU(slope) then zero where
+ * stride 1 or 2 along time): m + 2 row products per m output rows instead of 3 m (csrc/wino1d.hip), m = 2, 4 or 5
+ * (mq_wino1d_tile(H): the tile with the fewest products for H rows - 5 for the 10-bin bands: 14 instead of 30).
+ * th = ceil(H / m) row tiles, np = m + 2 positions; every tensor f32, channels-last, channel counts multiples of 4;
+ * `groups` = batch groups of the layer (N % groups == 0).
+ *   forward : V = input_transform(x) (np, N, th, W, C);  U = weight_transform(w_krsc (groups * K, 3 * S, C));
+ *             M = mq_conv_fprop(desc{N = np * N * th, H = 1, W, C, K, R = 1, S, stride (1, sw), pad (0, pw), groups = np * groups},
+ *             V, U_krsc) (np, N, th, Q, K);  y = output_transform(M, bias): act 2 = LeakyReLU(slope) then zero where
  *             padded[(m / d1) * d2 + m % d3] (m = output pixel), as mq_conv_fprop_leaky
- *   backward: Z = dy_transform(dy) (4, N, th, Q, K) and, if bias_partial != NULL, deterministic per-block column sums of dy:
+ *   backward: Z = dy_transform(dy) (np, N, th, Q, K) and, if bias_partial != NULL, deterministic per-block column sums of dy:
  *             bias_partial [mq_wino1d_dy_rows(...)][groups * K], db = its column sums (mq_colsum);
  *             dV = mq_conv_dgrad(that desc, Z, U_crsk);  dx = dx_transform(dV): with gate != NULL the result is multiplied by
  *             LeakyReLU'(gate) and zeroed where padded_in[...] (the producer layer's activation backward, mq_conv_dgrad_gated's
  *             contract);  dU = mq_conv_wgrad(that desc, V, Z);  dw_krsc = wgrad_inverse(dU). */
-int mq_wino1d_input_transform(const float *x, int N, int H, int W, int C, float *V, mqStream stream);
-int mq_wino1d_weight_transform(const float *w_krsc, int groups, int K, int C, int S, float *U_krsc, float *U_crsk, mqStream stream);
-int mq_wino1d_output_transform(const float *M, const float *bias, int N, int H, int Q, int K, int groups, int act, float slope,
+int mq_wino1d_tile(int H);
+int mq_wino1d_input_transform(const float *x, int N, int H, int W, int C, int m, float *V, mqStream stream);
+int mq_wino1d_weight_transform(const float *w_krsc, int groups, int K, int C, int S, int m, float *U_krsc, float *U_crsk, mqStream stream);
+int mq_wino1d_output_transform(const float *M, const float *bias, int N, int H, int Q, int K, int groups, int m, int act, float slope,
                                const uint8_t *padded, int64_t d1, int64_t d2, int64_t d3, float *y, mqStream stream);
-int mq_wino1d_dy_rows(int N, int H, int Q, int K, int groups);
-int mq_wino1d_dy_transform(const float *dy, int N, int H, int Q, int K, int groups, float *Z, float *bias_partial, mqStream stream);
-int mq_wino1d_dx_transform(const float *dV, int N, int H, int W, int C, const float *gate, float slope, const uint8_t *padded_in,
+int mq_wino1d_dy_rows(int N, int H, int Q, int K, int groups, int m);
+int mq_wino1d_dy_transform(const float *dy, int N, int H, int Q, int K, int groups, int m, float *Z, float *bias_partial, mqStream stream);
+int mq_wino1d_dx_transform(const float *dV, int N, int H, int W, int C, int m, const float *gate, float slope, const uint8_t *padded_in,
                            int64_t d1, int64_t d2, int64_t d3, float *dx, mqStream stream);
-int mq_wino1d_wgrad_inverse(const float *dU, int groups, int K, int C, int S, float *dw_krsc, mqStream stream);
+int mq_wino1d_wgrad_inverse(const float *dU, int groups, int K, int C, int S, int m, float *dw_krsc, mqStream stream);
 
 /* ------------------------------------------------------------------ optimiser
  * clip_grad_norm_ + Adam on flat arenas (train.py:401-407,485-492; torch.optim.Adam

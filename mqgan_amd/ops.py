@@ -650,8 +650,9 @@ class ConvLeakyFn(torch.autograd.Function):
         return dx, dw, None, db, None, None, None, None, None, None
 
 
-# ----------------------------------------------------------------------------- 1-D Winograd F(2, 3) along the rows (csrc/wino1d.hip)
+# ----------------------------------------------------------------------------- 1-D Winograd F(m, 3) along the rows (csrc/wino1d.hip)
 WINO1D_MIN_CHANNELS = int(os.environ.get("MQGAN_WINO1D_MINC", "128"))     # 0 switches the path off (A/B runs)
+WINO1D_TILE = int(os.environ.get("MQGAN_WINO1D_TILE", "0"))               # 0: the tile with the fewest products; 2, 4, 5: fixed
 
 
 def _wino1d_ok(d: ConvDesc) -> bool:
@@ -663,40 +664,47 @@ def _wino1d_ok(d: ConvDesc) -> bool:
             and d.N % d.groups == 0)
 
 
-def _wino1d_gemm_desc(d: ConvDesc) -> ConvDesc:
-    """The four transform positions as 4 x groups batch groups of one-row images (xi, n, row tile)."""
-    th = (d.H + 1) // 2
-    return conv_desc(4 * d.N * th, 1, d.W, d.C, d.K, 1, d.S, stride=(1, d.stride_w), pad=(0, d.pad_w), groups=4 * d.groups,
+def _wino1d_m(d: ConvDesc) -> int:
+    """Output rows per tile: F(m, 3) costs ceil(H / m) * (m + 2) row products - 5 for the 10-bin bands (14 instead of 20 with
+    F(2, 3) and 30 direct), 4 for 16 bins."""
+    return WINO1D_TILE if WINO1D_TILE in (2, 4, 5) else L().mq_wino1d_tile(d.H)
+
+
+def _wino1d_gemm_desc(d: ConvDesc, m: int) -> ConvDesc:
+    """The m + 2 transform positions as (m + 2) x groups batch groups of one-row images (xi, n, row tile)."""
+    th = -(-d.H // m)
+    return conv_desc((m + 2) * d.N * th, 1, d.W, d.C, d.K, 1, d.S, stride=(1, d.stride_w), pad=(0, d.pad_w), groups=(m + 2) * d.groups,
                      precision=d.precision)
 
 
 class ConvWino1dLeakyFn(torch.autograd.Function):
     """ConvLeakyFn for layers _wino1d_ok takes: y = padded ? 0 : LeakyReLU(conv(x, w) + bias) with the row taps as Winograd
-    F(2, 3) - two thirds of the multiplications, run as one batch-grouped (1 x S) convolution on the same f32 GEMM kernels
+    F(m, 3) - (m + 2) / 3m of the multiplications, run as one batch-grouped (1 x S) convolution on the same f32 GEMM kernels
     between HBM-bound transforms that also carry the epilogues (bias + LeakyReLU + mask forward; the producer's gate, the bias
     sums backward).  Same arguments, contract (``in_gate`` / ``pregated``) and gradients as ConvLeakyFn."""
 
     @staticmethod
     def forward(ctx, x, w_krsc, bias, mask, key, dmap, slope, in_gate=None, pregated=False):
         d = _desc_from_key(key)
-        th = (d.H + 1) // 2
+        m = _wino1d_m(d)
+        th, npos = -(-d.H // m), m + 2
         G = d.groups
         x, w_krsc = x.contiguous(), w_krsc.contiguous()
-        V = _empty((4 * d.N * th, 1, d.W, d.C), x)
-        check(L().mq_wino1d_input_transform(fptr(x), d.N, d.H, d.W, d.C, fptr(V), stream()), "mq_wino1d_input_transform")
-        U = _empty((4 * G * d.K, d.S, d.C), x)
-        Uc = _empty((4 * G * d.C, d.S, d.K), x)
-        check(L().mq_wino1d_weight_transform(fptr(w_krsc), G, d.K, d.C, d.S, fptr(U), fptr(Uc), stream()), "mq_wino1d_weight_transform")
-        dg = _wino1d_gemm_desc(d)
-        M = _empty((4 * d.N * th, 1, d.Q, d.K), x)
+        V = _empty((npos * d.N * th, 1, d.W, d.C), x)
+        check(L().mq_wino1d_input_transform(fptr(x), d.N, d.H, d.W, d.C, m, fptr(V), stream()), "mq_wino1d_input_transform")
+        U = _empty((npos * G * d.K, d.S, d.C), x)
+        Uc = _empty((npos * G * d.C, d.S, d.K), x)
+        check(L().mq_wino1d_weight_transform(fptr(w_krsc), G, d.K, d.C, d.S, m, fptr(U), fptr(Uc), stream()), "mq_wino1d_weight_transform")
+        dg = _wino1d_gemm_desc(d, m)
+        M = _empty((npos * d.N * th, 1, d.Q, d.K), x)
         _timed(None, _conv_flops(dg), lambda: check(
             L().mq_conv_fprop(C.byref(dg), fptr(V), fptr(U), None, fptr(M), stream()), "mq_conv_fprop"), key)
         y = _empty((d.N, d.H, d.Q, d.K), x)
-        check(L().mq_wino1d_output_transform(fptr(M), fptr(bias, True), d.N, d.H, d.Q, d.K, G, 2, float(slope),
+        check(L().mq_wino1d_output_transform(fptr(M), fptr(bias, True), d.N, d.H, d.Q, d.K, G, m, 2, float(slope),
                                              ptr(mask, torch.uint8, True), dmap[0], dmap[1], dmap[2], fptr(y), stream()),
               "mq_wino1d_output_transform")
         del M, U
-        ctx.key, ctx.dmap, ctx.slope = key, dmap, slope
+        ctx.key, ctx.dmap, ctx.slope, ctx.m = key, dmap, slope, m
         ctx.w_shape = tuple(w_krsc.shape)
         ctx.has_bias = bias is not None
         ctx.pregated = bool(pregated)
@@ -711,7 +719,8 @@ class ConvWino1dLeakyFn(torch.autograd.Function):
     def backward(ctx, dout):
         V, Uc, y, mask, x_gate, mask_in = ctx.saved_tensors
         d = _desc_from_key(ctx.key)
-        th = (d.H + 1) // 2
+        m = ctx.m
+        th, npos = -(-d.H // m), m + 2
         G = d.groups
         if ctx.slope != 0.2 and not ctx.pregated:
             raise _lib.MqganHipError("the pointwise backward kernel implements LeakyReLU(0.2) only")
@@ -729,30 +738,30 @@ class ConvWino1dLeakyFn(torch.autograd.Function):
         dx = dw = db = None
         part = None
         if want_db:
-            part = _empty((L().mq_wino1d_dy_rows(d.N, d.H, d.Q, d.K, G), G * d.K), dy)
-        Z = _empty((4 * d.N * th, 1, d.Q, d.K), dy)
-        check(L().mq_wino1d_dy_transform(fptr(dy), d.N, d.H, d.Q, d.K, G, fptr(Z), fptr(part, True), stream()), "mq_wino1d_dy_transform")
-        dg = _wino1d_gemm_desc(d)
+            part = _empty((L().mq_wino1d_dy_rows(d.N, d.H, d.Q, d.K, G, m), G * d.K), dy)
+        Z = _empty((npos * d.N * th, 1, d.Q, d.K), dy)
+        check(L().mq_wino1d_dy_transform(fptr(dy), d.N, d.H, d.Q, d.K, G, m, fptr(Z), fptr(part, True), stream()), "mq_wino1d_dy_transform")
+        dg = _wino1d_gemm_desc(d, m)
         if want_dx:
-            dV = _empty((4 * d.N * th, 1, d.W, d.C), dy)
+            dV = _empty((npos * d.N * th, 1, d.W, d.C), dy)
             _timed(None, _conv_flops(dg), lambda: check(
                 L().mq_conv_dgrad(C.byref(dg), fptr(Z), fptr(Uc), fptr(dV), stream()), "mq_conv_dgrad"), ctx.key)
             dx = _empty((d.N, d.H, d.W, d.C), dy)
             gd = ctx.in_gate[0] if ctx.in_gate is not None else (1, 0, 1)
             gs = float(ctx.in_gate[1]) if ctx.in_gate is not None else 1.0
-            check(L().mq_wino1d_dx_transform(fptr(dV), d.N, d.H, d.W, d.C, fptr(x_gate, True), gs, ptr(mask_in, torch.uint8, True),
+            check(L().mq_wino1d_dx_transform(fptr(dV), d.N, d.H, d.W, d.C, m, fptr(x_gate, True), gs, ptr(mask_in, torch.uint8, True),
                                              gd[0], gd[1], gd[2], fptr(dx), stream()), "mq_wino1d_dx_transform")
             del dV
         if want_dw:
             if not ctx.kept_v:
                 raise _lib.MqganHipError("ConvWino1dLeakyFn: weight gradient asked for a layer whose weights did not require one")
-            dU = _empty((4 * G * d.K, d.S, d.C), dy)
+            dU = _empty((npos * G * d.K, d.S, d.C), dy)
             nbytes = L().mq_conv_wgrad_workspace(C.byref(dg))
             ws = _ws_bytes(nbytes, dy)
             _timed(None, _conv_flops(dg), lambda: check(
                 L().mq_conv_wgrad(C.byref(dg), fptr(V), fptr(Z), fptr(dU), ptr(ws), nbytes, stream()), "mq_conv_wgrad"), ctx.key)
             dw = _empty(ctx.w_shape, dy)
-            check(L().mq_wino1d_wgrad_inverse(fptr(dU), G, d.K, d.C, d.S, fptr(dw), stream()), "mq_wino1d_wgrad_inverse")
+            check(L().mq_wino1d_wgrad_inverse(fptr(dU), G, d.K, d.C, d.S, m, fptr(dw), stream()), "mq_wino1d_wgrad_inverse")
         if want_db:
             db = colsum(part)
         return dx, dw, db, None, None, None, None, None, None
