@@ -475,6 +475,25 @@ int mq_wino3_output_transform_d2s(const float *M, int N, int H, int W, int C, co
                                   int64_t d1, int64_t d2, int64_t d3, float *dx, mqStream stream);
 int mq_wino3_wgrad_inverse_s2d(const float *P, int K, int C, float *dw_krsc, mqStream stream);
 
+/* ------------------------------------------------------------------ Winograd F(mh x mw, 3x3), tiles 4 x 4 and 4 x 5
+ * The same layers, transforms, layouts and call sequence as the mq_wino3_* functions above (plain and polyphase form), with
+ * (mh + 2)(mw + 2) positions per tile of mh x mw outputs: 36 per 16 (2.25 products per output) or 42 per 20 (2.10) instead of
+ * 25 per 9 (2.78).  Transform matrices per axis: csrc/wino_tables.h (point sets chosen for f32 accuracy: 1.2x / 1.8x the error of
+ * F(3x3, 3x3), csrc/winogradn.hip).  th = ceil(H / mh), tw = ceil(W / mw) tiles per image; the GEMM descriptor is
+ * (N = np * N * th, H = 1, W = tw, groups = np), np = (mh + 2)(mw + 2).  (mh, mw) = (4, 4) or (4, 5). */
+int mq_winon_input_transform(const float *x, int N, int H, int W, int C, float *V, int mh, int mw, mqStream stream);
+int mq_winon_output_transform(const float *M, const float *bias, int N, int H, int W, int K, int act, float slope, const uint8_t *padded,
+                              int64_t d1, int64_t d2, int64_t d3, float *y, int mh, int mw, mqStream stream);
+int mq_winon_weight_transform(const float *w_krsc, int K, int C, int flip_transpose, float *U, int mh, int mw, mqStream stream);
+int mq_winon_wgrad_inverse(const float *P, int K, int C, float *dw_krsc, int mh, int mw, mqStream stream);
+int mq_winon_dy_fused_rows(int N, int H, int W, int K, int mh, int mw);
+int mq_winon_dy_fused(const float *dy, int N, int H, int W, int K, float *Z, float *Vd, float *bias_partial, int mh, int mw, mqStream stream);
+int mq_winon_input_transform_s2d(const float *x, int N, int H, int W, int C, float *V, int mh, int mw, mqStream stream);
+int mq_winon_weight_transform_s2d(const float *w_krsc, int K, int C, int flip_transpose, float *U, int mh, int mw, mqStream stream);
+int mq_winon_output_transform_d2s(const float *M, int N, int H, int W, int C, const float *gate, float slope, const uint8_t *padded_in,
+                                  int64_t d1, int64_t d2, int64_t d3, float *dx, int mh, int mw, mqStream stream);
+int mq_winon_wgrad_inverse_s2d(const float *P, int K, int C, float *dw_krsc, int mh, int mw, mqStream stream);
+
 /* ------------------------------------------------------------------ one-dimensional Winograd F(m, 3) along the rows
  * The multi-bin discriminator's (3 x k) layers (discriminators.py:251-290: 3 taps and stride 1 along the bins, k taps and
  * stride 1 or 2 along time): m + 2 row products per m output rows instead of 3 m (csrc/wino1d.hip), m = 2, 4 or 5

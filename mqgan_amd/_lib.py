@@ -160,6 +160,16 @@ SIGNATURES = {
     "mq_wino3_wgrad_inverse": (_I, [_P, _I, _I, _P, _P]),
     "mq_wino3_dy_fused_rows": (_I, [_I, _I, _I, _I]),
     "mq_wino3_dy_fused": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "mq_winon_input_transform": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
+    "mq_winon_output_transform": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _P, _L, _L, _L, _P, _I, _I, _P]),
+    "mq_winon_input_transform_s2d": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
+    "mq_winon_weight_transform_s2d": (_I, [_P, _I, _I, _I, _P, _I, _I, _P]),
+    "mq_winon_output_transform_d2s": (_I, [_P, _I, _I, _I, _I, _P, _F, _P, _L, _L, _L, _P, _I, _I, _P]),
+    "mq_winon_wgrad_inverse_s2d": (_I, [_P, _I, _I, _P, _I, _I, _P]),
+    "mq_winon_weight_transform": (_I, [_P, _I, _I, _I, _P, _I, _I, _P]),
+    "mq_winon_wgrad_inverse": (_I, [_P, _I, _I, _P, _I, _I, _P]),
+    "mq_winon_dy_fused_rows": (_I, [_I, _I, _I, _I, _I, _I]),
+    "mq_winon_dy_fused": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P]),
     "mq_wino1d_tile": (_I, [_I]),
     "mq_wino1d_input_transform": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "mq_wino1d_weight_transform": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),

@@ -1,0 +1,55 @@
+// Transform matrices of one-dimensional Winograd F(m, 3), m = 4 and 5:  y = A^T [(G g) . (B^T d)]  (d: m + 2 inputs, g: 3
+// taps, y: m outputs).  Generated as exact rationals by tools/wino1d_matrices.py (Toom-Cook through the transposition
+// principle); the point sets are the ones with the smallest f32 error among those it surveys:
+//     F(4, 3): 0, 1, -1, 2, -1/2, inf        F(5, 3): 0, 1, -1, 2, -2, 1/2, inf
+// In both, the first input of a tile enters position 0 only and the last input the last position only, with coefficient 1.
+// Used along the rows by wino1d.hip and along both axes (nested) by winogradn.hip.
+#pragma once
+#include "common.h"
+
+namespace mq {
+namespace wt {
+namespace f4 {
+constexpr float BT[6][6] = {{1, 1.5f, -2, -1.5f, 1, 0},
+                            {0, 1.0f / 3, 5.0f / 6, 1.0f / 6, -1.0f / 3, 0},
+                            {0, 1.0f / 3, 1.0f / 6, -5.0f / 6, 1.0f / 3, 0},
+                            {0, -1.0f / 30, -1.0f / 15, 1.0f / 30, 1.0f / 15, 0},
+                            {0, -32.0f / 15, 16.0f / 15, 32.0f / 15, -16.0f / 15, 0},
+                            {0, 1, 1.5f, -2, -1.5f, 1}};
+constexpr float G[6][3] = {{1, 0, 0}, {1, 1, 1}, {1, -1, 1}, {1, 2, 4}, {1, -0.5f, 0.25f}, {0, 0, 1}};
+constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -0.5f, 0}, {0, 1, 1, 4, 0.25f, 0}, {0, 1, -1, 8, -0.125f, 1}};
+}  // namespace f4
+namespace f5 {
+constexpr float BT[7][7] = {{1, -2, -1.25f, 2.5f, 0.25f, -0.5f, 0},
+                            {0, -2.0f / 3, 2.0f / 3, 1.5f, -1.0f / 6, -1.0f / 3, 0},
+                            {0, -2.0f / 9, 2.0f / 3, -7.0f / 18, -1.0f / 6, 1.0f / 9, 0},
+                            {0, 1.0f / 36, -1.0f / 24, -1.0f / 18, 1.0f / 24, 1.0f / 36, 0},
+                            {0, 1.0f / 60, -1.0f / 24, 0, 1.0f / 24, -1.0f / 60, 0},
+                            {0, 128.0f / 45, 0, -32.0f / 9, 0, 32.0f / 45, 0},
+                            {0, -2, 4, 2.5f, -5, -0.5f, 1}};
+constexpr float G[7][3] = {{1, 0, 0}, {1, 1, 1}, {1, -1, 1}, {1, 2, 4}, {1, -2, 4}, {1, 0.5f, 0.25f}, {0, 0, 1}};
+constexpr float AT[5][7] = {{1, 1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0.5f, 0}, {0, 1, 1, 4, 4, 0.25f, 0},
+                            {0, 1, -1, 8, -8, 0.125f, 0}, {0, 1, 1, 16, 16, 0.0625f, 1}};
+}  // namespace f5
+static_assert(f4::BT[0][0] == 1.f && f4::BT[5][5] == 1.f && f5::BT[0][0] == 1.f && f5::BT[6][6] == 1.f, "shared-row coefficients");
+
+template <int M> __device__ __forceinline__ constexpr float bt(int i, int j) { if constexpr (M == 4) return f4::BT[i][j]; else return f5::BT[i][j]; }
+template <int M> __device__ __forceinline__ constexpr float g(int i, int j) { if constexpr (M == 4) return f4::G[i][j]; else return f5::G[i][j]; }
+template <int M> __device__ __forceinline__ constexpr float at(int i, int j) { if constexpr (M == 4) return f4::AT[i][j]; else return f5::AT[i][j]; }
+
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// acc += c * v with the constant known after unrolling: zero terms vanish, +-1 become adds
+__device__ __forceinline__ void axpy(float4 &acc, float c, float4 v)
+{
+    if (c == 0.f) return;
+    if (c == 1.f) { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; return; }
+    if (c == -1.f) { acc.x -= v.x; acc.y -= v.y; acc.z -= v.z; acc.w -= v.w; return; }
+    acc.x += c * v.x; acc.y += c * v.y; acc.z += c * v.z; acc.w += c * v.w;
+}
+__device__ __forceinline__ void axpy1(float &acc, float c, float v)
+{
+    if (c == 0.f) return;
+    acc += c * v;
+}
+}  // namespace wt
+}  // namespace mq

@@ -406,76 +406,113 @@ WINO_KEEP_V_MIB = int(os.environ.get("MQGAN_WINO_KEEP_MIB", "6144"))
 def _wino_ok(d: ConvDesc) -> bool:
     """3x3, stride 1, pad 1, no dilation, one group, f32 tensors on an f32-result engine, channel counts that fill the GEMM.
     Worth it when the GEMM work saved (proportional to C K) outweighs the transforms (proportional to C + K): with the default
-    threshold that is C K / (C + K) >= 45 for F(3x3, 3x3) (192 -> 64 pays, x1.13; 64 -> 64 does not, x0.83: tools/wino_micro.py)
-    and min(C, K) >= 128 for F(2x2, 3x3); an explicit MQGAN_WINO_MINC is a plain minimum on min(C, K)."""
+    threshold that is C K / (C + K) >= 45 for F(3x3, 3x3) (192 -> 64 pays, x1.13; 64 -> 64 does not, x0.83: tools/wino_micro.py),
+    >= 32 for the 4x4 / 4x5 tiles (64 -> 64 included: config-2 step 214.8 -> 212.7 ms) and min(C, K) >= 128 for F(2x2, 3x3); an
+    explicit MQGAN_WINO_MINC is a plain minimum on min(C, K)."""
     if not (WINO_MIN_CHANNELS > 0 and d.R == 3 and d.S == 3 and d.stride_h == 1 and d.stride_w == 1 and d.pad_h == 1 and d.pad_w == 1
             and d.dil_h == 1 and d.dil_w == 1 and d.groups == 1 and d.P == d.H and d.Q == d.W
             and d.precision in (PRECISIONS["f32"], PRECISIONS["f32x3"]) and d.C % 16 == 0 and d.K % 16 == 0):
         return False
-    if WINO_TILE == 3 and WINO_MIN_CHANNELS == 128 and "MQGAN_WINO_MINC" not in os.environ:
-        return min(d.C, d.K) >= 64 and d.C * d.K >= 45 * (d.C + d.K)
+    tile = _wino_tile(d.H, d.W)
+    if tile != (2, 2) and WINO_MIN_CHANNELS == 128 and "MQGAN_WINO_MINC" not in os.environ:
+        return min(d.C, d.K) >= 64 and d.C * d.K >= (45 if tile == (3, 3) else 32) * (d.C + d.K)
     return min(d.C, d.K) >= WINO_MIN_CHANNELS
 
 
-# output tile edge m of F(m x m, 3 x 3): 3 (default: 25 positions per 9 outputs, csrc/winograd3.hip) or 2 (16 per 4, winograd.hip)
-WINO_TILE = int(os.environ.get("MQGAN_WINO_TILE", "3"))
+# Output tile of F(mh x mw, 3x3).  "auto" (default): per image, the tile with the fewest products among 3x3 (25 positions per 9
+# outputs, csrc/winograd3.hip), 4x4 (36 per 16) and 4x5 (42 per 20; both csrc/winogradn.hip) - 4x5 for the refiner's T x 90
+# images; "3", "4", "45": that tile everywhere; "2": F(2x2, 3x3) (16 per 4, winograd.hip).
+WINO_TILE = os.environ.get("MQGAN_WINO_TILE", "auto")
+_WINO_TILES = {"2": (2, 2), "3": (3, 3), "4": (4, 4), "45": (4, 5)}
 
 
-def _wino_m() -> int:
-    if WINO_TILE not in (2, 3):
-        raise _lib.MqganHipError(f"MQGAN_WINO_TILE must be 2 or 3, got {WINO_TILE}")
-    return WINO_TILE
+def _wino_tile(H: int, W: int):
+    key = str(WINO_TILE)
+    if key in _WINO_TILES:
+        return _WINO_TILES[key]
+    if key != "auto":
+        raise _lib.MqganHipError(f"MQGAN_WINO_TILE must be auto, 2, 3, 4 or 45, got {WINO_TILE}")
+    cost = lambda t: -(-H // t[0]) * -(-W // t[1]) * (t[0] + 2) * (t[1] + 2)
+    return min(((3, 3), (4, 4), (4, 5)), key=cost)           # ties: the smaller tile (smaller error)
 
 
-def _wino_fn(name: str):
-    """Entry point of the active tile size: mq_wino_<name> (F(2x2,3x3)) or mq_wino3_<name> (F(3x3,3x3))."""
-    return getattr(L(), ("mq_wino3_" if _wino_m() == 3 else "mq_wino_") + name)
+def _wcall(tile, name: str, *args):
+    """mq_wino_<name> (2x2), mq_wino3_<name> (3x3) or mq_winon_<name>(..., mh, mw); the stream is appended."""
+    if tile == (2, 2):
+        return getattr(L(), "mq_wino_" + name)(*args, stream())
+    if tile == (3, 3):
+        return getattr(L(), "mq_wino3_" + name)(*args, stream())
+    return getattr(L(), "mq_winon_" + name)(*args, tile[0], tile[1], stream())
+
+
+def _wrows(tile, N: int, H: int, W: int, K: int) -> int:
+    """Rows of the per-block column sums the fused dy pass of this tile writes (0: shape not supported)."""
+    if tile == (2, 2):
+        return L().mq_wino_dy_fused_rows(N, H, W, K)
+    if tile == (3, 3):
+        return L().mq_wino3_dy_fused_rows(N, H, W, K)
+    return L().mq_winon_dy_fused_rows(N, H, W, K, tile[0], tile[1])
+
+
+def _wino_npos(tile) -> int:
+    return (tile[0] + 2) * (tile[1] + 2)
+
+
+def _wino_ntiles(tile, N: int, H: int, W: int) -> int:
+    return N * -(-H // tile[0]) * -(-W // tile[1])
+
+
+def _wino_gemm(tile, N: int, H: int, W: int, cin: int, cout: int, precision) -> ConvDesc:
+    """The transform positions as that many groups of one-row "images" (one per tile row: small images keep the kernels' 32-bit
+    image-relative offsets far from their limits) with batch-grouped 1x1 filters."""
+    n_pos = _wino_npos(tile)
+    return conv_desc(n_pos * N * -(-H // tile[0]), 1, -(-W // tile[1]), cin, cout, 1, 1, groups=n_pos, precision=precision)
 
 
 def _wino_tiles(d: ConvDesc) -> int:
-    m = _wino_m()
-    return d.N * ((d.H + m - 1) // m) * ((d.W + m - 1) // m)
+    return _wino_ntiles(_wino_tile(d.H, d.W), d.N, d.H, d.W)
 
 
-def _wino_np() -> int:
-    return (_wino_m() + 2) ** 2
+def _wino_np(d: ConvDesc) -> int:
+    return _wino_npos(_wino_tile(d.H, d.W))
 
 
 def _wino_gemm_desc(d: ConvDesc, cin: int, cout: int) -> ConvDesc:
-    """The transform positions as that many groups of one-row "images" (one per tile row: small images keep the kernels' 32-bit
-    image-relative offsets far from their limits) with batch-grouped 1x1 filters."""
-    m, n_pos = _wino_m(), _wino_np()
-    return conv_desc(n_pos * d.N * ((d.H + m - 1) // m), 1, (d.W + m - 1) // m, cin, cout, 1, 1, groups=n_pos, precision=d.precision)
+    return _wino_gemm(_wino_tile(d.H, d.W), d.N, d.H, d.W, cin, cout, d.precision)
 
 
 def _wino_in(t, d: ConvDesc, channels: int, dy_side: bool = False):
-    out = _empty((_wino_np() * _wino_tiles(d), 1, 1, channels), t)
-    if dy_side and _wino_m() == 3:         # the larger tile has the fused pass only: Z without V and without column sums
-        check(L().mq_wino3_dy_fused(fptr(t), d.N, d.H, d.W, channels, fptr(out), None, None, stream()), "mq_wino3_dy_fused")
+    tile = _wino_tile(d.H, d.W)
+    out = _empty((_wino_np(d) * _wino_tiles(d), 1, 1, channels), t)
+    if dy_side and tile != (2, 2):         # the larger tiles have the fused pass only: Z without V and without column sums
+        check(_wcall(tile, "dy_fused", fptr(t), d.N, d.H, d.W, channels, fptr(out), None, None), "mq_wino_dy_fused")
         return out
-    fn = L().mq_wino_dy_transform if dy_side else _wino_fn("input_transform")
-    check(fn(fptr(t), d.N, d.H, d.W, channels, fptr(out), stream()), "mq_wino_dy_transform" if dy_side else "mq_wino_input_transform")
+    if dy_side:
+        check(L().mq_wino_dy_transform(fptr(t), d.N, d.H, d.W, channels, fptr(out), stream()), "mq_wino_dy_transform")
+    else:
+        check(_wcall(tile, "input_transform", fptr(t), d.N, d.H, d.W, channels, fptr(out)), "mq_wino_input_transform")
     return out
 
 
 def _wino_conv(d: ConvDesc, x, w_krsc, bias, cin: int, cout: int, flip: bool, key, keep=None, V=None):
     """'same' 3x3 convolution of x (N, H, W, cin) with the KRSC weights (forward: flip False; input gradient: flip True).
     ``keep``: a list that receives the transformed input V.  ``V``: the already transformed input (x is then not read)."""
+    tile = _wino_tile(d.H, d.W)
     if V is None:
         V = _wino_in(x, d, cin)
     if keep is not None:
         keep.append(V)
-    U = _empty((_wino_np() * cout, 1, cin), V)
-    check(_wino_fn("weight_transform")(fptr(w_krsc), d.K, d.C, int(flip), fptr(U), stream()), "mq_wino_weight_transform")
+    U = _empty((_wino_np(d) * cout, 1, cin), V)
+    check(_wcall(tile, "weight_transform", fptr(w_krsc), d.K, d.C, int(flip), fptr(U)), "mq_wino_weight_transform")
     dg = _wino_gemm_desc(d, cin, cout)
-    M = _empty((_wino_np() * _wino_tiles(d), 1, 1, cout), V)
+    M = _empty((_wino_np(d) * _wino_tiles(d), 1, 1, cout), V)
     _timed(None, _conv_flops(dg), lambda: check(
         L().mq_conv_fprop(C.byref(dg), fptr(V), fptr(U), None, fptr(M), stream()), "mq_conv_fprop"), key)
     del V
     y = _empty((d.N, d.H, d.W, cout), M)
-    if _wino_m() == 3:
-        check(L().mq_wino3_output_transform(fptr(M), fptr(bias, True), d.N, d.H, d.W, cout, 0, 0.0, None, 1, 0, 1, fptr(y), stream()),
-              "mq_wino3_output_transform")
+    if tile != (2, 2):
+        check(_wcall(tile, "output_transform", fptr(M), fptr(bias, True), d.N, d.H, d.W, cout, 0, 0.0, None, 1, 0, 1, fptr(y)),
+              "mq_wino_output_transform")
     else:
         check(L().mq_wino_output_transform(fptr(M), fptr(bias, True), d.N, d.H, d.W, cout, fptr(y), stream()), "mq_wino_output_transform")
     return y
@@ -485,12 +522,13 @@ WINO_FUSED_DY = os.environ.get("MQGAN_WINO_FUSED_DY", "1") != "0"     # backward
 
 
 def _wino_dy_fused(dy, d: ConvDesc):
-    """(Z, V of dy, per-block column sums [rows][K]) in one pass over dy (mq_wino_dy_fused / mq_wino3_dy_fused)."""
-    rows = _wino_fn("dy_fused_rows")(d.N, d.H, d.W, d.K)
-    Z = _empty((_wino_np() * _wino_tiles(d), 1, 1, d.K), dy)
-    Vd = _empty((_wino_np() * _wino_tiles(d), 1, 1, d.K), dy)
+    """(Z, V of dy, per-block column sums [rows][K]) in one pass over dy (mq_wino_dy_fused / mq_wino3_dy_fused / mq_winon_dy_fused)."""
+    tile = _wino_tile(d.H, d.W)
+    rows = _wrows(tile, d.N, d.H, d.W, d.K)
+    Z = _empty((_wino_np(d) * _wino_tiles(d), 1, 1, d.K), dy)
+    Vd = _empty((_wino_np(d) * _wino_tiles(d), 1, 1, d.K), dy)
     part = _empty((rows, d.K), dy)
-    check(_wino_fn("dy_fused")(fptr(dy), d.N, d.H, d.W, d.K, fptr(Z), fptr(Vd), fptr(part), stream()), "mq_wino_dy_fused")
+    check(_wcall(tile, "dy_fused", fptr(dy), d.N, d.H, d.W, d.K, fptr(Z), fptr(Vd), fptr(part)), "mq_wino_dy_fused")
     return Z, Vd, part
 
 
@@ -502,7 +540,7 @@ class ConvWinoFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_krsc, w_crsk, bias, key):
         d = _desc_from_key(key)
-        keep_v = w_krsc.requires_grad and 4 * _wino_np() * _wino_tiles(d) * d.C <= WINO_KEEP_V_MIB << 20
+        keep_v = w_krsc.requires_grad and 4 * _wino_np(d) * _wino_tiles(d) * d.C <= WINO_KEEP_V_MIB << 20
         kept = [] if keep_v else None
         x, w_krsc = x.contiguous(), w_krsc.contiguous()
         y = _wino_conv(d, x, w_krsc, bias, d.C, d.K, False, key, keep=kept)
@@ -522,7 +560,7 @@ class ConvWinoFn(torch.autograd.Function):
         want_db = ctx.has_bias and ctx.needs_input_grad[3]
         Z = Vd = part = None
         if (WINO_FUSED_DY and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
-                and _wino_fn("dy_fused_rows")(d.N, d.H, d.W, d.K) > 0):
+                and _wrows(_wino_tile(d.H, d.W), d.N, d.H, d.W, d.K) > 0):
             Z, Vd, part = _wino_dy_fused(dy, d)
         if ctx.needs_input_grad[0]:
             dx = _wino_conv(d, dy, w_krsc, None, d.K, d.C, True, ctx.key, V=Vd)
@@ -532,14 +570,14 @@ class ConvWinoFn(torch.autograd.Function):
             if Z is None:
                 Z = _wino_in(dy, d, d.K, dy_side=True)
             dg = _wino_gemm_desc(d, d.C, d.K)
-            P = _empty((_wino_np() * d.K, 1, d.C), x)
+            P = _empty((_wino_np(d) * d.K, 1, d.C), x)
             nbytes = L().mq_conv_wgrad_workspace(C.byref(dg))
             ws = _ws_bytes(nbytes, x)
             _timed(None, _conv_flops(dg), lambda: check(
                 L().mq_conv_wgrad(C.byref(dg), fptr(V), fptr(Z), fptr(P), ptr(ws), nbytes, stream()), "mq_conv_wgrad"), ctx.key)
             del V, Z
             dw = _empty(ctx.w_shape, x)
-            check(_wino_fn("wgrad_inverse")(fptr(P), d.K, d.C, fptr(dw), stream()), "mq_wino_wgrad_inverse")
+            check(_wcall(_wino_tile(d.H, d.W), "wgrad_inverse", fptr(P), d.K, d.C, fptr(dw)), "mq_wino_wgrad_inverse")
         if want_db:
             db = colsum(part) if part is not None else _bias_grad(d, dy)
         return dx, dw, None, db, None
@@ -780,34 +818,42 @@ def _wino_s2d_ok(d: ConvDesc) -> bool:
             and min(d.C, d.K) >= WINO_S2D_MIN_CHANNELS)
 
 
+def _s2d_tile(d: ConvDesc):
+    """Tile of the 3x3 / stride-1 convolution over the (P, Q) polyphase grid; there is no F(2x2) form of it."""
+    t = _wino_tile(d.P, d.Q)
+    return (3, 3) if t == (2, 2) else t
+
+
 def _s2d_tiles(d: ConvDesc) -> int:
-    return d.N * ((d.P + 2) // 3) * ((d.Q + 2) // 3)
+    return _wino_ntiles(_s2d_tile(d), d.N, d.P, d.Q)
 
 
 def _s2d_gemm_desc(d: ConvDesc, cin: int, cout: int) -> ConvDesc:
-    return conv_desc(25 * d.N * ((d.P + 2) // 3), 1, (d.Q + 2) // 3, cin, cout, 1, 1, groups=25, precision=d.precision)
+    return _wino_gemm(_s2d_tile(d), d.N, d.P, d.Q, cin, cout, d.precision)
 
 
 class ConvWinoS2dLeakyFn(torch.autograd.Function):
-    """ConvLeakyFn for layers _wino_s2d_ok takes (see csrc/winograd3.hip, the polyphase section): 11.1 instead of 25 products per
-    output and channel pair.  Same arguments, contract (``in_gate`` / ``pregated``) and gradients as ConvLeakyFn."""
+    """ConvLeakyFn for layers _wino_s2d_ok takes (see csrc/winograd3.hip, the polyphase section): 11.1 (F(3x3, 3x3)), 9 (4x4) or 8.4
+    (4x5) instead of 25 products per output and channel pair.  Same arguments, contract (``in_gate`` / ``pregated``) and gradients
+    as ConvLeakyFn."""
 
     @staticmethod
     def forward(ctx, x, w_krsc, bias, mask, key, dmap, slope, in_gate=None, pregated=False):
         d = _desc_from_key(key)
-        tiles = _s2d_tiles(d)
+        tile, tiles = _s2d_tile(d), _s2d_tiles(d)
+        npos = _wino_npos(tile)
         x, w_krsc = x.contiguous(), w_krsc.contiguous()
-        V = _empty((25 * tiles, 1, 1, 4 * d.C), x)
-        check(L().mq_wino3_input_transform_s2d(fptr(x), d.N, d.H, d.W, d.C, fptr(V), stream()), "mq_wino3_input_transform_s2d")
-        U = _empty((25 * d.K, 1, 4 * d.C), x)
-        check(L().mq_wino3_weight_transform_s2d(fptr(w_krsc), d.K, d.C, 0, fptr(U), stream()), "mq_wino3_weight_transform_s2d")
+        V = _empty((npos * tiles, 1, 1, 4 * d.C), x)
+        check(_wcall(tile, "input_transform_s2d", fptr(x), d.N, d.H, d.W, d.C, fptr(V)), "mq_wino3_input_transform_s2d")
+        U = _empty((npos * d.K, 1, 4 * d.C), x)
+        check(_wcall(tile, "weight_transform_s2d", fptr(w_krsc), d.K, d.C, 0, fptr(U)), "mq_wino3_weight_transform_s2d")
         dg = _s2d_gemm_desc(d, 4 * d.C, d.K)
-        M = _empty((25 * tiles, 1, 1, d.K), x)
+        M = _empty((npos * tiles, 1, 1, d.K), x)
         _timed(None, _conv_flops(dg), lambda: check(
             L().mq_conv_fprop(C.byref(dg), fptr(V), fptr(U), None, fptr(M), stream()), "mq_conv_fprop"), key)
         y = _empty((d.N, d.P, d.Q, d.K), x)
-        check(L().mq_wino3_output_transform(fptr(M), fptr(bias, True), d.N, d.P, d.Q, d.K, 2, float(slope), ptr(mask, torch.uint8, True),
-                                            dmap[0], dmap[1], dmap[2], fptr(y), stream()), "mq_wino3_output_transform")
+        check(_wcall(tile, "output_transform", fptr(M), fptr(bias, True), d.N, d.P, d.Q, d.K, 2, float(slope), ptr(mask, torch.uint8, True),
+                     dmap[0], dmap[1], dmap[2], fptr(y)), "mq_wino3_output_transform")
         del M, U
         ctx.key, ctx.dmap, ctx.slope = key, dmap, slope
         ctx.w_shape = tuple(w_krsc.shape)
@@ -823,7 +869,8 @@ class ConvWinoS2dLeakyFn(torch.autograd.Function):
     def backward(ctx, dout):
         V, w_krsc, y, mask, x_gate, mask_in = ctx.saved_tensors
         d = _desc_from_key(ctx.key)
-        tiles = _s2d_tiles(d)
+        tile, tiles = _s2d_tile(d), _s2d_tiles(d)
+        npos = _wino_npos(tile)
         if ctx.slope != 0.2 and not ctx.pregated:
             raise _lib.MqganHipError("the pointwise backward kernel implements LeakyReLU(0.2) only")
         if ctx.pregated:
@@ -838,35 +885,35 @@ class ConvWinoS2dLeakyFn(torch.autograd.Function):
         want_dx, want_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         dx = dw = db = None
-        Z = _empty((25 * tiles, 1, 1, d.K), dy)
-        Vd = _empty((25 * tiles, 1, 1, d.K), dy) if want_dx else None
-        part = _empty((L().mq_wino3_dy_fused_rows(d.N, d.P, d.Q, d.K), d.K), dy) if want_db else None
-        check(L().mq_wino3_dy_fused(fptr(dy), d.N, d.P, d.Q, d.K, fptr(Z), fptr(Vd, True), fptr(part, True), stream()), "mq_wino3_dy_fused")
+        Z = _empty((npos * tiles, 1, 1, d.K), dy)
+        Vd = _empty((npos * tiles, 1, 1, d.K), dy) if want_dx else None
+        part = _empty((_wrows(tile, d.N, d.P, d.Q, d.K), d.K), dy) if want_db else None
+        check(_wcall(tile, "dy_fused", fptr(dy), d.N, d.P, d.Q, d.K, fptr(Z), fptr(Vd, True), fptr(part, True)), "mq_wino3_dy_fused")
         if want_dx:
-            Ut = _empty((25 * 4 * d.C, 1, d.K), dy)
-            check(L().mq_wino3_weight_transform_s2d(fptr(w_krsc), d.K, d.C, 1, fptr(Ut), stream()), "mq_wino3_weight_transform_s2d")
+            Ut = _empty((npos * 4 * d.C, 1, d.K), dy)
+            check(_wcall(tile, "weight_transform_s2d", fptr(w_krsc), d.K, d.C, 1, fptr(Ut)), "mq_wino3_weight_transform_s2d")
             dgt = _s2d_gemm_desc(d, d.K, 4 * d.C)
-            Mt = _empty((25 * tiles, 1, 1, 4 * d.C), dy)
+            Mt = _empty((npos * tiles, 1, 1, 4 * d.C), dy)
             _timed(None, _conv_flops(dgt), lambda: check(
                 L().mq_conv_fprop(C.byref(dgt), fptr(Vd), fptr(Ut), None, fptr(Mt), stream()), "mq_conv_fprop"), ctx.key)
             del Vd, Ut
             dx = _empty((d.N, d.H, d.W, d.C), dy)
             gd = ctx.in_gate[0] if ctx.in_gate is not None else (1, 0, 1)
             gs = float(ctx.in_gate[1]) if ctx.in_gate is not None else 1.0
-            check(L().mq_wino3_output_transform_d2s(fptr(Mt), d.N, d.H, d.W, d.C, fptr(x_gate, True), gs, ptr(mask_in, torch.uint8, True),
-                                                    gd[0], gd[1], gd[2], fptr(dx), stream()), "mq_wino3_output_transform_d2s")
+            check(_wcall(tile, "output_transform_d2s", fptr(Mt), d.N, d.H, d.W, d.C, fptr(x_gate, True), gs, ptr(mask_in, torch.uint8, True),
+                         gd[0], gd[1], gd[2], fptr(dx)), "mq_wino3_output_transform_d2s")
             del Mt
         if want_dw:
             if not ctx.kept_v:
                 raise _lib.MqganHipError("ConvWinoS2dLeakyFn: weight gradient asked for a layer whose weights did not require one")
             dg = _s2d_gemm_desc(d, 4 * d.C, d.K)
-            Pm = _empty((25 * d.K, 1, 4 * d.C), dy)
+            Pm = _empty((npos * d.K, 1, 4 * d.C), dy)
             nbytes = L().mq_conv_wgrad_workspace(C.byref(dg))
             ws = _ws_bytes(nbytes, dy)
             _timed(None, _conv_flops(dg), lambda: check(
                 L().mq_conv_wgrad(C.byref(dg), fptr(V), fptr(Z), fptr(Pm), ptr(ws), nbytes, stream()), "mq_conv_wgrad"), ctx.key)
             dw = _empty(ctx.w_shape, dy)
-            check(L().mq_wino3_wgrad_inverse_s2d(fptr(Pm), d.K, d.C, fptr(dw), stream()), "mq_wino3_wgrad_inverse_s2d")
+            check(_wcall(tile, "wgrad_inverse_s2d", fptr(Pm), d.K, d.C, fptr(dw)), "mq_wino3_wgrad_inverse_s2d")
         if want_db:
             db = colsum(part)
         return dx, dw, db, None, None, None, None, None, None

@@ -411,11 +411,13 @@ def _torch_conv(x, w, b, c):
 
 @pytest.mark.parametrize("precision", ["f32", "bf16", "f32x3"])
 @pytest.mark.parametrize("c", CONV_CASES, ids=lambda c: "N{N}H{H}W{W}C{C}K{K}R{R}S{S}".format(**c) + f"g{c.get('groups', 1)}")
-def test_conv_fprop_dgrad_wgrad(env, c, precision):
-    """precision="bf16": the operands are drawn bf16-representable, so rounding them inside the kernel is the
+def test_conv_fprop_dgrad_wgrad(env, monkeypatch, c, precision):
+    """The direct implicit-GEMM kernels (the Winograd routes some of these shapes would take are switched off: they have their
+    own tests).  precision="bf16": the operands are drawn bf16-representable, so rounding them inside the kernel is the
     identity and the bf16 MFMA engine (exact products, f32 accumulation) must meet the same bound as the f32 one.
     precision="f32x3" (three-term bf16 split of f32 operands) takes arbitrary f32 inputs and the f32 bound."""
     ops = env
+    monkeypatch.setattr(ops, "WINO_MIN_CHANNELS", 0)
     torch.manual_seed(0)
     G = c.get("groups", 1)
     rnd = (lambda v: v.bfloat16().double()) if precision == "bf16" else (lambda v: v)
@@ -455,9 +457,10 @@ WINO_CASES = [
 ]
 
 
-@pytest.fixture(params=[3, 2], ids=["F3x3", "F2x2"])
+@pytest.fixture(params=[3, 2, 4, 45, "auto"], ids=["F3x3", "F2x2", "F4x4", "F4x5", "auto"])
 def wino_tile(request):
-    """Both Winograd tile sizes: F(3x3, 3x3) (the default, csrc/winograd3.hip) and F(2x2, 3x3) (winograd.hip)."""
+    """Every Winograd tile: F(3x3, 3x3) (csrc/winograd3.hip), F(2x2, 3x3) (winograd.hip), F(4x4, 3x3) and F(4x5, 3x3)
+    (winogradn.hip), and the per-image choice ops makes by default."""
     from mqgan_amd import ops
     keep, ops.WINO_TILE = ops.WINO_TILE, request.param
     yield request.param
@@ -469,7 +472,7 @@ def wino_tile(request):
                                             dict(N=1, H=10, W=11, C=256, K=128, R=3, S=3, pad=(1, 1))],    # one / two spare rows
                          ids=lambda c: "N{N}H{H}W{W}C{C}K{K}".format(**c))
 def test_winograd_conv_fprop_dgrad_wgrad(env, c, precision, wino_tile):
-    """3x3 / stride 1 / pad 1 layers with >= 128 channels run as Winograd F(3x3, 3x3) or F(2x2, 3x3) (ops.ConvWinoFn):
+    """3x3 / stride 1 / pad 1 layers with >= 128 channels run as Winograd F(mh x mw, 3x3) (ops.ConvWinoFn), every tile shape:
     forward, input, weight and bias gradients against the float64 direct convolution.  The transforms add a few roundings to
     the direct kernels' error, so the bound is 4e-5 of the output scale instead of 2e-5."""
     ops = env
@@ -495,7 +498,7 @@ def test_winograd_conv_fprop_dgrad_wgrad(env, c, precision, wino_tile):
     assert_rel(wd.grad, w.grad, 4e-5, "wgrad")
     assert_rel(bd.grad, b.grad, 2e-5, "bias grad")
     # layers the path does not take stay on the direct kernels
-    for cc in (dict(c, C=64, K=64), ):
+    for cc in (dict(c, C=48, K=64), ):
         d2 = ops.conv_desc(cc["N"], cc["H"], cc["W"], cc["C"], cc["K"], 3, 3, pad=(1, 1), precision=precision)
         assert not ops._wino_ok(d2)
     assert not ops._wino_ok(ops.conv_desc(1, 8, 8, 128, 128, 3, 3, stride=(2, 2), pad=(1, 1), precision=precision))
@@ -550,7 +553,7 @@ def test_f32x3_engine_has_the_error_of_the_f32_engine(env, monkeypatch):
     assert errs["f32x3"][1] < 2.0 * errs["f32"][1] + 1e-7, errs
     monkeypatch.undo()
     assert ops._wino_ok(ops.conv_desc(N, H, W, Cc, K, 3, 3, pad=(1, 1)))
-    for tile, bound in ((2, 2.5e-6), (3, 4e-6)):
+    for tile, bound in ((2, 2.5e-6), (3, 4e-6), (4, 5e-6), (45, 7e-6)):
         monkeypatch.setattr(ops, "WINO_TILE", tile)
         d = ops.conv_desc(N, H, W, Cc, K, 3, 3, pad=(1, 1))
         e = (ops.conv(x.float().to(DEV), wk, wc, None, d).double().cpu() - ref) / scale
@@ -959,13 +962,17 @@ def test_wino1d_discriminator_chain_matches_direct_kernels(env, monkeypatch, H, 
     assert float(got[1][1, :, (W // 2 + 1) // 2:].abs().max()) == 0.0          # padded output frames are exactly zero
 
 
-@pytest.mark.parametrize("H,W,prec", [(12, 20, "f32"), (16, 14, "f32"), (12, 20, "f32x3")])
-def test_polyphase_winograd_5x5_stride2_chain_matches_direct_kernels(env, H, W, prec):
-    """The patch discriminator's 5x5 / stride-2 layers as F(3x3, 3x3) over the polyphase components of the input
-    (ops.ConvWinoS2dLeakyFn) against the direct kernels (ops.WINO_S2D_MIN_CHANNELS = 0): two such layers in a row (the second
-    one's input gradient carries the first one's LeakyReLU' / mask), frame masks, ragged 3x3 tile edges: outputs, input gradient,
-    weight and bias gradients."""
+@pytest.mark.parametrize("H,W,prec,tile", [(12, 20, "f32", 3), (16, 14, "f32", 3), (12, 20, "f32x3", 3),
+                                           (12, 20, "f32", 4), (16, 14, "f32", 4), (12, 20, "f32", 45), (16, 14, "f32", 45),
+                                           (12, 20, "f32x3", 45), (20, 32, "f32", "auto")])
+def test_polyphase_winograd_5x5_stride2_chain_matches_direct_kernels(env, monkeypatch, H, W, prec, tile):
+    """The patch discriminator's 5x5 / stride-2 layers as F(mh x mw, 3x3) over the polyphase components of the input
+    (ops.ConvWinoS2dLeakyFn; tiles 3x3, 4x4, 4x5 and the one ops picks) and on the direct kernels (ops.WINO_S2D_MIN_CHANNELS = 0):
+    two such layers in a row (the second one's input gradient carries the first one's LeakyReLU' / mask), frame masks, ragged tile
+    edges.  Outputs against each other; outputs, input gradient, weight and bias gradients of either path against float64 with the
+    LeakyReLU branch of every element taken from the tested path's own output (see the one-dimensional test above)."""
     ops = env
+    monkeypatch.setattr(ops, "WINO_TILE", tile)
     torch.manual_seed(33)
     N, C0, C1, C2 = 3, 128, 128, 144
     x0 = torch.randn(N, 2 * H, 2 * W, C0, device=DEV)
@@ -977,6 +984,7 @@ def test_polyphase_winograd_5x5_stride2_chain_matches_direct_kernels(env, H, W, 
     mask0[2, 5:] = 1
     mask1 = ops.mask_pool(mask0, 2, ceil_mode=True)
     mask2 = ops.mask_pool(mask1, 2, ceil_mode=True)
+    r = torch.randn((N, H // 2, W // 2, C2), device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
 
     def run(minc):
         keep = ops.WINO_S2D_MIN_CHANNELS
@@ -994,15 +1002,31 @@ def test_polyphase_winograd_5x5_stride2_chain_matches_direct_kernels(env, H, W, 
             y1, hon = ops.conv_leaky(x, k1, c1, b1v, d1, mask1, dm1, pregate=True, chain=True)
             assert hon and y1.grad_fn.__class__.__name__.startswith("ConvWinoS2dLeakyFn" if minc > 0 else "ConvLeakyFn")
             y2 = ops.conv_leaky(y1, k2, c2, b2v, d2, mask2, dm2, in_gate=(mask1, dm1, 0.2))
-            r = torch.randn(y2.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+            assert y2.shape == r.shape
             (y2 * r).sum().backward()
             return [t_.detach().clone() for t_ in (y1, y2, x.grad, w1v.grad, w2v.grad, b1v.grad, b2v.grad)]
         finally:
             ops.WINO_S2D_MIN_CHANNELS = keep
 
+    def ref64(gate1, gate2):
+        x = x0.double().cpu().requires_grad_(True)
+        w1v, w2v = w1.double().cpu().requires_grad_(True), w2.double().cpu().requires_grad_(True)
+        b1v, b2v = b1.double().cpu().requires_grad_(True), b2.double().cpu().requires_grad_(True)
+        h1 = F.conv2d(x.permute(0, 3, 1, 2), w1v, b1v, stride=2, padding=2)
+        y1 = torch.where(gate1.cpu().permute(0, 3, 1, 2), h1, 0.2 * h1).masked_fill(mask1.cpu().bool()[:, None, None, :], 0.0)
+        h2 = F.conv2d(y1, w2v, b2v, stride=2, padding=2)
+        y2 = torch.where(gate2.cpu().permute(0, 3, 1, 2), h2, 0.2 * h2).masked_fill(mask2.cpu().bool()[:, None, None, :], 0.0)
+        (y2 * r.double().cpu().permute(0, 3, 1, 2)).sum().backward()
+        return [y1.detach().permute(0, 2, 3, 1), y2.detach().permute(0, 2, 3, 1), x.grad, w1v.grad, w2v.grad, b1v.grad, b2v.grad]
+
+    names = ("y1", "y2", "dx", "dw1", "dw2", "db1", "db2")
     got, want = run(128), run(0)
-    for g_, w_, name in zip(got, want, ("y1", "y2", "dx", "dw1", "dw2", "db1", "db2")):
-        assert_rel(g_, w_, 4e-5, name)
+    assert_rel(got[0], want[0], 4e-5, "y1 against the direct kernels")
+    assert_rel(got[1], want[1], 4e-5, "y2 against the direct kernels")
+    for path, outs in (("winograd", got), ("direct", want)):
+        ref = ref64(outs[0] > 0, outs[1] > 0)
+        for g_, w_, name in zip(outs, ref, names):
+            assert_rel(g_.double().cpu().reshape(w_.shape), w_, 4e-5, f"{path} {name}")
 
 
 def test_masked_mae_leaky_gate(env):

@@ -271,12 +271,26 @@ def test_hifispeech_architecture_step_matches_oracle():
               "post.conv_out.weight", "out_proj.weight", "refiner.reproj.weight"):
         close(sd[k], otr.Pg[k], rtol=2e-5, atol=2e-7, msg=k)       # lr_g = 1e-7 at the first warm-up step
     pd, md = tr.patch_discriminator.state_dict(), tr.multibin_discriminator.state_dict()
+    lr_d = cfg["training"]["lr"] * cfg["training"]["lr_d_factor"]
+
+    def close_first_adam_step(got, want, rtol, msg):
+        """The first Adam step moves every weight by lr * g / (|g| + 1e-8) = +-lr_d (1.15e-4) except where |g| ~ 1e-8: there the
+        step size itself is rounding-sensitive, so the bound is a fraction (5 %) of one step.  Beyond that, the SIGN of a gradient
+        element within rounding of zero is not defined at f32: one LeakyReLU pre-activation of the discriminator that two f32
+        algorithms place on different sides of zero (|h| ~ 1e-6 of the rms: tests/test_gpu_kernels.py, the 1-D Winograd chain)
+        changes one pixel's gradient by a factor 5, which at this test's image sizes (a few thousand pixels per weight) flips the
+        sign of some tens of near-zero elements of that output channel's filter - each a difference of exactly two steps after
+        Adam.  So: at most 1e-4 of a tensor's elements may differ, and none by more than two steps."""
+        a, b = got.detach().float().cpu().numpy(), want.detach().float().cpu().numpy()
+        diff = np.abs(a - b)
+        bad = diff > 6e-6 + rtol * np.abs(b)
+        assert bad.mean() <= 1e-4, f"{msg}: {int(bad.sum())} of {bad.size} elements beyond 5 % of an Adam step"
+        assert diff.max() <= 2.02 * lr_d, f"{msg}: largest difference {diff.max():.3e} is more than two Adam steps ({lr_d:.3e})"
+
     for k in ("convs.1.weight_orig", "convs.3.weight_orig", "convs.5.weight_orig", "se_block.fc1.weight", "convs.2.bias"):
-        # the first Adam step moves every weight by lr * g / (|g| + 1e-8) = +-lr_d (1.15e-4) except where |g| ~ 1e-8: there
-        # the step size itself is rounding-sensitive, so the bound is a fraction (5 %) of one step
-        close(pd[k], otr.Pp[k], rtol=2e-5, atol=6e-6, msg="patch " + k)
+        close_first_adam_step(pd[k], otr.Pp[k], 2e-5, "patch " + k)
     for k in ("discriminators.0.convs.2.weight_orig", "discriminators.7.convs.4.weight_orig", "discriminators.3.convs.1.weight_u"):
-        close(md[k], otr.Pm[k], rtol=1e-4, atol=6e-6, msg="multibin " + k)
+        close_first_adam_step(md[k], otr.Pm[k], 1e-4, "multibin " + k)
     del tr
     torch.cuda.empty_cache()
 
