@@ -416,11 +416,13 @@ def reencode_line(n_files=128):
     return out
 
 
-def loader_line(device, n_files=288, file_frames=640):
+def loader_line(device, n_files=576, file_frames=640):
     """The same config-2 step fed by the real input pipeline instead of resident batches (the reference's loop
     train.py:511-537): synthetic .npy files on disk -> DataLoader (num_workers 0, random 512-frame crops, collate) -> pinned
     staging -> H2D on a side stream (PrefetchLoader) -> train_step.  Trainer._train_epoch itself is timed: one warm-up epoch,
-    one timed epoch.  The PCIe-inclusive rate - reported beside `value`, never as `value`."""
+    one timed epoch (18 steps; the epoch's start-up - the first batch cannot be prefetched - measured 146 ms, i.e. 8 ms per step
+    of this short epoch: 9- and 27-step epochs give 228.5 and 217.7 ms per step).  The PCIe-inclusive rate - reported beside
+    `value`, never as `value`."""
     import copy
     import tempfile
     from mqgan_amd.train import Trainer, synthetic_mel
