@@ -50,7 +50,7 @@ def kernel_build_id():
     """Hash of the conv kernel sources: ties a PMC traffic file to the build it was measured on."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("gemm_core.h", "igemm.hip", "igemm_h2.hip", "winograd.hip", "winograd3.hip", "winogradn.hip", "wino1d.hip", "wino_tables.h", "common.h"):
+    for f in ("gemm_core.h", "igemm.hip", "igemm_h2.hip", "winograd.hip", "winograd3.hip", "winogradn.hip", "wino1d.hip", "winow.hip", "wino_tables.h", "common.h"):
         with open(os.path.join(ROOT, "mqgan_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -592,11 +592,13 @@ def main():
                                        f"{mel} mels x {T} frames, batch {B}/GPU, FSQ {cfg['model']['generator']['fsq_levels']}, "
                                        "D active, FM off, train-mode dropout", "global_batch": world * B, "frames": T,
                            "parallelism": f"dp{world}",
-                           "conv_algorithm": ("implicit GEMM; 3x3 / stride-1 layers with >= 128 channels as Winograd F(3x3,3x3), the patch "
-                                              "discriminator's 5x5 / stride-2 layers as the same over the polyphase components of their "
-                                              "input, the multi-bin discriminator's (3 x k) layers as one-dimensional Winograd F(2,3) along "
-                                              "the bins: f32 transforms, products on the same MFMA engine, f32 accumulation "
-                                              "(MQGAN_WINO_MINC=0 / MQGAN_WINO_S2D_MINC=0 / MQGAN_WINO1D_MINC=0 switch them off)") if args.precision != "bf16"
+                           "conv_algorithm": ("implicit GEMM; where a cheaper exact-f32 form exists, Winograd with f32 transforms, products on the same "
+                                              "MFMA engine and f32 accumulation: 3x3 / stride-1 layers as F(4x5,3x3) / F(4x4) / F(3x3) (tile per "
+                                              "image), the patch discriminator's 5x5 / stride-2 layers as the same over the polyphase components "
+                                              "of their input and its 3x3 / stride-(2,1) layers as F(4,3) along time, the multi-bin "
+                                              "discriminator's (3 x k) layers as F(5,3) along the bins (its (3 x 5) layer nested with F(4,5) along "
+                                              "time), the encoder / decoder 1-D convolutions as F(4,3) / F(4,5) / F(2,7) "
+                                              "(MQGAN_WINO_MINC=0 / MQGAN_WINO_S2D_MINC=0 / MQGAN_WINO1D_MINC=0 / MQGAN_WINOW_MINC=0 switch them off)") if args.precision != "bf16"
                            else "implicit GEMM on bf16-storage kernels"},
                 "losses_finite": bool(finite), "roofline": roof,
                 "host_ms_per_step": host_ms, "collectives": collectives_of(tr, world, args.force_collectives)}
@@ -609,10 +611,11 @@ def main():
             keep, _ops.WINO_MIN_CHANNELS = _ops.WINO_MIN_CHANNELS, 0          # every layer on the direct kernels (A/B, same box)
             keep1, _ops.WINO1D_MIN_CHANNELS = _ops.WINO1D_MIN_CHANNELS, 0
             keep2, _ops.WINO_S2D_MIN_CHANNELS = _ops.WINO_S2D_MIN_CHANNELS, 0
+            keep3, _ops.WINOW_MIN_CHANNELS = _ops.WINOW_MIN_CHANNELS, 0
             try:
                 line["other_engines"]["fp32_direct"] = quick_engine(cfg, "fp32", device, batches, lens, B, T)
             finally:
-                _ops.WINO_MIN_CHANNELS, _ops.WINO1D_MIN_CHANNELS, _ops.WINO_S2D_MIN_CHANNELS = keep, keep1, keep2
+                _ops.WINO_MIN_CHANNELS, _ops.WINO1D_MIN_CHANNELS, _ops.WINO_S2D_MIN_CHANNELS, _ops.WINOW_MIN_CHANNELS = keep, keep1, keep2, keep3
         if world == 1 and not args.no_configs and args.config == "hifispeech" and args.precision == "fp32":
             del batches
             torch.cuda.empty_cache()

@@ -520,6 +520,29 @@ int mq_wino1d_dx_transform(const float *dV, int N, int H, int W, int C, int m, c
                            int64_t d1, int64_t d2, int64_t d3, float *dx, mqStream stream);
 int mq_wino1d_wgrad_inverse(const float *dU, int groups, int K, int C, int S, int m, float *dw_krsc, mqStream stream);
 
+/* ------------------------------------------------------------------ one-dimensional Winograd F(m, s) along the columns (time)
+ * Convolutions with `taps` = 3, 5 or 7 column taps, stride 1 and no dilation along the columns, R row taps with any stride,
+ * `pad_left` zero columns in front (the right padding follows from the output width Q), batch groups (csrc/winow.hip): the
+ * encoder / decoder blocks' 1-D convolutions (attentions.py:95-130), the patch discriminator's 3x3 / stride-(2, 1) layers
+ * (discriminators.py:86-173) and the (1 x 5) row convolutions inside the multi-bin discriminator's F(5, 3) form.
+ * m = mq_winow_tile(taps) outputs per tile (4, 4, 2), np = m + taps - 1 positions, tw = ceil(Q / m) tiles per row.
+ *   forward : V = input_transform(x) (np, N, H, tw, C);  (U_krsc, U_crsk) = weight_transform(w_krsc (groups * K, R * taps, C));
+ *             M = mq_conv_fprop(desc{N = np * N, H, W = tw, C, K, R, S = 1, stride (sh, 1), pad (ph, 0), groups = np * groups},
+ *             V, U_krsc) (np, N, P, tw, K);  y = output_transform(M, bias) (N, P, Q, K), epilogue as mq_wino1d_output_transform
+ *   backward: Z = dy_transform(dy) (np, N, P, tw, K) (+ per-block column sums of dy);  dV = mq_conv_dgrad(that desc, Z, U_crsk);
+ *             dx = dx_transform(dV) (gate / padded_in as mq_wino1d_dx_transform);  dU = mq_conv_wgrad(that desc, V, Z);
+ *             dw_krsc = wgrad_inverse(dU). */
+int mq_winow_tile(int taps);
+int mq_winow_input_transform(const float *x, int N, int H, int W, int C, int taps, int Q, int pad_left, float *V, mqStream stream);
+int mq_winow_weight_transform(const float *w_krsc, int groups, int K, int C, int R, int taps, float *U_krsc, float *U_crsk, mqStream stream);
+int mq_winow_output_transform(const float *M, const float *bias, int N, int P, int Q, int K, int taps, int groups, int act, float slope,
+                              const uint8_t *padded, int64_t d1, int64_t d2, int64_t d3, float *y, mqStream stream);
+int mq_winow_dy_rows(int N, int P, int Q, int K, int taps, int groups);
+int mq_winow_dy_transform(const float *dy, int N, int P, int Q, int K, int taps, int groups, float *Z, float *bias_partial, mqStream stream);
+int mq_winow_dx_transform(const float *dV, int N, int H, int W, int C, int taps, int Q, int pad_left, const float *gate, float slope,
+                          const uint8_t *padded_in, int64_t d1, int64_t d2, int64_t d3, float *dx, mqStream stream);
+int mq_winow_wgrad_inverse(const float *dU, int groups, int K, int C, int R, int taps, float *dw_krsc, mqStream stream);
+
 /* ------------------------------------------------------------------ optimiser
  * clip_grad_norm_ + Adam on flat arenas (train.py:401-407,485-492; torch.optim.Adam
  * defaults eps=1e-8, no weight decay, no amsgrad).

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MQGAN_HIP_LIB: load another build of the same ABI (kernel experiments); the default is the in-tree library
 LIB_PATH = os.environ.get("MQGAN_HIP_LIB") or os.path.join(_HERE, "libmqgan_hip.so")
 _lib = None
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class MqganHipError(RuntimeError):
@@ -178,6 +178,14 @@ SIGNATURES = {
     "mq_wino1d_dy_transform": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "mq_wino1d_dx_transform": (_I, [_P, _I, _I, _I, _I, _I, _P, _F, _P, _L, _L, _L, _P, _P]),
     "mq_wino1d_wgrad_inverse": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "mq_winow_tile": (_I, [_I]),
+    "mq_winow_input_transform": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "mq_winow_weight_transform": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "mq_winow_output_transform": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _L, _L, _L, _P, _P]),
+    "mq_winow_dy_rows": (_I, [_I, _I, _I, _I, _I, _I]),
+    "mq_winow_dy_transform": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "mq_winow_dx_transform": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _L, _L, _L, _P, _P]),
+    "mq_winow_wgrad_inverse": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "mq_sumsq": (_I, [_P, _L, _P, _P, _P]),
     "mq_multi_gather": (_I, [_P, _I, _L, _P, _P]),
     "mq_multi_gather_args": (_I, [_P, _I, _P, _P]),

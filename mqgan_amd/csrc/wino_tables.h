@@ -31,6 +31,48 @@ constexpr float G[7][3] = {{1, 0, 0}, {1, 1, 1}, {1, -1, 1}, {1, 2, 4}, {1, -2, 
 constexpr float AT[5][7] = {{1, 1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0.5f, 0}, {0, 1, 1, 4, 4, 0.25f, 0},
                             {0, 1, -1, 8, -8, 0.125f, 0}, {0, 1, 1, 16, 16, 0.0625f, 1}};
 }  // namespace f5
+// eight points 0, 1, -1, 2, -2, 1/2, -1/2, inf: F(4, 5) and F(2, 7) (the same B^T: it depends on the points only).  f32 error
+// against float64 at 512 channels: F(4, 5) 9.7e-7 rms / 7.4e-6 max, F(2, 7) 1.1e-6 / 7.1e-6 (direct: 4.6e-7 / 3.3e-6); with ten
+// points (F(4, 7), F(6, 5)) it is 4e-6 / 4e-5, which is why the 7-tap filter gets the 2-output tile.
+namespace p8 {
+constexpr float BT[8][8] = {{1, 0, -21.0f / 4, 0, 21.0f / 4, 0, -1, 0},
+                            {0, -2.0f / 9, -2.0f / 9, 17.0f / 18, 17.0f / 18, -2.0f / 9, -2.0f / 9, 0},
+                            {0, 2.0f / 9, -2.0f / 9, -17.0f / 18, 17.0f / 18, 2.0f / 9, -2.0f / 9, 0},
+                            {0, 1.0f / 180, 1.0f / 360, -1.0f / 36, -1.0f / 72, 1.0f / 45, 1.0f / 90, 0},
+                            {0, -1.0f / 180, 1.0f / 360, 1.0f / 36, -1.0f / 72, -1.0f / 45, 1.0f / 90, 0},
+                            {0, 64.0f / 45, 128.0f / 45, -16.0f / 9, -32.0f / 9, 16.0f / 45, 32.0f / 45, 0},
+                            {0, -64.0f / 45, 128.0f / 45, 16.0f / 9, -32.0f / 9, -16.0f / 45, 32.0f / 45, 0},
+                            {0, -1, 0, 21.0f / 4, 0, -21.0f / 4, 0, 1}};
+constexpr float G[8][7] = {{1, 0, 0, 0, 0, 0, 0},
+                           {1, 1, 1, 1, 1, 1, 1},
+                           {1, -1, 1, -1, 1, -1, 1},
+                           {1, 2, 4, 8, 16, 32, 64},
+                           {1, -2, 4, -8, 16, -32, 64},
+                           {1, 0.5f, 0.25f, 0.125f, 0.0625f, 0.03125f, 0.015625f},
+                           {1, -0.5f, 0.25f, -0.125f, 0.0625f, -0.03125f, 0.015625f},
+                           {0, 0, 0, 0, 0, 0, 1}};          // F(r taps): columns 0 .. r-2 as they stand, the row of inf has its 1 at r-1
+constexpr float AT[4][8] = {{1, 1, 1, 1, 1, 1, 1, 0},
+                            {0, 1, -1, 2, -2, 0.5f, -0.5f, 0},
+                            {0, 1, 1, 4, 4, 0.25f, 0.25f, 0},
+                            {0, 1, -1, 8, -8, 0.125f, -0.125f, 0}};  // F(m outputs): rows 0 .. m-1, the column of inf has its 1 in row m-1
+}  // namespace p8
+
+// F(M, S) along one axis, S taps: (4, 3) on the six points of f4, (4, 5) and (2, 7) on the eight points of p8
+template <int M, int S> __device__ __forceinline__ constexpr float bt2(int i, int j)
+{
+    if constexpr (S == 3) return f4::BT[i][j]; else return p8::BT[i][j];
+}
+template <int M, int S> __device__ __forceinline__ constexpr float g2(int i, int j)
+{
+    if constexpr (S == 3) return f4::G[i][j];
+    else return i == M + S - 2 ? (j == S - 1 ? 1.f : 0.f) : p8::G[i][j];
+}
+template <int M, int S> __device__ __forceinline__ constexpr float at2(int i, int j)
+{
+    if constexpr (S == 3) return f4::AT[i][j];
+    else return j == M + S - 2 ? (i == M - 1 ? 1.f : 0.f) : p8::AT[i][j];
+}
+
 static_assert(f4::BT[0][0] == 1.f && f4::BT[5][5] == 1.f && f5::BT[0][0] == 1.f && f5::BT[6][6] == 1.f, "shared-row coefficients");
 
 template <int M> __device__ __forceinline__ constexpr float bt(int i, int j) { if constexpr (M == 4) return f4::BT[i][j]; else return f5::BT[i][j]; }

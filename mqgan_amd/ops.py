@@ -688,6 +688,192 @@ class ConvLeakyFn(torch.autograd.Function):
         return dx, dw, None, db, None, None, None, None, None, None
 
 
+# ----------------------------------------------------------------------------- 1-D Winograd F(m, s) along the columns (csrc/winow.hip)
+WINOW_MIN_CHANNELS = int(os.environ.get("MQGAN_WINOW_MINC", "128"))       # 0 switches the path off (A/B runs)
+
+
+def _winow_ok(d: ConvDesc) -> bool:
+    """3, 5 or 7 taps with stride 1 along the columns (time), any taps / stride along the rows, any left padding, batch groups,
+    on an f32-result engine, with channel counts that fill the GEMM: the encoder / decoder 1-D convolutions, the patch
+    discriminator's 3x3 / stride-(2, 1) layers, the (1 x 5) row convolutions inside the multi-bin discriminator's F(m, 3) form."""
+    return (WINOW_MIN_CHANNELS > 0 and d.S in (3, 5, 7) and d.stride_w == 1 and d.dil_w == 1 and d.dil_h == 1 and d.Q >= 1
+            and d.precision in (PRECISIONS["f32"], PRECISIONS["f32x3"]) and d.C % 16 == 0 and d.K % 16 == 0
+            and min(d.C, d.K) >= WINOW_MIN_CHANNELS and d.N % d.groups == 0)
+
+
+def _ww_geom(d: ConvDesc):
+    """(outputs per tile, tiles per row, positions) of F(m, S) along the columns."""
+    m = L().mq_winow_tile(d.S)
+    return m, -(-d.Q // m), m + d.S - 1
+
+
+def _ww_desc(d: ConvDesc) -> ConvDesc:
+    """The positions as (m + S - 1) x groups batch groups of (H x tiles) images with (R x 1) filters."""
+    _, tw, npos = _ww_geom(d)
+    return conv_desc(npos * d.N, d.H, tw, d.C, d.K, d.R, 1, stride=(d.stride_h, 1), pad=(d.pad_h, 0), groups=npos * d.groups,
+                     out_hw=(d.P, tw), precision=d.precision)
+
+
+def _ww_weights(d: ConvDesc, w_krsc, need_crsk: bool):
+    """(U_krsc (np * groups * K, R, C), U_crsk (np * groups * C, R, K) or None) of KRSC weights (groups * K, R * S, C)."""
+    npos = _ww_geom(d)[2]
+    U = _empty((npos * d.groups * d.K, d.R, d.C), w_krsc)
+    Uc = _empty((npos * d.groups * d.C, d.R, d.K), w_krsc) if need_crsk else None
+    check(L().mq_winow_weight_transform(fptr(w_krsc), d.groups, d.K, d.C, d.R, d.S, fptr(U), fptr(Uc, True), stream()),
+          "mq_winow_weight_transform")
+    return U, Uc
+
+
+def _ww_fprop(d: ConvDesc, x, U, key, bias=None, act=0, slope=0.0, mask=None, dmap=(1, 0, 1)):
+    """(y (N, P, Q, K), V): the convolution of x (N, H, W, C) with the transformed filters U; V is the transformed input."""
+    _, tw, npos = _ww_geom(d)
+    V = _empty((npos * d.N, d.H, tw, d.C), x)
+    check(L().mq_winow_input_transform(fptr(x), d.N, d.H, d.W, d.C, d.S, d.Q, d.pad_w, fptr(V), stream()), "mq_winow_input_transform")
+    dg = _ww_desc(d)
+    M = _empty((npos * d.N, d.P, tw, d.K), x)
+    _timed(None, _conv_flops(dg), lambda: check(
+        L().mq_conv_fprop(C.byref(dg), fptr(V), fptr(U), None, fptr(M), stream()), "mq_conv_fprop"), key)
+    y = _empty((d.N, d.P, d.Q, d.K), x)
+    check(L().mq_winow_output_transform(fptr(M), fptr(bias, True), d.N, d.P, d.Q, d.K, d.S, d.groups, int(act), float(slope),
+                                        ptr(mask, torch.uint8, True), dmap[0], dmap[1], dmap[2], fptr(y), stream()),
+          "mq_winow_output_transform")
+    return y, V
+
+
+def _ww_dy(d: ConvDesc, dy, want_part: bool):
+    """(Z (np, N, P, tw, K), per-block column sums of dy [rows][groups * K] or None)."""
+    _, tw, npos = _ww_geom(d)
+    part = None
+    if want_part:
+        rows = L().mq_winow_dy_rows(d.N, d.P, d.Q, d.K, d.S, d.groups)
+        part = _empty((rows, d.groups * d.K), dy) if rows > 0 else None
+    Z = _empty((npos * d.N, d.P, tw, d.K), dy)
+    check(L().mq_winow_dy_transform(fptr(dy), d.N, d.P, d.Q, d.K, d.S, d.groups, fptr(Z), fptr(part, True), stream()), "mq_winow_dy_transform")
+    return Z, part
+
+
+def _ww_dgrad(d: ConvDesc, Z, Uc, key, gate=None, gslope=1.0, mask_in=None, gdmap=(1, 0, 1)):
+    """dx (N, H, W, C) from Z and the CRSK transformed filters; gate / mask_in: the producer layer's LeakyReLU' and frame mask."""
+    _, tw, npos = _ww_geom(d)
+    dg = _ww_desc(d)
+    dV = _empty((npos * d.N, d.H, tw, d.C), Z)
+    _timed(None, _conv_flops(dg), lambda: check(
+        L().mq_conv_dgrad(C.byref(dg), fptr(Z), fptr(Uc), fptr(dV), stream()), "mq_conv_dgrad"), key)
+    dx = _empty((d.N, d.H, d.W, d.C), Z)
+    check(L().mq_winow_dx_transform(fptr(dV), d.N, d.H, d.W, d.C, d.S, d.Q, d.pad_w, fptr(gate, True), float(gslope),
+                                    ptr(mask_in, torch.uint8, True), gdmap[0], gdmap[1], gdmap[2], fptr(dx), stream()),
+          "mq_winow_dx_transform")
+    return dx
+
+
+def _ww_wgrad(d: ConvDesc, V, Z, key):
+    """dw KRSC (groups * K, R * S, C) from the transformed input and output gradient."""
+    npos = _ww_geom(d)[2]
+    dg = _ww_desc(d)
+    dU = _empty((npos * d.groups * d.K, d.R, d.C), Z)
+    nbytes = L().mq_conv_wgrad_workspace(C.byref(dg))
+    ws = _ws_bytes(nbytes, Z)
+    _timed(None, _conv_flops(dg), lambda: check(
+        L().mq_conv_wgrad(C.byref(dg), fptr(V), fptr(Z), fptr(dU), ptr(ws), nbytes, stream()), "mq_conv_wgrad"), key)
+    dw = _empty((d.groups * d.K, d.R * d.S, d.C), Z)
+    check(L().mq_winow_wgrad_inverse(fptr(dU), d.groups, d.K, d.C, d.R, d.S, fptr(dw), stream()), "mq_winow_wgrad_inverse")
+    return dw
+
+
+class ConvWinoWFn(torch.autograd.Function):
+    """ConvFn for layers _winow_ok takes: the column taps as Winograd F(4, 3) / F(4, 5) / F(2, 7) - 1.5, 2 or 4 products per
+    output instead of 3, 5, 7 - on the same f32 GEMM kernels between HBM-bound transforms.  Same arguments and gradients as
+    ConvFn (the CRSK weights are not needed)."""
+
+    @staticmethod
+    def forward(ctx, x, w_krsc, w_crsk, bias, key):
+        d = _desc_from_key(key)
+        x, w_krsc = x.contiguous(), w_krsc.contiguous()
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        U, Uc = _ww_weights(d, w_krsc, need_dx)
+        y, V = _ww_fprop(d, x, U, key, bias=bias)
+        ctx.key = key
+        ctx.w_shape = tuple(w_krsc.shape)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(V if need_dw else None, Uc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        V, Uc = ctx.saved_tensors
+        d = _desc_from_key(ctx.key)
+        dy = dy.contiguous()
+        want_db = ctx.has_bias and ctx.needs_input_grad[3]
+        Z, part = _ww_dy(d, dy, want_db)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if Uc is None:
+                raise _lib.MqganHipError("ConvWinoWFn: input gradient asked for an input that did not require one")
+            dx = _ww_dgrad(d, Z, Uc, ctx.key)
+        if ctx.needs_input_grad[1]:
+            if V is None:
+                raise _lib.MqganHipError("ConvWinoWFn: weight gradient asked for weights that did not require one")
+            dw = _ww_wgrad(d, V, Z, ctx.key).view(ctx.w_shape)
+        if want_db:
+            db = colsum(part) if part is not None else _bias_grad(d, dy)
+        return dx, dw, None, db, None
+
+
+class ConvWinoWLeakyFn(torch.autograd.Function):
+    """ConvLeakyFn for layers _winow_ok takes (the patch discriminator's 3x3 / stride-(2, 1) layers): y = padded ? 0 :
+    LeakyReLU(conv(x, w) + bias) with the column taps as Winograd F(4, 3); bias + LeakyReLU + mask ride on the output transform,
+    the producer's gate on the input-gradient transform, the bias sums on the output-gradient transform.  Same arguments, contract
+    (``in_gate`` / ``pregated``) and gradients as ConvLeakyFn."""
+
+    @staticmethod
+    def forward(ctx, x, w_krsc, bias, mask, key, dmap, slope, in_gate=None, pregated=False):
+        d = _desc_from_key(key)
+        x, w_krsc = x.contiguous(), w_krsc.contiguous()
+        U, Uc = _ww_weights(d, w_krsc, True)
+        y, V = _ww_fprop(d, x, U, key, bias=bias, act=2, slope=slope, mask=mask, dmap=dmap)
+        del U
+        ctx.key, ctx.dmap, ctx.slope = key, dmap, slope
+        ctx.w_shape = tuple(w_krsc.shape)
+        ctx.has_bias = bias is not None
+        ctx.pregated = bool(pregated)
+        ctx.in_gate = None if in_gate is None else (in_gate[1], in_gate[2])
+        ctx.kept_v = w_krsc.requires_grad
+        ctx.save_for_backward(V if ctx.kept_v else None, Uc, None if ctx.pregated else y, mask, x if in_gate is not None else None,
+                              None if in_gate is None else in_gate[0])
+        return y
+
+    @staticmethod
+    def backward(ctx, dout):
+        V, Uc, y, mask, x_gate, mask_in = ctx.saved_tensors
+        d = _desc_from_key(ctx.key)
+        if ctx.slope != 0.2 and not ctx.pregated:
+            raise _lib.MqganHipError("the pointwise backward kernel implements LeakyReLU(0.2) only")
+        if ctx.pregated:
+            dy = dout.contiguous()
+        else:
+            Cc = y.shape[-1]
+            pd = PointwiseDesc(rows=y.numel() // Cc, C=Cc, act=ACT_LEAKY, mask_pre=0, mask_post=int(mask is not None),
+                               d1=ctx.dmap[0], d2=ctx.dmap[1], d3=ctx.dmap[2], p_drop=0.0, seed=0)
+            dy = torch.empty_like(y)
+            check(L().mq_pointwise_bwd(C.byref(pd), fptr(dout.contiguous()), fptr(y), None, ptr(mask, torch.uint8, True), None,
+                                       None, fptr(dy), None, None, None, None, stream()), "mq_pointwise_bwd")
+        want_dx, want_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        dx = dw = db = None
+        Z, part = _ww_dy(d, dy, want_db)
+        if want_dx:
+            gd = ctx.in_gate[0] if ctx.in_gate is not None else (1, 0, 1)
+            gs = float(ctx.in_gate[1]) if ctx.in_gate is not None else 1.0
+            dx = _ww_dgrad(d, Z, Uc, ctx.key, gate=x_gate, gslope=gs, mask_in=mask_in, gdmap=gd)
+        if want_dw:
+            if not ctx.kept_v:
+                raise _lib.MqganHipError("ConvWinoWLeakyFn: weight gradient asked for a layer whose weights did not require one")
+            dw = _ww_wgrad(d, V, Z, ctx.key).view(ctx.w_shape)
+        if want_db:
+            db = colsum(part) if part is not None else _bias_grad(d, dy)
+        return dx, dw, db, None, None, None, None, None, None
+
+
 # ----------------------------------------------------------------------------- 1-D Winograd F(m, 3) along the rows (csrc/wino1d.hip)
 WINO1D_MIN_CHANNELS = int(os.environ.get("MQGAN_WINO1D_MINC", "128"))     # 0 switches the path off (A/B runs)
 WINO1D_TILE = int(os.environ.get("MQGAN_WINO1D_TILE", "0"))               # 0: the tile with the fewest products; 2, 4, 5: fixed
@@ -734,15 +920,21 @@ class ConvWino1dLeakyFn(torch.autograd.Function):
         Uc = _empty((npos * G * d.C, d.S, d.K), x)
         check(L().mq_wino1d_weight_transform(fptr(w_krsc), G, d.K, d.C, d.S, m, fptr(U), fptr(Uc), stream()), "mq_wino1d_weight_transform")
         dg = _wino1d_gemm_desc(d, m)
-        M = _empty((npos * d.N * th, 1, d.Q, d.K), x)
-        _timed(None, _conv_flops(dg), lambda: check(
-            L().mq_conv_fprop(C.byref(dg), fptr(V), fptr(U), None, fptr(M), stream()), "mq_conv_fprop"), key)
+        nested = _winow_ok(dg)             # stride-1 column taps: the row convolutions themselves as F(m', S) along the columns
+        if nested:
+            U2, Uc = _ww_weights(dg, U, True)
+            M, V = _ww_fprop(dg, V, U2, key)
+            del U2
+        else:
+            M = _empty((npos * d.N * th, 1, d.Q, d.K), x)
+            _timed(None, _conv_flops(dg), lambda: check(
+                L().mq_conv_fprop(C.byref(dg), fptr(V), fptr(U), None, fptr(M), stream()), "mq_conv_fprop"), key)
         y = _empty((d.N, d.H, d.Q, d.K), x)
         check(L().mq_wino1d_output_transform(fptr(M), fptr(bias, True), d.N, d.H, d.Q, d.K, G, m, 2, float(slope),
                                              ptr(mask, torch.uint8, True), dmap[0], dmap[1], dmap[2], fptr(y), stream()),
               "mq_wino1d_output_transform")
         del M, U
-        ctx.key, ctx.dmap, ctx.slope, ctx.m = key, dmap, slope, m
+        ctx.key, ctx.dmap, ctx.slope, ctx.m, ctx.nested = key, dmap, slope, m, nested
         ctx.w_shape = tuple(w_krsc.shape)
         ctx.has_bias = bias is not None
         ctx.pregated = bool(pregated)
@@ -780,10 +972,14 @@ class ConvWino1dLeakyFn(torch.autograd.Function):
         Z = _empty((npos * d.N * th, 1, d.Q, d.K), dy)
         check(L().mq_wino1d_dy_transform(fptr(dy), d.N, d.H, d.Q, d.K, G, m, fptr(Z), fptr(part, True), stream()), "mq_wino1d_dy_transform")
         dg = _wino1d_gemm_desc(d, m)
+        Z2 = _ww_dy(dg, Z, False)[0] if ctx.nested else None       # V and Uc are then the column-transformed ones
         if want_dx:
-            dV = _empty((npos * d.N * th, 1, d.W, d.C), dy)
-            _timed(None, _conv_flops(dg), lambda: check(
-                L().mq_conv_dgrad(C.byref(dg), fptr(Z), fptr(Uc), fptr(dV), stream()), "mq_conv_dgrad"), ctx.key)
+            if ctx.nested:
+                dV = _ww_dgrad(dg, Z2, Uc, ctx.key)
+            else:
+                dV = _empty((npos * d.N * th, 1, d.W, d.C), dy)
+                _timed(None, _conv_flops(dg), lambda: check(
+                    L().mq_conv_dgrad(C.byref(dg), fptr(Z), fptr(Uc), fptr(dV), stream()), "mq_conv_dgrad"), ctx.key)
             dx = _empty((d.N, d.H, d.W, d.C), dy)
             gd = ctx.in_gate[0] if ctx.in_gate is not None else (1, 0, 1)
             gs = float(ctx.in_gate[1]) if ctx.in_gate is not None else 1.0
@@ -793,11 +989,14 @@ class ConvWino1dLeakyFn(torch.autograd.Function):
         if want_dw:
             if not ctx.kept_v:
                 raise _lib.MqganHipError("ConvWino1dLeakyFn: weight gradient asked for a layer whose weights did not require one")
-            dU = _empty((npos * G * d.K, d.S, d.C), dy)
-            nbytes = L().mq_conv_wgrad_workspace(C.byref(dg))
-            ws = _ws_bytes(nbytes, dy)
-            _timed(None, _conv_flops(dg), lambda: check(
-                L().mq_conv_wgrad(C.byref(dg), fptr(V), fptr(Z), fptr(dU), ptr(ws), nbytes, stream()), "mq_conv_wgrad"), ctx.key)
+            if ctx.nested:
+                dU = _ww_wgrad(dg, V, Z2, ctx.key)
+            else:
+                dU = _empty((npos * G * d.K, d.S, d.C), dy)
+                nbytes = L().mq_conv_wgrad_workspace(C.byref(dg))
+                ws = _ws_bytes(nbytes, dy)
+                _timed(None, _conv_flops(dg), lambda: check(
+                    L().mq_conv_wgrad(C.byref(dg), fptr(V), fptr(Z), fptr(dU), ptr(ws), nbytes, stream()), "mq_conv_wgrad"), ctx.key)
             dw = _empty(ctx.w_shape, dy)
             check(L().mq_wino1d_wgrad_inverse(fptr(dU), G, d.K, d.C, d.S, m, fptr(dw), stream()), "mq_wino1d_wgrad_inverse")
         if want_db:
@@ -1062,6 +1261,8 @@ def conv_leaky(x, w_krsc, w_crsk, bias, desc: ConvDesc, mask, dmap, slope: float
         return ret(ConvWino1dLeakyFn.apply(x, w_krsc, bias, mask, _desc_key(desc), tuple(dmap), slope, in_gate, pregate), pregate)
     if _wino_s2d_ok(desc):
         return ret(ConvWinoS2dLeakyFn.apply(x, w_krsc, bias, mask, _desc_key(desc), tuple(dmap), slope, in_gate, pregate), pregate)
+    if _winow_ok(desc):
+        return ret(ConvWinoWLeakyFn.apply(x, w_krsc, bias, mask, _desc_key(desc), tuple(dmap), slope, in_gate, pregate), pregate)
     return ret(ConvLeakyFn.apply(x, w_krsc, w_crsk, bias, mask, _desc_key(desc), tuple(dmap), slope, in_gate, pregate), pregate)
 
 
@@ -1074,6 +1275,8 @@ def conv(x, w_krsc, w_crsk, bias, desc: ConvDesc, out_f32: bool = False):
         return _thin_conv(x if desc.K == 1 else to_f32(x), w_krsc, w_crsk, bias, desc)
     if _wino_ok(desc):
         return ConvWinoFn.apply(to_f32(x), w_krsc, w_crsk, bias, _desc_key(desc))
+    if _winow_ok(desc):
+        return ConvWinoWFn.apply(to_f32(x), w_krsc, w_crsk, bias, _desc_key(desc))
     return ConvFn.apply(to_f32(x), w_krsc, w_crsk, bias, _desc_key(desc))
 
 

@@ -418,6 +418,7 @@ def test_conv_fprop_dgrad_wgrad(env, monkeypatch, c, precision):
     precision="f32x3" (three-term bf16 split of f32 operands) takes arbitrary f32 inputs and the f32 bound."""
     ops = env
     monkeypatch.setattr(ops, "WINO_MIN_CHANNELS", 0)
+    monkeypatch.setattr(ops, "WINOW_MIN_CHANNELS", 0)
     torch.manual_seed(0)
     G = c.get("groups", 1)
     rnd = (lambda v: v.bfloat16().double()) if precision == "bf16" else (lambda v: v)
@@ -535,6 +536,7 @@ def test_f32x3_engine_has_the_error_of_the_f32_engine(env, monkeypatch):
     ENGINES are compared: the layer would otherwise take the Winograd route (its own error: the last assertion)."""
     ops = env
     monkeypatch.setattr(ops, "WINO_MIN_CHANNELS", 0)
+    monkeypatch.setattr(ops, "WINOW_MIN_CHANNELS", 0)
     torch.manual_seed(5)
     N, H, W, Cc, K = 1, 16, 24, 512, 128
     x = torch.randn(N, H, W, Cc, dtype=torch.float64)
@@ -617,6 +619,7 @@ def test_full_size_conv_beyond_4gb_engines_agree(env, monkeypatch):
     for leg, prec, minc in (("f32", "f32", 0), ("f32x3", "f32x3", 0), ("wino", "f32", None)):
         if minc is not None:
             monkeypatch.setattr(ops, "WINO_MIN_CHANNELS", minc)
+            monkeypatch.setattr(ops, "WINOW_MIN_CHANNELS", minc)
         else:
             monkeypatch.undo()
         xd = x.clone().requires_grad_(True)
@@ -639,6 +642,59 @@ def test_full_size_conv_beyond_4gb_engines_agree(env, monkeypatch):
         err = float((a - c).abs().max()) / scale
         assert rms < (3e-5 if name == "wgrad" else 6e-6), f"{name}: Winograd route rms {rms:.2e}"
         assert err < (3e-4 if name == "wgrad" else 2e-4), f"{name}: Winograd route differs by {err:.2e} of the rms"
+
+
+WINOW_CASES = [
+    dict(N=3, H=1, W=52, C=128, K=144, R=1, S=3, pad=(0, 1)),                                  # encoder block, k = 3
+    dict(N=2, H=1, W=50, C=144, K=128, R=1, S=5, pad=(0, 2)),                                  # k = 5, ragged last tile
+    dict(N=2, H=1, W=33, C=128, K=128, R=1, S=7, pad=(0, 3)),                                  # k = 7: F(2, 7)
+    dict(N=2, H=1, W=40, C=128, K=128, R=1, S=7, pad=(0, 6), out_hw=(1, 40)),                  # decoder block: causal padding
+    dict(N=2, H=1, W=21, C=128, K=160, R=1, S=5, pad=(0, 4), out_hw=(1, 21)),
+    dict(N=2, H=1, W=18, C=128, K=128, R=1, S=3, pad=(0, 2), out_hw=(1, 18)),
+    dict(N=2, H=9, W=24, C=128, K=128, R=3, S=3, stride=(2, 1), pad=(1, 1)),                   # patch-D stride (2, 1), odd H
+    dict(N=4, H=1, W=30, C=128, K=128, R=1, S=5, pad=(0, 2), groups=2),                        # batch groups
+    dict(N=4, H=3, W=17, C=128, K=128, R=3, S=3, pad=(1, 1), groups=4),
+]
+
+
+@pytest.mark.parametrize("precision", ["f32", "f32x3"])
+@pytest.mark.parametrize("c", WINOW_CASES, ids=lambda c: "N{N}H{H}W{W}C{C}K{K}R{R}S{S}".format(**c) + f"g{c.get('groups', 1)}")
+def test_winow_conv_fprop_dgrad_wgrad(env, monkeypatch, c, precision):
+    """Convolutions with 3, 5 or 7 stride-1 taps along the columns (time) as one-dimensional Winograd F(4, 3) / F(4, 5) / F(2, 7)
+    (ops.ConvWinoWFn, csrc/winow.hip): "same" and causal padding, ragged last tiles, row taps with stride 2, batch groups - forward,
+    input, weight and bias gradients against the float64 direct convolution."""
+    ops = env
+    monkeypatch.setattr(ops, "WINO_MIN_CHANNELS", 0)            # the 3x3 cases would otherwise take the 2-D route
+    torch.manual_seed(0)
+    G = c.get("groups", 1)
+    x = torch.randn(c["N"], c["H"], c["W"], c["C"], dtype=torch.float64)
+    w = torch.randn(G * c["K"], c["C"], c["R"], c["S"], dtype=torch.float64) * 0.2
+    b = torch.randn(G * c["K"], dtype=torch.float64)
+    x.requires_grad_(True); w.requires_grad_(True); b.requires_grad_(True)
+    y_ref = _torch_conv(x, w, b, c)
+    r = torch.randn_like(y_ref)
+    (y_ref * r).sum().backward()
+    xd = x.detach().float().to(DEV).requires_grad_(True)
+    wd = w.detach().float().to(DEV).requires_grad_(True)
+    bd = b.detach().float().to(DEV).requires_grad_(True)
+    w_krsc, w_crsk = [], []
+    for gi in range(G):
+        a, bb = ops.weight_prep(wd[gi * c["K"]:(gi + 1) * c["K"]].contiguous(), None, True)
+        w_krsc.append(a); w_crsk.append(bb)
+    wk, wc = torch.cat(w_krsc, 0), torch.cat(w_crsk, 0)
+    desc = ops.conv_desc(c["N"], c["H"], c["W"], c["C"], c["K"], c["R"], c["S"], stride=c.get("stride", (1, 1)),
+                         pad=c.get("pad", (0, 0)), groups=G, out_hw=c.get("out_hw"), precision=precision)
+    assert ops._winow_ok(desc)
+    y = ops.conv(xd, wk, wc, bd, desc)
+    assert y.grad_fn.__class__.__name__.startswith("ConvWinoWFn")
+    assert tuple(y.shape) == tuple(y_ref.shape)
+    assert_rel(y, y_ref, 4e-5, "fprop")
+    (y * r.float().to(DEV)).sum().backward()
+    assert_rel(xd.grad, x.grad, 4e-5, "dgrad")
+    assert_rel(wd.grad, w.grad, 4e-5, "wgrad")
+    assert_rel(bd.grad, b.grad, 2e-5, "bias grad")
+    monkeypatch.setattr(ops, "WINOW_MIN_CHANNELS", 0)
+    assert not ops._winow_ok(desc)
 
 
 @pytest.mark.parametrize("c", [dict(N=2, H=24, W=18, C=32, K=48, R=3, S=3, pad=(1, 1)),
@@ -915,8 +971,8 @@ def test_wino1d_discriminator_chain_matches_direct_kernels(env, monkeypatch, H, 
         return torch.cat(ks, 0), torch.cat(cs, 0)
 
     def run(minc):
-        keep = ops.WINO1D_MIN_CHANNELS
-        ops.WINO1D_MIN_CHANNELS = minc
+        keep, keepw = ops.WINO1D_MIN_CHANNELS, ops.WINOW_MIN_CHANNELS
+        ops.WINO1D_MIN_CHANNELS = ops.WINOW_MIN_CHANNELS = minc       # 0: neither the row form nor the column form that would catch the layer next
         try:
             x = x0.clone().requires_grad_(True)
             w1v, w2v = w1.clone().requires_grad_(True), w2.clone().requires_grad_(True)
@@ -934,7 +990,7 @@ def test_wino1d_discriminator_chain_matches_direct_kernels(env, monkeypatch, H, 
             (y2 * r).sum().backward()
             return [t_.detach().clone() for t_ in (y1, y2, x.grad, w1v.grad, w2v.grad, b1v.grad, b2v.grad)]
         finally:
-            ops.WINO1D_MIN_CHANNELS = keep
+            ops.WINO1D_MIN_CHANNELS, ops.WINOW_MIN_CHANNELS = keep, keepw
 
     def ref64(gate1, gate2):
         """float64 on the CPU; LeakyReLU takes the branch gate* says (channels-last bool tensors)."""
@@ -1027,6 +1083,71 @@ def test_polyphase_winograd_5x5_stride2_chain_matches_direct_kernels(env, monkey
         ref = ref64(outs[0] > 0, outs[1] > 0)
         for g_, w_, name in zip(outs, ref, names):
             assert_rel(g_.double().cpu().reshape(w_.shape), w_, 4e-5, f"{path} {name}")
+
+
+@pytest.mark.parametrize("H,W,prec", [(20, 32, "f32"), (9, 21, "f32"), (20, 32, "f32x3")])
+def test_winow_stride21_chain_matches_direct_kernels(env, H, W, prec):
+    """The patch discriminator's 3x3 / stride-(2, 1) layers with the column taps as Winograd F(4, 3) (ops.ConvWinoWLeakyFn) and on
+    the direct kernels (ops.WINOW_MIN_CHANNELS = 0): two such layers in a row (the second one's input gradient carries the first
+    one's LeakyReLU' / mask), frame masks, odd heights, a ragged last tile.  Outputs against each other; outputs, input gradient,
+    weight and bias gradients of either path against float64 with the LeakyReLU branch of every element taken from the tested
+    path's own output."""
+    ops = env
+    torch.manual_seed(35)
+    N, C0, C1, C2 = 3, 128, 128, 160
+    H1, H2 = (H + 2 - 3) // 2 + 1, ((H + 2 - 3) // 2 + 1 + 2 - 3) // 2 + 1
+    x0 = torch.randn(N, H, W, C0, device=DEV)
+    w1 = torch.randn(C1, C0, 3, 3, device=DEV) * 0.05
+    w2 = torch.randn(C2, C1, 3, 3, device=DEV) * 0.05
+    b1, b2 = torch.randn(C1, device=DEV) * 0.1, torch.randn(C2, device=DEV) * 0.1
+    mask = torch.zeros(N, W, dtype=torch.uint8, device=DEV)
+    mask[1, W // 2:] = 1
+    mask[2, 5:] = 1
+    r = torch.randn((N, H2, W, C2), device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+
+    def run(minc):
+        keep = ops.WINOW_MIN_CHANNELS
+        ops.WINOW_MIN_CHANNELS = minc
+        try:
+            x = x0.clone().requires_grad_(True)
+            w1v, w2v = w1.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+            b1v, b2v = b1.clone().requires_grad_(True), b2.clone().requires_grad_(True)
+            k1, c1 = ops.weight_prep(w1v, None, True)
+            k2, c2 = ops.weight_prep(w2v, None, True)
+            d1 = ops.conv_desc(N, H, W, C0, C1, 3, 3, stride=(2, 1), pad=(1, 1), precision=prec)
+            d2 = ops.conv_desc(N, H1, W, C1, C2, 3, 3, stride=(2, 1), pad=(1, 1), precision=prec)
+            assert ops._winow_ok(d1) == (minc > 0) and ops._winow_ok(d2) == (minc > 0) and d2.P == H2
+            dm1, dm2 = (d1.P * d1.Q, d1.Q, d1.Q), (d2.P * d2.Q, d2.Q, d2.Q)
+            y1, hon = ops.conv_leaky(x, k1, c1, b1v, d1, mask, dm1, pregate=True, chain=True)
+            assert hon and y1.grad_fn.__class__.__name__.startswith("ConvWinoWLeakyFn" if minc > 0 else "ConvLeakyFn")
+            y2 = ops.conv_leaky(y1, k2, c2, b2v, d2, mask, dm2, in_gate=(mask, dm1, 0.2))
+            assert y2.shape == r.shape
+            (y2 * r).sum().backward()
+            return [t_.detach().clone() for t_ in (y1, y2, x.grad, w1v.grad, w2v.grad, b1v.grad, b2v.grad)]
+        finally:
+            ops.WINOW_MIN_CHANNELS = keep
+
+    def ref64(gate1, gate2):
+        x = x0.double().cpu().requires_grad_(True)
+        w1v, w2v = w1.double().cpu().requires_grad_(True), w2.double().cpu().requires_grad_(True)
+        b1v, b2v = b1.double().cpu().requires_grad_(True), b2.double().cpu().requires_grad_(True)
+        m = mask.cpu().bool()[:, None, None, :]
+        h1 = F.conv2d(x.permute(0, 3, 1, 2), w1v, b1v, stride=(2, 1), padding=1)
+        y1 = torch.where(gate1.cpu().permute(0, 3, 1, 2), h1, 0.2 * h1).masked_fill(m, 0.0)
+        h2 = F.conv2d(y1, w2v, b2v, stride=(2, 1), padding=1)
+        y2 = torch.where(gate2.cpu().permute(0, 3, 1, 2), h2, 0.2 * h2).masked_fill(m, 0.0)
+        (y2 * r.double().cpu().permute(0, 3, 1, 2)).sum().backward()
+        return [y1.detach().permute(0, 2, 3, 1), y2.detach().permute(0, 2, 3, 1), x.grad, w1v.grad, w2v.grad, b1v.grad, b2v.grad]
+
+    names = ("y1", "y2", "dx", "dw1", "dw2", "db1", "db2")
+    got, want = run(128), run(0)
+    assert_rel(got[0], want[0], 4e-5, "y1 against the direct kernels")
+    assert_rel(got[1], want[1], 4e-5, "y2 against the direct kernels")
+    for path, outs in (("winograd", got), ("direct", want)):
+        ref = ref64(outs[0] > 0, outs[1] > 0)
+        for g_, w_, name in zip(outs, ref, names):
+            assert_rel(g_.double().cpu().reshape(w_.shape), w_, 4e-5, f"{path} {name}")
+    assert float(got[1][1, :, W // 2:].abs().max()) == 0.0          # padded output frames are exactly zero
 
 
 def test_masked_mae_leaky_gate(env):

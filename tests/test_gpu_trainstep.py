@@ -332,15 +332,15 @@ def test_full_size_config2_winograd_against_direct_kernels():
     """BASELINE config 2 at full size, the two ALGORITHMS against each other: Winograd (F(3x3, 3x3) for the refiner's wide
     3x3 layers, 25 products per 9 outputs; the same over the polyphase components for the patch discriminator's 5x5 / stride-2
     layers; one-dimensional F(2, 3) along the bins for the multi-bin discriminator's (3 x k) layers) and the direct
-    implicit-GEMM kernels everywhere (WINO_MIN_CHANNELS = WINO_S2D_MIN_CHANNELS = WINO1D_MIN_CHANNELS = 0).  Same weights, same batch (two ragged items), G.eval():
+    implicit-GEMM kernels everywhere (WINO_MIN_CHANNELS = WINO_S2D_MIN_CHANNELS = WINO1D_MIN_CHANNELS = WINOW_MIN_CHANNELS = 0).  Same weights, same batch (two ragged items), G.eval():
     every loss, both gradient norms and the refiner's gradient arena itself agree to 1e-4."""
     from mqgan_amd import ops
     from mqgan_amd.train import Trainer, synthetic_mel
     res, grads, dgrads = {}, {}, {}
-    keep, keep1, keep2 = ops.WINO_MIN_CHANNELS, ops.WINO1D_MIN_CHANNELS, ops.WINO_S2D_MIN_CHANNELS
+    keep, keep1, keep2, keep3 = ops.WINO_MIN_CHANNELS, ops.WINO1D_MIN_CHANNELS, ops.WINO_S2D_MIN_CHANNELS, ops.WINOW_MIN_CHANNELS
     try:
         for name, minc in (("winograd", 128), ("direct", 0)):
-            ops.WINO_MIN_CHANNELS = ops.WINO1D_MIN_CHANNELS = ops.WINO_S2D_MIN_CHANNELS = minc
+            ops.WINO_MIN_CHANNELS = ops.WINO1D_MIN_CHANNELS = ops.WINO_S2D_MIN_CHANNELS = ops.WINOW_MIN_CHANNELS = minc
             cfg = _hifispeech_cfg("fp32")
             B, T, mel = cfg["data"]["batch_size"], cfg["data"]["crop_len"], cfg["model"]["mel_channels"]
             torch.manual_seed(42)
@@ -368,7 +368,7 @@ def test_full_size_config2_winograd_against_direct_kernels():
             del tr
             torch.cuda.empty_cache()
     finally:
-        ops.WINO_MIN_CHANNELS, ops.WINO1D_MIN_CHANNELS, ops.WINO_S2D_MIN_CHANNELS = keep, keep1, keep2
+        ops.WINO_MIN_CHANNELS, ops.WINO1D_MIN_CHANNELS, ops.WINO_S2D_MIN_CHANNELS, ops.WINOW_MIN_CHANNELS = keep, keep1, keep2, keep3
         ops.TIMER = None
     assert res["winograd"]["conv_tflop"] < 0.6 * res["direct"]["conv_tflop"], res      # the two runs really differ in algorithm
     for k in ("loss_d", "loss_g_total", "loss_recon_pre", "loss_recon_post", "loss_gan", "norm_g", "norm_d"):
