@@ -202,7 +202,7 @@ def cpu_baseline(seconds_budget=30.0):
                       + f" ({os.cpu_count()} logical CPUs visible); reference's own figure on 8 threads: 38 frames/s (BASELINE.md)"}
 
 
-def quick_engine(cfg, precision, device, batches, lens, B, T, steps=4, warmup=1):
+def quick_engine(cfg, precision, device, batches, lens, B, T, steps=4, warmup=2):
     """Step time of the same workload on another conv engine (training.precision)."""
     import copy
     from mqgan_amd.train import Trainer
