@@ -12,6 +12,10 @@
 
 namespace mq {
 
+// s / 2 = sigmoid(2 h) for s = 1 + tanh h (common.h: aptx_s = 2 * this): the kernels below take the exact factors 2 and 0.5 of
+// aptx(h) = s * 0.5 * h and of its derivative out by hand - same roundings in the same order, fewer multiplications
+__device__ __forceinline__ float aptx_half(float h) { return __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * h)); }
+
 constexpr int CB_TT = 4;     // time steps per block tile
 constexpr int CB_TM = 8;     // time steps per thread in the MLP backward (amortises the per-channel wave reductions)
 constexpr int CB_TC = 64;    // channels per block tile (fwd)
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(256) void cb2d_fwd_kernel(const float *__restrict__
 #pragma unroll
             for (int p = 0; p < CB_FP; ++p) {
                 const float h = fmaf(wk1, v[p], bk1);
-                float a = aptx_s(h) * 0.5f * h;
+                float a = aptx_half(h) * h;       // = aptx_s(h) * 0.5f * h bit for bit (the factors 2 and 0.5 are exact)
                 if (thresh16) a = rng[p].keep(e, thresh16) ? a * scale : 0.f;
                 acc[p] = fmaf(wk2, a, acc[p]);
             }
@@ -157,12 +161,14 @@ __global__ __launch_bounds__(256) void cb2d_bwd_mlp_kernel(const float *__restri
 #pragma unroll
                 for (int p = 0; p < CB_TM; ++p) {
                     const float h = fmaf(wk1, v[p], bk1);
-                    const float s = aptx_s(h);
+                    const float r = aptx_half(h);                              // s / 2, s = 1 + tanh h
                     float keep = 1.0f;
                     if (thresh16) keep = rng[p].keep(e, thresh16) ? scale : 0.f;
                     const float gk = on[p] ? g[p] * keep : 0.f;
-                    const float a = s * 0.5f * h;
-                    const float dh = gk * wk2 * 0.5f * (s + h * s * (2.0f - s));
+                    // a = s * 0.5 * h and dh = gk * wk2 * 0.5 * (s + h * s * (2 - s)) with the exact factors of two taken out:
+                    // the same roundings in the same order, five multiplications fewer
+                    const float a = r * h;
+                    const float dh = (gk * wk2) * fmaf(2.0f, a * (1.0f - r), r);
                     s_w2 = fmaf(gk, a, s_w2);
                     s_w1 = fmaf(dh, v[p], s_w1);
                     s_b1 += dh;
