@@ -193,3 +193,37 @@ def test_reencode_default_batching_is_the_reference_loop():
         assert inspect.signature(fn).parameters["bucket"].default == "order", fn.__name__
     srt = R.plan_batches(files, lengths, 4, "sorted", 0.25)
     assert srt != ref and sorted(f for b in srt for f in b) == sorted(files)
+
+
+def test_winograd_form_selection_per_layer():
+    """Which exact-f32 form ops picks for the convolutions of BASELINE config 2 (pure host logic + the library's tile tables):
+    refiner 3x3 -> F(4x5) on T x 90 images, polyphase 5x5/s2 -> F(4x5) on 40 x 128 and 20 x 64, multi-bin (3 x k) ->
+    F(5, 3) along 10 bins (nested along time when the column taps have stride 1), the patch discriminator's stride-(2, 1) layers
+    and the 1-D convolutions -> F(4, 3) / F(4, 5) / F(2, 7) along time; small layers and bf16 stay on the direct kernels."""
+    from mqgan_amd import ops
+    L = ops.L()
+    assert [L.mq_wino1d_tile(h) for h in (2, 6, 8, 9, 10, 16)] == [2, 2, 4, 5, 5, 4]
+    assert [L.mq_winow_tile(s) for s in (3, 5, 7, 4)] == [4, 4, 2, 0]
+    assert ops._wino_tile(512, 90) == (4, 5) and ops._wino_tile(64, 90) == (4, 5) and ops._wino_tile(40, 128) == (4, 5)
+    assert ops._wino_tile(20, 64) == (4, 5) and ops._wino_tile(16, 16) == (4, 4) and ops._wino_tile(9, 9) == (3, 3)
+    f32 = "f32"
+    refiner = ops.conv_desc(32, 256, 90, 128, 128, 3, 3, pad=(1, 1), precision=f32)
+    assert ops._wino_ok(refiner) and ops._wino_np(refiner) == 42 and ops._wino_tiles(refiner) == 32 * 64 * 18
+    assert ops._wino_ok(ops.conv_desc(32, 512, 90, 64, 64, 3, 3, pad=(1, 1), precision=f32))           # C K / (C + K) = 32
+    assert not ops._wino_ok(ops.conv_desc(32, 512, 90, 48, 64, 3, 3, pad=(1, 1), precision=f32))
+    assert not ops._wino_ok(ops.conv_desc(32, 256, 90, 128, 128, 3, 3, pad=(1, 1), precision="bf16"))
+    patch = ops.conv_desc(64, 80, 256, 256, 256, 5, 5, stride=(2, 2), pad=(2, 2), precision=f32)
+    assert ops._wino_s2d_ok(patch) and ops._s2d_tile(patch) == (4, 5)
+    mb35 = ops.conv_desc(512, 10, 512, 128, 128, 3, 5, pad=(1, 2), groups=8, precision=f32)
+    mb33 = ops.conv_desc(512, 10, 512, 128, 256, 3, 3, stride=(1, 2), pad=(1, 1), groups=8, precision=f32)
+    assert ops._wino1d_ok(mb35) and ops._wino1d_ok(mb33) and ops._wino1d_m(mb35) == 5
+    inner35, inner33 = ops._wino1d_gemm_desc(mb35, 5), ops._wino1d_gemm_desc(mb33, 5)
+    assert (inner35.N, inner35.H, inner35.S, inner35.groups) == (7 * 512 * 2, 1, 5, 56)
+    assert ops._winow_ok(inner35) and not ops._winow_ok(inner33)                     # stride 2 along time: no column form
+    g = ops._ww_desc(inner35)
+    assert (g.N, g.W, g.R, g.S, g.groups) == (8 * inner35.N, 128, 1, 1, 8 * 56)
+    d1 = ops.conv_desc(64, 20, 64, 384, 512, 3, 3, stride=(2, 1), pad=(1, 1), precision=f32)
+    assert not ops._wino_ok(d1) and ops._winow_ok(d1) and ops._ww_geom(d1) == (4, 16, 6)
+    dec = ops.conv_desc(32, 1, 512, 768, 512, 1, 7, pad=(0, 6), out_hw=(1, 512), precision=f32)       # causal k = 7
+    assert ops._winow_ok(dec) and ops._ww_geom(dec) == (2, 256, 8)
+    assert not ops._winow_ok(ops.conv_desc(32, 1, 512, 768, 512, 1, 7, pad=(0, 6), dil=(1, 2), out_hw=(1, 512), precision=f32))
