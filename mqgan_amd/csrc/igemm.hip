@@ -351,6 +351,32 @@ __device__ __forceinline__ void conv_nt_body(const float *__restrict__ act, cons
         }
         __syncthreads();
     }
+    if (!(fused || gated)) {
+        // Plain store (every Winograd GEMM, every layer without a fused activation) through a buffer descriptor that ends
+        // behind the tile's last valid row: rows >= Mtot and columns >= Ncols fall outside it, the lane-dependent part of the
+        // offset is formed once per column tile and the (tm, r) part is a scalar - no per-element address arithmetic or
+        // compares on the vector unit, whose instructions come out of the f32 matrix pipe's time (with reductions only C
+        // deep the epilogue was a quarter of a block's vector instructions: 4.0 per MFMA at C = 128).
+        const int rows_left = g.Mtot - m0 < GEMM_BM ? g.Mtot - m0 : GEMM_BM;
+        const unsigned pitch = (unsigned)g.Ncols * 4u;
+        const __amdgpu_buffer_rsrc_t ro = make_rsrc(o + (size_t)m0 * g.Ncols, (size_t)rows_left * pitch);
+        const int lane_row = acc_row<BN>(0, 0);                      // wave and lane part of the row index
+#pragma unroll
+        for (int tn = 0; tn < Cfg::TN; ++tn) {
+            const int n = n0 + acc_col<BN>(tn);
+            const bool colok = n < g.Ncols;
+            const float bv = (bias && colok) ? bias[(size_t)grp * g.Ncols + n] : 0.f;
+            const unsigned voff = colok ? (unsigned)lane_row * pitch + (unsigned)n * 4u : OOB;
+#pragma unroll
+            for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned soff = (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * pitch;       // uniform
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[tm][tn][r] + bv), ro, (int)voff, (int)soff, 0);
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int tn = 0; tn < Cfg::TN; ++tn) {
         const int n = n0 + acc_col<BN>(tn);
