@@ -353,10 +353,11 @@ __device__ __forceinline__ void conv_nt_body(const float *__restrict__ act, cons
     }
     if (!(fused || gated)) {
         // Plain store (every Winograd GEMM, every layer without a fused activation) through a buffer descriptor that ends
-        // behind the tile's last valid row: rows >= Mtot and columns >= Ncols fall outside it, the lane-dependent part of the
-        // offset is formed once per column tile and the (tm, r) part is a scalar - no per-element address arithmetic or
-        // compares on the vector unit, whose instructions come out of the f32 matrix pipe's time (with reductions only C
-        // deep the epilogue was a quarter of a block's vector instructions: 4.0 per MFMA at C = 128).
+        // behind the tile's last valid row: rows >= Mtot and columns >= Ncols fall outside it, so there are no compares and no
+        // 64-bit address arithmetic per element - one 32-bit add of a scalar (row step x pitch) to the lane's offset.  The whole
+        // offset is in the VECTOR operand on purpose: the scalar offset of a buffer instruction is not bounds-checked.  Vector
+        // instructions come out of the f32 matrix pipe's time; with reductions only C deep the epilogue was a quarter of a
+        // block's vector instructions (4.0 per MFMA at C = 128).
         const int rows_left = g.Mtot - m0 < GEMM_BM ? g.Mtot - m0 : GEMM_BM;
         const unsigned pitch = (unsigned)g.Ncols * 4u;
         const __amdgpu_buffer_rsrc_t ro = make_rsrc(o + (size_t)m0 * g.Ncols, (size_t)rows_left * pitch);
@@ -366,13 +367,14 @@ __device__ __forceinline__ void conv_nt_body(const float *__restrict__ act, cons
             const int n = n0 + acc_col<BN>(tn);
             const bool colok = n < g.Ncols;
             const float bv = (bias && colok) ? bias[(size_t)grp * g.Ncols + n] : 0.f;
-            const unsigned voff = colok ? (unsigned)lane_row * pitch + (unsigned)n * 4u : OOB;
+            // an invalid column starts beyond every valid offset and stays there: 0x80000000 + at most 128 rows x pitch
+            const unsigned voff = colok ? (unsigned)lane_row * pitch + (unsigned)n * 4u : 0x80000000u;
 #pragma unroll
             for (int tm = 0; tm < Cfg::TM; ++tm)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const unsigned soff = (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * pitch;       // uniform
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[tm][tn][r] + bv), ro, (int)voff, (int)soff, 0);
+                    const unsigned rstep = (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * pitch;      // uniform
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[tm][tn][r] + bv), ro, (int)(voff + rstep), 0, 0);
                 }
         }
         return;

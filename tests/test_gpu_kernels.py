@@ -1150,6 +1150,26 @@ def test_winow_stride21_chain_matches_direct_kernels(env, H, W, prec):
     assert float(got[1][1, :, W // 2:].abs().max()) == 0.0          # padded output frames are exactly zero
 
 
+@pytest.mark.parametrize("G,rows,Cc,K", [(1, 100, 128, 128), (3, 39, 128, 144), (2, 130, 256, 160), (1, 1, 128, 128), (4, 257, 128, 136)])
+def test_conv_plain_store_stays_inside_its_rows(env, G, rows, Cc, K):
+    """The plain-store epilogue of the f32 GEMM kernels writes through a buffer descriptor that ends behind the tile's last valid
+    row (csrc/igemm.hip: no per-element compares).  Ragged row counts and column counts, several batch groups, a sentinel
+    region right behind the output: the result is right and nothing behind it is touched."""
+    import ctypes as C
+    ops = env
+    from mqgan_amd.ops import L, fptr, stream, check
+    torch.manual_seed(7)
+    d = ops.conv_desc(G * rows, 1, 1, Cc, K, 1, 1, groups=G, precision="f32")
+    V = torch.randn(G * rows, 1, 1, Cc, device=DEV)
+    U = torch.randn(G * K, 1, Cc, device=DEV) * 0.05
+    buf = torch.full((G * rows + 256, K), 7.0, device=DEV)
+    check(L().mq_conv_fprop(C.byref(d), fptr(V), fptr(U), None, fptr(buf), stream()), "mq_conv_fprop")
+    torch.cuda.synchronize()
+    ref = torch.cat([V.view(G, rows, Cc)[g].double() @ U.view(G, K, Cc)[g].double().T for g in range(G)], 0)
+    assert_rel(buf[:G * rows], ref, 2e-5, "grouped 1x1 GEMM")
+    assert int((buf[G * rows:] != 7.0).sum()) == 0, "stores behind the last valid row"
+
+
 def test_masked_mae_leaky_gate(env):
     ops = env
     torch.manual_seed(10)
