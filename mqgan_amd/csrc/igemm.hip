@@ -581,28 +581,35 @@ __device__ __forceinline__ void conv_dgrad_parity_body(const float *__restrict__
         const int ihq = t % Ha, n = t / Ha;
         return ((size_t)n * g.OH + ihq * g.sh + a) * g.OW + iwq * g.sw + b;
     };
-    // padded flag of the tile's 128 rows, looked up once (LDS is free after the main loop's last barrier)
+    // Pixel index and padded flag of the tile's 128 rows, worked out ONCE per row by 128 threads (LDS is free after the main
+    // loop's last barrier) instead of once per accumulator register: the two divisions and two remainders of pixel_of() were
+    // ~60 vector instructions, 32 times per lane - 1.9 of the 4.2 vector instructions per MFMA this kernel issued, each of them
+    // 4 of the 64 cycles of an MFMA on the f32 pipe.  A group has fewer than 2^32 pixels (host check).
     unsigned char *padf = reinterpret_cast<unsigned char *>(smem);
-    if (gated) {
-        if (threadIdx.x < GEMM_BM) {
-            const int m = m0 + threadIdx.x;
-            unsigned char pd = 0;
-            if (epi.mask != nullptr && m < Mc) {
-                const int64_t mg = (int64_t)(gbase + pixel_of(m));
+    unsigned *rowpix = reinterpret_cast<unsigned *>(smem) + GEMM_BM / 4;
+    if (threadIdx.x < GEMM_BM) {
+        const int m = m0 + threadIdx.x;
+        unsigned char pd = 0;
+        unsigned pix = 0xFFFFFFFFu;
+        if (m < Mc) {
+            pix = (unsigned)pixel_of(m);
+            if (gated && epi.mask != nullptr) {
+                const int64_t mg = (int64_t)(gbase + pix);
                 pd = epi.mask[(mg / epi.d1) * epi.d2 + (mg % epi.d3)] != 0;
             }
-            padf[threadIdx.x] = pd;
         }
-        __syncthreads();
+        padf[threadIdx.x] = pd;
+        rowpix[threadIdx.x] = pix;
     }
+    __syncthreads();
 #pragma unroll
     for (int tm = 0; tm < Cfg::TM; ++tm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = acc_row<BN>(tm, r);
-            const int m = m0 + row;
-            if (m >= Mc) continue;
-            const size_t base = pixel_of(m) * g.Ncols;
+            const unsigned pix = rowpix[row];
+            if (pix == 0xFFFFFFFFu) continue;
+            const size_t base = (size_t)pix * g.Ncols;
             const bool pd = gated && padf[row] != 0;
 #pragma unroll
             for (int tn = 0; tn < Cfg::TN; ++tn) {
@@ -1277,6 +1284,7 @@ static int launch_nt(const mqConvDesc *d, const float *act, const float *w, cons
                 t0 += (int)cdiv((int64_t)ng * pi.Ha[c] * pi.Wb[c], GEMM_BM);
             }
         pi.tile0[pi.ncls] = t0;
+        MQ_REQUIRE((int64_t)ng * g.OH * g.OW < 0xFFFFFFFFll, "mq_conv_dgrad: a batch group of the strided input gradient has 2^32 pixels or more");
         dim3 pgrid(t0 * g.nNt, d->groups);
 #define MQ_PAR(BN_, W_) do { kname("conv_dgrad_parity_kernel<%d, %d>", BN_, W_); hipLaunchKernelGGL((conv_dgrad_parity_kernel<BN_, W_>), pgrid, dim3(256), 0, st, act, w, out, g, pi, act_gs, w_gs, ng, epi); } while (0)
 #define MQ_PARH(BN_, W_) do { kname("conv_dgrad_parity_bf16_kernel<%d, %d>", BN_, W_); hipLaunchKernelGGL((conv_dgrad_parity_bf16_kernel<BN_, W_>), pgrid, dim3(256), 0, st, act, w, out, g, pi, act_gs, w_gs, ng, epi); } while (0)
