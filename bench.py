@@ -287,11 +287,16 @@ def collectives_of(tr, world, forced):
     """What the step exchanged (rank 0's view)."""
     if not (world > 1 or forced):
         return None
-    return {"backend": dist.get_backend(), "ranks_counted_by_all_reduce": world, "forced_on_one_rank": bool(forced and world == 1),
+    out = dict(tr.bench_comm or {})          # exposed communication and per-rank step times of the timed region (timed_run)
+    out.update({"backend": dist.get_backend(), "ranks_counted_by_all_reduce": world, "forced_on_one_rank": bool(forced and world == 1),
             "gradient_buckets_per_step": len(tr.reducer_g.buckets) + len(tr.reducer_d.buckets),
             "bucket_MiB": [round((e - s) * 4 / 2**20, 1) for red in (tr.reducer_d, tr.reducer_g) for (s, e, _) in red.buckets],
             "asynchronous": not tr.reducer_g._blocking, "host_drains_stream_before_gloo_device_collective": tr.reducer_g._drain_first,
-            "loss_sum_all_reduces_total": getattr(tr.comm, "calls", None)}
+            "loss_sum_all_reduces_total": getattr(tr.comm, "calls", None),
+            "exposed_comm_note": "HIP events on the compute stream around every wait for a collective (the blocking loss-sum "
+                                 "all-reduces; the waits on the asynchronous gradient buckets after backward): time the step "
+                                 "could not hide behind compute; max over ranks"})
+    return out
 
 
 def timed_run(cfg, precision, B, T, steps, warmup, device, world, rank, force=False):
@@ -319,6 +324,11 @@ def timed_run(cfg, precision, B, T, steps, warmup, device, world, rank, force=Fa
     _trace(rank, "warm-up done")
     timer = ops.KernelTimer()
     ops.TIMER = timer
+    clock = getattr(tr.comm, "clock", None)          # HIP events around every point where the compute stream waits for a collective
+    if clock is not None:
+        clock.read_ms()
+        clock.enabled = True
+    calls0 = getattr(tr.comm, "calls", 0)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -328,11 +338,28 @@ def timed_run(cfg, precision, B, T, steps, warmup, device, world, rank, force=Fa
     for i in range(steps):
         last = tr.train_step(batches[i % len(batches)], lens)
     torch.cuda.synchronize()
+    own = time.perf_counter() - t0                   # this rank's own K steps, before it waits for the others
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
+    tr.bench_comm = None
+    if clock is not None:
+        clock.enabled = False
+        exposed = clock.read_ms() / steps
+        per_rank = torch.tensor([own / steps * 1e3, exposed], device=device, dtype=torch.float64)
+        allr = [torch.zeros_like(per_rank) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(allr, per_rank)
+        else:
+            allr = [per_rank]
+        ms = [float(t[0]) for t in allr]
+        ex = [float(t[1]) for t in allr]
+        tr.bench_comm = {"loss_sum_all_reduces_per_step": (getattr(tr.comm, "calls", 0) - calls0) / steps,
+                         "exposed_comm_ms_per_step": max(ex), "exposed_comm_ms_per_step_by_rank": [round(v, 3) for v in ex],
+                         "rank_ms_per_step_min": min(ms), "rank_ms_per_step_max": max(ms),
+                         "rank_ms_per_step": [round(v, 3) for v in ms]}
     if world > 1:
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -365,10 +392,33 @@ def _free_port():
         return sk.getsockname()[1]
 
 
+def visible_gpu_count():
+    """GPUs this process would see, WITHOUT initialising HIP (the launcher parent must stay free of GPU state: on this ROCm
+    build torch.cuda.device_count() falls back to hipGetDeviceCount, which opens KFD): the KFD topology lists one node per
+    agent, GPUs are the ones with SIMDs; HIP_/ROCR_/CUDA_VISIBLE_DEVICES narrow it.  No KFD at all = no GPU; None when the
+    topology exists but cannot be read (the ranks then find out themselves: set_device fails loudly)."""
+    n = 0
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.isdir(root):
+        return 0
+    try:
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+    except OSError:
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher in the environment: start the N ranks ourselves (one process per GPU,
-    torch.distributed.run on 127.0.0.1) as a CHILD of this process - which has made no GPU call - pass rank 0's JSON line
-    through on stdout and exit with the child's code."""
+    torch.distributed.run on 127.0.0.1) as a CHILD of this process - which makes no HIP call, not even a device count (see
+    visible_gpu_count) - pass rank 0's JSON line through on stdout and exit with the child's code."""
     import subprocess
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
@@ -478,8 +528,9 @@ def main():
     if not launched and args.gpus > 1:
         # no launcher: this process becomes one (before anything here touches a GPU) and relays the ranks' output
         backend = os.environ.get("MQGAN_BENCH_BACKEND", "nccl")
-        if backend == "nccl" and os.environ.get("MQGAN_BENCH_SHARE_GPU") != "1" and torch.cuda.device_count() < args.gpus:
-            raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} HIP device(s) are visible")
+        have = visible_gpu_count()
+        if backend == "nccl" and os.environ.get("MQGAN_BENCH_SHARE_GPU") != "1" and have is not None and have < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but only {have} GPU(s) are visible")
         raise SystemExit(self_launch(args.gpus))
 
     import __graft_entry__ as ge

@@ -179,6 +179,7 @@ class GradReducer:
         # the compute stream before it hands a bucket to gloo, so no queue ever waits on the device; the collectives stay
         # asynchronous, issued from the hooks and waited in finish() exactly as under RCCL (whose stream has normal priority
         # and whose ranks own their GPU).
+        self.clock = getattr(comm, "clock", None)       # StallClock of the trainer's communicator: exposed waits on the buckets
         self._drain_first = (not _ASYNC and self.enabled and arena.flat_grad.is_cuda and dist.get_backend(process_group) == "gloo")
         self._blocking = _BLOCKING
         if self.enabled:
@@ -239,7 +240,10 @@ class GradReducer:
             if not self._launched[b]:
                 self._launch(b)
         for i, h in enumerate(self._handles):
-            h.wait()
+            if self.clock is not None:
+                self.clock.bracket(h.wait)           # what the compute stream waits here was not hidden behind backward
+            else:
+                h.wait()
             if _TRACE:
                 import sys
                 print(f"[ddp rank {dist.get_rank(self.pg)}] handle {i} of {len(self._handles)} done", file=sys.stderr, flush=True)

@@ -92,6 +92,14 @@ class LSGANLoss(nn.Module):
         pad, mode = _padded_map(fake_mask, f)
         return ops.LsganGFn.apply(f, pad, mode, self.comm)
 
+    def generator_loss_deferred(self, fake_output, fake_mask, batch: "ops.SumsBatch"):
+        """generator_loss in two halves: the sums go into ``batch`` now; call the returned function AFTER ``batch.reduce()``
+        for the loss.  Lets every loss of a generator step share one all-reduce (mqgan_amd.train)."""
+        f = _bhw(fake_output)
+        pad, mode = _padded_map(fake_mask, f)
+        prepared = ops.lsgan_g_sums(f, pad, mode, batch)
+        return lambda: ops.LsganGFn.apply(f, pad, mode, None, prepared)
+
 
 class MaskedMelLoss(nn.Module):
     def __init__(self, loss_type: str = "charbonnier", group_size: int = 1, eps: float = 1e-6, comm: Comm = None):
@@ -112,6 +120,26 @@ def recon_loss(x, y, lengths, group_size=16, group_weight=0.25, comm: Comm = Non
     """loss_all + 0.25 * loss_group in ONE pass (train.py:419-425)."""
     return ops.MelLossFn.apply(x.contiguous(), y.contiguous(), lengths.to(torch.int32).contiguous(), 1, group_size, 1.0,
                                float(group_weight), comm)
+
+
+def recon_loss_deferred(x, y, lengths, batch: "ops.SumsBatch", group_size=16, group_weight=0.25):
+    """recon_loss in two halves (see LSGANLoss.generator_loss_deferred)."""
+    x, y, lengths = x.contiguous(), y.contiguous(), lengths.to(torch.int32).contiguous()
+    prepared = ops.mel_loss_sums(x, y, lengths, batch)
+    return lambda: ops.MelLossFn.apply(x, y, lengths, 1, group_size, 1.0, float(group_weight), None, prepared)
+
+
+def masked_mae_deferred(pred, target, mask, batch: "ops.SumsBatch", leaky_slope=None, n_bands: int = 1):
+    """masked_mae (n_bands == 1) / masked_mae_bands in two halves (see LSGANLoss.generator_loss_deferred)."""
+    pred, target = ops.to_f32(pred).contiguous(), ops.to_f32(target).contiguous()
+    if n_bands > 1:
+        if pred.shape[0] % n_bands != 0 or tuple(mask.shape) != (pred.shape[0] // n_bands, pred.shape[2]):
+            raise ValueError(f"masked_mae_bands: pred {tuple(pred.shape)}, mask {tuple(mask.shape)}, bands {n_bands}")
+        mask = mask.contiguous()
+        prepared = ops.masked_mae_sums(pred, target, mask, batch, bands=n_bands)
+        return lambda: ops.MaskedMaeBandsFn.apply(pred, target, mask, n_bands, None, leaky_slope, prepared)
+    prepared = ops.masked_mae_sums(pred, target, mask, batch)
+    return lambda: ops.MaskedMaeFn.apply(pred, target, mask, None, leaky_slope, prepared)
 
 
 def masked_mae_bands(pred, target, mask, n_bands: int, comm: Comm = None, leaky_slope=None):

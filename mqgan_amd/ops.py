@@ -1939,17 +1939,88 @@ def _reduce(comm, buf):
     return buf
 
 
+class SumsBatch:
+    """The numerators / counts of SEVERAL losses in one device buffer, so that they cross the data-parallel ranks in ONE
+    all-reduce: ``take(n)`` hands out the next n floats (16-byte aligned) for a *_sums kernel to fill, ``reduce()`` sums the
+    used part over the ranks once, and the *_final / backward kernels of every loss then read their slice.  The generator step
+    uses one batch for its two mel losses, the nine LSGAN generator losses and (with feature matching) every masked_mae:
+    one small collective instead of eleven or more (each of them a compute-stream <-> RCCL-stream round trip)."""
+
+    def __init__(self, like: torch.Tensor, comm=None, capacity: int = 4096):
+        self.buf = _empty((capacity,), like)
+        self.used = 0
+        self.comm = comm
+        self.reduced = False
+
+    def take(self, n: int, rows: int = 1) -> torch.Tensor:
+        if self.reduced:
+            raise _lib.MqganHipError("SumsBatch: take() after reduce()")
+        total = n * rows
+        if self.used + total > self.buf.numel():
+            raise _lib.MqganHipError(f"SumsBatch: capacity {self.buf.numel()} floats exceeded")
+        out = self.buf[self.used:self.used + total]
+        self.used += (total + 3) // 4 * 4
+        return out if rows == 1 else out.view(rows, n)
+
+    def reduce(self):
+        if self.reduced:
+            raise _lib.MqganHipError("SumsBatch: reduce() called twice")
+        self.reduced = True
+        if self.used:
+            _reduce(self.comm, self.buf[:self.used])
+
+
+def _sums_ready(prepared):
+    """A loss Function got its sums from a SumsBatch: they must have crossed the ranks before the final kernel reads them."""
+    batch, sums = prepared
+    if not batch.reduced:
+        raise _lib.MqganHipError("loss from a SumsBatch evaluated before SumsBatch.reduce()")
+    return sums
+
+
+def mel_loss_sums(x, y, lengths, batch: SumsBatch):
+    """First half of MelLossFn into a SumsBatch slice; pass the result as ``prepared``."""
+    B, T, Cc = x.shape
+    sums = batch.take(Cc + 1)
+    ws = _empty((64 * Cc,), x)
+    check(L().mq_mel_loss_sums(fptr(x), fptr(y), ptr(lengths, torch.int32), B, T, Cc, fptr(sums), fptr(ws), stream()),
+          "mq_mel_loss_sums")
+    return (batch, sums)
+
+
+def lsgan_g_sums(fake, pad, mode, batch: SumsBatch):
+    B, H, W = fake.shape
+    sums2 = batch.take(2)
+    check(L().mq_lsgan_g_sums(fptr(fake), ptr(pad, torch.uint8, True), mode, B, H, W, fptr(sums2), stream()), "mq_lsgan_g_sums")
+    return (batch, sums2)
+
+
+def masked_mae_sums(pred, target, padded, batch: SumsBatch, bands: int = 1):
+    """bands == 1: MaskedMaeFn's sums (2,); else MaskedMaeBandsFn's (bands, 2) for the row blocks of a multi-band feature map."""
+    GB, H, W, Cc = pred.shape
+    Bn = GB // bands
+    ws = _empty((512,), pred)
+    sums2 = batch.take(2, rows=bands) if bands > 1 else batch.take(2)
+    for j in range(bands):
+        check(L().mq_masked_mae_sums(fptr(pred[j * Bn:(j + 1) * Bn]), fptr(target[j * Bn:(j + 1) * Bn]), ptr(padded, torch.uint8),
+                                     Bn, H, W, Cc, fptr(sums2[j] if bands > 1 else sums2), fptr(ws), stream()), "mq_masked_mae_sums")
+    return (batch, sums2)
+
+
 class MelLossFn(torch.autograd.Function):
     """MaskedMelLoss('mse') for group sizes g1 and g2 in one pass: returns w1*loss(g1) + w2*loss(g2)."""
 
     @staticmethod
-    def forward(ctx, x, y, lengths, g1, g2, w1, w2, comm):
+    def forward(ctx, x, y, lengths, g1, g2, w1, w2, comm, prepared=None):
         B, T, Cc = x.shape
-        sums = _empty((Cc + 1,), x)
-        ws = _empty((64 * Cc,), x)
-        check(L().mq_mel_loss_sums(fptr(x), fptr(y), ptr(lengths, torch.int32), B, T, Cc, fptr(sums), fptr(ws), stream()),
-              "mq_mel_loss_sums")
-        _reduce(comm, sums)
+        if prepared is not None:
+            sums = _sums_ready(prepared)
+        else:
+            sums = _empty((Cc + 1,), x)
+            ws = _empty((64 * Cc,), x)
+            check(L().mq_mel_loss_sums(fptr(x), fptr(y), ptr(lengths, torch.int32), B, T, Cc, fptr(sums), fptr(ws), stream()),
+                  "mq_mel_loss_sums")
+            _reduce(comm, sums)
         out2 = _empty((2,), x)
         check(L().mq_mel_loss_final(fptr(sums), Cc, g1, g2, fptr(out2), stream()), "mq_mel_loss_final")
         ctx.save_for_backward(x, y, lengths, sums)
@@ -1966,7 +2037,7 @@ class MelLossFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         check(L().mq_mel_loss_bwd(fptr(x), fptr(y), ptr(lengths, torch.int32), B, T, Cc, g1, g2, w1, w2, fptr(sums),
                                   fptr(gout.contiguous().view(1)), fptr(dx), stream()), "mq_mel_loss_bwd")
-        return dx, None, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None, None
 
 
 def lsgan_d_prepare(pairs, state, decay, comm=None):
@@ -2013,11 +2084,15 @@ class LsganDFn(torch.autograd.Function):
 
 class LsganGFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, fake, pad, mode, comm):
+    def forward(ctx, fake, pad, mode, comm, prepared=None):
         B, H, W = fake.shape
-        sums2, out = _empty((2,), fake), _empty((1,), fake)
-        check(L().mq_lsgan_g_sums(fptr(fake), ptr(pad, torch.uint8, True), mode, B, H, W, fptr(sums2), stream()), "mq_lsgan_g_sums")
-        _reduce(comm, sums2)
+        out = _empty((1,), fake)
+        if prepared is not None:
+            sums2 = _sums_ready(prepared)
+        else:
+            sums2 = _empty((2,), fake)
+            check(L().mq_lsgan_g_sums(fptr(fake), ptr(pad, torch.uint8, True), mode, B, H, W, fptr(sums2), stream()), "mq_lsgan_g_sums")
+            _reduce(comm, sums2)
         check(L().mq_ratio_final(fptr(sums2), 0.0, fptr(out), stream()), "mq_ratio_final")
         ctx.save_for_backward(fake, pad, sums2)
         ctx.mode = mode
@@ -2030,7 +2105,7 @@ class LsganGFn(torch.autograd.Function):
         df = torch.empty_like(fake)
         check(L().mq_lsgan_g_bwd(fptr(fake), ptr(pad, torch.uint8, True), ctx.mode, B, H, W, fptr(sums2), fptr(gout.contiguous().view(1)),
                                  fptr(df), stream()), "mq_lsgan_g_bwd")
-        return df, None, None, None
+        return df, None, None, None, None
 
 
 class MaskedMaeFn(torch.autograd.Function):
@@ -2038,12 +2113,16 @@ class MaskedMaeFn(torch.autograd.Function):
     with respect to that layer's pre-activation."""
 
     @staticmethod
-    def forward(ctx, pred, target, padded, comm, leaky_slope=None):
+    def forward(ctx, pred, target, padded, comm, leaky_slope=None, prepared=None):
         B, H, W, Cc = pred.shape
-        sums2, ws, out = _empty((2,), pred), _empty((512,), pred), _empty((1,), pred)
-        check(L().mq_masked_mae_sums(fptr(pred), fptr(target), ptr(padded, torch.uint8), B, H, W, Cc, fptr(sums2), fptr(ws), stream()),
-              "mq_masked_mae_sums")
-        _reduce(comm, sums2)
+        out = _empty((1,), pred)
+        if prepared is not None:
+            sums2 = _sums_ready(prepared)
+        else:
+            sums2, ws = _empty((2,), pred), _empty((512,), pred)
+            check(L().mq_masked_mae_sums(fptr(pred), fptr(target), ptr(padded, torch.uint8), B, H, W, Cc, fptr(sums2), fptr(ws), stream()),
+                  "mq_masked_mae_sums")
+            _reduce(comm, sums2)
         check(L().mq_ratio_final(fptr(sums2), 1e-8, fptr(out), stream()), "mq_ratio_final")
         ctx.save_for_backward(pred, target, padded, sums2)
         ctx.leaky_slope = 1.0 if leaky_slope is None else float(leaky_slope)
@@ -2056,7 +2135,7 @@ class MaskedMaeFn(torch.autograd.Function):
         dp = torch.empty_like(pred)
         check(L().mq_masked_mae_bwd(fptr(pred), fptr(target), ptr(padded, torch.uint8), B, H, W, Cc, fptr(sums2),
                                     fptr(gout.contiguous().view(1)), ctx.leaky_slope, fptr(dp), stream()), "mq_masked_mae_bwd")
-        return dp, None, None, None, None
+        return dp, None, None, None, None, None
 
 
 class MaskedMaeBandsFn(torch.autograd.Function):
@@ -2066,14 +2145,18 @@ class MaskedMaeBandsFn(torch.autograd.Function):
     full-size tensor and an accumulation per band); the G normalisers travel in one all-reduce."""
 
     @staticmethod
-    def forward(ctx, pred, target, padded, G, comm, leaky_slope=None):
+    def forward(ctx, pred, target, padded, G, comm, leaky_slope=None, prepared=None):
         GB, H, W, Cc = pred.shape
         Bn = GB // G
-        sums2, ws, out = _empty((G, 2), pred), _empty((512,), pred), _empty((G,), pred)
-        for j in range(G):
-            check(L().mq_masked_mae_sums(fptr(pred[j * Bn:(j + 1) * Bn]), fptr(target[j * Bn:(j + 1) * Bn]), ptr(padded, torch.uint8),
-                                         Bn, H, W, Cc, fptr(sums2[j]), fptr(ws), stream()), "mq_masked_mae_sums")
-        _reduce(comm, sums2)
+        out = _empty((G,), pred)
+        if prepared is not None:
+            sums2 = _sums_ready(prepared)
+        else:
+            sums2, ws = _empty((G, 2), pred), _empty((512,), pred)
+            for j in range(G):
+                check(L().mq_masked_mae_sums(fptr(pred[j * Bn:(j + 1) * Bn]), fptr(target[j * Bn:(j + 1) * Bn]), ptr(padded, torch.uint8),
+                                             Bn, H, W, Cc, fptr(sums2[j]), fptr(ws), stream()), "mq_masked_mae_sums")
+            _reduce(comm, sums2)
         for j in range(G):
             check(L().mq_ratio_final(fptr(sums2[j]), 1e-8, fptr(out[j:j + 1]), stream()), "mq_ratio_final")
         ctx.save_for_backward(pred, target, padded, sums2)
@@ -2093,7 +2176,7 @@ class MaskedMaeBandsFn(torch.autograd.Function):
             check(L().mq_masked_mae_bwd(fptr(pred[j * Bn:(j + 1) * Bn]), fptr(target[j * Bn:(j + 1) * Bn]), ptr(padded, torch.uint8),
                                         Bn, H, W, Cc, fptr(sums2[j]), fptr(gout[j:j + 1]), ctx.leaky_slope,
                                         fptr(dp[j * Bn:(j + 1) * Bn]), stream()), "mq_masked_mae_bwd")
-        return dp, None, None, None, None, None
+        return dp, None, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------- optimiser

@@ -28,7 +28,7 @@ from . import ops
 from .comm import Comm, default_comm
 from .ddp import FlatArena, GradReducer, broadcast_arena
 from .discriminators import MelSpectrogramPatchDiscriminator2D, MultiBinDiscriminator, run_discriminators
-from .losses import masked_mae_bands, LSGANLoss, masked_mae, recon_loss
+from .losses import LSGANLoss, masked_mae_deferred, recon_loss_deferred
 from .nn_base import share_effective_weights
 from .preencoder import PreEncoder
 
@@ -392,14 +392,18 @@ class Trainer:
         self.reducer_g.start()
         self.patch_discriminator.eval()                  # never undone until the next epoch (:415-416 vs :505-506)
         self.multibin_discriminator.eval()
-        loss_pre = recon_loss(recon_pre, real, lens, comm=self.comm)     # all + 0.25 * group16 (:419-425)
-        loss_post = recon_loss(recon_post, real, lens, comm=self.comm)
+        # Every loss of this step is a ratio of sums over the batch: all their numerators / counts go into ONE buffer and cross
+        # the data-parallel ranks in ONE all-reduce (ops.SumsBatch) - the *_deferred calls launch the sums kernels now and
+        # return the function that forms the loss once the buffer has been reduced.
+        sums = ops.SumsBatch(real, self.comm)
+        loss_pre_f = recon_loss_deferred(recon_pre, real, lens, sums)     # all + 0.25 * group16 (:419-425)
+        loss_post_f = recon_loss_deferred(recon_post, real, lens, sums)
         d_active = self.epoch >= t["discriminator_train_start_epoch"]
         zero = torch.zeros((), device=self.device)
         loss_gan, loss_fm = zero, zero
         lam_g = lam_fm = 0.0
+        use_fm = d_active and bool(t["use_fm_loss"])
         if d_active:
-            use_fm = bool(t["use_fm_loss"])
             with share_effective_weights():              # the FM passes over `real` reuse the weight preparations
                 gl, gmask, gf = self._d1(recon_post, lens, feats=use_fm, detach_params=True)
                 gl2, gmask2, gf2 = self._d2(recon_post, lens, feats=use_fm, detach_params=True)
@@ -410,27 +414,37 @@ class Trainer:
             B = real.shape[0]
             G = self.multibin_discriminator.n_bins
             m0 = gmask2[:B].contiguous()
-            l1 = self.gan_loss.generator_loss(gl, gmask)
-            l2 = None
-            for g_ in self._bands(gl2):
-                l = self.gan_loss.generator_loss(g_, m0)
-                l2 = l if l2 is None else ops.add(l2, l)
-            loss_gan = ops.add(l1, l2, 0.5, 0.5 / G)
+            l1_f = self.gan_loss.generator_loss_deferred(gl, gmask, sums)
+            l2_f = [self.gan_loss.generator_loss_deferred(g_, m0, sums) for g_ in self._bands(gl2)]
             lam_g, lam_fm = t["loss_weights"]["Gloss_lambda"], t["loss_weights"]["fm_lambda"]
             if use_fm:
+                # gs: the feature's layer takes a pre-activation gradient
+                f1_f = [masked_mae_deferred(f, r, m, sums, leaky_slope=gs) for (r, m, _), (f, _, gs) in zip(rf, gf)]
+                # multi-bin features: one loss node per layer covers all bands (one gradient tensor per feature instead of a
+                # zero-filled slice gradient per band)
+                f2_f = [masked_mae_deferred(f, r, m[:r.shape[0] // G].contiguous(), sums, leaky_slope=gs, n_bands=G)
+                        for (r, m, _), (f, _, gs) in zip(rf2, gf2)]
+        sums.reduce()
+        loss_pre, loss_post = loss_pre_f(), loss_post_f()
+        if d_active:
+            l1 = l1_f()
+            l2 = None
+            for lf in l2_f:
+                l = lf()
+                l2 = l if l2 is None else ops.add(l2, l)
+            loss_gan = ops.add(l1, l2, 0.5, 0.5 / G)
+            if use_fm:
                 f1 = None
-                for (r, m, _), (f, _, gs) in zip(rf, gf):       # gs: the feature's layer takes a pre-activation gradient
-                    l = masked_mae(f, r, m, comm=self.comm, leaky_slope=gs)
+                for lf in f1_f:
+                    l = lf()
                     f1 = l if f1 is None else ops.add(f1, l)
                 f1 = ops.scale(f1, 1.0 / len(rf))
-                # multi-bin features: per band j the sum over the feature layers, then the reference's cumulative division
-                # inside the bin loop (train.py:466-472): f2 = sum_j S_j / nf^(G-j) / G.  One loss node per layer covers
-                # all bands (one gradient tensor per feature instead of a zero-filled slice gradient per band).
+                # per band j the sum over the feature layers, then the reference's cumulative division inside the bin loop
+                # (train.py:466-472): f2 = sum_j S_j / nf^(G-j) / G
                 nf = len(rf2)
                 S = None
-                for (r, m, _), (f, _, gs) in zip(rf2, gf2):
-                    Bn = r.shape[0] // G
-                    lb = masked_mae_bands(f, r, m[:Bn].contiguous(), G, comm=self.comm, leaky_slope=gs)
+                for lf in f2_f:
+                    lb = lf()
                     S = lb if S is None else S + lb
                 if getattr(self, "_fm_band_w", None) is None or self._fm_band_w[0] != (nf, G):
                     self._fm_band_w = ((nf, G), torch.tensor([1.0 / (float(nf) ** (G - j)) / G for j in range(G)],

@@ -37,6 +37,15 @@ class OracleTrainer:
         self.gan = O.LSGANState()
         self.d_training = True          # train.py:505-506 sets train() per epoch, :415-416 eval() in the G step
         self.last_norm_d = self.last_norm_g = None
+        # gradients as backward() left them (BEFORE clip_grad_norm_ scales them in place), by parameter name: what the parity
+        # tests compare the HIP path's gradient arenas with
+        self.last_grads_d: Dict[str, torch.Tensor] = {}
+        self.last_grads_g: Dict[str, torch.Tensor] = {}
+
+    @staticmethod
+    def _snapshot(*dicts):
+        return {("%d:" % i if len(dicts) > 1 else "") + k: p.grad.detach().clone()
+                for i, P in enumerate(dicts) for k, p in P.items() if p.requires_grad and p.grad is not None}
 
     # -- discriminator calls -------------------------------------------------
     def _d1(self, x, lens, feats=False):
@@ -59,6 +68,7 @@ class OracleTrainer:
         loss_mbd = loss_mbd / len(rl2)
         loss_d = loss_d1 + loss_mbd
         loss_d.backward()
+        self.last_grads_d = self._snapshot(self.Pp, self.Pm)        # keys "0:<patch name>" / "1:<multi-bin name>"
         clip = self.cfg["training"].get("clip_grad_norm", 1.0)
         if clip:
             self.last_norm_d = float(torch.nn.utils.clip_grad_norm_(self.d_params, clip))
@@ -104,6 +114,7 @@ class OracleTrainer:
         total = (lp * w.get("recon_lambda_pre", 1.0) + lq * w.get("recon_lambda_post", 2.0)
                  + loss_gan * lam_g + loss_fm * lam_fm)
         total.backward()
+        self.last_grads_g = self._snapshot(self.Pg)
         clip = t.get("clip_grad_norm", 1.0)
         if clip:
             self.last_norm_g = float(torch.nn.utils.clip_grad_norm_(self.g_params, clip))

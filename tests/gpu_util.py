@@ -40,6 +40,65 @@ def assert_rel(a, b, tol=1e-4, msg=""):
     assert e <= tol, f"{msg}: relative L2 error {e:.3e} > {tol:.1e}"
 
 
+def _stat(line):
+    """With MQGAN_TEST_STATS=<file> every element-wise check appends what it measured (how the bounds were chosen)."""
+    import os
+    path = os.environ.get("MQGAN_TEST_STATS")
+    if path:
+        with open(path, "a") as f:
+            f.write(line + "\n")
+
+
+def assert_elem(a, b, tol, cmax, msg="", edges=None, taps=False):
+    """Relative L2 AND element-wise bounds for the Winograd / polyphase / nested forms, whose failure modes are LOCAL (a wrong
+    edge tile, a mis-handled causal column): a relative L2 norm over the whole tensor absorbs those.
+
+      * ||a - b|| <= tol ||b||                              (as assert_rel)
+      * max |a - b| <= cmax * rms(b)                        (no element is off by more than the form's own rounding tail)
+      * edges = (first_h, last_h, first_w, last_w) for channels-last (N, H, W, C) tensors: the first / last rows and columns
+        - the ragged last tile, the padding columns of a causal filter - each meet both bounds on their own (relative L2 with
+        a factor 2: a slice has fewer elements to average over)
+      * taps=True for (K, C, R, S) weight gradients: every tap (r, s) meets the relative L2 bound on its own
+    """
+    a = a.detach().double().cpu() if isinstance(a, torch.Tensor) else torch.as_tensor(a).double()
+    b = b.detach().double().cpu() if isinstance(b, torch.Tensor) else torch.as_tensor(b).double()
+    a = a.reshape(b.shape)
+    rms = float(b.pow(2).mean().sqrt()) + 1e-30
+    e = float((a - b).norm() / (b.norm() + 1e-30))
+    m = float((a - b).abs().max()) / rms
+    _stat(f"{msg}\trel_l2={e:.3e}\tmax_over_rms={m:.3e}\ttol={tol:.1e}\tcmax={cmax:.1e}")
+    assert e <= tol, f"{msg}: relative L2 error {e:.3e} > {tol:.1e}"
+    assert m <= cmax, f"{msg}: largest element error {m:.3e} of the rms > {cmax:.1e}"
+    parts = []
+    if edges is not None and b.dim() == 4:
+        fh, lh, fw, lw = edges
+        H, W = b.shape[1], b.shape[2]
+        if fh:
+            parts.append((f"first {fh} row(s)", (slice(None), slice(0, min(fh, H)))))
+        if lh:
+            parts.append((f"last {lh} row(s)", (slice(None), slice(max(H - lh, 0), H))))
+        if fw:
+            parts.append((f"first {fw} column(s)", (slice(None), slice(None), slice(0, min(fw, W)))))
+        if lw:
+            parts.append((f"last {lw} column(s)", (slice(None), slice(None), slice(max(W - lw, 0), W))))
+    if taps and b.dim() == 4:
+        for r in range(b.shape[2]):
+            for s_ in range(b.shape[3]):
+                parts.append((f"tap ({r},{s_})", (slice(None), slice(None), r, s_)))
+    for name, sl in parts:
+        pa, pb = a[sl], b[sl]
+        if pb.numel() == 0:
+            continue
+        if float(pb.norm()) == 0.0:
+            assert float((pa - pb).abs().max()) <= cmax * rms, f"{msg}, {name}: nonzero where the reference is zero"
+            continue
+        pe = float((pa - pb).norm() / pb.norm())
+        pm = float((pa - pb).abs().max()) / rms
+        _stat(f"{msg} [{name}]\trel_l2={pe:.3e}\tmax_over_rms={pm:.3e}")
+        assert pe <= 2 * tol, f"{msg}, {name}: relative L2 error {pe:.3e} > {2 * tol:.1e}"
+        assert pm <= cmax, f"{msg}, {name}: largest element error {pm:.3e} of the rms > {cmax:.1e}"
+
+
 def check_param_grads(module, g, prefix, tol=2e-4, skip=()):
     for name, p in module.named_parameters():
         key = prefix + name

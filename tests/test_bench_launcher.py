@@ -47,4 +47,4 @@ def test_launcher_and_flag_disagreeing_is_an_error():
 
 def test_more_ranks_than_devices_is_an_error_for_rccl():
     out = _run(["--gpus", "2"], MQGAN_BENCH_BACKEND="nccl")          # this box has no GPU: refuse instead of running something else
-    assert out.returncode != 0 and "HIP device" in out.stderr
+    assert out.returncode != 0 and "GPU(s) are visible" in out.stderr

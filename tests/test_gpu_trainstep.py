@@ -215,15 +215,16 @@ def _hifispeech_cfg(precision="fp32"):
     return cfg
 
 
-def test_hifispeech_architecture_step_matches_oracle():
-    """BASELINE config 2's ARCHITECTURE (channels [512,512,512,768], refiner 64, the shipped discriminators, 80 mels)
-    on a small ragged batch: one optimisation step of the HIP path against oracle.train_step.OracleTrainer with the
-    same weights (G.eval(), D in train mode).  This is module-level parity at the widths the benchmark times:
-    C % 16 == 0 wave-uniform tap walks, BN = 128 tiles, split-K weight gradients, stride-parity dgrad at 256-512
-    channels.  Tolerance 1e-4 relative (north star) on losses / reconstructions, 2e-4 on gradient norms,
-    post-Adam tensors within 2e-5 of the oracle's (one Adam step moves a weight by ~lr = 1e-7..1e-4)."""
+_ORACLE_STEP = {}
+
+
+def _oracle_hifispeech_step():
+    """One OracleTrainer step of the config-2 architecture on the small ragged batch; computed once per session (CPU, ~1 min) and
+    shared by every Winograd variant of the test below."""
+    if _ORACLE_STEP:
+        return _ORACLE_STEP
     from oracle import train_step as TS
-    from mqgan_amd.train import Trainer, synthetic_mel
+    from mqgan_amd.train import synthetic_mel
     cfg = _hifispeech_cfg()
     m = cfg["model"]
     pc, mc = m["discriminator_patch"], m["discriminator_multibin"]
@@ -236,11 +237,53 @@ def test_hifispeech_architecture_step_matches_oracle():
     x = torch.from_numpy(np.stack([synthetic_mel(T, 80, 700 + b) for b in range(B)]))
     lens = torch.tensor([T, 41], dtype=torch.int32)
     x[1, 41:] = 0.0
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    otr = TS.OracleTrainer(TS.make_leaves(Pg), TS.make_leaves(Pp), TS.make_leaves(Pm), cfg, gen_training=False)
+    want = otr.step(x, lens)
+    _ORACLE_STEP.update(cfg=cfg, Pg=Pg, Pp=Pp, Pm=Pm, x=x, lens=lens, otr=otr, want=want)
+    return _ORACLE_STEP
+
+
+def _arena_grads(arena, *modules):
+    """{"<i>:<parameter name>": gradient} out of a FlatArena's gradient buffer (i = position of the module in ``modules``;
+    plain names for one module), the arena's parameters found by identity."""
+    off = {id(p): o for p, o in zip(arena.params, arena.offsets)}
+    out = {}
+    for i, mod in enumerate(modules):
+        for name, p in mod.named_parameters():
+            if id(p) in off:
+                o = off[id(p)]
+                out[(f"{i}:" if len(modules) > 1 else "") + name] = arena.flat_grad[o:o + p.numel()].view_as(p).detach().cpu()
+    return out
+
+
+# (MQGAN_WINO_TILE, MQGAN_WINOW_MINC): every shipped 2-D tile meets the oracle step once, with and without the column forms.
+# "45" is what "auto" picks for this test's 64 x 90 refiner images (and for config 2's).
+@pytest.mark.parametrize("wino_tile,winow_minc", [("45", 128), ("3", 128), ("4", 128), ("45", 0), ("auto", 128)],
+                         ids=["F4x5", "F3x3", "F4x4", "F4x5-no-column-forms", "auto"])
+def test_hifispeech_architecture_step_matches_oracle(monkeypatch, wino_tile, winow_minc):
+    """BASELINE config 2's ARCHITECTURE (channels [512,512,512,768], refiner 64, the shipped discriminators, 80 mels)
+    on a small ragged batch: one optimisation step of the HIP path against oracle.train_step.OracleTrainer with the
+    same weights (G.eval(), D in train mode), once per Winograd variant.  This is module-level parity at the widths the
+    benchmark times: C % 16 == 0 wave-uniform tap walks, BN = 128 tiles, split-K weight gradients, the Winograd / polyphase /
+    nested forms of DESIGN 3.6-3.9 (every layer >= 64 channels takes one).
+
+    Bars: losses / reconstructions 1e-4 relative (north star), gradient norms 2e-4; EVERY parameter gradient of both steps
+    (before clipping) against the oracle's: per tensor relative L2 <= 1e-4 and largest element error <= 5e-4 of the tensor's
+    largest element; after the first Adam step every weight whose gradient is not within rounding of zero is within 5 % of one
+    step of the oracle's, the others within two steps."""
+    from mqgan_amd import ops
+    from mqgan_amd.train import Trainer
+    monkeypatch.setattr(ops, "WINO_TILE", wino_tile)
+    monkeypatch.setattr(ops, "WINOW_MIN_CHANNELS", winow_minc)
+    o = _oracle_hifispeech_step()
+    cfg, otr, want, x, lens = o["cfg"], o["otr"], o["want"], o["x"], o["lens"]
+    B, T = x.shape[0], x.shape[1]
 
     tr = Trainer(cfg, device=DEV, build_data=False)
-    tr.generator.load_state_dict(Pg, strict=True)
-    tr.patch_discriminator.load_state_dict(Pp, strict=True)
-    tr.multibin_discriminator.load_state_dict(Pm, strict=True)
+    tr.generator.load_state_dict(o["Pg"], strict=True)
+    tr.patch_discriminator.load_state_dict(o["Pp"], strict=True)
+    tr.multibin_discriminator.load_state_dict(o["Pm"], strict=True)
     tr.arena_g.rebind()
     tr.arena_d.rebind()
     tr.generator.eval()
@@ -248,23 +291,51 @@ def test_hifispeech_architecture_step_matches_oracle():
     tr.multibin_discriminator.train()
     tr.epoch = 1
 
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
-    otr = TS.OracleTrainer(TS.make_leaves(Pg), TS.make_leaves(Pp), TS.make_leaves(Pm), cfg, gen_training=False)
-    want = otr.step(x, lens)
-
     xd, ld = x.to(DEV), lens.to(DEV)
     recon_pre, recon_post = tr.generator(xd, ld)
     close(recon_pre, want["recon_pre"], rtol=1e-4, atol=5e-5, msg="recon_pre")
     close(recon_post, want["recon_post"], rtol=1e-4, atol=5e-5, msg="recon_post")
     idx = tr.generator.encode(xd, (torch.arange(T, device=DEV)[None, :] >= ld[:, None])[:, None, :])
     assert len(torch.unique(idx)) > 8, "degenerate latent: the FSQ path is not exercised"
-    out = tr.train_step(xd, ld)
+    timer = ops.KernelTimer()
+    ops.TIMER = timer
+    try:
+        out = tr.train_step(xd, ld)
+    finally:
+        ops.TIMER = None
     for k in ("loss_d", "loss_g_total", "loss_recon_pre", "loss_recon_post", "loss_gan"):
         np.testing.assert_allclose(float(out[k]), float(want[k]), rtol=1e-4, atol=1e-6, err_msg=k)
     np.testing.assert_allclose(float(tr.optimizer_d.grad_norm()), otr.last_norm_d, rtol=2e-4)
     np.testing.assert_allclose(float(tr.optimizer_g.grad_norm()), otr.last_norm_g, rtol=2e-4)
     np.testing.assert_allclose(tr.gan_loss._state[:2].cpu().numpy(), [otr.gan.ema_real.item(), otr.gan.ema_fake.item()],
                                rtol=1e-4, atol=1e-7)
+
+    # ---- gradients, before clipping: every parameter of both steps
+    from gpu_util import _stat
+    got_g = _arena_grads(tr.arena_g, tr.generator)
+    got_d = _arena_grads(tr.arena_d, tr.patch_discriminator, tr.multibin_discriminator)
+    near_zero, failures = {}, []
+    for tag, got, ref in (("G", got_g, otr.last_grads_g), ("D", got_d, otr.last_grads_d)):
+        assert len(ref) > 20 and set(ref) <= set(got), (tag, sorted(set(ref) - set(got))[:5])
+        for k, gw in ref.items():
+            gg = got[k].double()
+            gw = gw.double()
+            scale = float(gw.abs().max())
+            if scale == 0.0:                                  # weight norm over a scalar (the 1 -> 1 depthwise filter): d/dv is exactly 0
+                assert float(gg.abs().max()) <= 1e-12, f"{tag} {k}: gradient must be zero, got {float(gg.abs().max()):.2e}"
+                continue
+            rel = float((gg - gw).norm() / gw.norm())
+            mx = float((gg - gw).abs().max()) / scale
+            _stat(f"oracle-step {wino_tile}/{winow_minc} grad {tag} {k}\trel_l2={rel:.3e}\tmax_over_max={mx:.3e}\tn={gw.numel()}")
+            if rel > 1e-4 or mx > 5e-4:
+                failures.append(f"{tag} {k}: relative L2 {rel:.2e}, largest element error {mx:.2e} of the largest element")
+            near_zero[(tag, k)] = (gw.abs() <= 1e-3 * scale).numpy()
+    assert not failures, "gradients against the oracle (bars 1e-4 / 5e-4):\n  " + "\n  ".join(failures)
+    # the layers this variant is about did run in their Winograd forms
+    names = " ".join(timer.summary().keys())
+    assert "conv_nt_kernel" in names
+
+    # ---- weights after the first Adam step
     sd = tr.generator.state_dict()
     for k in ("refiner.ups.0.conv.conv1.parametrizations.weight.original1", "refiner.mid.conv2.parametrizations.weight.original1",
               "refiner.pre.conv2.bias", "encoder_blocks.2.conv1.parametrizations.weight.original1", "decoder_blocks.0.conv2.weight_v",
@@ -273,24 +344,26 @@ def test_hifispeech_architecture_step_matches_oracle():
     pd, md = tr.patch_discriminator.state_dict(), tr.multibin_discriminator.state_dict()
     lr_d = cfg["training"]["lr"] * cfg["training"]["lr_d_factor"]
 
-    def close_first_adam_step(got, want, rtol, msg):
-        """The first Adam step moves every weight by lr * g / (|g| + 1e-8) = +-lr_d (1.15e-4) except where |g| ~ 1e-8: there the
-        step size itself is rounding-sensitive, so the bound is a fraction (5 %) of one step.  Beyond that, the SIGN of a gradient
-        element within rounding of zero is not defined at f32: one LeakyReLU pre-activation of the discriminator that two f32
-        algorithms place on different sides of zero (|h| ~ 1e-6 of the rms: tests/test_gpu_kernels.py, the 1-D Winograd chain)
-        changes one pixel's gradient by a factor 5, which at this test's image sizes (a few thousand pixels per weight) flips the
-        sign of some tens of near-zero elements of that output channel's filter - each a difference of exactly two steps after
-        Adam.  So: at most 1e-4 of a tensor's elements may differ, and none by more than two steps."""
-        a, b = got.detach().float().cpu().numpy(), want.detach().float().cpu().numpy()
+    def close_first_adam_step(got, ref, rtol, msg, nz):
+        """The first Adam step moves every weight by lr * g / (|g| + 1e-8) = +-lr_d (1.15e-4) except where |g| ~ 1e-8.  Where the
+        oracle's gradient element is NOT within rounding of zero (|g| > 1e-3 of the tensor's largest: the gradients themselves
+        were just held to 5e-4 of it) the HIP weight must be within 5 % of one step of the oracle's - a wrong gradient SIGN there
+        is two steps.  The remaining elements (``nz``) may land on either side: the sign of a gradient element within rounding of
+        zero is not defined at f32; they are held to two steps."""
+        a, b = got.detach().float().cpu().numpy(), ref.detach().float().cpu().numpy()
         diff = np.abs(a - b)
-        bad = diff > 6e-6 + rtol * np.abs(b)
-        assert bad.mean() <= 1e-4, f"{msg}: {int(bad.sum())} of {bad.size} elements beyond 5 % of an Adam step"
+        tight = ~nz.reshape(diff.shape)
+        assert tight.mean() > 0.9, f"{msg}: the tight bound covers only {tight.mean():.2f} of the tensor"
+        bad = (diff > 6e-6 + rtol * np.abs(b)) & tight
+        assert not bad.any(), f"{msg}: {int(bad.sum())} of {int(tight.sum())} elements with a well-defined gradient sign are beyond 5 % of an Adam step"
         assert diff.max() <= 2.02 * lr_d, f"{msg}: largest difference {diff.max():.3e} is more than two Adam steps ({lr_d:.3e})"
 
     for k in ("convs.1.weight_orig", "convs.3.weight_orig", "convs.5.weight_orig", "se_block.fc1.weight", "convs.2.bias"):
-        close_first_adam_step(pd[k], otr.Pp[k], 2e-5, "patch " + k)
-    for k in ("discriminators.0.convs.2.weight_orig", "discriminators.7.convs.4.weight_orig", "discriminators.3.convs.1.weight_u"):
-        close_first_adam_step(md[k], otr.Pm[k], 1e-4, "multibin " + k)
+        close_first_adam_step(pd[k], otr.Pp[k], 2e-5, "patch " + k, near_zero[("D", "0:" + k)])
+    for k in ("discriminators.0.convs.2.weight_orig", "discriminators.7.convs.4.weight_orig"):
+        close_first_adam_step(md[k], otr.Pm[k], 1e-4, "multibin " + k, near_zero[("D", "1:" + k)])
+    close(md["discriminators.3.convs.1.weight_u"], otr.Pm["discriminators.3.convs.1.weight_u"], rtol=1e-4, atol=6e-6,
+          msg="spectral-norm u after one power iteration")
     del tr
     torch.cuda.empty_cache()
 
