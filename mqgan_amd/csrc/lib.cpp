@@ -9,7 +9,13 @@ thread_local char g_kernel[128] = "";
 // 2: mqConvDesc gained `precision`; mq_conv_wgrad_bias, mq_taps_*, mq_cast_bf16, mq_conv_*_h added
 // 3: bf16-storage kernels (mq_h2_*, mq_conv_*_h2, mq_*_h); losses split into sums / final (global normalisers under data
 //    parallelism, per-element masks); deterministic codebook EMA with its own workspace query
+// 4: mq_conv_dgrad_gated / mq_conv_dgrad_h2_gated (the producer's LeakyReLU' / mask in the dgrad store), mq_wino_* (F(2x2, 3x3)),
+//    mq_spectral_prep_bands, mq_multi_gather
 // 5: mq_multi_gather_args (arena fill table by value), mq_last_kernel, mq_l2_screen_* / mq_l2_argmin_screened
+// 6: mq_wino3_* (F(3x3, 3x3), the polyphase *_s2d / *_d2s transforms, mq_wino3_dy_fused), mq_wino1d_* (F(m, 3) along the rows,
+//    mq_wino1d_tile)
+// 7: mq_winon_* (F(4x4) / F(4x5, 3x3): tile passed as (mh, mw)), mq_winow_* (F(4,3) / F(4,5) / F(2,7) along the columns),
+//    mq_winon_dy_fused / mq_winon_dy_fused_rows
 extern "C" int mq_abi_version(void) { return 7; }
 extern "C" const char *mq_last_error(void) { return mq::g_err; }
 extern "C" const char *mq_last_kernel(void) { return mq::g_kernel; }

@@ -142,8 +142,16 @@ def run_discriminators(bands: List[MelSpectrogramPatchDiscriminator2D], x, x_len
         return _run_discriminators(bands, x, x_lengths, return_features, need_input_grad, detach_params, pregate)
 
 
+# Parity-test hook: a list here receives, per _run_discriminators call, the list over layers of (activation > 0) as host bool
+# tensors (G*B, H, W, C) - which branch every LeakyReLU took.  A float64 / oracle twin of the step can then take the same
+# branches: two f32 algorithms disagree about the sign of a pre-activation within rounding of zero, and one such element changes
+# a whole receptive field of the gradients; which branch it takes is not a property of the convolutions under test.
+GATE_CAPTURE = None
+
+
 def _run_discriminators(bands, x, x_lengths, return_features, need_input_grad, detach_params, pregate=False):
     G = len(bands)
+    captured = [] if GATE_CAPTURE is not None else None
     d0 = bands[0]
     B, T, Fq = x.shape
     training = d0.training
@@ -192,4 +200,8 @@ def _run_discriminators(bands, x, x_lengths, return_features, need_input_grad, d
             out = ops.conv_leaky(out, wk, wc, bias, desc, mask, dmap, out_f32=(i >= n - 2))
             if return_features and d0.ret_features_map[i]:
                 feats.append((ops.to_f32(out), mask))
+        if captured is not None:
+            captured.append((ops.to_f32(out).detach() > 0).cpu())
+    if captured is not None:
+        GATE_CAPTURE.append(captured)
     return ops.to_f32(out), mask, feats

@@ -22,12 +22,23 @@ def L():
     return _lib.load()
 
 
+# MQGAN_POISON=1 (debugging): every buffer the kernels are handed "uninitialised" is filled with NaN first, so that an element
+# some kernel reads before any kernel wrote it shows up in the results instead of depending on what the allocator had there
+_POISON = os.environ.get("MQGAN_POISON") == "1"
+
+
 def _empty(shape, like, dtype=F32):
-    return torch.empty(shape, dtype=dtype, device=like.device)
+    t = torch.empty(shape, dtype=dtype, device=like.device)
+    if _POISON and t.is_floating_point():
+        t.fill_(float("nan"))
+    return t
 
 
 def _ws_bytes(nbytes, like):
-    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=like.device)
+    t = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=like.device)
+    if _POISON:
+        t.fill_(0xFF)            # four 0xFF bytes are a NaN
+    return t
 
 
 # ----------------------------------------------------------------------------- dropout seeds
@@ -414,6 +425,8 @@ def _wino_ok(d: ConvDesc) -> bool:
             and d.precision in (PRECISIONS["f32"], PRECISIONS["f32x3"]) and d.C % 16 == 0 and d.K % 16 == 0):
         return False
     tile = _wino_tile(d.H, d.W)
+    if tile != (2, 2) and d.K > 1024:      # the fused dy pass of the larger tiles (the only one they have) takes K <= 1024
+        return False
     if tile != (2, 2) and WINO_MIN_CHANNELS == 128 and "MQGAN_WINO_MINC" not in os.environ:
         return min(d.C, d.K) >= 64 and d.C * d.K >= (45 if tile == (3, 3) else 32) * (d.C + d.K)
     return min(d.C, d.K) >= WINO_MIN_CHANNELS

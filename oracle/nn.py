@@ -319,10 +319,13 @@ def _se_masked(P, prefix, x, padded_mask):
 
 
 def patch_discriminator(P: Params, prefix: str, x: torch.Tensor, lengths: torch.Tensor, strides, training: bool,
-                        return_features=False):
+                        return_features=False, gates=None):
     """discriminators.py:196-242.  x (B, T, F) -> logits (B,1,H,W), patch_mask (True = VALID)[, features].
 
     ``strides``: per-conv (sh, sw); paddings are (k-1)//2 per dim (:136,159).
+    ``gates`` (parity tests only): per layer a bool tensor (B, C, H, W) saying which LeakyReLU branch each element takes
+    (True: identity, False: slope) instead of the sign of the pre-activation - the branches another f32 implementation took,
+    so that elements within rounding of zero do not decide the comparison.
     """
     B, T, Fq = x.shape
     padded = sequence_mask(T, lengths)[:, None, None, :].expand(-1, 1, Fq, -1)       # :184-193
@@ -335,8 +338,8 @@ def patch_discriminator(P: Params, prefix: str, x: torch.Tensor, lengths: torch.
         w = sn_weight(P, prefix + f"convs.{i}.", training)
         kh, kw = w.shape[-2:]
         sh, sw = strides[i]
-        out = F.leaky_relu(F.conv2d(out, w, P[prefix + f"convs.{i}.bias"], stride=(sh, sw),
-                                    padding=((kh - 1) // 2, (kw - 1) // 2)), 0.2)
+        out = F.conv2d(out, w, P[prefix + f"convs.{i}.bias"], stride=(sh, sw), padding=((kh - 1) // 2, (kw - 1) // 2))
+        out = F.leaky_relu(out, 0.2) if gates is None else torch.where(gates[i], out, 0.2 * out)
         if sh > 1 or sw > 1:
             padded = F.max_pool2d(padded.float(), kernel_size=(sh, sw), stride=(sh, sw), ceil_mode=True).bool()
         out = out.masked_fill(padded, 0.0)
@@ -364,15 +367,17 @@ def multibin_strides(n_convs, n_no_strides):
 
 
 def multibin_discriminator(P: Params, prefix: str, x, lengths, n_bins: int, n_no_strides: int, training: bool,
-                           return_features=False):
-    """discriminators.py:292-311."""
+                           return_features=False, gates=None):
+    """discriminators.py:292-311.  ``gates``: as patch_discriminator, every tensor stacked over the bands (n_bins * B, ...)."""
     n_convs = 0
     while f"{prefix}discriminators.0.convs.{n_convs}.bias" in P:
         n_convs += 1
     strides = multibin_strides(n_convs, n_no_strides)
     outs, masks, feats = [], [], []
     for j, sub in enumerate(torch.split(x, x.shape[-1] // n_bins, dim=-1)):
-        r = patch_discriminator(P, f"{prefix}discriminators.{j}.", sub, lengths, strides, training, return_features)
+        B = x.shape[0]
+        gj = None if gates is None else [g[j * B:(j + 1) * B] for g in gates]
+        r = patch_discriminator(P, f"{prefix}discriminators.{j}.", sub, lengths, strides, training, return_features, gj)
         outs.append(r[0])
         masks.append(r[1])
         if return_features:

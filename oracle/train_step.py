@@ -48,11 +48,21 @@ class OracleTrainer:
                 for i, P in enumerate(dicts) for k, p in P.items() if p.requires_grad and p.grad is not None}
 
     # -- discriminator calls -------------------------------------------------
+    def _gates(self):
+        """Parity tests: ``self.gate_source`` = per discriminator call of a step (in this class's call order) the list over
+        layers of LeakyReLU branches (B or n_bins * B, C, H, W) another implementation took; None = the sign of the pre-activation."""
+        src = getattr(self, "gate_source", None)
+        if src is None:
+            return None
+        g = src[self._gate_call]
+        self._gate_call += 1
+        return g
+
     def _d1(self, x, lens, feats=False):
-        return O.patch_discriminator(self.Pp, "", x, lens, self.patch_strides, self.d_training, feats)
+        return O.patch_discriminator(self.Pp, "", x, lens, self.patch_strides, self.d_training, feats, self._gates())
 
     def _d2(self, x, lens, feats=False):
-        return O.multibin_discriminator(self.Pm, "", x, lens, self.n_bins, self.n_no_strides, self.d_training, feats)
+        return O.multibin_discriminator(self.Pm, "", x, lens, self.n_bins, self.n_no_strides, self.d_training, feats, self._gates())
 
     # -- train.py:380-410 ------------------------------------------------------
     def train_discriminator(self, real, recon, lens):
@@ -125,6 +135,7 @@ class OracleTrainer:
 
     # -- train.py:516-537 ------------------------------------------------------
     def step(self, x, lens, d_active=True):
+        self._gate_call = 0
         recon_pre, recon_post = O.preencoder_forward(self.Pg, x, lens, self.levels, self.gen_training, self.p_drop)
         loss_d = self.train_discriminator(x, recon_post, lens) if d_active else 0.0
         out = self.train_generator(x, recon_pre, recon_post, lens, d_active)

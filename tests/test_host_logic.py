@@ -212,6 +212,9 @@ def test_winograd_form_selection_per_layer():
     assert ops._wino_ok(ops.conv_desc(32, 512, 90, 64, 64, 3, 3, pad=(1, 1), precision=f32))           # C K / (C + K) = 32
     assert not ops._wino_ok(ops.conv_desc(32, 512, 90, 48, 64, 3, 3, pad=(1, 1), precision=f32))
     assert not ops._wino_ok(ops.conv_desc(32, 256, 90, 128, 128, 3, 3, pad=(1, 1), precision="bf16"))
+    # the larger tiles' fused dy pass takes K <= 1024: wider layers stay on the direct kernels instead of failing in backward
+    assert ops._wino_ok(ops.conv_desc(2, 64, 90, 1024, 1024, 3, 3, pad=(1, 1), precision=f32))
+    assert not ops._wino_ok(ops.conv_desc(2, 64, 90, 512, 1040, 3, 3, pad=(1, 1), precision=f32))
     patch = ops.conv_desc(64, 80, 256, 256, 256, 5, 5, stride=(2, 2), pad=(2, 2), precision=f32)
     assert ops._wino_s2d_ok(patch) and ops._s2d_tile(patch) == (4, 5)
     mb35 = ops.conv_desc(512, 10, 512, 128, 128, 3, 5, pad=(1, 2), groups=8, precision=f32)

@@ -24,8 +24,8 @@ for kv in sys.argv[1:]:
     old = getattr(ops, k)
     setattr(ops, k, type(old)(v) if not isinstance(old, str) else v)
     print("ops.%s = %r" % (k, getattr(ops, k)))
-o = T._oracle_hifispeech_step()
-cfg, otr, want, x, lens = o["cfg"], o["otr"], o["want"], o["x"], o["lens"]
+o = T._oracle_hifispeech_inputs()
+cfg, x, lens = o["cfg"], o["x"], o["lens"]
 tr = Trainer(cfg, device="cuda", build_data=False)
 tr.generator.load_state_dict(o["Pg"], strict=True)
 tr.patch_discriminator.load_state_dict(o["Pp"], strict=True)
@@ -33,7 +33,15 @@ tr.multibin_discriminator.load_state_dict(o["Pm"], strict=True)
 tr.arena_g.rebind(); tr.arena_d.rebind()
 tr.generator.eval(); tr.patch_discriminator.train(); tr.multibin_discriminator.train()
 tr.epoch = 1
+from mqgan_amd import discriminators as D_
+SHARE = os.environ.get("SHARE_GATES", "1") == "1"      # the oracle takes the LeakyReLU branches of the HIP run
+if SHARE:
+    D_.GATE_CAPTURE = []
 out = tr.train_step(x.cuda(), lens.cuda())
+o = T._oracle_hifispeech_step(D_.GATE_CAPTURE if SHARE else None)
+D_.GATE_CAPTURE = None
+otr, want = o["otr"], o["want"]
+print("LeakyReLU branches shared with the oracle:", SHARE)
 for k in ("loss_d", "loss_g_total", "loss_recon_pre", "loss_recon_post", "loss_gan"):
     print(f"{k:16s} hip {float(out[k]):.8f} oracle {float(want[k]):.8f} rel {abs(float(out[k]) - float(want[k])) / abs(float(want[k])):.1e}")
 print("norm_d", float(tr.optimizer_d.grad_norm()), otr.last_norm_d, " norm_g", float(tr.optimizer_g.grad_norm()), otr.last_norm_g)
@@ -61,3 +69,10 @@ for tag, got, ref, pref in (("G refiner", got_g, otr.last_grads_g, "refiner."), 
             continue
         rels.append(float((got[k].double() - gw.double()).norm() / gw.double().norm()))
     print(f"SUMMARY {tag:12s} tensors {len(rels):3d} median rel {statistics.median(rels):.2e} max {max(rels):.2e} above 1e-4: {sum(r > 1e-4 for r in rels)}")
+for tag, got, ref, hip_norm, o_norm in (("G", got_g, otr.last_grads_g, float(tr.optimizer_g.grad_norm()), otr.last_norm_g),
+                                        ("D", got_d, otr.last_grads_d, float(tr.optimizer_d.grad_norm()), otr.last_norm_d)):
+    extra = {k: float(v.double().norm()) for k, v in got.items() if k not in ref}
+    print(tag, "HIP-only tensors with a gradient:", {k: v for k, v in extra.items() if v > 0})
+    n_ref = sum(float(v.double().pow(2).sum()) for v in ref.values()) ** 0.5
+    n_got = sum(float(v.double().pow(2).sum()) for v in got.values()) ** 0.5
+    print(f"{tag} norm: HIP kernel {hip_norm:.7f}  float64 over the HIP arena {n_got:.7f} | oracle clip_grad_norm_ {o_norm:.7f}  float64 over the oracle's grads {n_ref:.7f}")
