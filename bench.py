@@ -50,7 +50,7 @@ def kernel_build_id():
     """Hash of the conv kernel sources: ties a PMC traffic file to the build it was measured on."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("gemm_core.h", "igemm.hip", "igemm_h2.hip", "winograd.hip", "winograd3.hip", "winogradn.hip", "wino1d.hip", "winow.hip", "wino_tables.h", "common.h"):
+    for f in ("gemm_core.h", "igemm.hip", "igemm_h2.hip", "winogradn.hip", "plan.cpp", "wino1d.hip", "winow.hip", "wino_tables.h", "common.h"):
         with open(os.path.join(ROOT, "mqgan_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

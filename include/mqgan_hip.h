@@ -422,65 +422,25 @@ int mq_masked_mae_sums(const float *pred, const float *target, const uint8_t *pa
 int mq_masked_mae_bwd(const float *pred, const float *target, const uint8_t *padded, int B, int H, int W, int C,
                       const float *sums2, const float *gout, float leaky_slope, float *dpred, mqStream stream);
 
-/* ------------------------------------------------------------------ Winograd F(2x2, 3x3)
- * The refiner's 3x3 / stride 1 / pad 1 convolutions (preencoder.py:86-102) as 16 batch-grouped GEMMs around HBM-bound
- * transforms (csrc/winograd.hip): 16 multiplications per 4 outputs instead of 36, f32 products and accumulation as in
- * mq_conv_fprop.  tiles = N * ceil(H/2) * ceil(W/2); every tensor f32, channels-last, channel counts multiples of 4.
- *   forward : V = input_transform(x) (16, tiles, C); U = weight_transform(w_krsc, flip 0) (16, K, C);
- *             M = mq_conv_fprop(desc{N = 16 * N * ceil(H/2), H = 1, W = ceil(W/2), C, K, R = S = 1, groups = 16}, V, U)
- *             (16, tiles, K);
- *             y = output_transform(M, bias)
- *   dgrad   : the same with dy in place of x and weight_transform(w_krsc, flip 1) (16, C, K) (the filter rotated by 180
- *             degrees and transposed)
- *   wgrad   : V as above; Z = dy_transform(dy) (16, tiles, K); P = mq_conv_wgrad(that desc, V, Z) (16, K, C);
- *             dw_krsc = wgrad_inverse(P) */
-int mq_wino_input_transform(const float *x, int N, int H, int W, int C, float *V, mqStream stream);
-int mq_wino_dy_transform(const float *dy, int N, int H, int W, int K, float *Z, mqStream stream);
-int mq_wino_output_transform(const float *M, const float *bias, int N, int H, int W, int K, float *y, mqStream stream);
-/* Backward of such a layer in ONE pass over dy: Z as mq_wino_dy_transform, Vd = mq_wino_input_transform(dy) (the input gradient's
- * transformed operand) and deterministic per-block column sums for the bias gradient: bias_partial is
- * [mq_wino_dy_fused_rows(N, H, W, K)][K] (0 rows: shape not supported, K > 1024), db[k] = sum over its rows (mq_colsum).  Z and
- * Vd are bit-identical to the separate transforms; the column sums are deterministic in an order of their own. */
-int mq_wino_dy_fused_rows(int N, int H, int W, int K);
-int mq_wino_dy_fused(const float *dy, int N, int H, int W, int K, float *Z, float *Vd, float *bias_partial, mqStream stream);
-int mq_wino_weight_transform(const float *w_krsc, int K, int C, int flip_transpose, float *U, mqStream stream);
-int mq_wino_wgrad_inverse(const float *P, int K, int C, float *dw_krsc, mqStream stream);
-
-/* The larger tile, F(3x3, 3x3) (csrc/winograd3.hip): 25 positions per 3x3 output tile (2.78 multiplications per output instead
- * of 4; transformed tensors 2.78x the activation instead of 4x), one-layer error 2.7e-6 of the output rms against 1.5e-6.
- * Same call sequence with tiles = N * ceil(H/3) * ceil(W/3) and groups = 25 in the GEMM descriptor
- * (N = 25 * N * ceil(H/3), H = 1, W = ceil(W/3)); mq_wino3_dy_fused is mq_wino_dy_fused (Vd may be NULL: Z and sums only). */
-int mq_wino3_input_transform(const float *x, int N, int H, int W, int C, float *V, mqStream stream);
-/* act 0: y = A^T M A + bias; act 2: LeakyReLU(slope) then zero where padded[(m / d1) * d2 + m % d3] (m = output pixel), as
- * mq_conv_fprop_leaky */
-int mq_wino3_output_transform(const float *M, const float *bias, int N, int H, int W, int K, int act, float slope, const uint8_t *padded,
-                              int64_t d1, int64_t d2, int64_t d3, float *y, mqStream stream);
-int mq_wino3_weight_transform(const float *w_krsc, int K, int C, int flip_transpose, float *U, mqStream stream);
-int mq_wino3_wgrad_inverse(const float *P, int K, int C, float *dw_krsc, mqStream stream);
-int mq_wino3_dy_fused_rows(int N, int H, int W, int K);
-int mq_wino3_dy_fused(const float *dy, int N, int H, int W, int K, float *Z, float *Vd, float *bias_partial, mqStream stream);
-/* 5x5 / stride 2 / pad 2 layers (discriminators.py:86-173, the patch discriminator's widest) as F(3x3, 3x3) over the four
- * polyphase components of the input (even H and W; x is (N, H, W, C), y (N, H/2, W/2, K)): X'[p][q][(rho, sigma, c)] =
- * x[2p + rho][2q + sigma][c] convolved with g'[(rho, sigma, c)][a][b] = w[c][2a + rho][2b + sigma] - 11.1 products per output and
- * channel pair instead of 25.  X' is never materialised: tiles = N * ceil(H/6) * ceil(W/6), GEMM descriptor with C' = 4C.
- *   forward : V = input_transform_s2d(x) (25, tiles, 4C);  U = weight_transform_s2d(w_krsc (K, 25, C), flip 0) (25, K, 4C);
- *             M = mq_conv_fprop(...);  y = mq_wino3_output_transform(M, bias, N, H/2, W/2, K, act, ...)
- *   dgrad   : (Z, Vd, sums) = mq_wino3_dy_fused(dy, N, H/2, W/2, K);  U' = weight_transform_s2d(flip 1) (25, 4C, K);
- *             M' = mq_conv_fprop(K -> 4C);  dx = output_transform_d2s(M'): written at full resolution, optionally gated by the
- *             producer layer's LeakyReLU' and mask (mq_conv_dgrad_gated's contract)
- *   wgrad   : P = mq_conv_wgrad(V, Z) (25, K, 4C);  dw_krsc (K, 25, C) = wgrad_inverse_s2d(P) */
-int mq_wino3_input_transform_s2d(const float *x, int N, int H, int W, int C, float *V, mqStream stream);
-int mq_wino3_weight_transform_s2d(const float *w_krsc, int K, int C, int flip_transpose, float *U, mqStream stream);
-int mq_wino3_output_transform_d2s(const float *M, int N, int H, int W, int C, const float *gate, float slope, const uint8_t *padded_in,
-                                  int64_t d1, int64_t d2, int64_t d3, float *dx, mqStream stream);
-int mq_wino3_wgrad_inverse_s2d(const float *P, int K, int C, float *dw_krsc, mqStream stream);
-
-/* ------------------------------------------------------------------ Winograd F(mh x mw, 3x3), tiles 4 x 4 and 4 x 5
- * The same layers, transforms, layouts and call sequence as the mq_wino3_* functions above (plain and polyphase form), with
- * (mh + 2)(mw + 2) positions per tile of mh x mw outputs: 36 per 16 (2.25 products per output) or 42 per 20 (2.10) instead of
- * 25 per 9 (2.78).  Transform matrices per axis: csrc/wino_tables.h (point sets chosen for f32 accuracy: 1.2x / 1.8x the error of
- * F(3x3, 3x3), csrc/winogradn.hip).  th = ceil(H / mh), tw = ceil(W / mw) tiles per image; the GEMM descriptor is
- * (N = np * N * th, H = 1, W = tw, groups = np), np = (mh + 2)(mw + 2).  (mh, mw) = (4, 4) or (4, 5). */
+/* ------------------------------------------------------------------ Winograd F(mh x mw, 3x3), tiles 3 x 3, 4 x 4 and 4 x 5
+ * The refiner's 3x3 / stride 1 / pad 1 convolutions (preencoder.py:86-102) as (mh + 2)(mw + 2) batch-grouped GEMMs around
+ * HBM-bound transforms (csrc/winogradn.hip): 25 products per 9 outputs (2.78 per output), 36 per 16 (2.25) or 42 per 20 (2.10)
+ * instead of 9 per output; f32 products on the same MFMA engine, f32 accumulation.  Transform matrices per axis:
+ * csrc/wino_tables.h (point sets chosen for f32 accuracy).  th = ceil(H / mh), tw = ceil(W / mw) tiles per image, np =
+ * (mh + 2)(mw + 2) positions; the GEMM descriptor is (N = np * N * th, H = 1, W = tw, R = S = 1, groups = np).
+ *   forward : V = input_transform(x) (np, tiles, C);  U = weight_transform(w, flip 0) (np, K, C);  M = mq_conv_fprop(that desc,
+ *             V, U) (np, tiles, K);  y = output_transform(M, bias [, act 2: LeakyReLU(slope) + mask as mq_conv_fprop_leaky])
+ *   dgrad   : the same with dy as input and weight_transform(w, flip 1) = U of the filter rotated by 180 degrees, (np, C, K)
+ *   wgrad   : Z = A dY A^T (mq_winon_dy_fused, which in the same pass over dy also writes Vd = B^T dy B for the input gradient
+ *             and per-block column sums [mq_winon_dy_fused_rows(...)][K] for the bias gradient; Vd / sums may be NULL; K <= 1024);
+ *             P = mq_conv_wgrad(that desc, V, Z) (np, K, C);  dw = wgrad_inverse(P) (KRSC)
+ * The *_s2d / *_d2s functions are the same tiles over the POLYPHASE form of a 5x5 / stride-2 / pad-2 layer (the patch
+ * discriminator's wide layers, discriminators.py:86-173): x[2p + rho][2q + sigma][c] as 4C channels on the (H/2, W/2) grid and
+ * g'[(rho, sigma, c)][a][b] = w[c][2a + rho][2b + sigma] (zero where an index would be 5) - 11.1 / 9 / 8.4 instead of 25 products
+ * per output.  input_transform_s2d reads x with that indexing (X' is never materialised); output_transform_d2s writes the input
+ * gradient at full resolution and applies the producer layer's gate (as mq_conv_dgrad_gated).  H and W even.
+ * mq_conv_plan / mq_conv_*_planned below run these sequences; the entry points stay public for callers with their own scheduling.
+ * (ABI 8 folded the F(3x3) kernels of mq_wino3_* into these and removed F(2x2, 3x3), mq_wino_*: no configuration selected it.) */
 int mq_winon_input_transform(const float *x, int N, int H, int W, int C, float *V, int mh, int mw, mqStream stream);
 int mq_winon_output_transform(const float *M, const float *bias, int N, int H, int W, int K, int act, float slope, const uint8_t *padded,
                               int64_t d1, int64_t d2, int64_t d3, float *y, int mh, int mw, mqStream stream);
@@ -563,6 +523,79 @@ int mq_multi_gather(const int64_t *table_dev, int n_tensors, int64_t total_block
  * table is consumed before the call returns: the caller may rewrite it immediately, however far the host runs ahead of
  * the stream (what the data-parallel gradient exchange uses; train.py:140-197 makes shapes, hence addresses, vary per step). */
 int mq_multi_gather_args(const int64_t *table_host, int n_tensors, float *dst, mqStream stream);
+
+/* ------------------------------------------------------------------ algorithm choice and planned execution (csrc/plan.cpp)
+ * WHICH form a convolution layer takes is decided behind this ABI: direct implicit GEMM, or one of the reduced-multiplication
+ * forms above and below - by the rule the Python package applies itself (mqgan_amd.ops calls mq_conv_plan; there is one copy of
+ * the eligibility logic, in csrc/plan.cpp).  A caller asks for a plan, allocates what the plan sizes and runs the planned calls:
+ *
+ *   mqConvPlan p;  mq_conv_plan(&desc, leaky, NULL, &p);              // NULL: configuration from the MQGAN_* environment
+ *   ws  = device buffer of max(p.ws_fprop, p.ws_backward) bytes, 256-byte aligned;  keep = p.keep_bytes bytes or NULL
+ *   mq_conv_fprop_planned(&p, x, w_krsc, bias, act, slope, mask, d1, d2, d3, y, keep, ws, bytes, stream);
+ *   mq_conv_backward_planned(&p, x, keep, w_krsc, w_crsk, dy, gate, ..., dx, dw, db, ws, bytes, stream);
+ *
+ * `leaky` = 1: the layer is conv -> LeakyReLU -> masked_fill (the discriminators, discriminators.py:219, 232; act 2 in the planned
+ * forward); 0: a plain convolution (+ bias).  Forms and the layers of the reference that take them:
+ *   MQ_FORM_DIRECT  everything else (mq_conv_fprop / _leaky, mq_conv_dgrad / _gated, mq_conv_wgrad / _bias)
+ *   MQ_FORM_WINO2D  plain 3x3 / stride 1 / pad 1, one group, C K / (C + K) >= 32: the refiner (preencoder.py:86-130) as
+ *                   F(mh x mw, 3x3), tile = fewest products for the image (4 x 5 for T x 90)
+ *   MQ_FORM_S2D     leaky 5x5 / stride 2 / pad 2, >= 128 channels: patch discriminator (discriminators.py:196-242), polyphase
+ *   MQ_FORM_WINO1D  leaky (3 x k), stride (1, 1 or 2), batch groups, >= 128 channels: multi-bin discriminator
+ *                   (discriminators.py:292-311) as F(m, 3) along the bins; `nested`: its (1 x k) row convolutions run as
+ *                   MQ_FORM_WINOW themselves when their column stride is 1
+ *   MQ_FORM_WINOW   3 / 5 / 7 stride-1 taps along time, >= 128 channels: encoder / decoder 1-D convolutions
+ *                   (attentions.py:95-130), the patch discriminator's 3x3 / stride-(2, 1) layers, as F(4,3) / F(4,5) / F(2,7)
+ * All reduced forms: f32 tensors, MQ_PRECISION_F32 / _F32X3, C % 16 == K % 16 == 0.  keep buffer: what forward hands to
+ * backward (the transformed input for the weight gradient, the CRSK transformed filters for the input gradient); without it
+ * backward transforms x / w again.  mqPlanCfg: the MQGAN_WINO_* switches as values (minimum channel counts: 0 = form off). */
+#define MQ_FORM_DIRECT 0
+#define MQ_FORM_WINO2D 1
+#define MQ_FORM_S2D 2
+#define MQ_FORM_WINO1D 3
+#define MQ_FORM_WINOW 4
+typedef struct {
+    int wino_minc;            /* MQGAN_WINO_MINC (128); with wino_minc_explicit = 0 eligibility is by benefit, C K / (C + K) */
+    int wino_minc_explicit;
+    int wino_tile;            /* MQGAN_WINO_TILE: 0 = auto, 3, 4, 45 */
+    int s2d_minc;             /* MQGAN_WINO_S2D_MINC (128) */
+    int wino1d_minc;          /* MQGAN_WINO1D_MINC (128) */
+    int wino1d_tile;          /* MQGAN_WINO1D_TILE: 0 = mq_wino1d_tile(H), 2, 4, 5 */
+    int winow_minc;           /* MQGAN_WINOW_MINC (128) */
+    int keep_mib;             /* MQGAN_WINO_KEEP_MIB (6144): larger transformed inputs are recomputed in backward */
+} mqPlanCfg;
+typedef struct {
+    int form;                 /* MQ_FORM_* */
+    int mh, mw;               /* output tile: WINO2D / S2D rows x columns; WINO1D mh = rows per tile; WINOW mw = columns per tile */
+    int nested;               /* WINO1D: row convolutions as WINOW */
+    int leaky;
+    int npos;                 /* transform positions */
+    int64_t tiles;
+    mqConvDesc desc;          /* the layer */
+    mqConvDesc gemm;          /* the batch-grouped GEMM / row / column convolution the form multiplies with */
+    mqConvDesc inner;         /* nested: the column form's convolution */
+    size_t keep_bytes, ws_fprop, ws_backward;
+    double flops;             /* 2 x multiplications of one forward pass in this form */
+} mqConvPlan;
+void mq_plan_cfg_default(mqPlanCfg *cfg);
+const char *mq_form_name(int form);
+int mq_conv_plan(const mqConvDesc *desc_host, int leaky, const mqPlanCfg *cfg_or_null, mqConvPlan *plan);
+/* y = epilogue(conv(x, w) + bias).  act 0 (plans with leaky = 0) / act 2 (leaky = 1): LeakyReLU(slope), then zero where
+ * mask[(m / d1) * d2 + m % d3] (m = output pixel; mask may be NULL).  keep: NULL or plan->keep_bytes bytes. */
+int mq_conv_fprop_planned(const mqConvPlan *plan, const float *x, const float *w_krsc, const float *bias, int act, float slope,
+                          const uint8_t *mask, int64_t d1, int64_t d2, int64_t d3, float *y, void *keep, void *workspace,
+                          size_t workspace_bytes, mqStream stream);
+/* Gradients from dy = the gradient with respect to the convolution's output BEFORE its activation (for a LeakyReLU layer apply
+ * LeakyReLU'(y) and the mask first, mq_pointwise_bwd, unless the consumer of y already did: mq_conv_dgrad_gated's contract).
+ * dx / dw / db NULL = not wanted.  x: needed by the direct form and when keep is NULL.  w_crsk: the direct input gradient only.
+ * gate (NULL = none): x itself when x came out of a LeakyReLU(gate_slope) + mask layer that expects the gradient with respect to
+ * ITS pre-activation: dx *= x > 0 ? 1 : gate_slope, zero where gate_mask[(m / g1) * g2 + m % g3] (m = input pixel). */
+int mq_conv_backward_planned(const mqConvPlan *plan, const float *x, const void *keep, const float *w_krsc, const float *w_crsk,
+                             const float *dy, const float *gate, float gate_slope, const uint8_t *gate_mask, int64_t g1, int64_t g2,
+                             int64_t g3, float *dx, float *dw, float *db, void *workspace, size_t workspace_bytes, mqStream stream);
+/* Timing hook: called before (phase 0) and after (phase 1, with mq_last_kernel()) every GEMM launch of the planned calls, with
+ * the launch's algorithmic flop count - bench.py records HIP events on the launch stream from it.  NULL switches it off. */
+typedef void (*mqLaunchHook)(int phase, double flops, const char *kernel);
+void mq_set_launch_hook(mqLaunchHook hook);
 
 #ifdef __cplusplus
 }

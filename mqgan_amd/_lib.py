@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MQGAN_HIP_LIB: load another build of the same ABI (kernel experiments); the default is the in-tree library
 LIB_PATH = os.environ.get("MQGAN_HIP_LIB") or os.path.join(_HERE, "libmqgan_hip.so")
 _lib = None
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class MqganHipError(RuntimeError):
@@ -29,6 +29,21 @@ class FsqDesc(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("N", "H", "W", "C", "K", "R", "S", "P", "Q", "stride_h", "stride_w", "pad_h",
                                        "pad_w", "dil_h", "dil_w", "groups", "precision")]
+
+
+class PlanCfg(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("wino_minc", "wino_minc_explicit", "wino_tile", "s2d_minc", "wino1d_minc", "wino1d_tile",
+                                       "winow_minc", "keep_mib")]
+
+
+class ConvPlan(C.Structure):
+    _fields_ = [("form", C.c_int), ("mh", C.c_int), ("mw", C.c_int), ("nested", C.c_int), ("leaky", C.c_int), ("npos", C.c_int),
+                ("tiles", C.c_int64), ("desc", ConvDesc), ("gemm", ConvDesc), ("inner", ConvDesc), ("keep_bytes", C.c_size_t),
+                ("ws_fprop", C.c_size_t), ("ws_backward", C.c_size_t), ("flops", C.c_double)]
+
+
+FORM_DIRECT, FORM_WINO2D, FORM_S2D, FORM_WINO1D, FORM_WINOW = range(5)
+LaunchHook = C.CFUNCTYPE(None, C.c_int, C.c_double, C.c_char_p)
 
 
 class Cb2dWeights(C.Structure):
@@ -143,23 +158,6 @@ SIGNATURES = {
     "mq_lsgan_g_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "mq_masked_mae_sums": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "mq_masked_mae_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _F, _P, _P]),
-    "mq_wino_input_transform": (_I, [_P, _I, _I, _I, _I, _P, _P]),
-    "mq_wino_dy_transform": (_I, [_P, _I, _I, _I, _I, _P, _P]),
-    "mq_wino_output_transform": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
-    "mq_wino_dy_fused_rows": (_I, [_I, _I, _I, _I]),
-    "mq_wino_dy_fused": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P]),
-    "mq_wino_weight_transform": (_I, [_P, _I, _I, _I, _P, _P]),
-    "mq_wino_wgrad_inverse": (_I, [_P, _I, _I, _P, _P]),
-    "mq_wino3_input_transform": (_I, [_P, _I, _I, _I, _I, _P, _P]),
-    "mq_wino3_output_transform": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _P, _L, _L, _L, _P, _P]),
-    "mq_wino3_input_transform_s2d": (_I, [_P, _I, _I, _I, _I, _P, _P]),
-    "mq_wino3_weight_transform_s2d": (_I, [_P, _I, _I, _I, _P, _P]),
-    "mq_wino3_output_transform_d2s": (_I, [_P, _I, _I, _I, _I, _P, _F, _P, _L, _L, _L, _P, _P]),
-    "mq_wino3_wgrad_inverse_s2d": (_I, [_P, _I, _I, _P, _P]),
-    "mq_wino3_weight_transform": (_I, [_P, _I, _I, _I, _P, _P]),
-    "mq_wino3_wgrad_inverse": (_I, [_P, _I, _I, _P, _P]),
-    "mq_wino3_dy_fused_rows": (_I, [_I, _I, _I, _I]),
-    "mq_wino3_dy_fused": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "mq_winon_input_transform": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
     "mq_winon_output_transform": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _P, _L, _L, _L, _P, _I, _I, _P]),
     "mq_winon_input_transform_s2d": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
@@ -186,6 +184,12 @@ SIGNATURES = {
     "mq_winow_dy_transform": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "mq_winow_dx_transform": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _L, _L, _L, _P, _P]),
     "mq_winow_wgrad_inverse": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "mq_plan_cfg_default": (None, [C.POINTER(PlanCfg)]),
+    "mq_form_name": (C.c_char_p, [_I]),
+    "mq_conv_plan": (_I, [C.POINTER(ConvDesc), _I, C.POINTER(PlanCfg), C.POINTER(ConvPlan)]),
+    "mq_conv_fprop_planned": (_I, [C.POINTER(ConvPlan), _P, _P, _P, _I, _F, _P, _L, _L, _L, _P, _P, _P, _Z, _P]),
+    "mq_conv_backward_planned": (_I, [C.POINTER(ConvPlan), _P, _P, _P, _P, _P, _P, _F, _P, _L, _L, _L, _P, _P, _P, _P, _Z, _P]),
+    "mq_set_launch_hook": (None, [LaunchHook]),
     "mq_sumsq": (_I, [_P, _L, _P, _P, _P]),
     "mq_multi_gather": (_I, [_P, _I, _L, _P, _P]),
     "mq_multi_gather_args": (_I, [_P, _I, _P, _P]),

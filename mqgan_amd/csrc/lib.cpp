@@ -16,6 +16,9 @@ thread_local char g_kernel[128] = "";
 //    mq_wino1d_tile)
 // 7: mq_winon_* (F(4x4) / F(4x5, 3x3): tile passed as (mh, mw)), mq_winow_* (F(4,3) / F(4,5) / F(2,7) along the columns),
 //    mq_winon_dy_fused / mq_winon_dy_fused_rows
-extern "C" int mq_abi_version(void) { return 7; }
+// 8: mq_conv_plan / mq_conv_fprop_planned / mq_conv_backward_planned (the algorithm choice and the Winograd / polyphase / nested
+//    sequences behind the ABI, csrc/plan.cpp), mq_set_launch_hook; mq_winon_* take the 3 x 3 tile as well - mq_wino3_* and the
+//    F(2x2, 3x3) functions mq_wino_* are gone
+extern "C" int mq_abi_version(void) { return 8; }
 extern "C" const char *mq_last_error(void) { return mq::g_err; }
 extern "C" const char *mq_last_kernel(void) { return mq::g_kernel; }

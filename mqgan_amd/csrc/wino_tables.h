@@ -9,6 +9,13 @@
 
 namespace mq {
 namespace wt {
+// F(3, 3) on the points 0, 1, -1, 2, inf: 25 products per 3 x 3 output tile when nested (2.78 per output); transform constants no
+// larger than 4.  The tile ops picks for images too small for the 4-wide tiles (winogradn.hip).
+namespace f3 {
+constexpr float BT[5][5] = {{2, -1, -2, 1, 0}, {0, -2, -1, 1, 0}, {0, 2, -3, 1, 0}, {0, -1, 0, 1, 0}, {0, 2, -1, -2, 1}};
+constexpr float G[5][3] = {{0.5f, 0, 0}, {-0.5f, -0.5f, -0.5f}, {-1.0f / 6, 1.0f / 6, -1.0f / 6}, {1.0f / 6, 1.0f / 3, 2.0f / 3}, {0, 0, 1}};
+constexpr float AT[3][5] = {{1, 1, 1, 1, 0}, {0, 1, -1, 2, 0}, {0, 1, 1, 4, 1}};
+}  // namespace f3
 namespace f4 {
 constexpr float BT[6][6] = {{1, 1.5f, -2, -1.5f, 1, 0},
                             {0, 1.0f / 3, 5.0f / 6, 1.0f / 6, -1.0f / 3, 0},
@@ -75,9 +82,18 @@ template <int M, int S> __device__ __forceinline__ constexpr float at2(int i, in
 
 static_assert(f4::BT[0][0] == 1.f && f4::BT[5][5] == 1.f && f5::BT[0][0] == 1.f && f5::BT[6][6] == 1.f, "shared-row coefficients");
 
-template <int M> __device__ __forceinline__ constexpr float bt(int i, int j) { if constexpr (M == 4) return f4::BT[i][j]; else return f5::BT[i][j]; }
-template <int M> __device__ __forceinline__ constexpr float g(int i, int j) { if constexpr (M == 4) return f4::G[i][j]; else return f5::G[i][j]; }
-template <int M> __device__ __forceinline__ constexpr float at(int i, int j) { if constexpr (M == 4) return f4::AT[i][j]; else return f5::AT[i][j]; }
+template <int M> __device__ __forceinline__ constexpr float bt(int i, int j)
+{
+    if constexpr (M == 3) return f3::BT[i][j]; else if constexpr (M == 4) return f4::BT[i][j]; else return f5::BT[i][j];
+}
+template <int M> __device__ __forceinline__ constexpr float g(int i, int j)
+{
+    if constexpr (M == 3) return f3::G[i][j]; else if constexpr (M == 4) return f4::G[i][j]; else return f5::G[i][j];
+}
+template <int M> __device__ __forceinline__ constexpr float at(int i, int j)
+{
+    if constexpr (M == 3) return f3::AT[i][j]; else if constexpr (M == 4) return f4::AT[i][j]; else return f5::AT[i][j];
+}
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 // acc += c * v with the constant known after unrolling: zero terms vanish, +-1 become adds

@@ -456,19 +456,20 @@ static int wn_blocks_for(int64_t work_items, int K4)
 
 using namespace mq;
 
-static bool wn_tile_ok(int mh, int mw) { return (mh == 4 && mw == 4) || (mh == 4 && mw == 5); }
+static bool wn_tile_ok(int mh, int mw) { return (mh == 3 && mw == 3) || (mh == 4 && mw == 4) || (mh == 4 && mw == 5); }
 
 static int wn_args(const void *a, const void *b, int N, int H, int W, int C, int mh, int mw, const char *who)
 {
     MQ_REQUIRE(a && b && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "%s: bad arguments (channels must be a multiple of 4, got %d)", who, C);
-    MQ_REQUIRE(wn_tile_ok(mh, mw), "%s: tile %d x %d (built: 4 x 4 and 4 x 5; 3 x 3 is mq_wino3_*, 2 x 2 mq_wino_*)", who, mh, mw);
+    MQ_REQUIRE(wn_tile_ok(mh, mw), "%s: tile %d x %d (built: 3 x 3, 4 x 4 and 4 x 5)", who, mh, mw);
     MQ_REQUIRE(((uintptr_t)a | (uintptr_t)b) % 16 == 0, "%s: tensors must be 16-byte aligned", who);
     return 0;
 }
 
 #define MQ_WN_LAUNCH(k_, grid_, ...)                                                                                \
     do {                                                                                                            \
-        if (mw == 4) hipLaunchKernelGGL((k_<4, 4>), grid_, dim3(256), 0, S(stream), __VA_ARGS__);                   \
+        if (mw == 3) hipLaunchKernelGGL((k_<3, 3>), grid_, dim3(256), 0, S(stream), __VA_ARGS__);                   \
+        else if (mw == 4) hipLaunchKernelGGL((k_<4, 4>), grid_, dim3(256), 0, S(stream), __VA_ARGS__);              \
         else hipLaunchKernelGGL((k_<4, 5>), grid_, dim3(256), 0, S(stream), __VA_ARGS__);                           \
     } while (0)
 

@@ -408,192 +408,171 @@ class ConvFn(torch.autograd.Function):
         return dx, dw, None, db, None
 
 
-# ----------------------------------------------------------------------------- Winograd F(2x2, 3x3) (csrc/winograd.hip)
-WINO_MIN_CHANNELS = int(os.environ.get("MQGAN_WINO_MINC", "128"))      # 0 switches the path off (A/B runs)
-# the transformed input V (4x the input) is kept for the weight gradient when it is at most this many MiB, else recomputed
-WINO_KEEP_V_MIB = int(os.environ.get("MQGAN_WINO_KEEP_MIB", "6144"))
+# ----------------------------------------------------------------------------- reduced-multiplication forms behind the C ABI
+# WHICH form a layer takes (direct implicit GEMM; Winograd F(mh x mw, 3x3); the same over the polyphase components of a 5x5 /
+# stride-2 layer; F(m, 3) along the rows, possibly nested with F(m', S) along the columns; F(m', S) along the columns) and HOW it
+# runs (which transforms, which batch-grouped GEMM, which buffers) is decided and executed in csrc/plan.cpp: mq_conv_plan,
+# mq_conv_fprop_planned, mq_conv_backward_planned.  This module holds the switches (module attributes, so that tests and A/B
+# runs can change them; their defaults come from the MQGAN_* environment) and ONE autograd Function over the planned calls.
+WINO_MIN_CHANNELS = int(os.environ.get("MQGAN_WINO_MINC", "128"))      # 3x3 / stride-1 layers; 0 switches the form off (A/B runs)
+WINO_TILE = os.environ.get("MQGAN_WINO_TILE", "auto")                  # auto: fewest products per image; "3", "4", "45"
+WINO_KEEP_V_MIB = int(os.environ.get("MQGAN_WINO_KEEP_MIB", "6144"))   # larger transformed inputs are recomputed in backward
+WINO_S2D_MIN_CHANNELS = int(os.environ.get("MQGAN_WINO_S2D_MINC", "128"))   # 5x5 / stride-2 layers (polyphase)
+WINO1D_MIN_CHANNELS = int(os.environ.get("MQGAN_WINO1D_MINC", "128"))  # (3 x k) layers, F(m, 3) along the rows
+WINO1D_TILE = int(os.environ.get("MQGAN_WINO1D_TILE", "0"))            # 0: the tile with the fewest products; 2, 4, 5: fixed
+WINOW_MIN_CHANNELS = int(os.environ.get("MQGAN_WINOW_MINC", "128"))    # 3 / 5 / 7 stride-1 taps along the columns
+
+FORM_DIRECT, FORM_WINO2D, FORM_S2D, FORM_WINO1D, FORM_WINOW = _lib.FORM_DIRECT, _lib.FORM_WINO2D, _lib.FORM_S2D, _lib.FORM_WINO1D, _lib.FORM_WINOW
+_PLANS = {}
 
 
+def _plan_cfg():
+    tile = str(WINO_TILE)
+    if tile not in ("auto", "3", "4", "45"):
+        raise _lib.MqganHipError(f"MQGAN_WINO_TILE must be auto, 3, 4 or 45, got {WINO_TILE} (F(2x2, 3x3) left the library in ABI 8)")
+    return (int(WINO_MIN_CHANNELS), int(WINO_MIN_CHANNELS != 128 or "MQGAN_WINO_MINC" in os.environ), 0 if tile == "auto" else int(tile),
+            int(WINO_S2D_MIN_CHANNELS), int(WINO1D_MIN_CHANNELS), int(WINO1D_TILE), int(WINOW_MIN_CHANNELS), int(WINO_KEEP_V_MIB))
+
+
+def conv_plan(d: ConvDesc, leaky: bool) -> "_lib.ConvPlan":
+    """mq_conv_plan for this descriptor under the module's current switches (cached): .form, .mh, .mw, .nested, .gemm, .flops,
+    .keep_bytes, .ws_fprop, .ws_backward.  ``leaky``: the layer is conv -> LeakyReLU -> masked_fill."""
+    cfg = _plan_cfg()
+    key = (_desc_key(d), bool(leaky), cfg)
+    p = _PLANS.get(key)
+    if p is None:
+        c = _lib.PlanCfg(*cfg)
+        p = _lib.ConvPlan()
+        check(L().mq_conv_plan(C.byref(d), int(bool(leaky)), C.byref(c), C.byref(p)), "mq_conv_plan")
+        _PLANS[key] = p
+    return p
+
+
+def form_name(p) -> str:
+    return L().mq_form_name(p.form).decode()
+
+
+# thin predicates over the plan (tests, tools)
 def _wino_ok(d: ConvDesc) -> bool:
-    """3x3, stride 1, pad 1, no dilation, one group, f32 tensors on an f32-result engine, channel counts that fill the GEMM.
-    Worth it when the GEMM work saved (proportional to C K) outweighs the transforms (proportional to C + K): with the default
-    threshold that is C K / (C + K) >= 45 for F(3x3, 3x3) (192 -> 64 pays, x1.13; 64 -> 64 does not, x0.83: tools/wino_micro.py),
-    >= 32 for the 4x4 / 4x5 tiles (64 -> 64 included: config-2 step 214.8 -> 212.7 ms) and min(C, K) >= 128 for F(2x2, 3x3); an
-    explicit MQGAN_WINO_MINC is a plain minimum on min(C, K)."""
-    if not (WINO_MIN_CHANNELS > 0 and d.R == 3 and d.S == 3 and d.stride_h == 1 and d.stride_w == 1 and d.pad_h == 1 and d.pad_w == 1
-            and d.dil_h == 1 and d.dil_w == 1 and d.groups == 1 and d.P == d.H and d.Q == d.W
-            and d.precision in (PRECISIONS["f32"], PRECISIONS["f32x3"]) and d.C % 16 == 0 and d.K % 16 == 0):
-        return False
-    tile = _wino_tile(d.H, d.W)
-    if tile != (2, 2) and d.K > 1024:      # the fused dy pass of the larger tiles (the only one they have) takes K <= 1024
-        return False
-    if tile != (2, 2) and WINO_MIN_CHANNELS == 128 and "MQGAN_WINO_MINC" not in os.environ:
-        return min(d.C, d.K) >= 64 and d.C * d.K >= (45 if tile == (3, 3) else 32) * (d.C + d.K)
-    return min(d.C, d.K) >= WINO_MIN_CHANNELS
+    return conv_plan(d, False).form == FORM_WINO2D
 
 
-# Output tile of F(mh x mw, 3x3).  "auto" (default): per image, the tile with the fewest products among 3x3 (25 positions per 9
-# outputs, csrc/winograd3.hip), 4x4 (36 per 16) and 4x5 (42 per 20; both csrc/winogradn.hip) - 4x5 for the refiner's T x 90
-# images; "3", "4", "45": that tile everywhere; "2": F(2x2, 3x3) (16 per 4, winograd.hip).
-WINO_TILE = os.environ.get("MQGAN_WINO_TILE", "auto")
-_WINO_TILES = {"2": (2, 2), "3": (3, 3), "4": (4, 4), "45": (4, 5)}
+def _wino_s2d_ok(d: ConvDesc) -> bool:
+    return conv_plan(d, True).form == FORM_S2D
 
 
-def _wino_tile(H: int, W: int):
-    key = str(WINO_TILE)
-    if key in _WINO_TILES:
-        return _WINO_TILES[key]
-    if key != "auto":
-        raise _lib.MqganHipError(f"MQGAN_WINO_TILE must be auto, 2, 3, 4 or 45, got {WINO_TILE}")
-    cost = lambda t: -(-H // t[0]) * -(-W // t[1]) * (t[0] + 2) * (t[1] + 2)
-    return min(((3, 3), (4, 4), (4, 5)), key=cost)           # ties: the smaller tile (smaller error)
+def _wino1d_ok(d: ConvDesc) -> bool:
+    return conv_plan(d, True).form == FORM_WINO1D
 
 
-def _wcall(tile, name: str, *args):
-    """mq_wino_<name> (2x2), mq_wino3_<name> (3x3) or mq_winon_<name>(..., mh, mw); the stream is appended."""
-    if tile == (2, 2):
-        return getattr(L(), "mq_wino_" + name)(*args, stream())
-    if tile == (3, 3):
-        return getattr(L(), "mq_wino3_" + name)(*args, stream())
-    return getattr(L(), "mq_winon_" + name)(*args, tile[0], tile[1], stream())
+def _winow_ok(d: ConvDesc) -> bool:
+    return conv_plan(d, False).form == FORM_WINOW or conv_plan(d, True).form == FORM_WINOW
 
 
-def _wrows(tile, N: int, H: int, W: int, K: int) -> int:
-    """Rows of the per-block column sums the fused dy pass of this tile writes (0: shape not supported)."""
-    if tile == (2, 2):
-        return L().mq_wino_dy_fused_rows(N, H, W, K)
-    if tile == (3, 3):
-        return L().mq_wino3_dy_fused_rows(N, H, W, K)
-    return L().mq_winon_dy_fused_rows(N, H, W, K, tile[0], tile[1])
+# HIP-event timing of the GEMM launches inside the planned calls: the library calls back around each of them (mq_set_launch_hook)
+_HOOK_STATE = {"start": None, "detail": None}
 
 
-def _wino_npos(tile) -> int:
-    return (tile[0] + 2) * (tile[1] + 2)
-
-
-def _wino_ntiles(tile, N: int, H: int, W: int) -> int:
-    return N * -(-H // tile[0]) * -(-W // tile[1])
-
-
-def _wino_gemm(tile, N: int, H: int, W: int, cin: int, cout: int, precision) -> ConvDesc:
-    """The transform positions as that many groups of one-row "images" (one per tile row: small images keep the kernels' 32-bit
-    image-relative offsets far from their limits) with batch-grouped 1x1 filters."""
-    n_pos = _wino_npos(tile)
-    return conv_desc(n_pos * N * -(-H // tile[0]), 1, -(-W // tile[1]), cin, cout, 1, 1, groups=n_pos, precision=precision)
-
-
-def _wino_tiles(d: ConvDesc) -> int:
-    return _wino_ntiles(_wino_tile(d.H, d.W), d.N, d.H, d.W)
-
-
-def _wino_np(d: ConvDesc) -> int:
-    return _wino_npos(_wino_tile(d.H, d.W))
-
-
-def _wino_gemm_desc(d: ConvDesc, cin: int, cout: int) -> ConvDesc:
-    return _wino_gemm(_wino_tile(d.H, d.W), d.N, d.H, d.W, cin, cout, d.precision)
-
-
-def _wino_in(t, d: ConvDesc, channels: int, dy_side: bool = False):
-    tile = _wino_tile(d.H, d.W)
-    out = _empty((_wino_np(d) * _wino_tiles(d), 1, 1, channels), t)
-    if dy_side and tile != (2, 2):         # the larger tiles have the fused pass only: Z without V and without column sums
-        check(_wcall(tile, "dy_fused", fptr(t), d.N, d.H, d.W, channels, fptr(out), None, None), "mq_wino_dy_fused")
-        return out
-    if dy_side:
-        check(L().mq_wino_dy_transform(fptr(t), d.N, d.H, d.W, channels, fptr(out), stream()), "mq_wino_dy_transform")
+def _launch_hook(phase, flops, kernel):
+    t = TIMER
+    if t is None:
+        return
+    if phase == 0:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        _HOOK_STATE["start"] = ev
     else:
-        check(_wcall(tile, "input_transform", fptr(t), d.N, d.H, d.W, channels, fptr(out)), "mq_wino_input_transform")
-    return out
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        t.records.append((kernel.decode() if kernel else "?", flops, _HOOK_STATE["start"], ev))
+        t.details.append(_HOOK_STATE["detail"])
 
 
-def _wino_conv(d: ConvDesc, x, w_krsc, bias, cin: int, cout: int, flip: bool, key, keep=None, V=None):
-    """'same' 3x3 convolution of x (N, H, W, cin) with the KRSC weights (forward: flip False; input gradient: flip True).
-    ``keep``: a list that receives the transformed input V.  ``V``: the already transformed input (x is then not read)."""
-    tile = _wino_tile(d.H, d.W)
-    if V is None:
-        V = _wino_in(x, d, cin)
-    if keep is not None:
-        keep.append(V)
-    U = _empty((_wino_np(d) * cout, 1, cin), V)
-    check(_wcall(tile, "weight_transform", fptr(w_krsc), d.K, d.C, int(flip), fptr(U)), "mq_wino_weight_transform")
-    dg = _wino_gemm_desc(d, cin, cout)
-    M = _empty((_wino_np(d) * _wino_tiles(d), 1, 1, cout), V)
-    _timed(None, _conv_flops(dg), lambda: check(
-        L().mq_conv_fprop(C.byref(dg), fptr(V), fptr(U), None, fptr(M), stream()), "mq_conv_fprop"), key)
-    del V
-    y = _empty((d.N, d.H, d.W, cout), M)
-    if tile != (2, 2):
-        check(_wcall(tile, "output_transform", fptr(M), fptr(bias, True), d.N, d.H, d.W, cout, 0, 0.0, None, 1, 0, 1, fptr(y)),
-              "mq_wino_output_transform")
-    else:
-        check(L().mq_wino_output_transform(fptr(M), fptr(bias, True), d.N, d.H, d.W, cout, fptr(y), stream()), "mq_wino_output_transform")
-    return y
+_LAUNCH_HOOK = _lib.LaunchHook(_launch_hook)       # kept alive for the lifetime of the module
+_hook_installed = False
 
 
-WINO_FUSED_DY = os.environ.get("MQGAN_WINO_FUSED_DY", "1") != "0"     # backward: dy read once for Z, the dgrad's V and the bias sums
+def _planned_call(key, fn):
+    """Run a planned entry point; with a KernelTimer active the library reports every GEMM launch to it."""
+    global _hook_installed
+    if TIMER is not None and not _hook_installed:
+        L().mq_set_launch_hook(_LAUNCH_HOOK)
+        _hook_installed = True
+    _HOOK_STATE["detail"] = key
+    fn()
 
 
-def _wino_dy_fused(dy, d: ConvDesc):
-    """(Z, V of dy, per-block column sums [rows][K]) in one pass over dy (mq_wino_dy_fused / mq_wino3_dy_fused / mq_winon_dy_fused)."""
-    tile = _wino_tile(d.H, d.W)
-    rows = _wrows(tile, d.N, d.H, d.W, d.K)
-    Z = _empty((_wino_np(d) * _wino_tiles(d), 1, 1, d.K), dy)
-    Vd = _empty((_wino_np(d) * _wino_tiles(d), 1, 1, d.K), dy)
-    part = _empty((rows, d.K), dy)
-    check(_wcall(tile, "dy_fused", fptr(dy), d.N, d.H, d.W, d.K, fptr(Z), fptr(Vd), fptr(part)), "mq_wino_dy_fused")
-    return Z, Vd, part
-
-
-class ConvWinoFn(torch.autograd.Function):
-    """ConvFn for 3x3 / stride-1 / pad-1 layers by Winograd F(2x2, 3x3): 2.25x fewer multiplications, run as one
-    batch-grouped (16 groups) 1x1 convolution on the same f32 GEMM kernels between HBM-bound transforms.  Same arguments and
-    gradients as ConvFn; the CRSK weights are not needed (the input gradient transforms the KRSC filter rotated)."""
+class ConvPlannedFn(torch.autograd.Function):
+    """One layer in the form mq_conv_plan chose for it, forward by mq_conv_fprop_planned and backward by
+    mq_conv_backward_planned (csrc/plan.cpp).  ``leaky`` None: y = conv(x, w) + bias.  ``leaky`` = (mask, dmap, slope): y = padded ?
+    0 : LeakyReLU(conv + bias) with the discriminators' gate contract - ``in_gate`` = (mask, dmap, slope) of the layer that produced
+    x and handed it out pregated (this layer's input gradient then carries that layer's LeakyReLU' and mask); ``pregated``: every
+    consumer of y applies LeakyReLU'(y) and the mask itself, so the incoming gradient is already the one with respect to the
+    pre-activation.  The transformed input (and the CRSK transformed filters) travel from forward to backward in the plan's keep
+    buffer when the weights need a gradient."""
 
     @staticmethod
-    def forward(ctx, x, w_krsc, w_crsk, bias, key):
+    def forward(ctx, x, w_krsc, w_crsk, bias, key, leaky=None, in_gate=None, pregated=False):
         d = _desc_from_key(key)
-        keep_v = w_krsc.requires_grad and 4 * _wino_np(d) * _wino_tiles(d) * d.C <= WINO_KEEP_V_MIB << 20
-        kept = [] if keep_v else None
+        p = conv_plan(d, leaky is not None)
         x, w_krsc = x.contiguous(), w_krsc.contiguous()
-        y = _wino_conv(d, x, w_krsc, bias, d.C, d.K, False, key, keep=kept)
-        ctx.key = key
+        mask, dmap, slope = (leaky[0], tuple(leaky[1]), float(leaky[2])) if leaky is not None else (None, (1, 0, 1), 0.0)
+        # the keep buffer carries the transformed input (weight gradient) and, for the row / column forms, the CRSK transformed
+        # filters (input gradient); the two-dimensional forms transform the rotated filter in backward instead
+        need_keep = p.keep_bytes > 0 and (ctx.needs_input_grad[1] or (ctx.needs_input_grad[0] and p.form in (FORM_WINO1D, FORM_WINOW)))
+        keep = _ws_bytes(p.keep_bytes, x) if need_keep else None
+        ws = _ws_bytes(p.ws_fprop, x) if p.ws_fprop else None
+        y = _empty((d.N, d.P, d.Q, d.K), x)
+        _planned_call(key, lambda: check(
+            L().mq_conv_fprop_planned(C.byref(p), fptr(x), fptr(w_krsc), fptr(bias, True), 2 if leaky is not None else 0, slope,
+                                      ptr(mask, torch.uint8, True), dmap[0], dmap[1], dmap[2], fptr(y), ptr(keep, torch.uint8, True),
+                                      ptr(ws, torch.uint8, True), p.ws_fprop, stream()), "mq_conv_fprop_planned"))
+        ctx.key, ctx.leaky_cfg = key, (None if leaky is None else (dmap, slope))
         ctx.w_shape = tuple(w_krsc.shape)
         ctx.has_bias = bias is not None
-        ctx.kept_v = keep_v
-        ctx.save_for_backward(kept[0] if keep_v else x, w_krsc)       # V stands in for x in the weight gradient
+        ctx.pregated = bool(pregated)
+        ctx.in_gate = None if in_gate is None else (tuple(in_gate[1]), float(in_gate[2]))
+        direct = p.form == FORM_DIRECT
+        # what backward reads: x for the direct weight gradient, as the gate tensor, or to transform again without a keep buffer
+        need_x = direct or in_gate is not None or keep is None
+        ctx.save_for_backward(x if need_x else None, keep, w_krsc, w_crsk if direct else None,
+                              y if (leaky is not None and not pregated) else None, mask, None if in_gate is None else in_gate[0])
         return y
 
     @staticmethod
-    def backward(ctx, dy):
-        x, w_krsc = ctx.saved_tensors
+    def backward(ctx, dout):
+        x, keep, w_krsc, w_crsk, y, mask, mask_in = ctx.saved_tensors
         d = _desc_from_key(ctx.key)
-        dy = dy.contiguous()
-        dx = dw = db = None
+        p = conv_plan(d, ctx.leaky_cfg is not None)
+        dy = dout.contiguous()
+        if ctx.leaky_cfg is not None and not ctx.pregated:
+            dmap, slope = ctx.leaky_cfg
+            if slope != 0.2:
+                raise _lib.MqganHipError("the pointwise backward kernel implements LeakyReLU(0.2) only")
+            Cc = y.shape[-1]
+            pd = PointwiseDesc(rows=y.numel() // Cc, C=Cc, act=ACT_LEAKY, mask_pre=0, mask_post=int(mask is not None),
+                               d1=dmap[0], d2=dmap[1], d3=dmap[2], p_drop=0.0, seed=0)
+            dh = torch.empty_like(y)
+            check(L().mq_pointwise_bwd(C.byref(pd), fptr(dy), fptr(y), None, ptr(mask, torch.uint8, True), None,
+                                       None, fptr(dh), None, None, None, None, stream()), "mq_pointwise_bwd")
+            dy = dh
+        want_dx, want_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         want_db = ctx.has_bias and ctx.needs_input_grad[3]
-        Z = Vd = part = None
-        if (WINO_FUSED_DY and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
-                and _wrows(_wino_tile(d.H, d.W), d.N, d.H, d.W, d.K) > 0):
-            Z, Vd, part = _wino_dy_fused(dy, d)
-        if ctx.needs_input_grad[0]:
-            dx = _wino_conv(d, dy, w_krsc, None, d.K, d.C, True, ctx.key, V=Vd)
-            del Vd
-        if ctx.needs_input_grad[1]:
-            V = x if ctx.kept_v else _wino_in(x, d, d.C)
-            if Z is None:
-                Z = _wino_in(dy, d, d.K, dy_side=True)
-            dg = _wino_gemm_desc(d, d.C, d.K)
-            P = _empty((_wino_np(d) * d.K, 1, d.C), x)
-            nbytes = L().mq_conv_wgrad_workspace(C.byref(dg))
-            ws = _ws_bytes(nbytes, x)
-            _timed(None, _conv_flops(dg), lambda: check(
-                L().mq_conv_wgrad(C.byref(dg), fptr(V), fptr(Z), fptr(P), ptr(ws), nbytes, stream()), "mq_conv_wgrad"), ctx.key)
-            del V, Z
-            dw = _empty(ctx.w_shape, x)
-            check(_wcall(_wino_tile(d.H, d.W), "wgrad_inverse", fptr(P), d.K, d.C, fptr(dw)), "mq_wino_wgrad_inverse")
-        if want_db:
-            db = colsum(part) if part is not None else _bias_grad(d, dy)
-        return dx, dw, None, db, None
+        if want_dx and p.form == FORM_DIRECT and w_crsk is None:
+            raise _lib.MqganHipError("conv backward wrt the input needs the CRSK weights")
+        if want_dw and keep is None and x is None:
+            raise _lib.MqganHipError("ConvPlannedFn: weight gradient asked for a layer whose weights did not require one")
+        dx = _empty((d.N, d.H, d.W, d.C), dy) if want_dx else None
+        dw = _empty(ctx.w_shape, dy) if want_dw else None
+        db = _empty((d.groups * d.K,), dy) if want_db else None
+        gmask, gdmap, gslope = (mask_in, ctx.in_gate[0], ctx.in_gate[1]) if ctx.in_gate is not None else (None, (1, 0, 1), 1.0)
+        ws = _ws_bytes(p.ws_backward, dy)
+        _planned_call(ctx.key, lambda: check(
+            L().mq_conv_backward_planned(C.byref(p), fptr(x, True), ptr(keep, torch.uint8, True), fptr(w_krsc), fptr(w_crsk, True), fptr(dy),
+                                         fptr(x, True) if ctx.in_gate is not None else None, gslope, ptr(gmask, torch.uint8, True),
+                                         gdmap[0], gdmap[1], gdmap[2], fptr(dx, True), fptr(dw, True), fptr(db, True),
+                                         ptr(ws, torch.uint8), p.ws_backward, stream()), "mq_conv_backward_planned"))
+        return dx, dw, None, db, None, None, None, None
 
 
 def _bias_grad(d, dy):
@@ -699,436 +678,6 @@ class ConvLeakyFn(torch.autograd.Function):
                                        None, fptr(dy), None, None, None, None, stream()), "mq_pointwise_bwd")
         dx, dw, db = _conv_backward(ctx, x, w_crsk, dy)
         return dx, dw, None, db, None, None, None, None, None, None
-
-
-# ----------------------------------------------------------------------------- 1-D Winograd F(m, s) along the columns (csrc/winow.hip)
-WINOW_MIN_CHANNELS = int(os.environ.get("MQGAN_WINOW_MINC", "128"))       # 0 switches the path off (A/B runs)
-
-
-def _winow_ok(d: ConvDesc) -> bool:
-    """3, 5 or 7 taps with stride 1 along the columns (time), any taps / stride along the rows, any left padding, batch groups,
-    on an f32-result engine, with channel counts that fill the GEMM: the encoder / decoder 1-D convolutions, the patch
-    discriminator's 3x3 / stride-(2, 1) layers, the (1 x 5) row convolutions inside the multi-bin discriminator's F(m, 3) form."""
-    return (WINOW_MIN_CHANNELS > 0 and d.S in (3, 5, 7) and d.stride_w == 1 and d.dil_w == 1 and d.dil_h == 1 and d.Q >= 1
-            and d.precision in (PRECISIONS["f32"], PRECISIONS["f32x3"]) and d.C % 16 == 0 and d.K % 16 == 0
-            and min(d.C, d.K) >= WINOW_MIN_CHANNELS and d.N % d.groups == 0)
-
-
-def _ww_geom(d: ConvDesc):
-    """(outputs per tile, tiles per row, positions) of F(m, S) along the columns."""
-    m = L().mq_winow_tile(d.S)
-    return m, -(-d.Q // m), m + d.S - 1
-
-
-def _ww_desc(d: ConvDesc) -> ConvDesc:
-    """The positions as (m + S - 1) x groups batch groups of (H x tiles) images with (R x 1) filters."""
-    _, tw, npos = _ww_geom(d)
-    return conv_desc(npos * d.N, d.H, tw, d.C, d.K, d.R, 1, stride=(d.stride_h, 1), pad=(d.pad_h, 0), groups=npos * d.groups,
-                     out_hw=(d.P, tw), precision=d.precision)
-
-
-def _ww_weights(d: ConvDesc, w_krsc, need_crsk: bool):
-    """(U_krsc (np * groups * K, R, C), U_crsk (np * groups * C, R, K) or None) of KRSC weights (groups * K, R * S, C)."""
-    npos = _ww_geom(d)[2]
-    U = _empty((npos * d.groups * d.K, d.R, d.C), w_krsc)
-    Uc = _empty((npos * d.groups * d.C, d.R, d.K), w_krsc) if need_crsk else None
-    check(L().mq_winow_weight_transform(fptr(w_krsc), d.groups, d.K, d.C, d.R, d.S, fptr(U), fptr(Uc, True), stream()),
-          "mq_winow_weight_transform")
-    return U, Uc
-
-
-def _ww_fprop(d: ConvDesc, x, U, key, bias=None, act=0, slope=0.0, mask=None, dmap=(1, 0, 1)):
-    """(y (N, P, Q, K), V): the convolution of x (N, H, W, C) with the transformed filters U; V is the transformed input."""
-    _, tw, npos = _ww_geom(d)
-    V = _empty((npos * d.N, d.H, tw, d.C), x)
-    check(L().mq_winow_input_transform(fptr(x), d.N, d.H, d.W, d.C, d.S, d.Q, d.pad_w, fptr(V), stream()), "mq_winow_input_transform")
-    dg = _ww_desc(d)
-    M = _empty((npos * d.N, d.P, tw, d.K), x)
-    _timed(None, _conv_flops(dg), lambda: check(
-        L().mq_conv_fprop(C.byref(dg), fptr(V), fptr(U), None, fptr(M), stream()), "mq_conv_fprop"), key)
-    y = _empty((d.N, d.P, d.Q, d.K), x)
-    check(L().mq_winow_output_transform(fptr(M), fptr(bias, True), d.N, d.P, d.Q, d.K, d.S, d.groups, int(act), float(slope),
-                                        ptr(mask, torch.uint8, True), dmap[0], dmap[1], dmap[2], fptr(y), stream()),
-          "mq_winow_output_transform")
-    return y, V
-
-
-def _ww_dy(d: ConvDesc, dy, want_part: bool):
-    """(Z (np, N, P, tw, K), per-block column sums of dy [rows][groups * K] or None)."""
-    _, tw, npos = _ww_geom(d)
-    part = None
-    if want_part:
-        rows = L().mq_winow_dy_rows(d.N, d.P, d.Q, d.K, d.S, d.groups)
-        part = _empty((rows, d.groups * d.K), dy) if rows > 0 else None
-    Z = _empty((npos * d.N, d.P, tw, d.K), dy)
-    check(L().mq_winow_dy_transform(fptr(dy), d.N, d.P, d.Q, d.K, d.S, d.groups, fptr(Z), fptr(part, True), stream()), "mq_winow_dy_transform")
-    return Z, part
-
-
-def _ww_dgrad(d: ConvDesc, Z, Uc, key, gate=None, gslope=1.0, mask_in=None, gdmap=(1, 0, 1)):
-    """dx (N, H, W, C) from Z and the CRSK transformed filters; gate / mask_in: the producer layer's LeakyReLU' and frame mask."""
-    _, tw, npos = _ww_geom(d)
-    dg = _ww_desc(d)
-    dV = _empty((npos * d.N, d.H, tw, d.C), Z)
-    _timed(None, _conv_flops(dg), lambda: check(
-        L().mq_conv_dgrad(C.byref(dg), fptr(Z), fptr(Uc), fptr(dV), stream()), "mq_conv_dgrad"), key)
-    dx = _empty((d.N, d.H, d.W, d.C), Z)
-    check(L().mq_winow_dx_transform(fptr(dV), d.N, d.H, d.W, d.C, d.S, d.Q, d.pad_w, fptr(gate, True), float(gslope),
-                                    ptr(mask_in, torch.uint8, True), gdmap[0], gdmap[1], gdmap[2], fptr(dx), stream()),
-          "mq_winow_dx_transform")
-    return dx
-
-
-def _ww_wgrad(d: ConvDesc, V, Z, key):
-    """dw KRSC (groups * K, R * S, C) from the transformed input and output gradient."""
-    npos = _ww_geom(d)[2]
-    dg = _ww_desc(d)
-    dU = _empty((npos * d.groups * d.K, d.R, d.C), Z)
-    nbytes = L().mq_conv_wgrad_workspace(C.byref(dg))
-    ws = _ws_bytes(nbytes, Z)
-    _timed(None, _conv_flops(dg), lambda: check(
-        L().mq_conv_wgrad(C.byref(dg), fptr(V), fptr(Z), fptr(dU), ptr(ws), nbytes, stream()), "mq_conv_wgrad"), key)
-    dw = _empty((d.groups * d.K, d.R * d.S, d.C), Z)
-    check(L().mq_winow_wgrad_inverse(fptr(dU), d.groups, d.K, d.C, d.R, d.S, fptr(dw), stream()), "mq_winow_wgrad_inverse")
-    return dw
-
-
-class ConvWinoWFn(torch.autograd.Function):
-    """ConvFn for layers _winow_ok takes: the column taps as Winograd F(4, 3) / F(4, 5) / F(2, 7) - 1.5, 2 or 4 products per
-    output instead of 3, 5, 7 - on the same f32 GEMM kernels between HBM-bound transforms.  Same arguments and gradients as
-    ConvFn (the CRSK weights are not needed)."""
-
-    @staticmethod
-    def forward(ctx, x, w_krsc, w_crsk, bias, key):
-        d = _desc_from_key(key)
-        x, w_krsc = x.contiguous(), w_krsc.contiguous()
-        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        U, Uc = _ww_weights(d, w_krsc, need_dx)
-        y, V = _ww_fprop(d, x, U, key, bias=bias)
-        ctx.key = key
-        ctx.w_shape = tuple(w_krsc.shape)
-        ctx.has_bias = bias is not None
-        ctx.save_for_backward(V if need_dw else None, Uc)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        V, Uc = ctx.saved_tensors
-        d = _desc_from_key(ctx.key)
-        dy = dy.contiguous()
-        want_db = ctx.has_bias and ctx.needs_input_grad[3]
-        Z, part = _ww_dy(d, dy, want_db)
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            if Uc is None:
-                raise _lib.MqganHipError("ConvWinoWFn: input gradient asked for an input that did not require one")
-            dx = _ww_dgrad(d, Z, Uc, ctx.key)
-        if ctx.needs_input_grad[1]:
-            if V is None:
-                raise _lib.MqganHipError("ConvWinoWFn: weight gradient asked for weights that did not require one")
-            dw = _ww_wgrad(d, V, Z, ctx.key).view(ctx.w_shape)
-        if want_db:
-            db = colsum(part) if part is not None else _bias_grad(d, dy)
-        return dx, dw, None, db, None
-
-
-class ConvWinoWLeakyFn(torch.autograd.Function):
-    """ConvLeakyFn for layers _winow_ok takes (the patch discriminator's 3x3 / stride-(2, 1) layers): y = padded ? 0 :
-    LeakyReLU(conv(x, w) + bias) with the column taps as Winograd F(4, 3); bias + LeakyReLU + mask ride on the output transform,
-    the producer's gate on the input-gradient transform, the bias sums on the output-gradient transform.  Same arguments, contract
-    (``in_gate`` / ``pregated``) and gradients as ConvLeakyFn."""
-
-    @staticmethod
-    def forward(ctx, x, w_krsc, bias, mask, key, dmap, slope, in_gate=None, pregated=False):
-        d = _desc_from_key(key)
-        x, w_krsc = x.contiguous(), w_krsc.contiguous()
-        U, Uc = _ww_weights(d, w_krsc, True)
-        y, V = _ww_fprop(d, x, U, key, bias=bias, act=2, slope=slope, mask=mask, dmap=dmap)
-        del U
-        ctx.key, ctx.dmap, ctx.slope = key, dmap, slope
-        ctx.w_shape = tuple(w_krsc.shape)
-        ctx.has_bias = bias is not None
-        ctx.pregated = bool(pregated)
-        ctx.in_gate = None if in_gate is None else (in_gate[1], in_gate[2])
-        ctx.kept_v = w_krsc.requires_grad
-        ctx.save_for_backward(V if ctx.kept_v else None, Uc, None if ctx.pregated else y, mask, x if in_gate is not None else None,
-                              None if in_gate is None else in_gate[0])
-        return y
-
-    @staticmethod
-    def backward(ctx, dout):
-        V, Uc, y, mask, x_gate, mask_in = ctx.saved_tensors
-        d = _desc_from_key(ctx.key)
-        if ctx.slope != 0.2 and not ctx.pregated:
-            raise _lib.MqganHipError("the pointwise backward kernel implements LeakyReLU(0.2) only")
-        if ctx.pregated:
-            dy = dout.contiguous()
-        else:
-            Cc = y.shape[-1]
-            pd = PointwiseDesc(rows=y.numel() // Cc, C=Cc, act=ACT_LEAKY, mask_pre=0, mask_post=int(mask is not None),
-                               d1=ctx.dmap[0], d2=ctx.dmap[1], d3=ctx.dmap[2], p_drop=0.0, seed=0)
-            dy = torch.empty_like(y)
-            check(L().mq_pointwise_bwd(C.byref(pd), fptr(dout.contiguous()), fptr(y), None, ptr(mask, torch.uint8, True), None,
-                                       None, fptr(dy), None, None, None, None, stream()), "mq_pointwise_bwd")
-        want_dx, want_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        want_db = ctx.has_bias and ctx.needs_input_grad[2]
-        dx = dw = db = None
-        Z, part = _ww_dy(d, dy, want_db)
-        if want_dx:
-            gd = ctx.in_gate[0] if ctx.in_gate is not None else (1, 0, 1)
-            gs = float(ctx.in_gate[1]) if ctx.in_gate is not None else 1.0
-            dx = _ww_dgrad(d, Z, Uc, ctx.key, gate=x_gate, gslope=gs, mask_in=mask_in, gdmap=gd)
-        if want_dw:
-            if not ctx.kept_v:
-                raise _lib.MqganHipError("ConvWinoWLeakyFn: weight gradient asked for a layer whose weights did not require one")
-            dw = _ww_wgrad(d, V, Z, ctx.key).view(ctx.w_shape)
-        if want_db:
-            db = colsum(part) if part is not None else _bias_grad(d, dy)
-        return dx, dw, db, None, None, None, None, None, None
-
-
-# ----------------------------------------------------------------------------- 1-D Winograd F(m, 3) along the rows (csrc/wino1d.hip)
-WINO1D_MIN_CHANNELS = int(os.environ.get("MQGAN_WINO1D_MINC", "128"))     # 0 switches the path off (A/B runs)
-WINO1D_TILE = int(os.environ.get("MQGAN_WINO1D_TILE", "0"))               # 0: the tile with the fewest products; 2, 4, 5: fixed
-
-
-def _wino1d_ok(d: ConvDesc) -> bool:
-    """3 taps, stride 1, pad 1 along the rows (any taps, stride 1 or 2 along the columns): the multi-bin discriminator's
-    (3 x k) layers, on an f32-result engine, with channel counts that fill the GEMM."""
-    return (WINO1D_MIN_CHANNELS > 0 and d.R == 3 and d.stride_h == 1 and d.pad_h == 1 and d.dil_h == 1 and d.dil_w == 1 and d.P == d.H
-            and d.H >= 2 and d.stride_w in (1, 2) and d.precision in (PRECISIONS["f32"], PRECISIONS["f32x3"])
-            and d.C % 16 == 0 and d.K % 16 == 0 and d.K <= 1024 and min(d.C, d.K) >= WINO1D_MIN_CHANNELS
-            and d.N % d.groups == 0)
-
-
-def _wino1d_m(d: ConvDesc) -> int:
-    """Output rows per tile: F(m, 3) costs ceil(H / m) * (m + 2) row products - 5 for the 10-bin bands (14 instead of 20 with
-    F(2, 3) and 30 direct), 4 for 16 bins."""
-    return WINO1D_TILE if WINO1D_TILE in (2, 4, 5) else L().mq_wino1d_tile(d.H)
-
-
-def _wino1d_gemm_desc(d: ConvDesc, m: int) -> ConvDesc:
-    """The m + 2 transform positions as (m + 2) x groups batch groups of one-row images (xi, n, row tile)."""
-    th = -(-d.H // m)
-    return conv_desc((m + 2) * d.N * th, 1, d.W, d.C, d.K, 1, d.S, stride=(1, d.stride_w), pad=(0, d.pad_w), groups=(m + 2) * d.groups,
-                     precision=d.precision)
-
-
-class ConvWino1dLeakyFn(torch.autograd.Function):
-    """ConvLeakyFn for layers _wino1d_ok takes: y = padded ? 0 : LeakyReLU(conv(x, w) + bias) with the row taps as Winograd
-    F(m, 3) - (m + 2) / 3m of the multiplications, run as one batch-grouped (1 x S) convolution on the same f32 GEMM kernels
-    between HBM-bound transforms that also carry the epilogues (bias + LeakyReLU + mask forward; the producer's gate, the bias
-    sums backward).  Same arguments, contract (``in_gate`` / ``pregated``) and gradients as ConvLeakyFn."""
-
-    @staticmethod
-    def forward(ctx, x, w_krsc, bias, mask, key, dmap, slope, in_gate=None, pregated=False):
-        d = _desc_from_key(key)
-        m = _wino1d_m(d)
-        th, npos = -(-d.H // m), m + 2
-        G = d.groups
-        x, w_krsc = x.contiguous(), w_krsc.contiguous()
-        V = _empty((npos * d.N * th, 1, d.W, d.C), x)
-        check(L().mq_wino1d_input_transform(fptr(x), d.N, d.H, d.W, d.C, m, fptr(V), stream()), "mq_wino1d_input_transform")
-        U = _empty((npos * G * d.K, d.S, d.C), x)
-        Uc = _empty((npos * G * d.C, d.S, d.K), x)
-        check(L().mq_wino1d_weight_transform(fptr(w_krsc), G, d.K, d.C, d.S, m, fptr(U), fptr(Uc), stream()), "mq_wino1d_weight_transform")
-        dg = _wino1d_gemm_desc(d, m)
-        nested = _winow_ok(dg)             # stride-1 column taps: the row convolutions themselves as F(m', S) along the columns
-        if nested:
-            U2, Uc = _ww_weights(dg, U, True)
-            M, V = _ww_fprop(dg, V, U2, key)
-            del U2
-        else:
-            M = _empty((npos * d.N * th, 1, d.Q, d.K), x)
-            _timed(None, _conv_flops(dg), lambda: check(
-                L().mq_conv_fprop(C.byref(dg), fptr(V), fptr(U), None, fptr(M), stream()), "mq_conv_fprop"), key)
-        y = _empty((d.N, d.H, d.Q, d.K), x)
-        check(L().mq_wino1d_output_transform(fptr(M), fptr(bias, True), d.N, d.H, d.Q, d.K, G, m, 2, float(slope),
-                                             ptr(mask, torch.uint8, True), dmap[0], dmap[1], dmap[2], fptr(y), stream()),
-              "mq_wino1d_output_transform")
-        del M, U
-        ctx.key, ctx.dmap, ctx.slope, ctx.m, ctx.nested = key, dmap, slope, m, nested
-        ctx.w_shape = tuple(w_krsc.shape)
-        ctx.has_bias = bias is not None
-        ctx.pregated = bool(pregated)
-        ctx.in_gate = None if in_gate is None else (in_gate[1], in_gate[2])
-        keep_v = w_krsc.requires_grad
-        ctx.kept_v = keep_v
-        ctx.save_for_backward(V if keep_v else None, Uc, None if ctx.pregated else y, mask, x if in_gate is not None else None,
-                              None if in_gate is None else in_gate[0])
-        return y
-
-    @staticmethod
-    def backward(ctx, dout):
-        V, Uc, y, mask, x_gate, mask_in = ctx.saved_tensors
-        d = _desc_from_key(ctx.key)
-        m = ctx.m
-        th, npos = -(-d.H // m), m + 2
-        G = d.groups
-        if ctx.slope != 0.2 and not ctx.pregated:
-            raise _lib.MqganHipError("the pointwise backward kernel implements LeakyReLU(0.2) only")
-        if ctx.pregated:
-            dy = dout.contiguous()
-        else:
-            Cc = y.shape[-1]
-            pd = PointwiseDesc(rows=y.numel() // Cc, C=Cc, act=ACT_LEAKY, mask_pre=0, mask_post=int(mask is not None),
-                               d1=ctx.dmap[0], d2=ctx.dmap[1], d3=ctx.dmap[2], p_drop=0.0, seed=0)
-            dy = torch.empty_like(y)
-            check(L().mq_pointwise_bwd(C.byref(pd), fptr(dout.contiguous()), fptr(y), None, ptr(mask, torch.uint8, True), None,
-                                       None, fptr(dy), None, None, None, None, stream()), "mq_pointwise_bwd")
-        want_dx, want_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        want_db = ctx.has_bias and ctx.needs_input_grad[2]
-        dx = dw = db = None
-        part = None
-        if want_db:
-            part = _empty((L().mq_wino1d_dy_rows(d.N, d.H, d.Q, d.K, G, m), G * d.K), dy)
-        Z = _empty((npos * d.N * th, 1, d.Q, d.K), dy)
-        check(L().mq_wino1d_dy_transform(fptr(dy), d.N, d.H, d.Q, d.K, G, m, fptr(Z), fptr(part, True), stream()), "mq_wino1d_dy_transform")
-        dg = _wino1d_gemm_desc(d, m)
-        Z2 = _ww_dy(dg, Z, False)[0] if ctx.nested else None       # V and Uc are then the column-transformed ones
-        if want_dx:
-            if ctx.nested:
-                dV = _ww_dgrad(dg, Z2, Uc, ctx.key)
-            else:
-                dV = _empty((npos * d.N * th, 1, d.W, d.C), dy)
-                _timed(None, _conv_flops(dg), lambda: check(
-                    L().mq_conv_dgrad(C.byref(dg), fptr(Z), fptr(Uc), fptr(dV), stream()), "mq_conv_dgrad"), ctx.key)
-            dx = _empty((d.N, d.H, d.W, d.C), dy)
-            gd = ctx.in_gate[0] if ctx.in_gate is not None else (1, 0, 1)
-            gs = float(ctx.in_gate[1]) if ctx.in_gate is not None else 1.0
-            check(L().mq_wino1d_dx_transform(fptr(dV), d.N, d.H, d.W, d.C, m, fptr(x_gate, True), gs, ptr(mask_in, torch.uint8, True),
-                                             gd[0], gd[1], gd[2], fptr(dx), stream()), "mq_wino1d_dx_transform")
-            del dV
-        if want_dw:
-            if not ctx.kept_v:
-                raise _lib.MqganHipError("ConvWino1dLeakyFn: weight gradient asked for a layer whose weights did not require one")
-            if ctx.nested:
-                dU = _ww_wgrad(dg, V, Z2, ctx.key)
-            else:
-                dU = _empty((npos * G * d.K, d.S, d.C), dy)
-                nbytes = L().mq_conv_wgrad_workspace(C.byref(dg))
-                ws = _ws_bytes(nbytes, dy)
-                _timed(None, _conv_flops(dg), lambda: check(
-                    L().mq_conv_wgrad(C.byref(dg), fptr(V), fptr(Z), fptr(dU), ptr(ws), nbytes, stream()), "mq_conv_wgrad"), ctx.key)
-            dw = _empty(ctx.w_shape, dy)
-            check(L().mq_wino1d_wgrad_inverse(fptr(dU), G, d.K, d.C, d.S, m, fptr(dw), stream()), "mq_wino1d_wgrad_inverse")
-        if want_db:
-            db = colsum(part)
-        return dx, dw, db, None, None, None, None, None, None
-
-
-# ----------------------------------------------------------------------------- 5x5 / stride-2 layers: polyphase + F(3x3, 3x3)
-WINO_S2D_MIN_CHANNELS = int(os.environ.get("MQGAN_WINO_S2D_MINC", "128"))     # 0 switches the path off (A/B runs)
-
-
-def _wino_s2d_ok(d: ConvDesc) -> bool:
-    """5x5, stride 2, pad 2, one group, even image: the patch discriminator's wide layers as a 3x3 / stride-1 convolution over the
-    four polyphase components of the input, run as Winograd F(3x3, 3x3) (csrc/winograd3.hip)."""
-    return (WINO_S2D_MIN_CHANNELS > 0 and d.R == 5 and d.S == 5 and d.stride_h == 2 and d.stride_w == 2 and d.pad_h == 2 and d.pad_w == 2
-            and d.dil_h == 1 and d.dil_w == 1 and d.groups == 1 and d.H % 2 == 0 and d.W % 2 == 0 and d.P == d.H // 2 and d.Q == d.W // 2
-            and d.precision in (PRECISIONS["f32"], PRECISIONS["f32x3"]) and d.C % 16 == 0 and d.K % 16 == 0 and d.K <= 1024
-            and min(d.C, d.K) >= WINO_S2D_MIN_CHANNELS)
-
-
-def _s2d_tile(d: ConvDesc):
-    """Tile of the 3x3 / stride-1 convolution over the (P, Q) polyphase grid; there is no F(2x2) form of it."""
-    t = _wino_tile(d.P, d.Q)
-    return (3, 3) if t == (2, 2) else t
-
-
-def _s2d_tiles(d: ConvDesc) -> int:
-    return _wino_ntiles(_s2d_tile(d), d.N, d.P, d.Q)
-
-
-def _s2d_gemm_desc(d: ConvDesc, cin: int, cout: int) -> ConvDesc:
-    return _wino_gemm(_s2d_tile(d), d.N, d.P, d.Q, cin, cout, d.precision)
-
-
-class ConvWinoS2dLeakyFn(torch.autograd.Function):
-    """ConvLeakyFn for layers _wino_s2d_ok takes (see csrc/winograd3.hip, the polyphase section): 11.1 (F(3x3, 3x3)), 9 (4x4) or 8.4
-    (4x5) instead of 25 products per output and channel pair.  Same arguments, contract (``in_gate`` / ``pregated``) and gradients
-    as ConvLeakyFn."""
-
-    @staticmethod
-    def forward(ctx, x, w_krsc, bias, mask, key, dmap, slope, in_gate=None, pregated=False):
-        d = _desc_from_key(key)
-        tile, tiles = _s2d_tile(d), _s2d_tiles(d)
-        npos = _wino_npos(tile)
-        x, w_krsc = x.contiguous(), w_krsc.contiguous()
-        V = _empty((npos * tiles, 1, 1, 4 * d.C), x)
-        check(_wcall(tile, "input_transform_s2d", fptr(x), d.N, d.H, d.W, d.C, fptr(V)), "mq_wino3_input_transform_s2d")
-        U = _empty((npos * d.K, 1, 4 * d.C), x)
-        check(_wcall(tile, "weight_transform_s2d", fptr(w_krsc), d.K, d.C, 0, fptr(U)), "mq_wino3_weight_transform_s2d")
-        dg = _s2d_gemm_desc(d, 4 * d.C, d.K)
-        M = _empty((npos * tiles, 1, 1, d.K), x)
-        _timed(None, _conv_flops(dg), lambda: check(
-            L().mq_conv_fprop(C.byref(dg), fptr(V), fptr(U), None, fptr(M), stream()), "mq_conv_fprop"), key)
-        y = _empty((d.N, d.P, d.Q, d.K), x)
-        check(_wcall(tile, "output_transform", fptr(M), fptr(bias, True), d.N, d.P, d.Q, d.K, 2, float(slope), ptr(mask, torch.uint8, True),
-                     dmap[0], dmap[1], dmap[2], fptr(y)), "mq_wino3_output_transform")
-        del M, U
-        ctx.key, ctx.dmap, ctx.slope = key, dmap, slope
-        ctx.w_shape = tuple(w_krsc.shape)
-        ctx.has_bias = bias is not None
-        ctx.pregated = bool(pregated)
-        ctx.in_gate = None if in_gate is None else (in_gate[1], in_gate[2])
-        ctx.kept_v = w_krsc.requires_grad
-        ctx.save_for_backward(V if ctx.kept_v else None, w_krsc, None if ctx.pregated else y, mask, x if in_gate is not None else None,
-                              None if in_gate is None else in_gate[0])
-        return y
-
-    @staticmethod
-    def backward(ctx, dout):
-        V, w_krsc, y, mask, x_gate, mask_in = ctx.saved_tensors
-        d = _desc_from_key(ctx.key)
-        tile, tiles = _s2d_tile(d), _s2d_tiles(d)
-        npos = _wino_npos(tile)
-        if ctx.slope != 0.2 and not ctx.pregated:
-            raise _lib.MqganHipError("the pointwise backward kernel implements LeakyReLU(0.2) only")
-        if ctx.pregated:
-            dy = dout.contiguous()
-        else:
-            Cc = y.shape[-1]
-            pd = PointwiseDesc(rows=y.numel() // Cc, C=Cc, act=ACT_LEAKY, mask_pre=0, mask_post=int(mask is not None),
-                               d1=ctx.dmap[0], d2=ctx.dmap[1], d3=ctx.dmap[2], p_drop=0.0, seed=0)
-            dy = torch.empty_like(y)
-            check(L().mq_pointwise_bwd(C.byref(pd), fptr(dout.contiguous()), fptr(y), None, ptr(mask, torch.uint8, True), None,
-                                       None, fptr(dy), None, None, None, None, stream()), "mq_pointwise_bwd")
-        want_dx, want_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        want_db = ctx.has_bias and ctx.needs_input_grad[2]
-        dx = dw = db = None
-        Z = _empty((npos * tiles, 1, 1, d.K), dy)
-        Vd = _empty((npos * tiles, 1, 1, d.K), dy) if want_dx else None
-        part = _empty((_wrows(tile, d.N, d.P, d.Q, d.K), d.K), dy) if want_db else None
-        check(_wcall(tile, "dy_fused", fptr(dy), d.N, d.P, d.Q, d.K, fptr(Z), fptr(Vd, True), fptr(part, True)), "mq_wino3_dy_fused")
-        if want_dx:
-            Ut = _empty((npos * 4 * d.C, 1, d.K), dy)
-            check(_wcall(tile, "weight_transform_s2d", fptr(w_krsc), d.K, d.C, 1, fptr(Ut)), "mq_wino3_weight_transform_s2d")
-            dgt = _s2d_gemm_desc(d, d.K, 4 * d.C)
-            Mt = _empty((npos * tiles, 1, 1, 4 * d.C), dy)
-            _timed(None, _conv_flops(dgt), lambda: check(
-                L().mq_conv_fprop(C.byref(dgt), fptr(Vd), fptr(Ut), None, fptr(Mt), stream()), "mq_conv_fprop"), ctx.key)
-            del Vd, Ut
-            dx = _empty((d.N, d.H, d.W, d.C), dy)
-            gd = ctx.in_gate[0] if ctx.in_gate is not None else (1, 0, 1)
-            gs = float(ctx.in_gate[1]) if ctx.in_gate is not None else 1.0
-            check(_wcall(tile, "output_transform_d2s", fptr(Mt), d.N, d.H, d.W, d.C, fptr(x_gate, True), gs, ptr(mask_in, torch.uint8, True),
-                         gd[0], gd[1], gd[2], fptr(dx)), "mq_wino3_output_transform_d2s")
-            del Mt
-        if want_dw:
-            if not ctx.kept_v:
-                raise _lib.MqganHipError("ConvWinoS2dLeakyFn: weight gradient asked for a layer whose weights did not require one")
-            dg = _s2d_gemm_desc(d, 4 * d.C, d.K)
-            Pm = _empty((npos * d.K, 1, 4 * d.C), dy)
-            nbytes = L().mq_conv_wgrad_workspace(C.byref(dg))
-            ws = _ws_bytes(nbytes, dy)
-            _timed(None, _conv_flops(dg), lambda: check(
-                L().mq_conv_wgrad(C.byref(dg), fptr(V), fptr(Z), fptr(Pm), ptr(ws), nbytes, stream()), "mq_conv_wgrad"), ctx.key)
-            dw = _empty(ctx.w_shape, dy)
-            check(_wcall(tile, "wgrad_inverse_s2d", fptr(Pm), d.K, d.C, fptr(dw)), "mq_wino3_wgrad_inverse_s2d")
-        if want_db:
-            db = colsum(part)
-        return dx, dw, db, None, None, None, None, None, None
 
 
 class LeakyGateFn(torch.autograd.Function):
@@ -1270,12 +819,8 @@ def conv_leaky(x, w_krsc, w_crsk, bias, desc: ConvDesc, mask, dmap, slope: float
     x = to_f32(x)
     if desc.C % 4 != 0 or _h_ok(desc, desc.C):
         return ret(pointwise(conv(x, w_krsc, w_crsk, bias, desc), act=ACT_LEAKY, mask=mask, mask_post=mask is not None, dmap=dmap))
-    if _wino1d_ok(desc):
-        return ret(ConvWino1dLeakyFn.apply(x, w_krsc, bias, mask, _desc_key(desc), tuple(dmap), slope, in_gate, pregate), pregate)
-    if _wino_s2d_ok(desc):
-        return ret(ConvWinoS2dLeakyFn.apply(x, w_krsc, bias, mask, _desc_key(desc), tuple(dmap), slope, in_gate, pregate), pregate)
-    if _winow_ok(desc):
-        return ret(ConvWinoWLeakyFn.apply(x, w_krsc, bias, mask, _desc_key(desc), tuple(dmap), slope, in_gate, pregate), pregate)
+    if conv_plan(desc, True).form != FORM_DIRECT:          # F(m, 3) along the rows, polyphase F(mh x mw, 3x3), F(m, S) along the columns
+        return ret(ConvPlannedFn.apply(x, w_krsc, None, bias, _desc_key(desc), (mask, tuple(dmap), slope), in_gate, pregate), pregate)
     return ret(ConvLeakyFn.apply(x, w_krsc, w_crsk, bias, mask, _desc_key(desc), tuple(dmap), slope, in_gate, pregate), pregate)
 
 
@@ -1286,10 +831,8 @@ def conv(x, w_krsc, w_crsk, bias, desc: ConvDesc, out_f32: bool = False):
         return ConvH2Fn.apply(to_bf16(x), w_krsc, w_crsk, bias, _desc_key(desc), None, out_f32)
     if _is_thin(desc):
         return _thin_conv(x if desc.K == 1 else to_f32(x), w_krsc, w_crsk, bias, desc)
-    if _wino_ok(desc):
-        return ConvWinoFn.apply(to_f32(x), w_krsc, w_crsk, bias, _desc_key(desc))
-    if _winow_ok(desc):
-        return ConvWinoWFn.apply(to_f32(x), w_krsc, w_crsk, bias, _desc_key(desc))
+    if conv_plan(desc, False).form != FORM_DIRECT:         # F(mh x mw, 3x3) or F(m, S) along the columns
+        return ConvPlannedFn.apply(to_f32(x), w_krsc, None, bias, _desc_key(desc))
     return ConvFn.apply(to_f32(x), w_krsc, w_crsk, bias, _desc_key(desc))
 
 

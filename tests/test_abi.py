@@ -16,7 +16,7 @@ def declared():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     out = {}
-    for m in re.finditer(r"\b(?:int|size_t|const char \*)\s*(mq_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(?:int|size_t|void|const char \*)\s*(mq_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
         name, args = m.group(1), m.group(2).strip()
         n = 0 if args in ("", "void") else args.count(",") + 1
         out[name] = n
@@ -42,7 +42,7 @@ def test_library_exports_every_declared_symbol(built):
     for name, nargs in d.items():
         assert hasattr(lib, name), name
         assert len(_lib.SIGNATURES[name][1]) == nargs, (name, nargs, len(_lib.SIGNATURES[name][1]))
-    assert lib.mq_abi_version() == 7 == _lib.ABI_VERSION
+    assert lib.mq_abi_version() == 8 == _lib.ABI_VERSION
     # nm agrees (extern "C", no mangling)
     syms = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     for name in d:
@@ -59,6 +59,33 @@ def test_host_side_validation_rejects_bad_shapes_without_a_gpu(built):
     rc = lib.mq_conv_fprop(C.byref(d), C.c_void_p(16), C.c_void_p(16), None, C.c_void_p(16), None)
     assert rc != 0 and b"groups" in lib.mq_last_error()
     assert lib.mq_conv_wgrad_workspace(C.byref(d)) == 0
+
+
+def test_planned_calls_validate_on_the_host(built):
+    """mq_conv_plan / mq_conv_*_planned: struct layouts agree between the header and ctypes (the plan echoes the descriptor),
+    and the planned calls refuse a short workspace or a plan / epilogue mismatch before any launch."""
+    import ctypes as C
+    from mqgan_amd import _lib
+    lib = _lib.load()
+    d = _lib.ConvDesc(N=4, H=16, W=20, C=128, K=144, R=3, S=3, P=16, Q=20, stride_h=1, stride_w=1, pad_h=1, pad_w=1, dil_h=1,
+                      dil_w=1, groups=1, precision=0)
+    cfg = _lib.PlanCfg()
+    lib.mq_plan_cfg_default(C.byref(cfg))
+    assert cfg.keep_mib > 0 and cfg.wino_tile in (0, 3, 4, 45)
+    p = _lib.ConvPlan()
+    assert lib.mq_conv_plan(C.byref(d), 0, C.byref(cfg), C.byref(p)) == 0
+    assert (p.desc.N, p.desc.K, p.desc.pad_w, p.desc.precision) == (4, 144, 1, 0)            # the struct layout round-trips
+    assert p.form == _lib.FORM_WINO2D and lib.mq_form_name(p.form) == b"winograd2d" and p.gemm.groups == p.npos == (p.mh + 2) * (p.mw + 2)
+    assert p.ws_fprop > 0 and p.ws_backward > 0 and p.keep_bytes % 256 == 0
+    a = C.c_void_p(256)
+    rc = lib.mq_conv_fprop_planned(C.byref(p), a, a, None, 0, 0.0, None, 1, 0, 1, a, None, a, p.ws_fprop - 1, None)
+    assert rc != 0 and b"workspace" in lib.mq_last_error()
+    rc = lib.mq_conv_fprop_planned(C.byref(p), a, a, None, 2, 0.2, None, 1, 0, 1, a, None, a, p.ws_fprop, None)
+    assert rc != 0 and b"plan was made for" in lib.mq_last_error()
+    rc = lib.mq_conv_backward_planned(C.byref(p), None, None, a, None, a, None, 1.0, None, 1, 0, 1, None, a, None, a, p.ws_backward, None)
+    assert rc != 0 and b"keep buffer or x" in lib.mq_last_error()
+    cfg.wino_tile = 2
+    assert lib.mq_conv_plan(C.byref(d), 0, C.byref(cfg), C.byref(p)) != 0 and b"wino_tile" in lib.mq_last_error()
 
 
 def test_ops_refuse_cpu_tensors(built):

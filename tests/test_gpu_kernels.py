@@ -471,10 +471,10 @@ WINO_CASES = [
 ]
 
 
-@pytest.fixture(params=[3, 2, 4, 45, "auto"], ids=["F3x3", "F2x2", "F4x4", "F4x5", "auto"])
+@pytest.fixture(params=["3", "4", "45", "auto"], ids=["F3x3", "F4x4", "F4x5", "auto"])
 def wino_tile(request):
-    """Every Winograd tile: F(3x3, 3x3) (csrc/winograd3.hip), F(2x2, 3x3) (winograd.hip), F(4x4, 3x3) and F(4x5, 3x3)
-    (winogradn.hip), and the per-image choice ops makes by default."""
+    """Every Winograd tile - F(3x3, 3x3), F(4x4, 3x3) and F(4x5, 3x3) (csrc/winogradn.hip) - and the per-image choice mq_conv_plan
+    makes by default."""
     from mqgan_amd import ops
     keep, ops.WINO_TILE = ops.WINO_TILE, request.param
     yield request.param
@@ -486,7 +486,7 @@ def wino_tile(request):
                                             dict(N=1, H=10, W=11, C=256, K=128, R=3, S=3, pad=(1, 1))],    # one / two spare rows
                          ids=lambda c: "N{N}H{H}W{W}C{C}K{K}".format(**c))
 def test_winograd_conv_fprop_dgrad_wgrad(env, c, precision, wino_tile):
-    """3x3 / stride 1 / pad 1 layers with >= 128 channels run as Winograd F(mh x mw, 3x3) (ops.ConvWinoFn), every tile shape:
+    """3x3 / stride 1 / pad 1 layers with >= 128 channels run as Winograd F(mh x mw, 3x3) (ops.ConvPlannedFn), every tile shape:
     forward, input, weight and bias gradients against the float64 direct convolution.  The transforms add a few roundings to
     the direct kernels' error; bounds: WINO_TOL / WINO2D_CMAX above, the edge rows / columns and every filter tap on their own."""
     ops = env
@@ -505,7 +505,7 @@ def test_winograd_conv_fprop_dgrad_wgrad(env, c, precision, wino_tile):
     desc = ops.conv_desc(c["N"], c["H"], c["W"], c["C"], c["K"], 3, 3, pad=(1, 1), precision=precision)
     assert ops._wino_ok(desc)
     y = ops.conv(xd, wk, wc, bd, desc)
-    assert y.grad_fn.__class__.__name__.startswith("ConvWinoFn")
+    assert y.grad_fn.__class__.__name__.startswith("ConvPlannedFn") and ops.conv_plan(desc, False).form == ops.FORM_WINO2D
     tag = f"wino2d {wino_tile} {precision} N{c['N']}H{c['H']}W{c['W']}C{c['C']}K{c['K']}"
     edges = (1, 5, 1, 5)          # first row / column (the zero padding) and whatever the last - possibly ragged - tile covers
     assert_elem(y, y_ref, WINO_TOL, WINO2D_CMAX, tag + " fprop", edges=edges)
@@ -570,7 +570,7 @@ def test_f32x3_engine_has_the_error_of_the_f32_engine(env, monkeypatch):
     assert errs["f32x3"][1] < 2.0 * errs["f32"][1] + 1e-7, errs
     monkeypatch.undo()
     assert ops._wino_ok(ops.conv_desc(N, H, W, Cc, K, 3, 3, pad=(1, 1)))
-    for tile, bound in ((2, 2.5e-6), (3, 4e-6), (4, 5e-6), (45, 7e-6)):
+    for tile, bound in ((3, 4e-6), (4, 5e-6), (45, 7e-6)):
         monkeypatch.setattr(ops, "WINO_TILE", tile)
         d = ops.conv_desc(N, H, W, Cc, K, 3, 3, pad=(1, 1))
         e = (ops.conv(x.float().to(DEV), wk, wc, None, d).double().cpu() - ref) / scale
@@ -676,7 +676,7 @@ WINOW_CASES = [
 @pytest.mark.parametrize("c", WINOW_CASES, ids=lambda c: "N{N}H{H}W{W}C{C}K{K}R{R}S{S}".format(**c) + f"g{c.get('groups', 1)}")
 def test_winow_conv_fprop_dgrad_wgrad(env, monkeypatch, c, precision):
     """Convolutions with 3, 5 or 7 stride-1 taps along the columns (time) as one-dimensional Winograd F(4, 3) / F(4, 5) / F(2, 7)
-    (ops.ConvWinoWFn, csrc/winow.hip): "same" and causal padding, ragged last tiles, row taps with stride 2, batch groups - forward,
+    (ops.ConvPlannedFn, csrc/winow.hip): "same" and causal padding, ragged last tiles, row taps with stride 2, batch groups - forward,
     input, weight and bias gradients against the float64 direct convolution."""
     ops = env
     monkeypatch.setattr(ops, "WINO_MIN_CHANNELS", 0)            # the 3x3 cases would otherwise take the 2-D route
@@ -701,7 +701,7 @@ def test_winow_conv_fprop_dgrad_wgrad(env, monkeypatch, c, precision):
                          pad=c.get("pad", (0, 0)), groups=G, out_hw=c.get("out_hw"), precision=precision)
     assert ops._winow_ok(desc)
     y = ops.conv(xd, wk, wc, bd, desc)
-    assert y.grad_fn.__class__.__name__.startswith("ConvWinoWFn")
+    assert y.grad_fn.__class__.__name__.startswith("ConvPlannedFn") and ops.conv_plan(desc, False).form == ops.FORM_WINOW
     assert tuple(y.shape) == tuple(y_ref.shape)
     tag = f"winow {precision} H{c['H']}W{c['W']}C{c['C']}K{c['K']}R{c['R']}S{c['S']}p{c['pad'][1]}g{G}"
     edges = (0, 0, max(c["pad"][1], 1), 4)     # the columns that see the (causal) left padding, and the last tile
@@ -1001,7 +1001,7 @@ def test_wino1d_discriminator_chain_matches_direct_kernels(env, monkeypatch, H, 
             assert ops._wino1d_ok(d1) == (minc > 0) and ops._wino1d_ok(d2) == (minc > 0)
             dm1, dm2 = (d1.P * d1.Q, d1.Q, d1.Q), (d2.P * d2.Q, d2.Q, d2.Q)
             y1, hon = ops.conv_leaky(x, k1, c1, b1v, d1, mask1, dm1, pregate=True, chain=True)
-            assert hon and y1.grad_fn.__class__.__name__.startswith("ConvWino1dLeakyFn" if minc > 0 else "ConvLeakyFn")
+            assert hon and y1.grad_fn.__class__.__name__.startswith("ConvPlannedFn" if minc > 0 else "ConvLeakyFn")
             y2 = ops.conv_leaky(y1, k2, c2, b2v, d2, mask2, dm2, in_gate=(mask1, dm1, 0.2))
             assert y2.shape == r.shape
             (y2 * r).sum().backward()
@@ -1042,7 +1042,7 @@ def test_wino1d_discriminator_chain_matches_direct_kernels(env, monkeypatch, H, 
                                            (12, 20, "f32x3", 45), (20, 32, "f32", "auto")])
 def test_polyphase_winograd_5x5_stride2_chain_matches_direct_kernels(env, monkeypatch, H, W, prec, tile):
     """The patch discriminator's 5x5 / stride-2 layers as F(mh x mw, 3x3) over the polyphase components of the input
-    (ops.ConvWinoS2dLeakyFn; tiles 3x3, 4x4, 4x5 and the one ops picks) and on the direct kernels (ops.WINO_S2D_MIN_CHANNELS = 0):
+    (ops.ConvPlannedFn; tiles 3x3, 4x4, 4x5 and the one ops picks) and on the direct kernels (ops.WINO_S2D_MIN_CHANNELS = 0):
     two such layers in a row (the second one's input gradient carries the first one's LeakyReLU' / mask), frame masks, ragged tile
     edges.  Outputs against each other; outputs, input gradient, weight and bias gradients of either path against float64 with the
     LeakyReLU branch of every element taken from the tested path's own output (see the one-dimensional test above)."""
@@ -1075,7 +1075,7 @@ def test_polyphase_winograd_5x5_stride2_chain_matches_direct_kernels(env, monkey
             assert ops._wino_s2d_ok(d1) == (minc > 0) and ops._wino_s2d_ok(d2) == (minc > 0)
             dm1, dm2 = (d1.P * d1.Q, d1.Q, d1.Q), (d2.P * d2.Q, d2.Q, d2.Q)
             y1, hon = ops.conv_leaky(x, k1, c1, b1v, d1, mask1, dm1, pregate=True, chain=True)
-            assert hon and y1.grad_fn.__class__.__name__.startswith("ConvWinoS2dLeakyFn" if minc > 0 else "ConvLeakyFn")
+            assert hon and y1.grad_fn.__class__.__name__.startswith("ConvPlannedFn" if minc > 0 else "ConvLeakyFn")
             y2 = ops.conv_leaky(y1, k2, c2, b2v, d2, mask2, dm2, in_gate=(mask1, dm1, 0.2))
             assert y2.shape == r.shape
             (y2 * r).sum().backward()
@@ -1108,7 +1108,7 @@ def test_polyphase_winograd_5x5_stride2_chain_matches_direct_kernels(env, monkey
 
 @pytest.mark.parametrize("H,W,prec", [(20, 32, "f32"), (9, 21, "f32"), (20, 32, "f32x3")])
 def test_winow_stride21_chain_matches_direct_kernels(env, H, W, prec):
-    """The patch discriminator's 3x3 / stride-(2, 1) layers with the column taps as Winograd F(4, 3) (ops.ConvWinoWLeakyFn) and on
+    """The patch discriminator's 3x3 / stride-(2, 1) layers with the column taps as Winograd F(4, 3) (ops.ConvPlannedFn) and on
     the direct kernels (ops.WINOW_MIN_CHANNELS = 0): two such layers in a row (the second one's input gradient carries the first
     one's LeakyReLU' / mask), frame masks, odd heights, a ragged last tile.  Outputs against each other; outputs, input gradient,
     weight and bias gradients of either path against float64 with the LeakyReLU branch of every element taken from the tested
@@ -1140,7 +1140,7 @@ def test_winow_stride21_chain_matches_direct_kernels(env, H, W, prec):
             assert ops._winow_ok(d1) == (minc > 0) and ops._winow_ok(d2) == (minc > 0) and d2.P == H2
             dm1, dm2 = (d1.P * d1.Q, d1.Q, d1.Q), (d2.P * d2.Q, d2.Q, d2.Q)
             y1, hon = ops.conv_leaky(x, k1, c1, b1v, d1, mask, dm1, pregate=True, chain=True)
-            assert hon and y1.grad_fn.__class__.__name__.startswith("ConvWinoWLeakyFn" if minc > 0 else "ConvLeakyFn")
+            assert hon and y1.grad_fn.__class__.__name__.startswith("ConvPlannedFn" if minc > 0 else "ConvLeakyFn")
             y2 = ops.conv_leaky(y1, k2, c2, b2v, d2, mask, dm2, in_gate=(mask, dm1, 0.2))
             assert y2.shape == r.shape
             (y2 * r).sum().backward()

@@ -83,36 +83,6 @@ def test_pad_collate_drops_failed_loads_and_pads_to_the_batch_crop():
     assert x.shape == (2, 50, 4) and lens.tolist() == [50, 20]
 
 
-def test_winograd_f2x2_3x3_identities():
-    """The algebra csrc/winograd.hip implements, in float64: forward Y = A^T[(G g G^T) . (B^T d B)]A equals the direct 3x3
-    correlation of a 4x4 tile; the weight gradient is G^T[(B^T d B) . (A dY A^T)]G; the input gradient is the same forward
-    form applied to dy with the filter rotated by 180 degrees (a 'same' convolution)."""
-    rng = np.random.default_rng(3)
-    Bt = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], float)
-    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], float)
-    At = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], float)
-    d, g, dY = rng.standard_normal((4, 4)), rng.standard_normal((3, 3)), rng.standard_normal((2, 2))
-    direct = np.array([[(d[a:a + 3, b:b + 3] * g).sum() for b in range(2)] for a in range(2)])
-    V, U = Bt @ d @ Bt.T, G @ g @ G.T
-    np.testing.assert_allclose(At @ (U * V) @ At.T, direct, rtol=1e-12, atol=1e-12)
-    # d(sum(Y * dY)) / dg
-    want_dg = np.array([[(d[r:r + 2, s:s + 2] * dY).sum() for s in range(3)] for r in range(3)])
-    Z = At.T @ dY @ At
-    np.testing.assert_allclose(G.T @ (V * Z) @ G, want_dg, rtol=1e-12, atol=1e-12)
-    # input gradient of a padded 'same' convolution = 'same' convolution of dy with the rotated filter
-    H = W = 6
-    x, w, gy = rng.standard_normal((H, W)), rng.standard_normal((3, 3)), rng.standard_normal((H, W))
-    xp = np.pad(x, 1)
-    dx = np.zeros_like(xp)
-    for h in range(H):
-        for ww in range(W):
-            dx[h:h + 3, ww:ww + 3] += gy[h, ww] * w
-    gp = np.pad(gy, 1)
-    rot = w[::-1, ::-1]
-    same = np.array([[(gp[h:h + 3, ww:ww + 3] * rot).sum() for ww in range(W)] for h in range(H)])
-    np.testing.assert_allclose(dx[1:-1, 1:-1], same, rtol=1e-12, atol=1e-12)
-
-
 def test_bench_traffic_lookup_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
     """bench.pmc_traffic: bytes per launch only from a PMC pass taken on the kernel sources that are being run (hash of the
     conv kernel files); another build reads as None with the file named as stale; unknown kernels read as None."""
@@ -195,38 +165,102 @@ def test_reencode_default_batching_is_the_reference_loop():
     assert srt != ref and sorted(f for b in srt for f in b) == sorted(files)
 
 
-def test_winograd_form_selection_per_layer():
-    """Which exact-f32 form ops picks for the convolutions of BASELINE config 2 (pure host logic + the library's tile tables):
-    refiner 3x3 -> F(4x5) on T x 90 images, polyphase 5x5/s2 -> F(4x5) on 40 x 128 and 20 x 64, multi-bin (3 x k) ->
-    F(5, 3) along 10 bins (nested along time when the column taps have stride 1), the patch discriminator's stride-(2, 1) layers
-    and the 1-D convolutions -> F(4, 3) / F(4, 5) / F(2, 7) along time; small layers and bf16 stay on the direct kernels."""
+def test_conv_plan_form_selection_per_layer():
+    """mq_conv_plan (csrc/plan.cpp: the ONE copy of the eligibility logic; host code, no GPU needed): which exact-f32 form the
+    convolutions of BASELINE config 2 take - refiner 3x3 -> F(4x5) on T x 90 images, polyphase 5x5/s2 -> F(4x5) on 40 x 128 and
+    20 x 64, multi-bin (3 x k) -> F(5, 3) along 10 bins (nested along time when the column taps have stride 1), the patch
+    discriminator's stride-(2, 1) layers and the 1-D convolutions -> F(4, 3) / F(4, 5) / F(2, 7) along time; small layers and bf16
+    stay on the direct kernels - and the GEMM descriptors / buffer sizes it reports."""
     from mqgan_amd import ops
     L = ops.L()
     assert [L.mq_wino1d_tile(h) for h in (2, 6, 8, 9, 10, 16)] == [2, 2, 4, 5, 5, 4]
     assert [L.mq_winow_tile(s) for s in (3, 5, 7, 4)] == [4, 4, 2, 0]
-    assert ops._wino_tile(512, 90) == (4, 5) and ops._wino_tile(64, 90) == (4, 5) and ops._wino_tile(40, 128) == (4, 5)
-    assert ops._wino_tile(20, 64) == (4, 5) and ops._wino_tile(16, 16) == (4, 4) and ops._wino_tile(9, 9) == (3, 3)
     f32 = "f32"
+
+    def tile(H, W):
+        p = ops.conv_plan(ops.conv_desc(1, H, W, 128, 128, 3, 3, pad=(1, 1), precision=f32), False)
+        assert p.form == ops.FORM_WINO2D
+        return p.mh, p.mw
+    assert tile(512, 90) == (4, 5) and tile(64, 90) == (4, 5) and tile(40, 128) == (4, 5)
+    assert tile(20, 64) == (4, 5) and tile(16, 16) == (4, 4) and tile(9, 9) == (3, 3)
     refiner = ops.conv_desc(32, 256, 90, 128, 128, 3, 3, pad=(1, 1), precision=f32)
-    assert ops._wino_ok(refiner) and ops._wino_np(refiner) == 42 and ops._wino_tiles(refiner) == 32 * 64 * 18
+    p = ops.conv_plan(refiner, False)
+    assert ops.form_name(p) == "winograd2d" and p.npos == 42 and p.tiles == 32 * 64 * 18
+    assert (p.gemm.N, p.gemm.H, p.gemm.W, p.gemm.R, p.gemm.S, p.gemm.groups) == (42 * 32 * 64, 1, 18, 1, 1, 42)
+    assert p.flops == 2.0 * 42 * p.tiles * 128 * 128
+    assert p.keep_bytes >= 4 * 42 * p.tiles * 128 and p.ws_fprop >= 4 * 42 * p.tiles * 256 and p.ws_backward > p.ws_fprop
+    assert ops.conv_plan(refiner, True).form != ops.FORM_WINO2D            # a LeakyReLU 3x3 layer goes the row way (F(m, 3))
     assert ops._wino_ok(ops.conv_desc(32, 512, 90, 64, 64, 3, 3, pad=(1, 1), precision=f32))           # C K / (C + K) = 32
     assert not ops._wino_ok(ops.conv_desc(32, 512, 90, 48, 64, 3, 3, pad=(1, 1), precision=f32))
     assert not ops._wino_ok(ops.conv_desc(32, 256, 90, 128, 128, 3, 3, pad=(1, 1), precision="bf16"))
-    # the larger tiles' fused dy pass takes K <= 1024: wider layers stay on the direct kernels instead of failing in backward
+    # the fused dy pass takes K <= 1024: wider layers stay on the direct kernels instead of failing in backward
     assert ops._wino_ok(ops.conv_desc(2, 64, 90, 1024, 1024, 3, 3, pad=(1, 1), precision=f32))
     assert not ops._wino_ok(ops.conv_desc(2, 64, 90, 512, 1040, 3, 3, pad=(1, 1), precision=f32))
     patch = ops.conv_desc(64, 80, 256, 256, 256, 5, 5, stride=(2, 2), pad=(2, 2), precision=f32)
-    assert ops._wino_s2d_ok(patch) and ops._s2d_tile(patch) == (4, 5)
+    p = ops.conv_plan(patch, True)
+    assert p.form == ops.FORM_S2D and (p.mh, p.mw) == (4, 5) and p.gemm.C == 4 * 256 and p.gemm.groups == 42
+    assert ops.conv_plan(patch, False).form == ops.FORM_DIRECT              # the polyphase form exists for the leaky layers
     mb35 = ops.conv_desc(512, 10, 512, 128, 128, 3, 5, pad=(1, 2), groups=8, precision=f32)
     mb33 = ops.conv_desc(512, 10, 512, 128, 256, 3, 3, stride=(1, 2), pad=(1, 1), groups=8, precision=f32)
-    assert ops._wino1d_ok(mb35) and ops._wino1d_ok(mb33) and ops._wino1d_m(mb35) == 5
-    inner35, inner33 = ops._wino1d_gemm_desc(mb35, 5), ops._wino1d_gemm_desc(mb33, 5)
-    assert (inner35.N, inner35.H, inner35.S, inner35.groups) == (7 * 512 * 2, 1, 5, 56)
-    assert ops._winow_ok(inner35) and not ops._winow_ok(inner33)                     # stride 2 along time: no column form
-    g = ops._ww_desc(inner35)
-    assert (g.N, g.W, g.R, g.S, g.groups) == (8 * inner35.N, 128, 1, 1, 8 * 56)
+    p35, p33 = ops.conv_plan(mb35, True), ops.conv_plan(mb33, True)
+    assert p35.form == ops.FORM_WINO1D and p33.form == ops.FORM_WINO1D and p35.mh == 5
+    assert (p35.gemm.N, p35.gemm.H, p35.gemm.S, p35.gemm.groups) == (7 * 512 * 2, 1, 5, 56)
+    assert p35.nested == 1 and p33.nested == 0                              # stride 2 along time: no column form inside
+    g = p35.inner
+    assert (g.N, g.W, g.R, g.S, g.groups) == (8 * p35.gemm.N, 128, 1, 1, 8 * 56)
     d1 = ops.conv_desc(64, 20, 64, 384, 512, 3, 3, stride=(2, 1), pad=(1, 1), precision=f32)
-    assert not ops._wino_ok(d1) and ops._winow_ok(d1) and ops._ww_geom(d1) == (4, 16, 6)
+    p = ops.conv_plan(d1, True)
+    assert not ops._wino_ok(d1) and p.form == ops.FORM_WINOW and (p.mw, p.npos) == (4, 6) and p.gemm.W == 16
     dec = ops.conv_desc(32, 1, 512, 768, 512, 1, 7, pad=(0, 6), out_hw=(1, 512), precision=f32)       # causal k = 7
-    assert ops._winow_ok(dec) and ops._ww_geom(dec) == (2, 256, 8)
+    p = ops.conv_plan(dec, False)
+    assert p.form == ops.FORM_WINOW and (p.mw, p.npos, p.gemm.W) == (2, 8, 256)
     assert not ops._winow_ok(ops.conv_desc(32, 1, 512, 768, 512, 1, 7, pad=(0, 6), dil=(1, 2), out_hw=(1, 512), precision=f32))
+    # the switches are values of the plan's configuration
+    import pytest
+    keep = ops.WINO_TILE
+    try:
+        ops.WINO_TILE = "3"
+        assert tile(512, 90) == (3, 3)
+        ops.WINO_TILE = "2"
+        with pytest.raises(Exception, match="auto, 3, 4 or 45"):
+            tile(512, 90)
+    finally:
+        ops.WINO_TILE = keep
+
+
+def test_conv_plan_of_every_config2_layer():
+    """The plan of every convolution of BASELINE config 2 (hifispeech, batch 32 x 512 frames x 80 mels) that the default path
+    runs in a reduced-multiplication form: the table DESIGN 3.6-3.9 describes, as the library computes it."""
+    from mqgan_amd import ops
+    f32 = "f32"
+    W2 = "winograd2d"
+    table = []
+    # refiner (preencoder.py:86-130): T x 90 images at 512 / 256 / 128 / 64 frames, 64 ... 512 channels
+    for T, cin, cout in ((512, 64, 64), (256, 64, 128), (256, 128, 128), (128, 128, 256), (128, 256, 256), (64, 256, 512), (64, 512, 512),
+                         (128, 768, 256), (256, 384, 128), (512, 192, 64)):
+        table.append((ops.conv_desc(32, T, 90, cin, cout, 3, 3, pad=(1, 1), precision=f32), False, W2, (4, 5)))
+    # patch discriminator (discriminators.py:196-242), real + fake as one batch of 64 in eval mode
+    table.append((ops.conv_desc(64, 80, 256, 256, 256, 5, 5, stride=(2, 2), pad=(2, 2), precision=f32), True, "polyphase-winograd2d", (4, 5)))
+    table.append((ops.conv_desc(64, 40, 128, 256, 384, 5, 5, stride=(2, 2), pad=(2, 2), precision=f32), True, "polyphase-winograd2d", (4, 5)))
+    table.append((ops.conv_desc(64, 20, 64, 384, 512, 3, 3, stride=(2, 1), pad=(1, 1), precision=f32), True, "winograd-columns", (0, 4)))
+    table.append((ops.conv_desc(64, 10, 64, 512, 512, 3, 3, stride=(2, 1), pad=(1, 1), precision=f32), True, "winograd-columns", (0, 4)))
+    # multi-bin discriminator (discriminators.py:292-311): 8 bands x 64 images of 10 bins
+    table.append((ops.conv_desc(512, 10, 512, 128, 128, 3, 5, pad=(1, 2), groups=8, precision=f32), True, "winograd-rows", (5, 4)))
+    table.append((ops.conv_desc(512, 10, 512, 128, 256, 3, 3, stride=(1, 2), pad=(1, 1), groups=8, precision=f32), True, "winograd-rows", (5, 0)))
+    table.append((ops.conv_desc(512, 10, 256, 256, 256, 3, 3, stride=(1, 2), pad=(1, 1), groups=8, precision=f32), True, "winograd-rows", (5, 0)))
+    table.append((ops.conv_desc(512, 10, 128, 256, 384, 3, 3, stride=(1, 2), pad=(1, 1), groups=8, precision=f32), True, "winograd-rows", (5, 0)))
+    # encoder / decoder 1-D convolutions (attentions.py:95-130): k = 3, 3, 5, 7; causal left padding in the decoder
+    for cin, cout, k in ((512, 512, 3), (512, 512, 5), (512, 768, 7), (768, 768, 7)):
+        table.append((ops.conv_desc(32, 1, 512, cin, cout, 1, k, pad=(0, k // 2), precision=f32), False, "winograd-columns", (0, 2 if k == 7 else 4)))
+        table.append((ops.conv_desc(32, 1, 512, cout, cin, 1, k, pad=(0, k - 1), out_hw=(1, 512), precision=f32), False, "winograd-columns",
+                      (0, 2 if k == 7 else 4)))
+    # what stays direct: single-channel first layers / logits (thin path in Python), the 12-channel entry of the refiner
+    table.append((ops.conv_desc(32, 512, 90, 64, 12, 1, 1, precision=f32), False, "direct", (0, 0)))
+    table.append((ops.conv_desc(64, 80, 512, 1, 256, 5, 5, stride=(1, 2), pad=(2, 2), precision=f32), True, "direct", (0, 0)))
+    for d, leaky, form, tile in table:
+        p = ops.conv_plan(d, leaky)
+        assert ops.form_name(p) == form and (p.mh, p.mw) == tile, (ops._desc_key(d), leaky, ops.form_name(p), p.mh, p.mw)
+        if form != "direct":
+            direct = 2.0 * d.N * d.P * d.Q * d.K * d.C * d.R * d.S
+            assert p.flops < 0.62 * direct and p.ws_fprop > 0 and p.ws_backward > 0 and p.keep_bytes > 0
+

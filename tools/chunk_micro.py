@@ -40,6 +40,7 @@ for name, N, H, W, Cc, K in CASES:
     x = torch.randn(N, H, W, Cc, device=DEV)
     w = torch.randn(K, Cc, 3, 3, device=DEV) * 0.02
     wk, wc = ops.weight_prep(w, None, True)
+    wk, wc = wk.detach(), wc.detach()
     bias = torch.randn(K, device=DEV)
     dy = torch.randn(N, H, W, K, device=DEV)
     line = f"{name:18s}"
@@ -48,15 +49,19 @@ for name, N, H, W, Cc, K in CASES:
         key = ops._desc_key(d)
         vm_mib = 4 * 42 * n * (H // 4) * (W // 5) * (Cc + K) / 2**20
 
-        def fwd():
-            for i in range(0, N, n):
-                ops._wino_conv(d, x[i:i + n], wk, bias, Cc, K, False, key)
+        xs = [x[i:i + n].clone().requires_grad_(True) for i in range(0, N, n)]
 
-        def dgrad():
-            for i in range(0, N, n):
-                Z, Vd, part = ops._wino_dy_fused(dy[i:i + n], d)
-                ops._wino_conv(d, None, wk, None, K, Cc, True, key, V=Vd)
-        line += f" | n={n:2d} V+M {vm_mib:6.0f} MiB fwd {tm(fwd):6.3f} dgrad {tm(dgrad):6.3f}"
+        def fwd():
+            with torch.no_grad():
+                for xi in xs:
+                    ops.conv(xi, wk, wc, bias, d)
+
+        def fwd_dgrad():
+            for i, xi in enumerate(xs):
+                xi.grad = None
+                ops.conv(xi, wk, wc, bias, d).backward(dy[i * n:(i + 1) * n])
+        tf = tm(fwd)
+        line += f" | n={n:2d} V+M {vm_mib:6.0f} MiB fwd {tf:6.3f} dgrad {tm(fwd_dgrad) - tf:6.3f}"
     print(line, flush=True)
     del x, w, wk, wc, dy
     torch.cuda.empty_cache()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Winograd F(2x2, 3x3) against the direct f32 kernels on the refiner's 3x3 layers of BASELINE config 2 (hifispeech):
+"""The Winograd form mq_conv_plan picks (F(4x5, 3x3) for these images) against the direct f32 kernels on the refiner's 3x3 layers of BASELINE config 2 (hifispeech):
 forward + input gradient + weight gradient of one layer, HIP-event time."""
 import os
 import sys
@@ -54,13 +54,14 @@ for name, N, H, W, Cc, K in CASES:
         return y
     res["direct fprop"] = tm(direct)
     res["direct bwd"] = tm(lambda: ops._conv_backward_f32(d, key, x, wc, dy, tuple(wk.shape), True, True, True))
-    res["wino fprop"] = tm(lambda: ops._wino_conv(d, x, wk, bias, Cc, K, False, key))
+    res["wino fprop"] = tm(lambda: ops.conv(x, wk, wc, bias, d))
 
-    class Ctx:
-        pass
-    ctx = Ctx()
-    ctx.key, ctx.w_shape, ctx.has_bias, ctx.needs_input_grad, ctx.saved_tensors, ctx.kept_v = key, tuple(wk.shape), True, (True, True, False, True, False), (x, wk), False
-    res["wino bwd"] = tm(lambda: ops.ConvWinoFn.backward(ctx, dy))
+    xg, wkg, bg = x.clone().requires_grad_(True), wk.detach().clone().requires_grad_(True), bias.clone().requires_grad_(True)
+
+    def wino_fb():
+        xg.grad = wkg.grad = bg.grad = None
+        ops.conv(xg, wkg, wc, bg, d).backward(dy)
+    res["wino bwd"] = tm(wino_fb) - res["wino fprop"]
     dsum, wsum = res["direct fprop"] + res["direct bwd"], res["wino fprop"] + res["wino bwd"]
     print(f"{name:24s} direct {res['direct fprop']:7.3f} + {res['direct bwd']:7.3f} = {dsum:7.3f} ms ({3 * flops / dsum / 1e9:6.1f} TF/s)   "
           f"winograd {res['wino fprop']:7.3f} + {res['wino bwd']:7.3f} = {wsum:7.3f} ms   x{dsum / wsum:4.2f}", flush=True)
