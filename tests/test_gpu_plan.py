@@ -1,0 +1,83 @@
+"""-m gpu: the planned convolution calls as a CONSUMER OF THE HEADER would use them - ctypes only, torch just owns the memory
+(INTEGRATION.md section 2): mq_conv_plan picks the form, mq_conv_fprop_planned / mq_conv_backward_planned run it, and the results
+equal those of the same calls under a configuration with every reduced form switched off (the direct kernels)."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import DEV, assert_elem  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    from mqgan_amd import _lib
+    return _lib, _lib.load()
+
+
+CASES = [
+    # name, desc kwargs, leaky, expected form
+    ("refiner 3x3", dict(N=2, H=12, W=15, C=128, K=144, R=3, S=3, P=12, Q=15, stride_h=1, stride_w=1, pad_h=1, pad_w=1), False, "winograd2d"),
+    ("patch-D 5x5 s2", dict(N=2, H=24, W=40, C=128, K=128, R=5, S=5, P=12, Q=20, stride_h=2, stride_w=2, pad_h=2, pad_w=2), True, "polyphase-winograd2d"),
+    ("multi-bin 3x5 g2", dict(N=4, H=10, W=37, C=128, K=128, R=3, S=5, P=10, Q=37, stride_h=1, stride_w=1, pad_h=1, pad_w=2, groups=2), True,
+     "winograd-rows"),
+    ("multi-bin 3x3 s(1,2)", dict(N=4, H=10, W=36, C=128, K=160, R=3, S=3, P=10, Q=18, stride_h=1, stride_w=2, pad_h=1, pad_w=1, groups=2), True,
+     "winograd-rows"),
+    ("decoder causal k7", dict(N=2, H=1, W=45, C=128, K=128, R=1, S=7, P=1, Q=45, stride_h=1, stride_w=1, pad_h=0, pad_w=6), False, "winograd-columns"),
+    ("patch-D 3x3 s(2,1)", dict(N=2, H=9, W=22, C=128, K=128, R=3, S=3, P=5, Q=22, stride_h=2, stride_w=1, pad_h=1, pad_w=1), True, "winograd-columns"),
+]
+
+
+@pytest.mark.parametrize("name,kw,leaky,form", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("use_keep", [True, False], ids=["keep", "no-keep"])
+def test_planned_calls_through_ctypes_equal_the_direct_form(lib, name, kw, leaky, form, use_keep):
+    _lib, L = lib
+    torch.manual_seed(3)
+    d = _lib.ConvDesc(dil_h=1, dil_w=1, groups=kw.get("groups", 1), precision=0, **{k: v for k, v in kw.items() if k != "groups"})
+    G = d.groups
+    x = torch.nn.functional.leaky_relu(torch.randn(d.N, d.H, d.W, d.C, device=DEV), 0.2)
+    w_krsc = torch.randn(G * d.K, d.R * d.S, d.C, device=DEV) * 0.05          # (taps, channels) rows; channel blocks of 16 inside
+    bias = torch.randn(G * d.K, device=DEV)
+    dy = torch.randn(d.N, d.P, d.Q, d.K, device=DEV)
+    mask = torch.zeros(d.N, d.Q, dtype=torch.uint8, device=DEV)
+    mask[-1, d.Q // 2:] = 1
+    gmask = torch.zeros(d.N, d.W, dtype=torch.uint8, device=DEV)
+    gmask[-1, d.W // 2:] = 1
+    # CRSK twin of the weights for the direct input gradient: undo the channel blocking, transpose, block again
+    CB = 16
+    plain = w_krsc.view(G, d.K, d.C // CB, d.R * d.S, CB).permute(0, 1, 3, 2, 4).reshape(G, d.K, d.R * d.S, d.C)
+    w_crsk = plain.permute(0, 3, 2, 1).reshape(G, d.C, d.R * d.S, d.K // CB, CB).permute(0, 1, 3, 2, 4).contiguous().view(G * d.C, d.R * d.S, d.K)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    out = {}
+    for leg in ("planned", "direct"):
+        cfg = _lib.PlanCfg()
+        L.mq_plan_cfg_default(C.byref(cfg))
+        if leg == "direct":
+            cfg.wino_minc = cfg.s2d_minc = cfg.wino1d_minc = cfg.winow_minc = 0
+            cfg.wino_minc_explicit = 1
+        p = _lib.ConvPlan()
+        assert L.mq_conv_plan(C.byref(d), int(leaky), C.byref(cfg), C.byref(p)) == 0, L.mq_last_error()
+        assert L.mq_form_name(p.form).decode() == (form if leg == "planned" else "direct")
+        ws = torch.empty(max(p.ws_fprop, p.ws_backward, 256), dtype=torch.uint8, device=DEV)
+        keep = torch.empty(max(p.keep_bytes, 256), dtype=torch.uint8, device=DEV) if (use_keep and p.keep_bytes) else None
+        y = torch.empty(d.N, d.P, d.Q, d.K, device=DEV)
+        rc = L.mq_conv_fprop_planned(C.byref(p), P(x), P(w_krsc), P(bias), 2 if leaky else 0, 0.2, P(mask) if leaky else None, d.P * d.Q, d.Q, d.Q,
+                                     P(y), P(keep), P(ws), ws.numel(), st)
+        assert rc == 0, L.mq_last_error()
+        dx, dw, db = torch.empty_like(x), torch.empty_like(w_krsc), torch.empty_like(bias)
+        gate = leaky                          # the leaky layers sit in gated chains: x came out of a LeakyReLU + mask layer
+        rc = L.mq_conv_backward_planned(C.byref(p), P(x), P(keep), P(w_krsc), P(w_crsk), P(dy), P(x) if gate else None, 0.2,
+                                        P(gmask) if gate else None, d.H * d.W, d.W, d.W, P(dx), P(dw), P(db), P(ws), ws.numel(), st)
+        assert rc == 0, L.mq_last_error()
+        torch.cuda.synchronize()
+        out[leg] = (y, dx, dw, db)
+    for nm, a, b in zip(("y", "dx", "dw", "db"), out["planned"], out["direct"]):
+        assert_elem(a, b, 2e-5, 2e-4, f"plan ctypes {name} {nm}")
+    if leaky:
+        assert float(out["planned"][0][-1, :, d.Q // 2:].abs().max()) == 0.0        # padded output frames
+        assert float(out["planned"][1][-1, :, d.W // 2:].abs().max()) == 0.0        # padded input frames of the gated gradient
