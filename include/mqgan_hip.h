@@ -258,13 +258,18 @@ typedef struct {
     const float *b2;    /* 1 */
 } mqCb2dWeights;
 
+/* Dropout (p_drop > 0): the keep decision of every (pixel, hidden unit) is drawn once, in the forward call (a counter-seeded
+ * xorshift + Weyl stream per pixel; same Bernoulli(1 - p) law as the pointwise kernels' Philox, 16 bits per decision), left as
+ * one bit each in keep_bits - mq_convblock2d_keep_bytes(B, T, C0) bytes, [C0 / 32][B * T * C0] words - and read back by the backward
+ * call: nothing is drawn twice.  keep_bits may be NULL when p_drop == 0. */
+size_t mq_convblock2d_keep_bytes(int B, int T, int C0);
 int mq_convblock2d_fwd(const mqCb2dWeights *w_host, const float *x, const uint8_t *mask, int B, int T, int C0,
-                       float p_drop, uint64_t seed, float *y, float *v_save, mqStream stream);
+                       float p_drop, uint64_t seed, float *y, float *v_save, uint32_t *keep_bits, mqStream stream);
 /* grads: dx (B,T,C0); dwdw (25), dbdw (1), dw1 (C0), db1 (C0), dw2 (C0), db2 (1).
  * workspace bytes: mq_convblock2d_bwd_workspace(B, T, C0). */
 size_t mq_convblock2d_bwd_workspace(int B, int T, int C0);
 int mq_convblock2d_bwd(const mqCb2dWeights *w_host, const float *x, const float *v_save, const float *dy,
-                       const uint8_t *mask, int B, int T, int C0, float p_drop, uint64_t seed, float *dx, float *dwdw,
+                       const uint8_t *mask, int B, int T, int C0, float p_drop, const uint32_t *keep_bits, float *dx, float *dwdw,
                        float *dbdw, float *dw1, float *db1, float *dw2, float *db2, void *workspace, mqStream stream);
 
 /* ------------------------------------------------------------------ pointwise

@@ -107,9 +107,10 @@ SIGNATURES = {
     "mq_spectral_prep_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "mq_spectral_prep_bands": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "mq_spectral_prep_bands_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
-    "mq_convblock2d_fwd": (_I, [C.POINTER(Cb2dWeights), _P, _P, _I, _I, _I, _F, _U64, _P, _P, _P]),
+    "mq_convblock2d_keep_bytes": (_Z, [_I, _I, _I]),
+    "mq_convblock2d_fwd": (_I, [C.POINTER(Cb2dWeights), _P, _P, _I, _I, _I, _F, _U64, _P, _P, _P, _P]),
     "mq_convblock2d_bwd_workspace": (_Z, [_I, _I, _I]),
-    "mq_convblock2d_bwd": (_I, [C.POINTER(Cb2dWeights), _P, _P, _P, _P, _I, _I, _I, _F, _U64, _P, _P, _P, _P, _P, _P, _P,
+    "mq_convblock2d_bwd": (_I, [C.POINTER(Cb2dWeights), _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P,
                                 _P, _P]),
     "mq_pointwise_fwd": (_I, [C.POINTER(PointwiseDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "mq_pointwise_bwd": (_I, [C.POINTER(PointwiseDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

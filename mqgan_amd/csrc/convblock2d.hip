@@ -16,14 +16,36 @@ namespace mq {
 // aptx(h) = s * 0.5 * h and of its derivative out by hand - same roundings in the same order, fewer multiplications
 __device__ __forceinline__ float aptx_half(float h) { return __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * h)); }
 
+// Dropout of the hidden vector.  r3 drew the keep decisions from Philox4x32-7 in the forward AND again in the backward kernel: 28
+// quarter-rate integer multiplications per 8 hidden units - as many issue slots as the arithmetic of those units (exp + rcp
+// included).  Now each thread runs one cheap stream per pixel (xorshift32 + a Weyl sequence, seeded by a hash of (seed, pixel);
+// 16 bits per hidden unit, threshold as in common.h: drop iff u16 < thresh16), the forward kernel leaves the decisions as ONE BIT
+// per (pixel, hidden unit) in HBM ([unit / 32][pixel] words: coalesced, C0 / 8 bytes per pixel against the C0 exp + rcp it
+// stands for) and the backward kernel reads them back instead of drawing again.
+struct DropStream {
+    uint32_t s, w;
+    __device__ __forceinline__ void seed(uint64_t seed, int64_t pixel)
+    {
+        auto mix = [](uint32_t x) {
+            x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+            return x;
+        };
+        const uint32_t lo = (uint32_t)pixel, hi = (uint32_t)((uint64_t)pixel >> 32);
+        s = mix((uint32_t)seed ^ (lo * 0x9E3779B1u) ^ mix(hi + 0x85ebca6bu));
+        s = s ? s : 0x6d2b79f5u;                                   // xorshift has no zero state
+        w = mix((uint32_t)(seed >> 32) ^ lo ^ 0xc2b2ae35u);
+    }
+    __device__ __forceinline__ uint32_t next()                     // two 16-bit uniforms
+    {
+        s ^= s << 13; s ^= s >> 17; s ^= s << 5;
+        w += 0x9E3779B9u;
+        return s + w;
+    }
+};
+
 constexpr int CB_TT = 4;     // time steps per block tile
 constexpr int CB_TM = 8;     // time steps per thread in the MLP backward (amortises the per-channel wave reductions)
 constexpr int CB_TC = 64;    // channels per block tile (fwd)
-
-__device__ __forceinline__ uint64_t cb_group(int64_t pixel, int k, int groups_per_pixel)
-{
-    return (uint64_t)pixel * (uint64_t)groups_per_pixel + (uint64_t)(k >> 3);
-}
 
 // Forward.  Block tile CB_FT time steps x CB_TC channels; thread = channel c, CB_FP consecutive time steps, so the three MLP
 // weights of a hidden unit are read from LDS once for CB_FP pixels and the per-pixel chains are independent (packed f32 math).
@@ -33,7 +55,8 @@ __global__ __launch_bounds__(256) void cb2d_fwd_kernel(const float *__restrict__
                                                        const float *__restrict__ w1, const float *__restrict__ b1,
                                                        const float *__restrict__ w2, const float *__restrict__ b2, int B, int T,
                                                        int C0, uint32_t thresh16, float scale, uint64_t seed,
-                                                       float *__restrict__ y, float *__restrict__ v_save)
+                                                       float *__restrict__ y, float *__restrict__ v_save,
+                                                       uint32_t *__restrict__ keep_bits)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float *sw1 = sm, *sb1 = sm + C0, *sw2 = sm + 2 * C0;
@@ -75,25 +98,49 @@ __global__ __launch_bounds__(256) void cb2d_fwd_kernel(const float *__restrict__
         if (v_save && inb[p]) v_save[pix[p]] = v[p];
         acc[p] = bias2;
     }
-    const int gpp = (C0 + 7) >> 3;
-    for (int k0 = 0; k0 < C0; k0 += 8) {
-        Drop8 rng[CB_FP];
-        if (thresh16) {
-#pragma unroll
-            for (int p = 0; p < CB_FP; ++p) rng[p] = Drop8(seed, cb_group(pix[p], k0, gpp));
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = k0 + e;
-            if (k >= C0) break;
+    if (thresh16 == 0) {                            // eval mode: no dropout, no random numbers
+        for (int k = 0; k < C0; ++k) {
             const float wk1 = sw1[k], bk1 = sb1[k], wk2 = sw2[k];
 #pragma unroll
             for (int p = 0; p < CB_FP; ++p) {
                 const float h = fmaf(wk1, v[p], bk1);
-                float a = aptx_half(h) * h;       // = aptx_s(h) * 0.5f * h bit for bit (the factors 2 and 0.5 are exact)
-                if (thresh16) a = rng[p].keep(e, thresh16) ? a * scale : 0.f;
-                acc[p] = fmaf(wk2, a, acc[p]);
+                acc[p] = fmaf(wk2, aptx_half(h) * h, acc[p]);       // = aptx_s(h) * 0.5f * h bit for bit (the factors 2 and 0.5 are exact)
             }
+        }
+    } else {
+        const int64_t npix = (int64_t)B * T * C0;
+        DropStream rng[CB_FP];
+#pragma unroll
+        for (int p = 0; p < CB_FP; ++p) rng[p].seed(seed, pix[p]);
+        for (int k32 = 0; k32 < C0; k32 += 32) {
+            uint32_t dropped[CB_FP];                 // bit e set: hidden unit k32 + e of this pixel is dropped
+#pragma unroll
+            for (int p = 0; p < CB_FP; ++p) dropped[p] = 0u;
+#pragma unroll 4
+            for (int e2 = 0; e2 < 16; ++e2) {
+                uint32_t word[CB_FP];
+#pragma unroll
+                for (int p = 0; p < CB_FP; ++p) word[p] = rng[p].next();
+#pragma unroll
+                for (int hlf = 0; hlf < 2; ++hlf) {
+                    const int e = 2 * e2 + hlf, k = k32 + e;
+                    if (k >= C0) break;
+                    const float wk1 = sw1[k], bk1 = sb1[k], wk2s = sw2[k] * scale;
+#pragma unroll
+                    for (int p = 0; p < CB_FP; ++p) {
+                        const float h = fmaf(wk1, v[p], bk1);
+                        const float a = aptx_half(h) * h;
+                        // drop iff u16 < thresh16, without compare / select: the sign of (u16 - thresh16) as a mask of all ones
+                        const uint32_t u = hlf ? (word[p] >> 16) : (word[p] & 0xffffu);
+                        const uint32_t m = (uint32_t)((int32_t)(u - thresh16) >> 31);
+                        dropped[p] |= m & (1u << e);
+                        acc[p] = fmaf(wk2s, __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, a) & ~m), acc[p]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < CB_FP; ++p)
+                if (inb[p]) keep_bits[(int64_t)(k32 >> 5) * npix + pix[p]] = ~dropped[p];
         }
     }
 #pragma unroll
@@ -106,9 +153,9 @@ __global__ __launch_bounds__(256) void cb2d_fwd_kernel(const float *__restrict__
 __global__ __launch_bounds__(256) void cb2d_bwd_mlp_kernel(const float *__restrict__ v_save, const float *__restrict__ dy,
                                                            const uint8_t *__restrict__ mask, const float *__restrict__ w1,
                                                            const float *__restrict__ b1, const float *__restrict__ w2, int B, int T,
-                                                           int C0, uint32_t thresh16, float scale, uint64_t seed,
-                                                           float *__restrict__ dv, float *__restrict__ part, int ntiles_c,
-                                                           int ntiles_t)
+                                                           int C0, uint32_t thresh16, float scale,
+                                                           const uint32_t *__restrict__ keep_bits, float *__restrict__ dv,
+                                                           float *__restrict__ part, int ntiles_c, int ntiles_t)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float *sw1 = sm, *sb1 = sm + C0, *sw2 = sm + 2 * C0;
@@ -123,7 +170,7 @@ __global__ __launch_bounds__(256) void cb2d_bwd_mlp_kernel(const float *__restri
     for (int i = tid; i < 12 * C0; i += 256) wacc[i] = 0.f;
     __syncthreads();
     float *my = wacc + wave * 3 * C0;
-    const int gpp = (C0 + 7) >> 3;
+    const int64_t npix = (int64_t)B * T * C0;
     float db2 = 0.f;
     const int64_t ntiles = (int64_t)B * ntiles_t * ntiles_c;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -146,15 +193,13 @@ __global__ __launch_bounds__(256) void cb2d_bwd_mlp_kernel(const float *__restri
             v[p] = on[p] ? v_save[pix[p]] : 0.f;
             dva[p] = 0.f;
         }
-        for (int k0 = 0; k0 < C0; k0 += 8) {
-            Drop8 rng[CB_TM];
-            if (thresh16) {
+        for (int k32 = 0; k32 < C0; k32 += 32) {
+            uint32_t bits[CB_TM];
 #pragma unroll
-                for (int p = 0; p < CB_TM; ++p) rng[p] = Drop8(seed, cb_group(pix[p], k0, gpp));
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int k = k0 + e;
+            for (int p = 0; p < CB_TM; ++p) bits[p] = (thresh16 && on[p]) ? keep_bits[(int64_t)(k32 >> 5) * npix + pix[p]] : ~0u;
+#pragma unroll 4
+            for (int e = 0; e < 32; ++e) {
+                const int k = k32 + e;
                 if (k >= C0) break;
                 const float wk1 = sw1[k], bk1 = sb1[k], wk2 = sw2[k];
                 float s_w2 = 0.f, s_w1 = 0.f, s_b1 = 0.f;
@@ -162,8 +207,7 @@ __global__ __launch_bounds__(256) void cb2d_bwd_mlp_kernel(const float *__restri
                 for (int p = 0; p < CB_TM; ++p) {
                     const float h = fmaf(wk1, v[p], bk1);
                     const float r = aptx_half(h);                              // s / 2, s = 1 + tanh h
-                    float keep = 1.0f;
-                    if (thresh16) keep = rng[p].keep(e, thresh16) ? scale : 0.f;
+                    const float keep = ((bits[p] >> e) & 1u) ? scale : 0.f;    // scale = 1 without dropout
                     const float gk = on[p] ? g[p] * keep : 0.f;
                     // a = s * 0.5 * h and dh = gk * wk2 * 0.5 * (s + h * s * (2 - s)) with the exact factors of two taken out:
                     // the same roundings in the same order, five multiplications fewer
@@ -250,14 +294,24 @@ __global__ __launch_bounds__(256) void cb2d_bwd_stencil_kernel(const float *__re
     }
 }
 
-// sums `nparts` rows of `width` floats
-__global__ void cb2d_reduce_kernel(const float *__restrict__ part, int nparts, int width, float *__restrict__ out)
+// sums `nparts` rows of `width` floats: block = 64 columns x 16 row groups (1024 threads), thread (c, g) adds rows g, g + 16, ...
+// in that order, the 16 group sums are combined in a fixed order - deterministic, and 16x the loads in flight of one thread per
+// column (r3: 0.24 ms per call, latency-bound on 1024 dependent loads)
+__global__ __launch_bounds__(1024) void cb2d_reduce_kernel(const float *__restrict__ part, int nparts, int width, float *__restrict__ out)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= width) return;
+    __shared__ float red[16][64];
+    const int c = blockIdx.x * 64 + threadIdx.x, g = threadIdx.y;
     float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * width + i];
-    out[i] = s;
+    if (c < width)
+        for (int p = g; p < nparts; p += 16) s += part[(size_t)p * width + c];
+    red[g][threadIdx.x] = s;
+    __syncthreads();
+    if (g == 0 && c < width) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][threadIdx.x];
+        out[c] = t;
+    }
 }
 
 struct CbPlan {
@@ -313,15 +367,22 @@ static int cb_check(const mqCb2dWeights *w, int B, int T, int C0, float p, const
     return 0;
 }
 
+extern "C" size_t mq_convblock2d_keep_bytes(int B, int T, int C0)
+{
+    if (B <= 0 || T <= 0 || C0 <= 0) return 0;
+    return (size_t)cdiv(C0, 32) * (size_t)B * T * C0 * sizeof(uint32_t);
+}
+
 extern "C" int mq_convblock2d_fwd(const mqCb2dWeights *w, const float *x, const uint8_t *mask, int B, int T, int C0, float p_drop,
-                                  uint64_t seed, float *y, float *v_save, mqStream stream)
+                                  uint64_t seed, float *y, float *v_save, uint32_t *keep_bits, mqStream stream)
 {
     if (cb_check(w, B, T, C0, p_drop, "mq_convblock2d_fwd")) return 1;
     MQ_REQUIRE(x && mask && y, "mq_convblock2d_fwd: null pointer");
+    MQ_REQUIRE(p_drop == 0.f || keep_bits, "mq_convblock2d_fwd: dropout needs the keep-bit buffer (mq_convblock2d_keep_bytes)");
     const size_t shm = (size_t)(3 * C0 + (CB_FT + 4) * (CB_TC + 4)) * sizeof(float);
     dim3 grid((unsigned)cdiv(C0, CB_TC), (unsigned)cdiv(T, CB_FT), B);
     hipLaunchKernelGGL(cb2d_fwd_kernel, grid, dim3(256), shm, S(stream), x, mask, w->wdw, w->bdw, w->w1, w->b1, w->w2, w->b2, B, T,
-                       C0, p_drop > 0.f ? drop_thresh16(p_drop) : 0u, p_drop > 0.f ? drop_scale(p_drop) : 1.0f, seed, y, v_save);
+                       C0, p_drop > 0.f ? drop_thresh16(p_drop) : 0u, p_drop > 0.f ? drop_scale(p_drop) : 1.0f, seed, y, v_save, keep_bits);
     MQ_LAUNCH_CHECK("mq_convblock2d_fwd");
     return 0;
 }
@@ -333,10 +394,11 @@ extern "C" size_t mq_convblock2d_bwd_workspace(int B, int T, int C0)
 }
 
 extern "C" int mq_convblock2d_bwd(const mqCb2dWeights *w, const float *x, const float *v_save, const float *dy, const uint8_t *mask,
-                                  int B, int T, int C0, float p_drop, uint64_t seed, float *dx, float *dwdw, float *dbdw, float *dw1,
-                                  float *db1, float *dw2, float *db2, void *workspace, mqStream stream)
+                                  int B, int T, int C0, float p_drop, const uint32_t *keep_bits, float *dx, float *dwdw, float *dbdw,
+                                  float *dw1, float *db1, float *dw2, float *db2, void *workspace, mqStream stream)
 {
     if (cb_check(w, B, T, C0, p_drop, "mq_convblock2d_bwd")) return 1;
+    MQ_REQUIRE(p_drop == 0.f || keep_bits, "mq_convblock2d_bwd: dropout needs the keep bits the forward call wrote");
     MQ_REQUIRE(x && v_save && dy && mask && dx && dwdw && dbdw && dw1 && db1 && dw2 && db2 && workspace,
                "mq_convblock2d_bwd: null pointer");
     const CbPlan p = cb_plan(B, T, C0);
@@ -347,10 +409,10 @@ extern "C" int mq_convblock2d_bwd(const mqCb2dWeights *w, const float *x, const 
     hipStream_t st = S(stream);
     const size_t shm = (size_t)(15 * C0) * sizeof(float);
     hipLaunchKernelGGL(cb2d_bwd_mlp_kernel, dim3(p.grid_mlp), dim3(256), shm, st, v_save, dy, mask, w->w1, w->b1, w->w2, B, T, C0, th,
-                       sc, seed, dv, p1, p.ntc_mlp, p.ntt_mlp);
+                       sc, keep_bits, dv, p1, p.ntc_mlp, p.ntt_mlp);
     hipLaunchKernelGGL(cb2d_bwd_stencil_kernel, dim3(p.grid_st), dim3(256), 0, st, x, dv, w->wdw, B, T, C0, dx, p2, p.ntc_st, p.ntt);
-    hipLaunchKernelGGL(cb2d_reduce_kernel, dim3((unsigned)cdiv(3 * C0 + 1, 256)), dim3(256), 0, st, p1, p.grid_mlp, 3 * C0 + 1, r1);
-    hipLaunchKernelGGL(cb2d_reduce_kernel, dim3(1), dim3(256), 0, st, p2, p.grid_st, 26, r2);
+    hipLaunchKernelGGL(cb2d_reduce_kernel, dim3((unsigned)cdiv(3 * C0 + 1, 64)), dim3(64, 16), 0, st, p1, p.grid_mlp, 3 * C0 + 1, r1);
+    hipLaunchKernelGGL(cb2d_reduce_kernel, dim3(1), dim3(64, 16), 0, st, p2, p.grid_st, 26, r2);
     hipLaunchKernelGGL(cb2d_scatter_kernel, dim3((unsigned)cdiv(C0 > 32 ? C0 : 32, 256)), dim3(256), 0, st, r1, r2, C0, dw1, db1, dw2,
                        db2, dwdw, dbdw);
     MQ_LAUNCH_CHECK("mq_convblock2d_bwd");

@@ -1363,15 +1363,17 @@ class ConvBlock2DFn(torch.autograd.Function):
             fptr(t)
         y = torch.empty_like(x)
         v = torch.empty_like(x)
+        # dropout decisions: drawn once here, one bit per (pixel, hidden unit), read back by the backward kernel
+        bits = _ws_bytes(L().mq_convblock2d_keep_bytes(B, T, C0), x) if p_drop > 0 else None
         check(L().mq_convblock2d_fwd(C.byref(w), fptr(x), ptr(mask, torch.uint8), B, T, C0, float(p_drop), seed, fptr(y), fptr(v),
-                                     stream()), "mq_convblock2d_fwd")
-        ctx.save_for_backward(x, v, mask, wdw, bdw, w1, b1, w2, b2)
+                                     ptr(bits, torch.uint8, True), stream()), "mq_convblock2d_fwd")
+        ctx.save_for_backward(x, v, mask, wdw, bdw, w1, b1, w2, b2, bits)
         ctx.cfg = (float(p_drop), seed)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, v, mask, wdw, bdw, w1, b1, w2, b2 = ctx.saved_tensors
+        x, v, mask, wdw, bdw, w1, b1, w2, b2, bits = ctx.saved_tensors
         B, T, C0 = x.shape
         p_drop, seed = ctx.cfg
         w = Cb2dWeights(wdw=wdw.data_ptr(), bdw=bdw.data_ptr(), w1=w1.data_ptr(), b1=b1.data_ptr(), w2=w2.data_ptr(),
@@ -1380,7 +1382,7 @@ class ConvBlock2DFn(torch.autograd.Function):
         g = [torch.empty_like(t) for t in (wdw, bdw, w1, b1, w2, b2)]
         ws = _ws_bytes(L().mq_convblock2d_bwd_workspace(B, T, C0), x)
         check(L().mq_convblock2d_bwd(C.byref(w), fptr(x), fptr(v), fptr(dy.contiguous()), ptr(mask, torch.uint8), B, T, C0, p_drop,
-                                     seed, fptr(dx), fptr(g[0]), fptr(g[1]), fptr(g[2]), fptr(g[3]), fptr(g[4]), fptr(g[5]), ptr(ws),
+                                     ptr(bits, torch.uint8, True), fptr(dx), fptr(g[0]), fptr(g[1]), fptr(g[2]), fptr(g[3]), fptr(g[4]), fptr(g[5]), ptr(ws),
                                      stream()), "mq_convblock2d_bwd")
         return (dx, None) + tuple(g) + (None, None)
 

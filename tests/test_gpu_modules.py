@@ -112,6 +112,41 @@ def test_convblock2d_large_vs_oracle_and_dropout():
     assert err < 0.05, err
 
 
+def test_convblock2d_dropout_forward_and_backward_use_the_same_decisions():
+    """Train-mode ConvBlock2D: the keep decisions are drawn once in the forward kernel and read back (one bit per pixel and hidden
+    unit) by the backward kernel.  y is linear in conv_out's weights w2 and bias: y(w2 + d) - y(w2) under the SAME seed is the
+    directional derivative exactly, so it must equal what the backward call returns for dw2 - it would not if the two kernels
+    disagreed about a single decision.  Also: the drop rate is the configured one, and two seeds differ."""
+    from mqgan_amd import ops
+    torch.manual_seed(1)
+    B, T, C0 = 2, 37, 96
+    x = torch.randn(B, T, C0, device=DEV, requires_grad=True)
+    mask = u8mask(torch.tensor([T, 20]), T)
+    wdw, bdw = torch.randn(25, device=DEV) * 0.2, torch.randn(1, device=DEV) * 0.1
+    w1, b1 = torch.randn(C0, device=DEV), torch.randn(C0, device=DEV) * 0.1
+    w2, b2 = (torch.randn(C0, device=DEV) * 0.1).requires_grad_(True), torch.randn(1, device=DEV) * 0.1
+    r = torch.randn(B, T, C0, device=DEV)
+    y = ops.ConvBlock2DFn.apply(x, mask, wdw, bdw, w1, b1, w2, b2, 0.1, 1234)
+    (y * r).sum().backward()
+    delta = torch.randn(C0, device=DEV) * 0.05
+    with torch.no_grad():
+        y2 = ops.ConvBlock2DFn.apply(x.detach(), mask, wdw, bdw, w1, b1, w2.detach() + delta, b2, 0.1, 1234)
+        y3 = ops.ConvBlock2DFn.apply(x.detach(), mask, wdw, bdw, w1, b1, w2.detach(), b2, 0.1, 99)
+        ye = ops.ConvBlock2DFn.apply(x.detach(), mask, wdw, bdw, w1, b1, w2.detach(), b2, 0.0, 0)
+    lhs = float(((y2 - y.detach()) * r).sum())
+    rhs = float((w2.grad * delta).sum())
+    assert abs(lhs - rhs) <= 2e-4 * (abs(rhs) + float((w2.grad.abs() * delta.abs()).sum())), (lhs, rhs)
+    assert not torch.equal(y3, y.detach())                                 # another seed, other decisions
+    # drop rate: with w2 = 1, w1 = 0, b1 = 1 every hidden unit contributes the same constant a / (1 - p) or 0
+    with torch.no_grad():
+        ones, zeros = torch.ones(C0, device=DEV), torch.zeros(C0, device=DEV)
+        yk = ops.ConvBlock2DFn.apply(x.detach(), mask * 0, wdw, bdw, zeros, ones, ones, b2 * 0, 0.1, 7)
+        y0 = ops.ConvBlock2DFn.apply(x.detach(), mask * 0, wdw, bdw, zeros, ones, ones, b2 * 0, 0.0, 7)
+    kept = float((yk / y0).mean()) * (1.0 - 0.1)            # fraction kept (the scale 1 / (1 - p_realised) divides out)
+    assert abs(kept - 0.9) < 2e-3, kept
+    assert float((ye - y.detach()).abs().max()) > 0
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
 def test_resblock1d_g3(tag):
     from mqgan_amd.attentions import ResidualBlock1D
