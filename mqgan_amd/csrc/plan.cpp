@@ -121,8 +121,9 @@ mqConvDesc wino2d_desc(int N, int H, int W, int cin, int cout, int mh, int mw, i
 // SAME code paths dry, so the sizes it reports and the bytes the planned calls touch cannot drift apart.
 struct Carver {
     char *base;
-    size_t used = 0, peak = 0;
-    explicit Carver(void *p) : base(static_cast<char *>(p)) {}
+    size_t cap, used = 0, peak = 0;
+    Carver(void *p, size_t capacity) : base(static_cast<char *>(p)), cap(capacity) {}
+    bool over() const { return peak > cap; }      // checked before every launch (MQ_TRY): nothing runs on a pointer past the end
     void *take_bytes(size_t bytes)
     {
         char *p = base ? base + used : nullptr;
@@ -179,9 +180,12 @@ void keep_layout(const mqConvPlan &p, const Sizes &s, size_t *v_floats, size_t *
 }
 
 // every launch of the planned paths goes through MQ_TRY: skipped when the path runs dry (workspace sizing)
-#define MQ_TRY(call)                       \
-    do {                                   \
-        if (!dry && (call) != 0) return 1; \
+#define MQ_TRY(call)                                                                                              \
+    do {                                                                                                          \
+        if (!dry) {                                                                                               \
+            if (ws.over()) return fail("planned call: workspace carved past its end (%zu > %zu bytes)", ws.peak, ws.cap); \
+            if ((call) != 0) return 1;                                                                            \
+        }                                                                                                         \
     } while (0)
 
 // one GEMM launch, reported to the launch hook (bench.py's live HIP-event timing) with its algorithmic flops
@@ -195,10 +199,11 @@ int gemm_call(const mqConvDesc &g, F &&f)
 }
 
 int fprop_impl(const mqConvPlan *p, const float *x, const float *w_krsc, const float *bias, int act, float slope, const uint8_t *mask,
-               int64_t d1, int64_t d2, int64_t d3, float *y, void *keep, void *workspace, mqStream st, bool dry, size_t *peak);
+               int64_t d1, int64_t d2, int64_t d3, float *y, void *keep, void *workspace, size_t workspace_bytes, mqStream st, bool dry,
+               size_t *peak);
 int backward_impl(const mqConvPlan *p, const float *x, const void *keep, const float *w_krsc, const float *w_crsk, const float *dy,
                   const float *gate, float gate_slope, const uint8_t *gate_mask, int64_t g1, int64_t g2, int64_t g3, float *dx, float *dw,
-                  float *db, void *workspace, mqStream st, bool dry, size_t *peak);
+                  float *db, void *workspace, size_t workspace_bytes, mqStream st, bool dry, size_t *peak);
 
 }  // namespace
 
@@ -287,10 +292,10 @@ extern "C" int mq_conv_plan(const mqConvDesc *desc, int leaky, const mqPlanCfg *
     // configuration - no keep buffer, every gradient wanted
     size_t peak = 0;
     float dummy = 0.f;       // non-NULL stand-ins for "wanted"
-    if (fprop_impl(p, &dummy, &dummy, nullptr, leaky ? 2 : 0, 0.2f, nullptr, 1, 0, 1, &dummy, nullptr, nullptr, nullptr, true, &peak)) return 1;
+    if (fprop_impl(p, &dummy, &dummy, nullptr, leaky ? 2 : 0, 0.2f, nullptr, 1, 0, 1, &dummy, nullptr, nullptr, 0, nullptr, true, &peak)) return 1;
     p->ws_fprop = peak;
-    if (backward_impl(p, &dummy, nullptr, &dummy, &dummy, &dummy, nullptr, 1.f, nullptr, 1, 0, 1, &dummy, &dummy, &dummy, nullptr, nullptr,
-                      true, &peak))
+    if (backward_impl(p, &dummy, nullptr, &dummy, &dummy, &dummy, nullptr, 1.f, nullptr, 1, 0, 1, &dummy, &dummy, &dummy, nullptr, 0,
+                      nullptr, true, &peak))
         return 1;
     p->ws_backward = peak;
     return 0;
@@ -309,16 +314,18 @@ extern "C" int mq_conv_fprop_planned(const mqConvPlan *p, const float *x, const 
     MQ_REQUIRE(p->ws_fprop == 0 || (workspace && workspace_bytes >= p->ws_fprop), "mq_conv_fprop_planned: workspace of %zu bytes needed, %zu given",
                p->ws_fprop, workspace_bytes);
     MQ_REQUIRE(((uintptr_t)workspace | (uintptr_t)keep) % 256 == 0, "mq_conv_fprop_planned: workspace and keep buffer must be 256-byte aligned");
-    return fprop_impl(p, x, w_krsc, bias, act, slope, mask, d1, d2, d3, y, keep, workspace, st, false, nullptr);
+    return fprop_impl(p, x, w_krsc, bias, act, slope, mask, d1, d2, d3, y, keep, workspace, workspace_bytes, st, false, nullptr);
 }
 
 namespace {
 int fprop_impl(const mqConvPlan *p, const float *x, const float *w_krsc, const float *bias, int act, float slope, const uint8_t *mask,
-               int64_t d1, int64_t d2, int64_t d3, float *y, void *keep, void *workspace, mqStream st, bool dry, size_t *peak)
+               int64_t d1, int64_t d2, int64_t d3, float *y, void *keep, void *workspace, size_t workspace_bytes, mqStream st, bool dry,
+               size_t *peak)
 {
     if (!mask) { d1 = 1; d2 = 0; d3 = 1; }
     const mqConvDesc &d = p->desc;
     if (peak) *peak = 0;
+    Carver ws(workspace, workspace_bytes), kp(keep, keep ? p->keep_bytes : 0);
     if (p->form == MQ_FORM_DIRECT) {
         if (act == 2) MQ_TRY(mq_conv_fprop_leaky(&d, x, w_krsc, bias, mask, d1, d2, d3, slope, y, st));
         else MQ_TRY(mq_conv_fprop(&d, x, w_krsc, bias, y, st));
@@ -327,7 +334,6 @@ int fprop_impl(const mqConvPlan *p, const float *x, const float *w_krsc, const f
     const Sizes s = sizes_of(*p);
     size_t kv = 0, kuc = 0;
     keep_layout(*p, s, &kv, &kuc);
-    Carver ws(workspace), kp(keep);
     struct PeakOut {
         Carver &c; size_t *out;
         ~PeakOut() { if (out) *out = c.peak; }
@@ -404,18 +410,19 @@ extern "C" int mq_conv_backward_planned(const mqConvPlan *p, const float *x, con
     MQ_REQUIRE(p->form != MQ_FORM_DIRECT || !dx || w_crsk, "mq_conv_backward_planned: the direct input gradient needs the CRSK weights");
     MQ_REQUIRE(!dw || x || (keep && p->keep_bytes > 0), "mq_conv_backward_planned: the weight gradient needs the keep buffer or x");
     MQ_REQUIRE(p->form != MQ_FORM_WINO2D || !gate, "mq_conv_backward_planned: the plain 3x3 form has no gated input gradient (its layers feed APTx, not LeakyReLU)");
-    return backward_impl(p, x, keep, w_krsc, w_crsk, dy, gate, gate_slope, gate_mask, g1, g2, g3, dx, dw, db, workspace, st, false, nullptr);
+    return backward_impl(p, x, keep, w_krsc, w_crsk, dy, gate, gate_slope, gate_mask, g1, g2, g3, dx, dw, db, workspace, workspace_bytes, st, false,
+                         nullptr);
 }
 
 namespace {
 int backward_impl(const mqConvPlan *p, const float *x, const void *keep, const float *w_krsc, const float *w_crsk, const float *dy,
                   const float *gate, float gate_slope, const uint8_t *gate_mask, int64_t g1, int64_t g2, int64_t g3, float *dx, float *dw,
-                  float *db, void *workspace, mqStream st, bool dry, size_t *peak)
+                  float *db, void *workspace, size_t workspace_bytes, mqStream st, bool dry, size_t *peak)
 {
     if (!gate_mask) { g1 = 1; g2 = 0; g3 = 1; }
     if (!gate) gate_slope = 1.f;
     const mqConvDesc &d = p->desc;
-    Carver ws(workspace);
+    Carver ws(workspace, workspace_bytes);
     struct PeakOut {
         Carver &c; size_t *out;
         ~PeakOut() { if (out) *out = c.peak; }
@@ -458,13 +465,16 @@ int backward_impl(const mqConvPlan *p, const float *x, const void *keep, const f
         const int GH = s2d ? d.P : d.H, GW = s2d ? d.Q : d.W;          // the grid the tiles cover
         const int cin = (s2d ? 4 : 1) * d.C;
         const size_t prow = mq_winon_dy_fused_rows(d.N, GH, GW, d.K, mh, mw);
-        float *Z = dw ? ws.take(s.M) : nullptr;
-        float *part = (db && prow && Z) ? ws.take(prow * d.K) : nullptr;       // the column sums ride on the pass that writes Z
+        // decisions by what is WANTED, never by the carved pointers: those are NULL in the dry (sizing) run
+        const bool need_Z = dw != nullptr, need_Vd = dx != nullptr;
+        const bool need_part = db != nullptr && prow > 0 && need_Z;        // the column sums ride on the pass that writes Z
+        float *Z = need_Z ? ws.take(s.M) : nullptr;
+        float *part = need_part ? ws.take(prow * d.K) : nullptr;
         const size_t m0 = ws.mark();
-        float *Vd = dx ? ws.take(s.M) : nullptr;
+        float *Vd = need_Vd ? ws.take(s.M) : nullptr;
         // one pass over dy: Z = A dY A^T (weight gradient), Vd = B^T dy B (input gradient), per-block column sums (bias)
-        if (Z) MQ_TRY(mq_winon_dy_fused(dy, d.N, GH, GW, d.K, Z, Vd, part, mh, mw, st));
-        else if (Vd) MQ_TRY(mq_winon_input_transform(dy, d.N, GH, GW, d.K, Vd, mh, mw, st));
+        if (need_Z) MQ_TRY(mq_winon_dy_fused(dy, d.N, GH, GW, d.K, Z, Vd, part, mh, mw, st));
+        else if (need_Vd) MQ_TRY(mq_winon_input_transform(dy, d.N, GH, GW, d.K, Vd, mh, mw, st));
         if (dx) {
             float *Ut = ws.take(s.U), *Mt = ws.take((size_t)p->npos * p->tiles * cin);
             const mqConvDesc gt = wino2d_desc(d.N, GH, GW, d.K, cin, mh, mw, d.precision);
@@ -490,7 +500,7 @@ int backward_impl(const mqConvPlan *p, const float *x, const void *keep, const f
             if (s2d) MQ_TRY(mq_winon_wgrad_inverse_s2d(P, d.K, d.C, dw, mh, mw, st));
             else MQ_TRY(mq_winon_wgrad_inverse(P, d.K, d.C, dw, mh, mw, st));
         }
-        if (db) MQ_TRY(bias_from(part, prow));
+        if (db) MQ_TRY(bias_from(part, need_part ? prow : 0));
         return 0;
     }
 

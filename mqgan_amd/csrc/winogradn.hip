@@ -356,7 +356,9 @@ __global__ __launch_bounds__(256) void winon_weight_kernel(const float *__restri
     const int64_t total = (int64_t)K * C;
     const int cb = chan_block(C);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C), k = (int)(i / C);
+        // the index that is contiguous in the OUTPUT runs fastest over the lanes (c for U[xi][k][c], k for the flipped
+        // U[xi][c][k]): coalesced stores; the strided reads of the small filter bank come from L2
+        const int c = flip ? (int)(i / K) : (int)(i % C), k = flip ? (int)(i % K) : (int)(i / C);
         float g[3][3];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(256) void winon_weight_s2d_kernel(const float *__re
     const int64_t total = (int64_t)K * Cp;
     const int cb = chan_block(C);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int cp = (int)(i % Cp), k = (int)(i / Cp);
+        const int cp = flip ? (int)(i / K) : (int)(i % Cp), k = flip ? (int)(i % K) : (int)(i / Cp);     // see winon_weight_kernel
         const int ph = cp / C, c = cp - ph * C, rho = ph >> 1, sigma = ph & 1;
         float g[3][3];
 #pragma unroll

@@ -216,14 +216,32 @@ __global__ __launch_bounds__(256) void winow_weight_kernel(const float *__restri
         float g[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) g[s] = wr[kidx(r * S + s, c, R * S, cbc)];
-        const int grp = gk / K, k = gk - grp * K;
 #pragma unroll
         for (int xi = 0; xi < NP; ++xi) {
             float u = 0.f;
 #pragma unroll
             for (int s = 0; s < S; ++s) wt::axpy1(u, wt::g2<M, S>(xi, s), g[s]);
             U_krsc[((size_t)xi * GK + gk) * R * C + kidx(r, c, R, cbc)] = u;
-            if (U_crsk) U_crsk[(((size_t)xi * groups + grp) * C + c) * R * K + kidx(r, k, R, cbk)] = u;
+        }
+    }
+    if (!U_crsk) return;
+    // the CRSK copy in a pass of its own with k running fastest: contiguous stores per 16-channel block instead of 64 lines per
+    // wave store; the strided re-read of w comes from L2
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        const int r = (int)((i / K) % R);
+        const int c = (int)((i / ((int64_t)K * R)) % C);
+        const int grp = (int)(i / ((int64_t)K * R * C));
+        const float *wr = w + ((size_t)grp * K + k) * R * S * C;
+        float g[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) g[s] = wr[kidx(r * S + s, c, R * S, cbc)];
+#pragma unroll
+        for (int xi = 0; xi < NP; ++xi) {
+            float u = 0.f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) wt::axpy1(u, wt::g2<M, S>(xi, s), g[s]);
+            U_crsk[(((size_t)xi * groups + grp) * C + c) * R * K + kidx(r, k, R, cbk)] = u;
         }
     }
 }

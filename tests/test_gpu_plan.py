@@ -33,8 +33,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("name,kw,leaky,form", CASES, ids=[c[0] for c in CASES])
-@pytest.mark.parametrize("use_keep", [True, False], ids=["keep", "no-keep"])
-def test_planned_calls_through_ctypes_equal_the_direct_form(lib, name, kw, leaky, form, use_keep):
+def test_planned_calls_through_ctypes_equal_the_direct_form(lib, name, kw, leaky, form):
     _lib, L = lib
     torch.manual_seed(3)
     d = _lib.ConvDesc(dil_h=1, dil_w=1, groups=kw.get("groups", 1), precision=0, **{k: v for k, v in kw.items() if k != "groups"})
@@ -54,7 +53,8 @@ def test_planned_calls_through_ctypes_equal_the_direct_form(lib, name, kw, leaky
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
     out = {}
-    for leg in ("planned", "direct"):
+    for leg in ("planned", "planned-no-keep", "direct"):       # with and without the forward -> backward keep buffer
+        use_keep = leg == "planned"
         cfg = _lib.PlanCfg()
         L.mq_plan_cfg_default(C.byref(cfg))
         if leg == "direct":
@@ -62,22 +62,34 @@ def test_planned_calls_through_ctypes_equal_the_direct_form(lib, name, kw, leaky
             cfg.wino_minc_explicit = 1
         p = _lib.ConvPlan()
         assert L.mq_conv_plan(C.byref(d), int(leaky), C.byref(cfg), C.byref(p)) == 0, L.mq_last_error()
-        assert L.mq_form_name(p.form).decode() == (form if leg == "planned" else "direct")
-        ws = torch.empty(max(p.ws_fprop, p.ws_backward, 256), dtype=torch.uint8, device=DEV)
-        keep = torch.empty(max(p.keep_bytes, 256), dtype=torch.uint8, device=DEV) if (use_keep and p.keep_bytes) else None
+        assert L.mq_form_name(p.form).decode() == (form if leg != "direct" else "direct")
+        # 0xFF bytes = NaNs: whatever a planned call reads from its buffers it must have written itself
+        nws = (max(p.ws_fprop, p.ws_backward, 256) + 255) // 256 * 256
+        arena = torch.full((nws + 4096 + max(p.keep_bytes, 256),), 0xFF, dtype=torch.uint8, device=DEV)
+        ws, guard = arena[:nws], arena[nws:nws + 4096]
+        guard.fill_(0x5A)
+        keep = arena[nws + 4096:] if (use_keep and p.keep_bytes) else None
         y = torch.empty(d.N, d.P, d.Q, d.K, device=DEV)
         rc = L.mq_conv_fprop_planned(C.byref(p), P(x), P(w_krsc), P(bias), 2 if leaky else 0, 0.2, P(mask) if leaky else None, d.P * d.Q, d.Q, d.Q,
-                                     P(y), P(keep), P(ws), ws.numel(), st)
+                                     P(y), P(keep), P(ws), nws, st)
         assert rc == 0, L.mq_last_error()
-        dx, dw, db = torch.empty_like(x), torch.empty_like(w_krsc), torch.empty_like(bias)
+        # the buffers are exactly as large as the plan says, and each leg's keep buffer sits right behind its workspace in one
+        # allocation: a planned call that carved past the end of its workspace would corrupt what it handed to backward (round 4:
+        # the sizing pass under-counted the bias partials of the two-dimensional forms - found by exactly this adjacency)
+        ws.fill_(0xFF)
+        dx, dw, db = torch.full_like(x, float("nan")), torch.full_like(w_krsc, float("nan")), torch.full_like(bias, float("nan"))
         gate = leaky                          # the leaky layers sit in gated chains: x came out of a LeakyReLU + mask layer
         rc = L.mq_conv_backward_planned(C.byref(p), P(x), P(keep), P(w_krsc), P(w_crsk), P(dy), P(x) if gate else None, 0.2,
-                                        P(gmask) if gate else None, d.H * d.W, d.W, d.W, P(dx), P(dw), P(db), P(ws), ws.numel(), st)
+                                        P(gmask) if gate else None, d.H * d.W, d.W, d.W, P(dx), P(dw), P(db), P(ws), nws, st)
         assert rc == 0, L.mq_last_error()
         torch.cuda.synchronize()
+        assert bool((guard == 0x5A).all()), f"{leg}: a planned call wrote past the end of its workspace"
         out[leg] = (y, dx, dw, db)
-    for nm, a, b in zip(("y", "dx", "dw", "db"), out["planned"], out["direct"]):
-        assert_elem(a, b, 2e-5, 2e-4, f"plan ctypes {name} {nm}")
+    for leg in ("planned", "planned-no-keep"):
+        for nm, a, b in zip(("y", "dx", "dw", "db"), out[leg], out["direct"]):
+            assert_elem(a, b, 2e-5, 2e-4, f"plan ctypes {name} {leg} {nm}")
+    for a, b in zip(out["planned"], out["planned-no-keep"]):
+        assert torch.equal(a, b)                                  # the keep buffer holds exactly what backward would recompute
     if leaky:
         assert float(out["planned"][0][-1, :, d.Q // 2:].abs().max()) == 0.0        # padded output frames
         assert float(out["planned"][1][-1, :, d.W // 2:].abs().max()) == 0.0        # padded input frames of the gated gradient
