@@ -87,6 +87,12 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned b
 {
     return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
 }
+// the same with a wave-uniform byte offset in the instruction's SCALAR operand (added to the address after the bounds check of the
+// vector offset: callers keep vector + scalar offset inside the row the vector offset points into)
+__device__ __forceinline__ float4 buf_load4s(__amdgpu_buffer_rsrc_t r, unsigned byte_off, int scalar_off)
+{
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, scalar_off, 0));
+}
 
 // KORDER: (k0,k2,k1,k3) image = natural accumulation order (the nearest-neighbour search needs it, see the header
 // comment).  Otherwise the quad is stored as loaded - no register shuffles - and every accumulator sums k in the
@@ -114,7 +120,9 @@ __device__ __forceinline__ void lds_store_k4(float *dst, float4 v)
 //   3. wait for the loads, write them to the other LDS buffer, barrier.
 // Global-load latency is covered by phase 2; there are no branches in the loop (past the end of K the
 // loaders' buffer descriptors return zeros without touching memory).
-template <int BN, bool KORDER = true, class ALoad, class BLoad>
+// ZERO_FIRST: the accumulators come in undefined and the very first MFMA of every tile takes C = 0 (an inline constant of the
+// instruction) instead of 64 register moves per wave in front of the loop - worth it when the reduction is only a few K-steps deep.
+template <int BN, bool KORDER = true, bool ZERO_FIRST = false, class ALoad, class BLoad>
 __device__ __forceinline__ void nt_gemm_mainloop(ALoad &la, BLoad &lb, int nk, float *smem,
                                                  f32x16 (&acc)[GemmCfg<BN>::TM][GemmCfg<BN>::TN])
 {
@@ -147,8 +155,9 @@ __device__ __forceinline__ void nt_gemm_mainloop(ALoad &la, BLoad &lb, int nk, f
 
     // One K-step; `cur` (the LDS buffer being read) is a compile-time constant, the loop below is unrolled by two:
     // all LDS addresses are loop-invariant registers + immediates instead of per-step vector adds.
-    auto k_step = [&](int kt, auto cur_tag) {
+    auto k_step = [&](int kt, auto cur_tag, auto first_tag) {
         constexpr int cur = decltype(cur_tag)::value;
+        constexpr bool first = decltype(first_tag)::value;
         // phase 1
 #pragma unroll
         for (int j = 0; j < Cfg::A_SLOTS; ++j) ra[j] = la.fetch(j);
@@ -169,8 +178,14 @@ __device__ __forceinline__ void nt_gemm_mainloop(ALoad &la, BLoad &lb, int nk, f
 #pragma unroll
                 for (int tm = 0; tm < Cfg::TM; ++tm)
 #pragma unroll
-                    for (int tn = 0; tn < Cfg::TN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].x, b[tn].x, acc[tm][tn], 0, 0, 0);
+                    for (int tn = 0; tn < Cfg::TN; ++tn) {
+                        if (first && q == 0) {
+                            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].x, b[tn].x, zero, 0, 0, 0);
+                        } else {
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].x, b[tn].x, acc[tm][tn], 0, 0, 0);
+                        }
+                    }
 #pragma unroll
                 for (int tm = 0; tm < Cfg::TM; ++tm)
 #pragma unroll
@@ -197,12 +212,24 @@ __device__ __forceinline__ void nt_gemm_mainloop(ALoad &la, BLoad &lb, int nk, f
         store_next();
         __syncthreads();
     };
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-        k_step(kt, std::integral_constant<int, 0>{});
-        k_step(kt + 1, std::integral_constant<int, 1>{});
+    using c0 = std::integral_constant<int, 0>;
+    using c1 = std::integral_constant<int, 1>;
+    if constexpr (ZERO_FIRST) {
+        k_step(0, c0{}, std::true_type{});            // nk >= 1
+        int kt = 1;
+        for (; kt + 1 < nk; kt += 2) {
+            k_step(kt, c1{}, std::false_type{});
+            k_step(kt + 1, c0{}, std::false_type{});
+        }
+        if (kt < nk) k_step(kt, c1{}, std::false_type{});
+    } else {
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            k_step(kt, c0{}, std::false_type{});
+            k_step(kt + 1, c1{}, std::false_type{});
+        }
+        if (kt < nk) k_step(kt, c0{}, std::false_type{});
     }
-    if (kt < nk) k_step(kt, std::integral_constant<int, 0>{});
 }
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -409,13 +436,13 @@ __device__ __forceinline__ void nt_gemm_mainloop_split(ALoad &la, BLoad &lb, int
     if (kt < nk) k_step(kt, std::integral_constant<int, 0>{});
 }
 
-template <class E, int BN, class ALoad, class BLoad>
+template <class E, int BN, bool ZERO_FIRST = false, class ALoad, class BLoad>
 __device__ __forceinline__ void nt_gemm_run(ALoad &la, BLoad &lb, int nk, float *smem,
                                             f32x16 (&acc)[GemmCfg<BN, E>::TM][GemmCfg<BN, E>::TN])
 {
     if constexpr (E::SPLIT) nt_gemm_mainloop_split<BN>(la, lb, nk, smem, acc);
     else if constexpr (E::BF16) nt_gemm_mainloop_bf16<BN, E>(la, lb, nk, smem, acc);
-    else nt_gemm_mainloop<BN, false>(la, lb, nk, smem, acc);
+    else nt_gemm_mainloop<BN, false, ZERO_FIRST>(la, lb, nk, smem, acc);
 }
 
 // row / column of accumulator register r of tile (tm, tn) inside the block tile

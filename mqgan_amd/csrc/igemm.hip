@@ -272,6 +272,38 @@ struct DenseBLoader {
     }
 };
 
+// MODE 4 (the Winograd-domain GEMMs: R = S = 1, stride 1, no padding, C % 16 == 0): both operands are dense row-major matrices
+// [rows][Kdim].  No tap walk, no coordinates, no divisions: the row part of the address is a loop-invariant vector offset (rows past
+// the end of the tile's matrix fall outside the descriptor and read zeros), the K-step is a scalar offset in the load instruction,
+// and per K-step a slot costs ONE select (the steps the pipeline prefetches past the end of the reduction).
+template <class E>
+struct DenseRowLoader {
+    static constexpr int NS = E::NS;
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned row_[NS], off_[NS];
+    int Kdim, soff;
+    // base: first row of the tile; rows: valid rows from there on
+    __device__ __forceinline__ void init(const float *base, int rows, int Kdim_)
+    {
+        Kdim = Kdim_;
+        rsrc = make_rsrc(base, (size_t)(rows < 0 ? 0 : rows) * Kdim_ * E::ESZ);
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const int r = (threadIdx.x / E::QPR) + E::ROWS * j;
+            row_[j] = r < rows ? (unsigned)r * (unsigned)Kdim_ * (unsigned)E::ESZ + 16u * (threadIdx.x % E::QPR) : OOB;
+        }
+        soff = 0;
+    }
+    __device__ __forceinline__ void stage(int k0)
+    {
+        const bool kv = k0 < Kdim;                     // wave-uniform
+        soff = kv ? k0 * E::ESZ : 0;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) off_[j] = kv ? row_[j] : OOB;
+    }
+    __device__ __forceinline__ float4 fetch(int j) const { return buf_load4s(rsrc, off_[j], soff); }
+};
+
 template <int BN>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[GemmCfg<BN>::TM][GemmCfg<BN>::TN])   // TM/TN do not depend on the engine
 {
@@ -302,12 +334,24 @@ __device__ __forceinline__ void conv_nt_body(const float *__restrict__ act, cons
     const float *abase = at(act, (size_t)grp * act_group_stride);
 
     f32x16 acc[Cfg::TM][Cfg::TN];
+    const int nk = (g.Kdim + E::BK - 1) / E::BK;
+    if constexpr (MODE == 4) {
+        static_assert(E::BK == 16 && !DGRAD, "dense mode: f32 / split engine forward GEMMs");
+        DenseRowLoader<E> la, lb;
+        la.init(at(abase, (size_t)m0 * g.Kdim), g.Mtot - m0, g.Kdim);
+        lb.init(at(wgt, (size_t)grp * w_group_stride + (size_t)n0 * g.Kdim), g.Ncols - n0, g.Kdim);
+        if constexpr (!E::SPLIT && !E::BF16) {
+            nt_gemm_run<E, BN, true>(la, lb, nk, smem, acc);          // accumulators zeroed by the first MFMA (C = 0)
+        } else {
+            zero_acc<BN>(acc);
+            nt_gemm_run<E, BN>(la, lb, nk, smem, acc);
+        }
+    } else {
     zero_acc<BN>(acc);
     constexpr bool UNI = MODE == 3;
     static_assert(!UNI || E::BK == 16, "uniform walk needs CB == BK");
     DenseBLoader<(MODE > 0), E, UNI> lb;
     lb.init(at(wgt, (size_t)grp * w_group_stride), n0, g.Ncols, g.Kdim);
-    const int nk = (g.Kdim + E::BK - 1) / E::BK;
     if constexpr (MODE == 0) {
         static_assert(!E::BF16 && !E::SPLIT, "scalar path is f32 only");
         ScalarALoader<DGRAD> la;
@@ -330,6 +374,7 @@ __device__ __forceinline__ void conv_nt_body(const float *__restrict__ act, cons
             la.set_row(j, v, n, DGRAD ? oh + g.ph : oh * g.sh - g.ph, DGRAD ? ow + g.pw : ow * g.sw - g.pw);
         }
         nt_gemm_run<E, BN>(la, lb, nk, smem, acc);
+    }
     }
 
     float *o = out + (size_t)grp * g.Mtot * g.Ncols;
@@ -816,7 +861,20 @@ __device__ __forceinline__ void conv_wgrad_body(const float *__restrict__ x, con
             tw[j] = dB[j] * g.sw + tap_w;
         }
     }
+    int so_a = 0, so_b = 0;                              // MODE 4: wave-uniform byte offsets of the step's first pixel (scalar operand)
     auto offsets = [&]() {
+        if constexpr (MODE == 4) {
+            // dense (R = S = 1, stride 1, no padding: the Winograd-domain weight gradients): x is the [pixels][C] matrix itself.
+            // Per slot one compare + select; the pixel walk is a scalar offset in the load instructions.
+            const int left = m_end - s_p;
+            so_a = (s_p - pix0) * g.K * 4;
+            so_b = (s_p - pix0) * g.IC * 4;
+#pragma unroll
+            for (int j = 0; j < AP; ++j) oa[j] = ((dA[j] < left) & (ka < g.K)) ? (unsigned)vA[j] : OOB;
+#pragma unroll
+            for (int j = 0; j < BP; ++j) ob[j] = ((dB[j] < left) & bv[0]) ? (unsigned)vB[j] : OOB;
+            return;
+        }
         if constexpr (MODE == 3) {
             const int left = m_end - s_p;                    // pixels of this split from the step's first one on
             const int s_a = (s_p - pix0) * g.K * 4;
@@ -848,6 +906,10 @@ __device__ __forceinline__ void conv_wgrad_body(const float *__restrict__ x, con
         }
     };
     auto advance = [&]() {                               // all slots move on by BKP pixels
+        if constexpr (MODE == 4) {
+            s_p += BKP;
+            return;
+        }
         if constexpr (MODE == 3) {                           // scalar unit only
             s_p += BKP;
             s_ow += BKP;
@@ -883,7 +945,12 @@ __device__ __forceinline__ void conv_wgrad_body(const float *__restrict__ x, con
         }
     };
     auto fetch = [&]() {
-        if (MODE > 0) {
+        if (MODE == 4) {
+#pragma unroll
+            for (int j = 0; j < AP; ++j) ra[j] = buf_load4s(rs_dy, oa[j], so_a);
+#pragma unroll
+            for (int j = 0; j < BP; ++j) rb[j] = buf_load4s(rs_x, ob[j], so_b);
+        } else if (MODE > 0) {
 #pragma unroll
             for (int j = 0; j < AP; ++j) ra[j] = buf_load4(rs_dy, oa[j]);
 #pragma unroll
@@ -1318,14 +1385,19 @@ static int launch_nt(const mqConvDesc *d, const float *act, const float *w, cons
     wg.step_h = DGRAD ? -g.dh : g.dh;
     wg.step_w = DGRAD ? -g.dw : g.dw;
     wg.CB = cb; wg.nchunks = g.IC / cb;
-    const int mode = vec ? (wide ? ((g.IC % 16 == 0 && !bf16) ? 3 : 2) : 1) : 0;
+    int mode = vec ? (wide ? ((g.IC % 16 == 0 && !bf16) ? 3 : 2) : 1) : 0;
+    // dense GEMM (what the Winograd forms multiply with): 1x1, stride 1, no padding - the activation tensor IS the A matrix
+    if (!DGRAD && mode == 3 && !hmode && d->R == 1 && d->S == 1 && d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 0 && d->pad_w == 0 &&
+        d->P == d->H && d->Q == d->W && (size_t)GEMM_BM * g.Kdim * sizeof(float) < 0x7FFFFFF0ull && getenv("MQGAN_NO_DENSE") == nullptr)
+        mode = 4;
     dim3 grid(g.nMt * g.nNt, d->groups), block(256);
 #define MQ_NT(BN_, M_) do { kname("conv_nt_kernel<%d, %s, %d>", BN_, tf(DGRAD), M_); hipLaunchKernelGGL((conv_nt_kernel<BN_, DGRAD, M_>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs, epi); } while (0)
 #define MQ_NTH(BN_, M_) do { kname("conv_nt_bf16_kernel<%d, %s, %d>", BN_, tf(DGRAD), M_); hipLaunchKernelGGL((conv_nt_bf16_kernel<BN_, DGRAD, M_>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs, epi); } while (0)
 #define MQ_NTX(BN_, M_) do { kname("conv_nt_x3_kernel<%d, %s, %d>", BN_, tf(DGRAD), M_); hipLaunchKernelGGL((conv_nt_x3_kernel<BN_, DGRAD, M_>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs, epi); } while (0)
 #define MQ_NTHH(BN_) do { kname("conv_nt_h_kernel<%d, %s>", BN_, tf(DGRAD)); hipLaunchKernelGGL((conv_nt_h_kernel<BN_, DGRAD>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs, epi); } while (0)
-#define MQ_NT3(BN_) do { if (hmode) MQ_NTHH(BN_); else if (x3) { if (mode == 3) MQ_NTX(BN_, 3); else if (mode == 2) MQ_NTX(BN_, 2); else MQ_NTX(BN_, 1); } \
+#define MQ_NT3(BN_) do { if (hmode) MQ_NTHH(BN_); else if (x3) { if (mode == 4) { if constexpr (!DGRAD) MQ_NTX(BN_, 4); } else if (mode == 3) MQ_NTX(BN_, 3); else if (mode == 2) MQ_NTX(BN_, 2); else MQ_NTX(BN_, 1); } \
                          else if (bf16) { if (mode == 2) MQ_NTH(BN_, 2); else MQ_NTH(BN_, 1); } \
+                         else if (mode == 4) { if constexpr (!DGRAD) MQ_NT(BN_, 4); } \
                          else if (mode == 3) MQ_NT(BN_, 3); else if (mode == 2) MQ_NT(BN_, 2); else if (mode == 1) MQ_NT(BN_, 1); \
                          else MQ_NT(BN_, 0); } while (0)
     if (BN == 128) MQ_NT3(128);
@@ -1496,17 +1568,21 @@ static int wgrad_impl(const mqConvDesc *d, const float *x, const float *dy, floa
                      split_imgs * d->H * d->W * d->C * sizeof(float) < 0x7FFFFFF0ull;
     dim3 grid(g.nKt * g.nCt, d->groups, g.splits), block(256);
     const bool bf16 = d->precision == MQ_PRECISION_BF16 && wgrad_vec_shape(d);
-    const int mode = vec ? (d->Q >= (bf16 ? 32 : WG_BK) ? 3 : (d->Q >= WG_BK ? 2 : 1)) : 0;
+    int mode = vec ? (d->Q >= (bf16 ? 32 : WG_BK) ? 3 : (d->Q >= WG_BK ? 2 : 1)) : 0;
     const bool x3 = d->precision == MQ_PRECISION_F32X3 && wgrad_vec_shape(d);
+    // dense (the Winograd-domain weight gradients): 1x1, stride 1, no padding - x is the [pixels][C] matrix itself
+    if (mode > 0 && !bf16 && d->R == 1 && d->S == 1 && d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 0 && d->pad_w == 0 &&
+        d->P == d->H && d->Q == d->W && getenv("MQGAN_NO_DENSE") == nullptr)
+        mode = 4;
     MQ_REQUIRE(!(bf16 || x3) || vec, "%s: bf16 engines need 16-byte aligned tensors below the 2 GB-per-split span", who);
     // fused bias partials: vector path only; one split writes straight into dbias
     float *bias_target = (dbias && mode > 0) ? (g.splits > 1 ? bias_ws : dbias) : nullptr;
 #define MQ_WG(A_, B_, M_) do { kname("conv_wgrad_kernel<%d, %d, %d>", A_, B_, M_); hipLaunchKernelGGL((conv_wgrad_kernel<A_, B_, M_>), grid, block, 0, st, x, dy, target, bias_target, g, d->groups); } while (0)
 #define MQ_WGH(A_, B_, M_) do { kname("conv_wgrad_bf16_kernel<%d, %d, %d>", A_, B_, M_); hipLaunchKernelGGL((conv_wgrad_bf16_kernel<A_, B_, M_>), grid, block, 0, st, x, dy, target, bias_target, g, d->groups); } while (0)
 #define MQ_WGX(A_, B_, M_) do { kname("conv_wgrad_x3_kernel<%d, %d, %d>", A_, B_, M_); hipLaunchKernelGGL((conv_wgrad_x3_kernel<A_, B_, M_>), grid, block, 0, st, x, dy, target, bias_target, g, d->groups); } while (0)
-#define MQ_WG3(A_, B_) do { if (x3) { if (mode == 3) MQ_WGX(A_, B_, 3); else MQ_WGX(A_, B_, 1); } \
+#define MQ_WG3(A_, B_) do { if (x3) { if (mode == 4) MQ_WGX(A_, B_, 4); else if (mode == 3) MQ_WGX(A_, B_, 3); else MQ_WGX(A_, B_, 1); } \
                             else if (bf16) { if (mode == 3) MQ_WGH(A_, B_, 3); else if (mode == 2) MQ_WGH(A_, B_, 2); else MQ_WGH(A_, B_, 1); } \
-                            else if (mode == 3) MQ_WG(A_, B_, 3); else if (mode == 1) MQ_WG(A_, B_, 1); else MQ_WG(A_, B_, 0); } while (0)
+                            else if (mode == 4) MQ_WG(A_, B_, 4); else if (mode == 3) MQ_WG(A_, B_, 3); else if (mode == 1) MQ_WG(A_, B_, 1); else MQ_WG(A_, B_, 0); } while (0)
     if (g.bmk == 64) MQ_WG3(64, 256);
     else MQ_WG3(128, 128);
 #undef MQ_WG3
