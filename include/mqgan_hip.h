@@ -427,7 +427,7 @@ int mq_masked_mae_sums(const float *pred, const float *target, const uint8_t *pa
 int mq_masked_mae_bwd(const float *pred, const float *target, const uint8_t *padded, int B, int H, int W, int C,
                       const float *sums2, const float *gout, float leaky_slope, float *dpred, mqStream stream);
 
-/* ------------------------------------------------------------------ Winograd F(mh x mw, 3x3), tiles 3 x 3, 4 x 4 and 4 x 5
+/* ------------------------------------------------------------------ Winograd F(mh x mw, 3x3), tiles 3 x 3, 4 x 4, 4 x 5 (and 6 x 6)
  * The refiner's 3x3 / stride 1 / pad 1 convolutions (preencoder.py:86-102) as (mh + 2)(mw + 2) batch-grouped GEMMs around
  * HBM-bound transforms (csrc/winogradn.hip): 25 products per 9 outputs (2.78 per output), 36 per 16 (2.25) or 42 per 20 (2.10)
  * instead of 9 per output; f32 products on the same MFMA engine, f32 accumulation.  Transform matrices per axis:
@@ -445,6 +445,9 @@ int mq_masked_mae_bwd(const float *pred, const float *target, const uint8_t *pad
  * per output.  input_transform_s2d reads x with that indexing (X' is never materialised); output_transform_d2s writes the input
  * gradient at full resolution and applies the producer layer's gate (as mq_conv_dgrad_gated).  H and W even.
  * mq_conv_plan / mq_conv_*_planned below run these sequences; the entry points stay public for callers with their own scheduling.
+ * Tile 6 x 6 (64 products per 36 outputs, 1.78) is built but never chosen by the plan unless asked for (wino_tile 6): measured on
+ * config 2 it takes the step from 191.7 to 187.7 ms at twice the rounding error of 4 x 5 (6.1e-6 against 3.2e-6 of the layer's output,
+ * relative L2 against float64).  For that tile mq_winon_dy_fused is two launches (Z, then Vd as an input transform).
  * (ABI 8 folded the F(3x3) kernels of mq_wino3_* into these and removed F(2x2, 3x3), mq_wino_*: no configuration selected it.) */
 int mq_winon_input_transform(const float *x, int N, int H, int W, int C, float *V, int mh, int mw, mqStream stream);
 int mq_winon_output_transform(const float *M, const float *bias, int N, int H, int W, int K, int act, float slope, const uint8_t *padded,
@@ -561,7 +564,7 @@ int mq_multi_gather_args(const int64_t *table_host, int n_tensors, float *dst, m
 typedef struct {
     int wino_minc;            /* MQGAN_WINO_MINC (128); with wino_minc_explicit = 0 eligibility is by benefit, C K / (C + K) */
     int wino_minc_explicit;
-    int wino_tile;            /* MQGAN_WINO_TILE: 0 = auto, 3, 4, 45 */
+    int wino_tile;            /* MQGAN_WINO_TILE: 0 = auto, 3, 4, 45, 6 (F(6x6): opt-in only, twice the error of F(4x5)) */
     int s2d_minc;             /* MQGAN_WINO_S2D_MINC (128) */
     int wino1d_minc;          /* MQGAN_WINO1D_MINC (128) */
     int wino1d_tile;          /* MQGAN_WINO1D_TILE: 0 = mq_wino1d_tile(H), 2, 4, 5 */

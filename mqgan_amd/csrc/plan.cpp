@@ -51,6 +51,7 @@ void wino2d_tile(int H, int W, int forced, int *mh, int *mw)
     if (forced == 3) { *mh = 3; *mw = 3; return; }
     if (forced == 4) { *mh = 4; *mw = 4; return; }
     if (forced == 45) { *mh = 4; *mw = 5; return; }
+    if (forced == 6) { *mh = 6; *mw = 6; return; }
     const int th[3] = {3, 4, 4}, tw[3] = {3, 4, 5};
     long best = -1;
     for (int i = 0; i < 3; ++i) {
@@ -240,8 +241,8 @@ extern "C" int mq_conv_plan(const mqConvDesc *desc, int leaky, const mqPlanCfg *
     mqPlanCfg cfg;
     if (cfg_in) cfg = *cfg_in;
     else mq_plan_cfg_default(&cfg);
-    MQ_REQUIRE(cfg.wino_tile == 0 || cfg.wino_tile == 3 || cfg.wino_tile == 4 || cfg.wino_tile == 45,
-               "mq_conv_plan: wino_tile must be 0 (auto), 3, 4 or 45, got %d (F(2x2, 3x3) left the library in ABI 8)", cfg.wino_tile);
+    MQ_REQUIRE(cfg.wino_tile == 0 || cfg.wino_tile == 3 || cfg.wino_tile == 4 || cfg.wino_tile == 45 || cfg.wino_tile == 6,
+               "mq_conv_plan: wino_tile must be 0 (auto), 3, 4, 45 or 6, got %d (F(2x2, 3x3) left the library in ABI 8)", cfg.wino_tile);
     const mqConvDesc &d = *desc;
     memset(p, 0, sizeof(*p));
     p->desc = d;

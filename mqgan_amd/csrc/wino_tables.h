@@ -62,6 +62,15 @@ constexpr float AT[4][8] = {{1, 1, 1, 1, 1, 1, 1, 0},
                             {0, 1, -1, 2, -2, 0.5f, -0.5f, 0},
                             {0, 1, 1, 4, 4, 0.25f, 0.25f, 0},
                             {0, 1, -1, 8, -8, 0.125f, -0.125f, 0}};  // F(m outputs): rows 0 .. m-1, the column of inf has its 1 in row m-1
+// F(6, 3) on the same eight points: A^T has two more rows of powers, G is the first three columns.  Nested as F(6x6, 3x3): 64
+// products per 36 outputs = 1.78 per output; f32 error against float64 at 512 channels 4.6e-6 rms / 4.9e-5 max (F(4x5): 2.4e-6 /
+// 2.2e-5; of the point sets tools/wino1d_matrices.py surveys for 8 points this one is the most accurate)
+constexpr float AT6[6][8] = {{1, 1, 1, 1, 1, 1, 1, 0},
+                             {0, 1, -1, 2, -2, 0.5f, -0.5f, 0},
+                             {0, 1, 1, 4, 4, 0.25f, 0.25f, 0},
+                             {0, 1, -1, 8, -8, 0.125f, -0.125f, 0},
+                             {0, 1, 1, 16, 16, 0.0625f, 0.0625f, 0},
+                             {0, 1, -1, 32, -32, 0.03125f, -0.03125f, 1}};
 }  // namespace p8
 
 // F(M, S) along one axis, S taps: (4, 3) on the six points of f4, (4, 5) and (2, 7) on the eight points of p8
@@ -84,15 +93,18 @@ static_assert(f4::BT[0][0] == 1.f && f4::BT[5][5] == 1.f && f5::BT[0][0] == 1.f 
 
 template <int M> __device__ __forceinline__ constexpr float bt(int i, int j)
 {
-    if constexpr (M == 3) return f3::BT[i][j]; else if constexpr (M == 4) return f4::BT[i][j]; else return f5::BT[i][j];
+    if constexpr (M == 3) return f3::BT[i][j]; else if constexpr (M == 4) return f4::BT[i][j];
+    else if constexpr (M == 5) return f5::BT[i][j]; else return p8::BT[i][j];
 }
 template <int M> __device__ __forceinline__ constexpr float g(int i, int j)
 {
-    if constexpr (M == 3) return f3::G[i][j]; else if constexpr (M == 4) return f4::G[i][j]; else return f5::G[i][j];
+    if constexpr (M == 3) return f3::G[i][j]; else if constexpr (M == 4) return f4::G[i][j];
+    else if constexpr (M == 5) return f5::G[i][j]; else return i == 7 ? (j == 2 ? 1.f : 0.f) : p8::G[i][j];
 }
 template <int M> __device__ __forceinline__ constexpr float at(int i, int j)
 {
-    if constexpr (M == 3) return f3::AT[i][j]; else if constexpr (M == 4) return f4::AT[i][j]; else return f5::AT[i][j];
+    if constexpr (M == 3) return f3::AT[i][j]; else if constexpr (M == 4) return f4::AT[i][j];
+    else if constexpr (M == 5) return f5::AT[i][j]; else return p8::AT6[i][j];
 }
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }

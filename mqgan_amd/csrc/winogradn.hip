@@ -111,8 +111,11 @@ __global__ __launch_bounds__(256) void winon_dy_fused_kernel(const float *__rest
         int k4, tj, ti;
         int64_t tile, n;
         wn_tile_of(i, K4, tw, th, k4, tile, tj, ti, n);
+        // the 8 x 8 window of F(6x6) and the intermediate of Z do not fit the register file together: there this kernel reads
+        // the tile's own 36 outputs only and V' comes from winon_input_kernel (mq_winon_dy_fused launches both)
+        constexpr bool SHARED = NPH * NPW <= 42;
         float4 d[NPH][NPW];
-        wn_load_window<MH, MW>(y4, n, H, W, K4, k4, ti, tj, d);
+        if constexpr (SHARED) wn_load_window<MH, MW>(y4, n, H, W, K4, k4, ti, tj, d);
         {   // Z = Ah y Aw^T, y = the tile's own outputs where they exist (ragged last tiles): window positions 1 .. m
             float4 t[NPH][MW];
 #pragma unroll
@@ -120,8 +123,10 @@ __global__ __launch_bounds__(256) void winon_dy_fused_kernel(const float *__rest
                 float4 y[MH];
 #pragma unroll
                 for (int a = 0; a < MH; ++a) {
-                    const bool in = MH * ti + a < H && MW * tj + b < W;
-                    y[a] = in ? d[1 + a][1 + b] : wt::zero4();
+                    const int h = MH * ti + a, w = MW * tj + b;
+                    const bool in = h < H && w < W;
+                    if constexpr (SHARED) y[a] = in ? d[1 + a][1 + b] : wt::zero4();
+                    else y[a] = in ? y4[((n * H + h) * W + w) * K4 + k4] : wt::zero4();
                     wt::axpy(bsum, 1.f, y[a]);
                 }
 #pragma unroll
@@ -143,7 +148,8 @@ __global__ __launch_bounds__(256) void winon_dy_fused_kernel(const float *__rest
                 }
         }
         // a tile's window may reach output positions of the NEXT tile that lie beyond a ragged edge: those are zeros already
-        if (V != nullptr) wn_input_tf_store<MH, MW>(d, V4, tiles, tile, K4, k4);
+        if constexpr (SHARED)
+            if (V != nullptr) wn_input_tf_store<MH, MW>(d, V4, tiles, tile, K4, k4);
     }
     if (partial == nullptr) return;
     s_sum[threadIdx.x] = bsum;
@@ -458,12 +464,12 @@ static int wn_blocks_for(int64_t work_items, int K4)
 
 using namespace mq;
 
-static bool wn_tile_ok(int mh, int mw) { return (mh == 3 && mw == 3) || (mh == 4 && mw == 4) || (mh == 4 && mw == 5); }
+static bool wn_tile_ok(int mh, int mw) { return (mh == 3 && mw == 3) || (mh == 4 && mw == 4) || (mh == 4 && mw == 5) || (mh == 6 && mw == 6); }
 
 static int wn_args(const void *a, const void *b, int N, int H, int W, int C, int mh, int mw, const char *who)
 {
     MQ_REQUIRE(a && b && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "%s: bad arguments (channels must be a multiple of 4, got %d)", who, C);
-    MQ_REQUIRE(wn_tile_ok(mh, mw), "%s: tile %d x %d (built: 3 x 3, 4 x 4 and 4 x 5)", who, mh, mw);
+    MQ_REQUIRE(wn_tile_ok(mh, mw), "%s: tile %d x %d (built: 3 x 3, 4 x 4, 4 x 5 and 6 x 6)", who, mh, mw);
     MQ_REQUIRE(((uintptr_t)a | (uintptr_t)b) % 16 == 0, "%s: tensors must be 16-byte aligned", who);
     return 0;
 }
@@ -472,6 +478,7 @@ static int wn_args(const void *a, const void *b, int N, int H, int W, int C, int
     do {                                                                                                            \
         if (mw == 3) hipLaunchKernelGGL((k_<3, 3>), grid_, dim3(256), 0, S(stream), __VA_ARGS__);                   \
         else if (mw == 4) hipLaunchKernelGGL((k_<4, 4>), grid_, dim3(256), 0, S(stream), __VA_ARGS__);              \
+        else if (mw == 6) hipLaunchKernelGGL((k_<6, 6>), grid_, dim3(256), 0, S(stream), __VA_ARGS__);              \
         else hipLaunchKernelGGL((k_<4, 5>), grid_, dim3(256), 0, S(stream), __VA_ARGS__);                           \
     } while (0)
 
@@ -499,6 +506,10 @@ extern "C" int mq_winon_dy_fused(const float *dy, int N, int H, int W, int K, fl
     const int th = (H + mh - 1) / mh, tw = (W + mw - 1) / mw;
     const dim3 grid(blocks);
     MQ_WN_LAUNCH(winon_dy_fused_kernel, grid, dy, (int64_t)N, H, W, K / 4, th, tw, Z, Vd, bias_partial);
+    if (mw == 6 && Vd) {
+        const dim3 gv(ew_grid((int64_t)N * th * tw * (K / 4), 256));
+        hipLaunchKernelGGL((winon_input_kernel<6, 6>), gv, dim3(256), 0, S(stream), dy, (int64_t)N, H, W, K / 4, th, tw, Vd);
+    }
     MQ_LAUNCH_CHECK("mq_winon_dy_fused");
     return 0;
 }

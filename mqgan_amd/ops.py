@@ -415,7 +415,7 @@ class ConvFn(torch.autograd.Function):
 # mq_conv_fprop_planned, mq_conv_backward_planned.  This module holds the switches (module attributes, so that tests and A/B
 # runs can change them; their defaults come from the MQGAN_* environment) and ONE autograd Function over the planned calls.
 WINO_MIN_CHANNELS = int(os.environ.get("MQGAN_WINO_MINC", "128"))      # 3x3 / stride-1 layers; 0 switches the form off (A/B runs)
-WINO_TILE = os.environ.get("MQGAN_WINO_TILE", "auto")                  # auto: fewest products per image; "3", "4", "45"
+WINO_TILE = os.environ.get("MQGAN_WINO_TILE", "auto")                  # auto: fewest products per image; "3", "4", "45", "6"
 WINO_KEEP_V_MIB = int(os.environ.get("MQGAN_WINO_KEEP_MIB", "6144"))   # larger transformed inputs are recomputed in backward
 WINO_S2D_MIN_CHANNELS = int(os.environ.get("MQGAN_WINO_S2D_MINC", "128"))   # 5x5 / stride-2 layers (polyphase)
 WINO1D_MIN_CHANNELS = int(os.environ.get("MQGAN_WINO1D_MINC", "128"))  # (3 x k) layers, F(m, 3) along the rows
@@ -428,8 +428,8 @@ _PLANS = {}
 
 def _plan_cfg():
     tile = str(WINO_TILE)
-    if tile not in ("auto", "3", "4", "45"):
-        raise _lib.MqganHipError(f"MQGAN_WINO_TILE must be auto, 3, 4 or 45, got {WINO_TILE} (F(2x2, 3x3) left the library in ABI 8)")
+    if tile not in ("auto", "3", "4", "45", "6"):
+        raise _lib.MqganHipError(f"MQGAN_WINO_TILE must be auto, 3, 4, 45 or 6, got {WINO_TILE} (F(2x2, 3x3) left the library in ABI 8)")
     return (int(WINO_MIN_CHANNELS), int(WINO_MIN_CHANNELS != 128 or "MQGAN_WINO_MINC" in os.environ), 0 if tile == "auto" else int(tile),
             int(WINO_S2D_MIN_CHANNELS), int(WINO1D_MIN_CHANNELS), int(WINO1D_TILE), int(WINOW_MIN_CHANNELS), int(WINO_KEEP_V_MIB))
 

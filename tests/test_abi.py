@@ -71,7 +71,7 @@ def test_planned_calls_validate_on_the_host(built):
                       dil_w=1, groups=1, precision=0)
     cfg = _lib.PlanCfg()
     lib.mq_plan_cfg_default(C.byref(cfg))
-    assert cfg.keep_mib > 0 and cfg.wino_tile in (0, 3, 4, 45)
+    assert cfg.keep_mib > 0 and cfg.wino_tile in (0, 3, 4, 45, 6)
     p = _lib.ConvPlan()
     assert lib.mq_conv_plan(C.byref(d), 0, C.byref(cfg), C.byref(p)) == 0
     assert (p.desc.N, p.desc.K, p.desc.pad_w, p.desc.precision) == (4, 144, 1, 0)            # the struct layout round-trips

@@ -471,7 +471,7 @@ WINO_CASES = [
 ]
 
 
-@pytest.fixture(params=["3", "4", "45", "auto"], ids=["F3x3", "F4x4", "F4x5", "auto"])
+@pytest.fixture(params=["3", "4", "45", "6", "auto"], ids=["F3x3", "F4x4", "F4x5", "F6x6", "auto"])
 def wino_tile(request):
     """Every Winograd tile - F(3x3, 3x3), F(4x4, 3x3) and F(4x5, 3x3) (csrc/winogradn.hip) - and the per-image choice mq_conv_plan
     makes by default."""

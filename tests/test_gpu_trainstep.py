@@ -270,8 +270,8 @@ def _arena_grads(arena, *modules):
 
 # (MQGAN_WINO_TILE, MQGAN_WINOW_MINC): every shipped 2-D tile meets the oracle step once, with and without the column forms.
 # "45" is what "auto" picks for this test's 64 x 90 refiner images (and for config 2's).
-@pytest.mark.parametrize("wino_tile,winow_minc", [("45", 128), ("3", 128), ("4", 128), ("45", 0), ("auto", 128)],
-                         ids=["F4x5", "F3x3", "F4x4", "F4x5-no-column-forms", "auto"])
+@pytest.mark.parametrize("wino_tile,winow_minc", [("45", 128), ("3", 128), ("4", 128), ("6", 128), ("45", 0), ("auto", 128)],
+                         ids=["F4x5", "F3x3", "F4x4", "F6x6", "F4x5-no-column-forms", "auto"])
 def test_hifispeech_architecture_step_matches_oracle(monkeypatch, wino_tile, winow_minc):
     """BASELINE config 2's ARCHITECTURE (channels [512,512,512,768], refiner 64, the shipped discriminators, 80 mels)
     on a small ragged batch: one optimisation step of the HIP path against oracle.train_step.OracleTrainer with the

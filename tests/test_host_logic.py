@@ -221,8 +221,10 @@ def test_conv_plan_form_selection_per_layer():
     try:
         ops.WINO_TILE = "3"
         assert tile(512, 90) == (3, 3)
+        ops.WINO_TILE = "6"                      # built, never chosen unless asked for
+        assert tile(512, 90) == (6, 6)
         ops.WINO_TILE = "2"
-        with pytest.raises(Exception, match="auto, 3, 4 or 45"):
+        with pytest.raises(Exception, match="auto, 3, 4, 45 or 6"):
             tile(512, 90)
     finally:
         ops.WINO_TILE = keep

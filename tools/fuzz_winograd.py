@@ -49,7 +49,7 @@ def run(desc_args, G, C, K, R, S, N, H, W, route):
 worst = worst_max = 0.0
 for i in range(cases):
     if i % 2 == 0:
-        route = "2d" + rnd.choice(["", "3", "4", "45"])
+        route = "2d" + rnd.choice(["", "3", "4", "45", "6"])
         C, K = rnd.choice([128, 144, 256]), rnd.choice([128, 160, 256])
         N, H, W = rnd.randint(1, 3), rnd.randint(1, 23), rnd.randint(1, 27)
         args, G, R, S = dict(pad=(1, 1)), 1, 3, 3

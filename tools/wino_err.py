@@ -30,7 +30,7 @@ yd = F.conv2d(xd.permute(0, 3, 1, 2), wd, padding=1).permute(0, 2, 3, 1)
 (yd * r0.double().cpu()).sum().backward()
 ref = [yd.detach(), xd.grad, wd.grad]
 print(f"3x3 stride 1, N {N} {H}x{W} C {Cc} -> K {K}: relative L2 / max-over-rms against float64")
-for tile in (0, 3, 4, 45):
+for tile in (0, 3, 4, 45, 6):
     ops.WINO_MIN_CHANNELS, ops.WINO_TILE = (0, "auto") if tile == 0 else (128, tile)
     x = x0.clone().requires_grad_(True)
     w = w0.clone().requires_grad_(True)
@@ -47,7 +47,7 @@ w0 = torch.randn(K, Cc, 5, 5, device=DEV) * 0.03
 b0 = torch.zeros(K, device=DEV)
 r0 = torch.randn(N, H2 // 2, W2 // 2, K, device=DEV)
 print(f"5x5 stride 2 + LeakyReLU, N {N} {H2}x{W2} C {Cc} -> K {K}")
-for tile in (0, 3, 4, 45):
+for tile in (0, 3, 4, 45, 6):
     ops.WINO_S2D_MIN_CHANNELS, ops.WINO_TILE = (0, "auto") if tile == 0 else (128, tile)
     x = x0.clone().requires_grad_(True)
     w = w0.clone().requires_grad_(True)
