@@ -725,6 +725,11 @@ struct WgradGeom {
 
 // Block tile BMK (output channels k) x BNC (filter columns kk), 4 waves of 64 x 64 each:
 //   <128, 128> general;  <64, 256> when K <= 64 (refiner top level, logits convs) so that rows are not wasted.
+// f32 engine only (r4), for the shapes those two pad by 4x and more:
+//   <256, 32>  filter rows of at most 32 columns (the 1x1 GEMMs behind the C = 1 first layers: 25 taps, 24 / 12 band taps):
+//              4 waves of 64 x 32, one column tile per wave;
+//   <64, 64>   K <= 64 and at most 64 columns (the 64 -> 64 level in the Winograd domain): every wave holds the whole 64 x 64
+//              tile and takes a quarter of each step's pixels; the four partial tiles are added in a fixed order at the end.
 // MODE 0: scalar loads (C or K not a multiple of 4); 1: vector loads, pixel coordinates by division;
 //      2: vector loads, pixel coordinates walked incrementally per thread (OW >= 16: at most BKP/16 row wraps per step);
 //      3: OW >= BKP - the first pixel of the step is walked on the scalar unit and every thread adds its constant
@@ -748,6 +753,10 @@ struct WgradCfg {
     static constexpr int LDA = BF16 ? BMK / 2 + 16 : BMK + 4;        // row pitch in 4-byte units
     static constexpr int LDB = BF16 ? BNC / 2 + 16 : BNC + 4;        // (f32: +4 keeps float4 stores aligned, shifts banks)
     static constexpr int LDS_FLOATS = NIMG * 2 * BKP * (LDA + LDB);
+    static constexpr bool WSPLIT = BMK == 64 && BNC == 64;           // waves split the pixels of a step instead of the tile
+    static constexpr int NTN = BNC >= 64 ? 2 : 1;                    // 32-column MFMA tiles per wave
+    static_assert(ENG == 0 || (BNC >= 128), "the narrow tiles exist for the f32 engine only");
+    static_assert(!WSPLIT || LDS_FLOATS >= 64 * 64, "the partial-tile reduction reuses the operand buffers");
 };
 
 template <int BMK, int BNC, int MODE, int ENG>
@@ -760,13 +769,16 @@ __device__ __forceinline__ void conv_wgrad_body(const float *__restrict__ x, con
     constexpr int IMG_A = 2 * WC::BKP * WC::LDA, IMG_B = 2 * WC::BKP * WC::LDB;     // one image, both buffers
     constexpr int BKP = WC::BKP;
     constexpr int LDA = WC::LDA, LDB = WC::LDB;
-    constexpr int AP = BMK * BKP / 1024, BP = BNC * BKP / 1024;   // load passes per thread and step (BKP pixels x BMK / BNC floats)
+    constexpr int AP = BMK * BKP / 1024, BP = BNC * BKP >= 1024 ? BNC * BKP / 1024 : 1;   // load passes per thread and step (BKP pixels x BMK / BNC floats)
     constexpr int AQ = BMK / 4, BQ = BNC / 4;            // float4 quads per pixel row
-    constexpr int WNW = BNC / 64;                        // waves along the column axis
+    constexpr bool WSPLIT = WC::WSPLIT;
+    constexpr int NTN = WC::NTN;
+    constexpr int WNW = WSPLIT ? 4 : (BNC >= 64 ? BNC / 64 : 1);   // waves along the column axis (WSPLIT: along the pixels)
+    constexpr bool BHALF = BNC * BKP < 1024;             // fewer B quads than threads: the upper threads stage nothing
     float *At = smem;                                    // [2][BKP][LDA]  dy tile   (pixel, k)
     float *Bt = smem + WC::NIMG * 2 * BKP * LDA;         // [2][BKP][LDB]  x gather  (pixel, kk)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WNW, wn = wave % WNW, li = lane & 31, lh = lane >> 5;
+    const int wm = WSPLIT ? 0 : wave / WNW, wn = WSPLIT ? 0 : wave % WNW, li = lane & 31, lh = lane >> 5;
     // All tiles of one (split, group) read the same pixel range of x and dy.  Blocks are dispatched round-robin
     // over the 8 XCDs, so the linear block id is remapped such that each XCD works through whole (split, group)
     // sets one after the other: the pixel range is fetched into ONE L2 instead of all eight.
@@ -801,7 +813,7 @@ __device__ __forceinline__ void conv_wgrad_body(const float *__restrict__ x, con
     // filter layout (common.h: kidx) by the epilogue.
     for (int t = 0; t < 4; ++t) {
         int kk = kkb + t;
-        bv[t] = kk < g.RSC;
+        bv[t] = kk < g.RSC && !(BHALF && bpix >= BKP);
         int kc = bv[t] ? kk : 0;
         const int tap = kc / g.IC;
         bc[t] = kc - tap * g.IC;
@@ -809,11 +821,11 @@ __device__ __forceinline__ void conv_wgrad_body(const float *__restrict__ x, con
         bs[t] = tap - br[t] * g.S;
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NTN];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NTN; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
@@ -1023,9 +1035,11 @@ __device__ __forceinline__ void conv_wgrad_body(const float *__restrict__ x, con
 #pragma unroll
             for (int j = 0; j < AP; ++j)
                 *reinterpret_cast<float4 *>(&At[(buf * BKP + apix + (256 / AQ) * j) * LDA + 4 * aq]) = ra[j];
+            if (!BHALF || bpix < BKP) {
 #pragma unroll
-            for (int j = 0; j < BP; ++j)
-                *reinterpret_cast<float4 *>(&Bt[(buf * BKP + bpix + (256 / BQ) * j) * LDB + 4 * bq]) = rb[j];
+                for (int j = 0; j < BP; ++j)
+                    *reinterpret_cast<float4 *>(&Bt[(buf * BKP + bpix + (256 / BQ) * j) * LDB + 4 * bq]) = rb[j];
+            }
         }
     };
 
@@ -1099,15 +1113,28 @@ __device__ __forceinline__ void conv_wgrad_body(const float *__restrict__ x, con
             }
         } else {
             const float *Ac = At + cur * BKP * LDA + wm * 64 + 2 * li;
-            const float *Bc = Bt + cur * BKP * LDB + wn * 64 + 2 * li;
+            if constexpr (NTN == 2) {
+                const float *Bc = Bt + cur * BKP * LDB + wn * 64 + 2 * li;
+                constexpr int NS = WSPLIT ? BKP / 8 : BKP / 2;              // pixel pairs this wave multiplies
+                const int s0 = WSPLIT ? wave * NS : 0;
 #pragma unroll
-            for (int s = 0; s < BKP / 2; ++s) {
-                const float2 a = *reinterpret_cast<const float2 *>(Ac + (2 * s + lh) * LDA);
-                const float2 b = *reinterpret_cast<const float2 *>(Bc + (2 * s + lh) * LDB);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.y, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[1][1], 0, 0, 0);
+                for (int s = 0; s < NS; ++s) {
+                    const float2 a = *reinterpret_cast<const float2 *>(Ac + (2 * (s0 + s) + lh) * LDA);
+                    const float2 b = *reinterpret_cast<const float2 *>(Bc + (2 * (s0 + s) + lh) * LDB);
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.y, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[1][1], 0, 0, 0);
+                }
+            } else {
+                const float *Bc = Bt + cur * BKP * LDB + li;               // one 32-column tile, column li
+#pragma unroll
+                for (int s = 0; s < BKP / 2; ++s) {
+                    const float2 a = *reinterpret_cast<const float2 *>(Ac + (2 * s + lh) * LDA);
+                    const float b = Bc[(2 * s + lh) * LDB];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b, acc[0][0], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b, acc[1][0], 0, 0, 0);
+                }
             }
         }
         advance();
@@ -1138,13 +1165,38 @@ __device__ __forceinline__ void conv_wgrad_body(const float *__restrict__ x, con
         }
     }
 
+    if constexpr (WSPLIT) {
+        // the four waves hold partial sums of the same tile: ((w3 + w2) + w1) + w0 through LDS, element (register, lane)
+        float *red = smem;
+        for (int w = 3; w >= 1; --w) {
+            __syncthreads();                             // the operand buffers / the previous round's values are no longer read
+            if (wave == w) {
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) red[((tm * 2 + tn) * 16 + r) * 64 + lane] = acc[tm][tn][r];
+            }
+            __syncthreads();
+            if (wave == w - 1) {
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[tm][tn][r] = red[((tm * 2 + tn) * 16 + r) * 64 + lane] + acc[tm][tn][r];
+            }
+        }
+        if (wave != 0) return;
+    }
     // slab [split][group][K][RSC]
     float *o = out + ((size_t)split * groups + grp) * (size_t)g.K * g.RSC;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const int colp = c0 + wn * 64 + (BF16 ? 32 * tn + li : 2 * li + tn);   // plain (tap, channel) index
+        for (int tn = 0; tn < NTN; ++tn) {
+            const int colp = c0 + wn * 64 + (BF16 ? 32 * tn + li : (NTN == 2 ? 2 * li + tn : li));   // plain (tap, channel) index
             if (colp >= g.RSC) continue;
             const int tap = colp / g.IC;
             const int col = kidx(tap, colp - tap * g.IC, g.R * g.S, chan_block(g.IC));
@@ -1426,6 +1478,10 @@ static void wgrad_plan(const mqConvDesc *d, WgradGeom &g)
     g.RSC = d->R * d->S * d->C;
     g.bmk = g.K <= 64 ? 64 : 128;
     g.bnc = g.K <= 64 ? 256 : 128;
+    if (d->precision == MQ_PRECISION_F32 && wgrad_vec_shape(d) && getenv("MQGAN_NO_NARROW_WGRAD") == nullptr) {
+        if (g.RSC <= 32 && g.K > 32) { g.bmk = 256; g.bnc = 32; }         // skinny filter rows: no column padding
+        else if (g.K <= 64 && g.RSC <= 64) { g.bmk = 64; g.bnc = 64; }
+    }
     g.nKt = (int)cdiv(g.K, g.bmk);
     g.nCt = (int)cdiv(g.RSC, g.bnc);
     // Split the pixel reduction so that the grid fills whole rounds of the resident block slots (256 CUs x the
@@ -1433,7 +1489,7 @@ static void wgrad_plan(const mqConvDesc *d, WgradGeom &g)
     // fill  tiles*s / (rounds * slots), charging a little for every extra round of slabs (write + re-read).
     const int64_t tiles = (int64_t)g.nKt * g.nCt * d->groups;
     const bool x3 = d->precision == MQ_PRECISION_F32X3 && wgrad_vec_shape(d);
-    const int64_t slots = x3 ? 512 : 256 * ((g.bmk == 64 ? 3 : 4) - (bk == 32 ? 1 : 0));   // resident blocks per CU (registers / LDS)
+    const int64_t slots = x3 ? 512 : 256 * ((g.bmk == 128 ? 4 : 3) - (bk == 32 ? 1 : 0));   // resident blocks per CU (registers / LDS)
     int64_t max_splits = cdiv(g.Mtot, bk * 32);
     if (max_splits > 512) max_splits = 512;
     if (max_splits < 1) max_splits = 1;
@@ -1583,8 +1639,14 @@ static int wgrad_impl(const mqConvDesc *d, const float *x, const float *dy, floa
 #define MQ_WG3(A_, B_) do { if (x3) { if (mode == 4) MQ_WGX(A_, B_, 4); else if (mode == 3) MQ_WGX(A_, B_, 3); else MQ_WGX(A_, B_, 1); } \
                             else if (bf16) { if (mode == 3) MQ_WGH(A_, B_, 3); else if (mode == 2) MQ_WGH(A_, B_, 2); else MQ_WGH(A_, B_, 1); } \
                             else if (mode == 4) MQ_WG(A_, B_, 4); else if (mode == 3) MQ_WG(A_, B_, 3); else if (mode == 1) MQ_WG(A_, B_, 1); else MQ_WG(A_, B_, 0); } while (0)
-    if (g.bmk == 64) MQ_WG3(64, 256);
+#define MQ_WGF(A_, B_) do { if (mode == 4) MQ_WG(A_, B_, 4); else if (mode == 3) MQ_WG(A_, B_, 3); else if (mode == 1) MQ_WG(A_, B_, 1); else MQ_WG(A_, B_, 0); } while (0)
+    if (g.bnc == 32 || g.bnc == 64) {
+        MQ_REQUIRE(!bf16 && !x3, "%s: the narrow weight-gradient tiles belong to the f32 engine", who);
+        if (g.bnc == 32) MQ_WGF(256, 32);
+        else MQ_WGF(64, 64);
+    } else if (g.bmk == 64) MQ_WG3(64, 256);
     else MQ_WG3(128, 128);
+#undef MQ_WGF
 #undef MQ_WG3
 #undef MQ_WGX
 #undef MQ_WGH

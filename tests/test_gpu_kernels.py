@@ -383,6 +383,13 @@ CONV_CASES = [
     dict(N=2, H=40, W=64, C=256, K=256, R=5, S=5, stride=(2, 2), pad=(2, 2)),                 # patch-D convs.1 width (C2)
     dict(N=1, H=16, W=48, C=384, K=384, R=7, S=7, stride=(2, 2), pad=(3, 3)),                 # patch-D convs.1 width (C3)
     dict(N=1, H=64, W=90, C=192, K=64, R=3, S=3, pad=(1, 1)),                                 # refiner ups.2.conv1 (C2)
+    # the narrow weight-gradient tiles of the f32 engine (r4): <256, 32> for filter rows of <= 32 columns, <64, 64> for K <= 64
+    dict(N=2, H=20, W=33, C=28, K=256, R=1, S=1),                                             # patch-D conv0 behind its tap gather
+    dict(N=16, H=3, W=40, C=24, K=128, R=1, S=1, groups=8),                                   # band conv0: grouped, half a row tile
+    dict(N=2, H=9, W=11, C=12, K=64, R=1, S=1),                                               # refiner pre: 12 columns, narrow image
+    dict(N=2, H=12, W=20, C=4, K=48, R=3, S=3, pad=(1, 1)),                                   # <64, 64> with taps (36 columns)
+    dict(N=1, H=130, W=90, C=64, K=64, R=1, S=1),                                             # <64, 64> dense, split pixel range
+    dict(N=2, H=10, W=30, C=64, K=12, R=1, S=1),                                              # <64, 64>, 12 rows
 ]
 
 
