@@ -209,11 +209,17 @@ __device__ __forceinline__ void conv_h2_body(const void *__restrict__ act_v, con
         }
     };
     auto dma_a = [&](int stage, int j) {
+#ifdef MQ_H2_ABLATE
+        if ((MQ_H2_ABLATE & 8) && j > 0) return;
+#endif
         const bool ok = rv_[j] & kv & ((unsigned)(bh_[j] + hoff) < (unsigned)g.IH) & ((unsigned)(bw_[j] + woff) < (unsigned)g.IW);
         const unsigned vo = ok ? (unsigned)(rowbase_[j] + aoff) : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, lds_ptr(smem + stage * STAGE + wave * 1024 + j * 8192), 16, vo, 0, 0, 0);
     };
     auto dma_b = [&](int stage, int j) {
+#ifdef MQ_H2_ABLATE
+        if ((MQ_H2_ABLATE & 4) && j > 0) return;
+#endif
         const unsigned vo = ((rowoffB[j] != OOB) & kv) ? rowoffB[j] + (unsigned)bcol : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, lds_ptr(smem + stage * STAGE + H2_BM * H2_ROWB + wave * 1024 + j * 8192), 16,
                                                  vo, 0, 0, 0);
@@ -281,16 +287,27 @@ __device__ __forceinline__ void conv_h2_body(const void *__restrict__ act_v, con
         // phase behind the barrier (walker + activation pieces) and of the following phase (weight pieces): both waves of a
         // SIMD leave the barrier together, so a block of scalar work in front of the MFMAs would idle the pipe for both.
         bf16x8 fa[2][4], fb[2][TN];
+        // MQ_H2_ABLATE (tools/h2_ablate.sh; never in the shipped library): WRONG results on purpose, to see which traffic the loop's
+        // time follows - bit 0: a quarter of the A fragment reads, bit 1: 1 / TN of the B fragment reads, bit 2: one B DMA piece per
+        // tile, bit 3: one A DMA piece per tile
+#ifndef MQ_H2_ABLATE
+#define MQ_H2_ABLATE 0
+#endif
         auto ld_a = [&](const char *base, int sx, auto set_tag) {
             constexpr int set = decltype(set_tag)::value;
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt) fa[set][tt] = *reinterpret_cast<const bf16x8 *>(base + a16[sx] + tt * 16 * H2_ROWB);
+            for (int tt = 0; tt < 4; ++tt) {
+                if ((MQ_H2_ABLATE & 1) && tt > 0) { fa[set][tt] = fa[set][0]; continue; }
+                fa[set][tt] = *reinterpret_cast<const bf16x8 *>(base + a16[sx] + tt * 16 * H2_ROWB);
+            }
         };
         auto ld_b = [&](const char *base, int sx, int h, auto set_tag) {
             constexpr int set = decltype(set_tag)::value;
 #pragma unroll
-            for (int tt = 0; tt < TN; ++tt)
+            for (int tt = 0; tt < TN; ++tt) {
+                if ((MQ_H2_ABLATE & 2) && tt > 0) { fb[set][tt] = fb[set][0]; continue; }
                 fb[set][tt] = *reinterpret_cast<const bf16x8 *>(base + b16[sx] + (h * TN + tt) * 16 * H2_ROWB);
+            }
         };
         auto mm_row = [&](auto sa_tag, auto sb_tag, auto h_tag, auto tm_tag) {
             constexpr int sa = decltype(sa_tag)::value, sb = decltype(sb_tag)::value, h = decltype(h_tag)::value;
