@@ -77,6 +77,156 @@ __device__ __forceinline__ unsigned short f2bf(float v)
 struct ElemBF16 { static constexpr int ESZ = 2; static constexpr bool F32 = false; };
 struct ElemF32 { static constexpr int ESZ = 4; static constexpr bool F32 = true; };
 
+// ---- epilogue of the H2 kernels: bias, activation / gate, store (f32 straight from the accumulators, bf16 transposed through a
+// per-wave LDS patch).  row_ok(m): output row m of the tile's enumeration exists;  out_index(m): element offset of its column 0.
+template <class ET, int TN, bool MF16, class RowOk, class OutIdx>
+__device__ __forceinline__ void h2_epilogue(f32x16 (&acc)[MF16 ? 1 : 2][MF16 ? 1 : TN], f32x4v (&acc16)[MF16 ? 4 : 1][MF16 ? 2 * TN : 1],
+                                            const H2Geom &g, const H2Epi &epi, void *__restrict__ out, char *smem, int m0, int n0, int grp,
+                                            RowOk &&row_ok, OutIdx &&out_index)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    // ---- epilogue.  LDS is free once every wave's DMAs have landed and its fragment reads are back.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    constexpr int STG_ROWB = 64 * TN;                             // bytes of one staged bf16 row: 32 * TN columns
+    constexpr int STG_WAVE = 32 * STG_ROWB;                       // one wave stages 32 rows (one tm) at a time
+    unsigned char *padf = reinterpret_cast<unsigned char *>(smem) + 8 * STG_WAVE;
+    const bool fused = epi.act == 2, gated = epi.act == 3;
+    if (fused || gated) {
+        if (tid < H2_BM) {
+            const int m = m0 + tid;
+            unsigned char pd = 0;
+            if (epi.mask != nullptr && row_ok(m)) {
+                const int64_t mg = (int64_t)(out_index(m) / (size_t)g.Ncols);    // output pixel, counted over all groups
+                pd = epi.mask[(mg / epi.d1) * epi.d2 + (mg % epi.d3)] != 0;
+            }
+            padf[tid] = pd;
+        }
+        __syncthreads();
+    }
+    auto bf2f = [](unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); };
+    // visit the accumulator elements of one 32-row half of the wave tile: fn(row in half, column in wave tile, value)
+    auto for_half = [&](auto half_tag, auto &&fn) {
+        constexpr int half = decltype(half_tag)::value;
+        if constexpr (MF16) {
+#pragma unroll
+            for (int th = 0; th < 2; ++th)
+#pragma unroll
+                for (int tn = 0; tn < 2 * TN; ++tn)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        fn(th * 16 + (lane >> 4) * 4 + j, tn * 16 + (lane & 15), acc16[2 * half + th][tn][j]);
+        } else {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) fn((r & 3) + 8 * (r >> 2) + 4 * lh, tn * 32 + li, acc[half][tn][r]);
+        }
+    };
+    // bias of this lane's columns: column index inside the wave tile -> slot
+    constexpr int NBV = MF16 ? 2 * TN : TN;
+    float bv[NBV];
+#pragma unroll
+    for (int tn = 0; tn < NBV; ++tn) {
+        const int n = n0 + wn * 32 * TN + (MF16 ? tn * 16 + (lane & 15) : tn * 32 + li);
+        bv[tn] = (epi.bias && n < g.Ncols) ? epi.bias[(size_t)grp * g.Ncols + n] : 0.f;
+    }
+    auto bias_of = [&](int cl) { return bv[MF16 ? cl >> 4 : cl >> 5]; };
+    if (ET::F32 || epi.out_f32) {
+        // f32 output: a lane-group's 32 columns are 128 contiguous bytes per row - stored straight from the accumulators
+        float *of = reinterpret_cast<float *>(out);
+        auto store_half = [&](auto half_tag) {
+            constexpr int half = decltype(half_tag)::value;
+            for_half(half_tag, [&](int rl, int cl, float a) {
+                const int row = wm * 64 + half * 32 + rl;
+                const int m = m0 + row, n = n0 + wn * 32 * TN + cl;
+                if (row_ok(m) && n < g.Ncols) {
+                    float v = a + bias_of(cl);
+                    if (fused) {
+                        v = v > 0.f ? v : epi.slope * v;
+                        v = padf[row] ? 0.f : v;
+                    }
+                    if (gated) {
+                        v = bf2f(epi.gate[out_index(m) + n]) > 0.f ? v : epi.slope * v;
+                        v = padf[row] ? 0.f : v;
+                    }
+                    of[out_index(m) + n] = v;
+                }
+            });
+        };
+        store_half(std::integral_constant<int, 0>{});
+        store_half(std::integral_constant<int, 1>{});
+        return;
+    }
+    // bf16 output: 2-byte stores straight from the MFMA layout (one column per lane) were measured SLOWER than f32 output
+    // with twice the bytes.  Each wave transposes its tile through a private LDS patch instead - written element-wise,
+    // read back row-wise - and stores 16 bytes per lane: 4 * TN lanes cover the 64 * TN contiguous bytes of a row.
+    unsigned short *oh_ = reinterpret_cast<unsigned short *>(out);
+    char *stg = smem + wave * STG_WAVE;
+    auto stage_half = [&](auto half_tag) {
+        constexpr int half = decltype(half_tag)::value;
+        constexpr int CPR = 4 * TN;                                   // 16-byte chunks per row
+        constexpr int NIT = (32 * CPR + 63) / 64;
+        // gated store: this lane's chunks of the gate tensor are requested before the tile is staged, so their latency
+        // hides behind the LDS transpose instead of sitting in front of every store
+        uint4 gq[NIT];
+        if (gated) {
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int q = i * 64 + lane;
+                const int rl = q / CPR, c16 = q - rl * CPR;
+                const int m = m0 + wm * 64 + half * 32 + rl;
+                const int n = n0 + wn * 32 * TN + c16 * 8;
+                gq[i] = make_uint4(0, 0, 0, 0);
+                if (rl < 32 && row_ok(m) && n < g.Ncols) gq[i] = *reinterpret_cast<const uint4 *>(epi.gate + out_index(m) + n);
+            }
+        }
+        for_half(half_tag, [&](int rl, int cl, float a) {
+            float v = a + bias_of(cl);
+            if (fused) {
+                v = v > 0.f ? v : epi.slope * v;
+                v = padf[wm * 64 + half * 32 + rl] ? 0.f : v;
+            }
+            *reinterpret_cast<unsigned short *>(stg + rl * STG_ROWB + cl * 2) = f2bf(v);
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // own writes (the patch is private to the wave)
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int q = i * 64 + lane;
+            const int rl = q / CPR, c16 = q - rl * CPR;
+            const int m = m0 + wm * 64 + half * 32 + rl;
+            const int n = n0 + wn * 32 * TN + c16 * 8;
+            if (rl < 32 && row_ok(m) && n < g.Ncols) {
+                uint4 v = *reinterpret_cast<const uint4 *>(stg + rl * STG_ROWB + c16 * 16);
+                if (gated) {
+                    // the staged values are the bf16 gradient an ungated launch would have stored; gate them as the
+                    // stand-alone pointwise backward does (f32 product, one more rounding): bit-identical to the two passes
+                    const bool pd = padf[wm * 64 + half * 32 + rl] != 0;
+                    const unsigned vw[4] = {v.x, v.y, v.z, v.w}, gw[4] = {gq[i].x, gq[i].y, gq[i].z, gq[i].w};
+                    unsigned ow[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float lo = bf2f((unsigned short)(vw[e] & 0xFFFFu)), hi = bf2f((unsigned short)(vw[e] >> 16));
+                        lo = bf2f((unsigned short)(gw[e] & 0xFFFFu)) > 0.f ? lo : epi.slope * lo;
+                        hi = bf2f((unsigned short)(gw[e] >> 16)) > 0.f ? hi : epi.slope * hi;
+                        lo = pd ? 0.f : lo;
+                        hi = pd ? 0.f : hi;
+                        ow[e] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+                    }
+                    v = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                }
+                *reinterpret_cast<uint4 *>(oh_ + out_index(m) + n) = v;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // reads done before the second half overwrites the patch
+    };
+    stage_half(std::integral_constant<int, 0>{});
+    stage_half(std::integral_constant<int, 1>{});
+}
+
 // TN: 32-column MFMA tiles per wave along N (block tile N = 64 * TN); CBK: channel block in ELEMENTS (bf16: 64 or 32,
 // f32: 16, i.e. 128- or 64-byte runs); PARITY: dgrad by stride parity (tap subset and output scatter per class)
 template <class ET, int TN, int NSTAGE, int CBK, bool PARITY, bool MF16 = false>
@@ -463,13 +613,6 @@ __device__ __forceinline__ void conv_h2_body(const void *__restrict__ act_v, con
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // trailing (zero-filling) DMAs must not outlive the block's LDS
 
-    // ---- epilogue.  LDS is free once every wave's DMAs have landed and its fragment reads are back.
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    constexpr int STG_ROWB = 64 * TN;                             // bytes of one staged bf16 row: 32 * TN columns
-    constexpr int STG_WAVE = 32 * STG_ROWB;                       // one wave stages 32 rows (one tm) at a time
-    unsigned char *padf = reinterpret_cast<unsigned char *>(smem) + 8 * STG_WAVE;
-    const bool fused = epi.act == 2, gated = epi.act == 3;
     auto out_index = [&](int m) -> size_t {                       // element offset of column 0 of output row m
         if constexpr (PARITY) {
             const int iwq = m % OWc, t2 = m / OWc;
@@ -479,136 +622,283 @@ __device__ __forceinline__ void conv_h2_body(const void *__restrict__ act_v, con
             return ((size_t)grp * Mc + m) * g.Ncols;
         }
     };
-    if (fused || gated) {
-        if (tid < H2_BM) {
-            const int m = m0 + tid;
-            unsigned char pd = 0;
-            if (epi.mask != nullptr && m < Mc) {
-                const int64_t mg = (int64_t)(out_index(m) / (size_t)g.Ncols);    // output pixel, counted over all groups
-                pd = epi.mask[(mg / epi.d1) * epi.d2 + (mg % epi.d3)] != 0;
-            }
-            padf[tid] = pd;
-        }
-        __syncthreads();
+    h2_epilogue<ET, TN, MF16>(acc, acc16, g, epi, out, smem, m0, n0, grp, [&](int m) { return m < Mc; }, out_index);
+}
+
+// ------------------------------------------------------------------------------------------ shared-row variant (r4)
+// What the loop above is bound by (tools/h2_ablate.sh): its time follows the bytes the LDS-DMA moves (a quarter of the
+// DMA: -24..-33 %), not the fragment reads (30 % of them: -9..-12 %).  For filters with three stride-1 taps along the columns the
+// three activation tiles of (chunk, tap row, tap col 0..2) are ONE tile shifted by a pixel - if the GEMM's rows enumerate the
+// output pixels over a width padded by two (n, oh, owp), owp in [0, OW + 2): row q + 1 is then always the pixel to the right, the
+// two extra positions per image row read the zero padding that a real neighbour needs, and their own outputs are never stored
+// (2 / (OW + 2) of the MFMAs: 1.4 % at 144 columns).  So the activation tile is staged ONCE per (chunk, tap row) as 256 + 2 rows
+// and the three column taps read their fragments at row offsets 0, 1, 2; only the weight tile changes every K-step:
+//   DMA bytes per three K-steps   3 x (32 + 8 TN) KB  ->  33 + 3 x 8 TN KB      (TN = 3: 168 -> 105 KB)
+// Same reduction order (chunk, tap row, tap col, channel), same MFMAs: results bit-identical to conv_h2_kernel.
+// LDS: two 264-row activation images (the second is filled during the three K-steps of the first) + two weight stages.
+// bf16, 64-channel chunks (C % 64 == 0), S = 3, 5 or 7 stride-1 taps along the columns (256 + S - 1 rows, S K-steps per image, padded
+// width OW + S - 1), dilation 1 there, stride 1 along the rows; 16x16x32 MFMAs.
+constexpr int H2S_AROWS = 264;                                    // 256 + S - 1 <= 262 rows in whole 8-row DMA pieces
+constexpr int H2S_AEXT = H2S_AROWS * H2_ROWB;
+
+template <int TN, int S>
+__device__ __forceinline__ void conv_h2s_body(const void *__restrict__ act_v, const void *__restrict__ wgt_v, void *__restrict__ out,
+                                              const H2Geom &g, const H2Epi &epi, size_t act_group_stride, char *smem)
+{
+    constexpr int BN = 64 * TN;
+    constexpr int BSZ = BN * H2_ROWB;
+    char *smemA = smem, *smemB = smem + 2 * H2S_AEXT;
+    const char *act = reinterpret_cast<const char *>(act_v);
+    const char *wgt = reinterpret_cast<const char *>(wgt_v);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int grp = blockIdx.y;
+    static_assert(S == 3 || S == 5 || S == 7, "column taps");
+    const int OWp = g.OW + S - 1;
+    const int Mp = g.ng * g.OH * OWp;                             // GEMM rows over the padded width (host: nMt = ceil(Mp / 256))
+    const int tile = xcd_remap(blockIdx.x, g.nMt * g.nNt);
+    const int mt = tile / g.nNt, nt = tile - mt * g.nNt;
+    const int m0 = mt * H2_BM, n0 = nt * BN;
+    const int step_h = __builtin_amdgcn_readfirstlane(g.step_h);
+    const int smin = g.step_w < 0 ? (S - 1) * g.step_w : 0;       // lowest column offset among the S taps
+    const int nR = __builtin_amdgcn_readfirstlane(g.nR);
+
+    // ---- DMA slots (see conv_h2_body).  Activation pieces p = wave + 8 j, j = 0 .. 3, and piece 32 (wave 0 only) cover the
+    // extended rows 8 p .. 8 p + 7; extended row e is the padded-width position q = m0 + e.
+    const int lrow = lane >> 3;
+    const int lc = (lane & 7) ^ ((((wave & 1) << 2) | (lane >> 4)) & 7);
+    const int cin_b = lc * 16;
+    const int img0 = m0 / (g.OH * OWp);
+    const size_t img_elems = (size_t)g.IH * g.IW * g.IC;
+    const char *abase = act + ((size_t)grp * act_group_stride + (size_t)img0 * img_elems) * 2;
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(abase, (act_group_stride - (size_t)img0 * img_elems) * 2);
+    const char *wbase = wgt + ((size_t)grp * g.Ncols + n0) * g.Kp * 2;
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(wbase, (size_t)(g.Ncols - n0 < BN ? g.Ncols - n0 : BN) * g.Kp * 2);
+    int bh_[5], rowbase_[5];
+    bool rv_[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int pc = j < 4 ? wave + 8 * j : 32;
+        const int e = 8 * pc + lrow;
+        const int q = m0 + e;
+        bool v = e < H2_BM + S - 1 && q < Mp && (j < 4 || wave == 0);
+        const int qq = v ? q : m0;
+        const int owp = qq % OWp, t = qq / OWp;
+        const int oh = t % g.OH, n = t / g.OH - img0;
+        const int col = owp + g.add_w + smin;                      // input column of this extended row
+        v = v && (unsigned)col < (unsigned)g.IW;
+        const int bh = oh * g.mul_h + g.add_h;
+        rv_[j] = v;
+        bh_[j] = bh;
+        rowbase_[j] = (((n * g.IH + bh) * g.IW + (v ? col : 0)) * g.IC) * 2 + cin_b;
     }
-    auto bf2f = [](unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); };
-    // visit the accumulator elements of one 32-row half of the wave tile: fn(row in half, column in wave tile, value)
-    auto for_half = [&](auto half_tag, auto &&fn) {
-        constexpr int half = decltype(half_tag)::value;
-        if constexpr (MF16) {
+    unsigned rowoffB[TN];
 #pragma unroll
-            for (int th = 0; th < 2; ++th)
-#pragma unroll
-                for (int tn = 0; tn < 2 * TN; ++tn)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        fn(th * 16 + (lane >> 4) * 4 + j, tn * 16 + (lane & 15), acc16[2 * half + th][tn][j]);
-        } else {
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) fn((r & 3) + 8 * (r >> 2) + 4 * lh, tn * 32 + li, acc[half][tn][r]);
-        }
+    for (int j = 0; j < TN; ++j) {
+        const int row = 8 * (wave + 8 * j) + lrow;
+        rowoffB[j] = (n0 + row < g.Ncols) ? (unsigned)row * (unsigned)g.Kp * 2u + (unsigned)cin_b : OOB;
+    }
+    // ---- scalar walks: the weight tile moves every K-step over (chunk, tap row, tap col), the activation image every third one
+    const int RS = g.R * g.S;
+    int b_js = 0, b_jr = 0, b_ch = nR > 0 ? 0 : g.nchunks;         // next weight tile to stage
+    int a_jr = 0, a_ch = b_ch;                                     // next activation image to stage
+    int bcol = 0, hoffA = 0, aoffA = 0;
+    bool kvB = false, kvA = false;
+    auto walk_b = [&]() {
+        bcol = ((b_ch * RS + b_jr * g.S + b_js) * 64) * 2;
+        kvB = b_ch < g.nchunks;
+        ++b_js;
+        const bool c2 = b_js >= S;
+        b_js = c2 ? 0 : b_js;
+        b_jr += c2 ? 1 : 0;
+        const bool c3 = b_jr >= nR;
+        b_jr = c3 ? 0 : b_jr;
+        b_ch += c3 ? 1 : 0;
     };
-    // bias of this lane's columns: column index inside the wave tile -> slot
-    constexpr int NBV = MF16 ? 2 * TN : TN;
-    float bv[NBV];
-#pragma unroll
-    for (int tn = 0; tn < NBV; ++tn) {
-        const int n = n0 + wn * 32 * TN + (MF16 ? tn * 16 + (lane & 15) : tn * 32 + li);
-        bv[tn] = (epi.bias && n < g.Ncols) ? epi.bias[(size_t)grp * g.Ncols + n] : 0.f;
-    }
-    auto bias_of = [&](int cl) { return bv[MF16 ? cl >> 4 : cl >> 5]; };
-    if (ET::F32 || epi.out_f32) {
-        // f32 output: a lane-group's 32 columns are 128 contiguous bytes per row - stored straight from the accumulators
-        float *of = reinterpret_cast<float *>(out);
-        auto store_half = [&](auto half_tag) {
-            constexpr int half = decltype(half_tag)::value;
-            for_half(half_tag, [&](int rl, int cl, float a) {
-                const int row = wm * 64 + half * 32 + rl;
-                const int m = m0 + row, n = n0 + wn * 32 * TN + cl;
-                if (m < Mc && n < g.Ncols) {
-                    float v = a + bias_of(cl);
-                    if (fused) {
-                        v = v > 0.f ? v : epi.slope * v;
-                        v = padf[row] ? 0.f : v;
-                    }
-                    if (gated) {
-                        v = bf2f(epi.gate[out_index(m) + n]) > 0.f ? v : epi.slope * v;
-                        v = padf[row] ? 0.f : v;
-                    }
-                    of[out_index(m) + n] = v;
-                }
-            });
-        };
-        store_half(std::integral_constant<int, 0>{});
-        store_half(std::integral_constant<int, 1>{});
-        return;
-    }
-    // bf16 output: 2-byte stores straight from the MFMA layout (one column per lane) were measured SLOWER than f32 output
-    // with twice the bytes.  Each wave transposes its tile through a private LDS patch instead - written element-wise,
-    // read back row-wise - and stores 16 bytes per lane: 4 * TN lanes cover the 64 * TN contiguous bytes of a row.
-    unsigned short *oh_ = reinterpret_cast<unsigned short *>(out);
-    char *stg = smem + wave * STG_WAVE;
-    auto stage_half = [&](auto half_tag) {
-        constexpr int half = decltype(half_tag)::value;
-        constexpr int CPR = 4 * TN;                                   // 16-byte chunks per row
-        constexpr int NIT = (32 * CPR + 63) / 64;
-        // gated store: this lane's chunks of the gate tensor are requested before the tile is staged, so their latency
-        // hides behind the LDS transpose instead of sitting in front of every store
-        uint4 gq[NIT];
-        if (gated) {
-#pragma unroll
-            for (int i = 0; i < NIT; ++i) {
-                const int q = i * 64 + lane;
-                const int rl = q / CPR, c16 = q - rl * CPR;
-                const int m = m0 + wm * 64 + half * 32 + rl;
-                const int n = n0 + wn * 32 * TN + c16 * 8;
-                gq[i] = make_uint4(0, 0, 0, 0);
-                if (rl < 32 && m < Mc && n < g.Ncols) gq[i] = *reinterpret_cast<const uint4 *>(epi.gate + out_index(m) + n);
-            }
-        }
-        for_half(half_tag, [&](int rl, int cl, float a) {
-            float v = a + bias_of(cl);
-            if (fused) {
-                v = v > 0.f ? v : epi.slope * v;
-                v = padf[wm * 64 + half * 32 + rl] ? 0.f : v;
-            }
-            *reinterpret_cast<unsigned short *>(stg + rl * STG_ROWB + cl * 2) = f2bf(v);
-        });
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // own writes (the patch is private to the wave)
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            const int q = i * 64 + lane;
-            const int rl = q / CPR, c16 = q - rl * CPR;
-            const int m = m0 + wm * 64 + half * 32 + rl;
-            const int n = n0 + wn * 32 * TN + c16 * 8;
-            if (rl < 32 && m < Mc && n < g.Ncols) {
-                uint4 v = *reinterpret_cast<const uint4 *>(stg + rl * STG_ROWB + c16 * 16);
-                if (gated) {
-                    // the staged values are the bf16 gradient an ungated launch would have stored; gate them as the
-                    // stand-alone pointwise backward does (f32 product, one more rounding): bit-identical to the two passes
-                    const bool pd = padf[wm * 64 + half * 32 + rl] != 0;
-                    const unsigned vw[4] = {v.x, v.y, v.z, v.w}, gw[4] = {gq[i].x, gq[i].y, gq[i].z, gq[i].w};
-                    unsigned ow[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float lo = bf2f((unsigned short)(vw[e] & 0xFFFFu)), hi = bf2f((unsigned short)(vw[e] >> 16));
-                        lo = bf2f((unsigned short)(gw[e] & 0xFFFFu)) > 0.f ? lo : epi.slope * lo;
-                        hi = bf2f((unsigned short)(gw[e] >> 16)) > 0.f ? hi : epi.slope * hi;
-                        lo = pd ? 0.f : lo;
-                        hi = pd ? 0.f : hi;
-                        ow[e] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
-                    }
-                    v = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-                }
-                *reinterpret_cast<uint4 *>(oh_ + out_index(m) + n) = v;
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // reads done before the second half overwrites the patch
+    auto walk_a = [&]() {
+        hoffA = a_jr * step_h;
+        aoffA = ((hoffA * g.IW) * g.IC + a_ch * 64) * 2;
+        kvA = a_ch < g.nchunks;
+        ++a_jr;
+        const bool c3 = a_jr >= nR;
+        a_jr = c3 ? 0 : a_jr;
+        a_ch += c3 ? 1 : 0;
     };
-    stage_half(std::integral_constant<int, 0>{});
-    stage_half(std::integral_constant<int, 1>{});
+    // branch-free: a scalar branch inside the K-step makes the compiler drain its wait counters at the join.  Piece 32 belongs to
+    // wave 0; the other waves issue the same instruction out of range into a 1 KB patch of their own behind the stages (zeros)
+    auto dma_ax = [&](int stage, auto j_tag) {
+        constexpr int j = decltype(j_tag)::value;
+        const bool ok = rv_[j] & kvA & ((unsigned)(bh_[j] + hoffA) < (unsigned)g.IH);
+        const unsigned vo = ok ? (unsigned)(rowbase_[j] + aoffA) : OOB;
+        char *dst = smemA + stage * H2S_AEXT + wave * 1024 + j * 8192;
+        if constexpr (j == 4) dst = wave == 0 ? smemA + stage * H2S_AEXT + 32 * 1024 : smemB + 2 * BSZ + wave * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, lds_ptr(dst), 16, vo, 0, 0, 0);
+    };
+    auto dma_b = [&](int stage, int j) {
+        const unsigned vo = ((rowoffB[j] != OOB) & kvB) ? rowoffB[j] + (unsigned)bcol : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, lds_ptr(smemB + stage * BSZ + wave * 1024 + j * 8192), 16, vo, 0, 0, 0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    using I4 = std::integral_constant<int, 4>;
+
+    f32x16 acc_unused[1][1];
+    f32x4v acc16[4][2 * TN];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2 * TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc16[a][b][r] = 0.f;
+
+    // ---- fragment addresses (16x16x32: lane (r = l & 15, g = l >> 4) holds k = 8 g .. 8 g + 7 of a 32-deep substep).  A row of
+    // the activation image shifted by d pixels is physical row R + d: its chunk swizzle is ((R + d) >> 1) & 7
+    const int r16 = lane & 15, g4 = lane >> 4;
+    int b16[2];
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx) b16[sx] = (wn * 32 * TN + r16) * H2_ROWB + (((4 * sx + g4) ^ ((r16 >> 1) & 7)) << 4);
+    const int nsuper = g.nchunks * nR;
+
+    bf16x8 fa[2][4], fb[2][TN];
+    // fragment offsets of the three column taps: tap js reads column base + js * step_w = image row q + d, d = js (forward) or
+    // 2 - js (input gradient); row R + d carries the chunk swizzle ((R + d) >> 1) & 7.  Indexed by compile-time js only.
+    int a16t[S][2];
+#pragma unroll
+    for (int js = 0; js < S; ++js) {
+        const int rr = r16 + (g.step_w < 0 ? S - 1 - js : js);
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) a16t[js][sx] = (wm * 64 + rr) * H2_ROWB + (((4 * sx + g4) ^ ((rr >> 1) & 7)) << 4);
+    }
+    auto ld_a = [&](const char *base, auto js_tag, auto sx_tag, auto set_tag) {
+        constexpr int set = decltype(set_tag)::value, js = decltype(js_tag)::value, sx = decltype(sx_tag)::value;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) fa[set][tt] = *reinterpret_cast<const bf16x8 *>(base + a16t[js][sx] + tt * 16 * H2_ROWB);
+    };
+    auto ld_b = [&](const char *base, int sx, int h, auto set_tag) {
+        constexpr int set = decltype(set_tag)::value;
+#pragma unroll
+        for (int tt = 0; tt < TN; ++tt) fb[set][tt] = *reinterpret_cast<const bf16x8 *>(base + b16[sx] + (h * TN + tt) * 16 * H2_ROWB);
+    };
+    auto mm_row = [&](auto sa_tag, auto sb_tag, auto h_tag, auto tm_tag) {
+        constexpr int sa = decltype(sa_tag)::value, sb = decltype(sb_tag)::value, h = decltype(h_tag)::value;
+        constexpr int tm = decltype(tm_tag)::value;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+            acc16[tm][h * TN + tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[sa][tm], fb[sb][tn], acc16[tm][h * TN + tn], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mm = [&](auto sa_tag, auto sb_tag, auto h_tag) {
+        mm_row(sa_tag, sb_tag, h_tag, I0{});
+        mm_row(sa_tag, sb_tag, h_tag, I1{});
+        mm_row(sa_tag, sb_tag, h_tag, I2{});
+        mm_row(sa_tag, sb_tag, h_tag, I3{});
+    };
+
+    // ---- prologue: image 0 and weight tile 0
+    walk_a();
+    dma_ax(0, I0{}); dma_ax(0, I1{}); dma_ax(0, I2{}); dma_ax(0, I3{}); dma_ax(0, I4{});
+    walk_b();
+#pragma unroll
+    for (int j = 0; j < TN; ++j) dma_b(0, j);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int sA = 0, sB = 0;
+    ld_a(smemA, I0{}, I0{}, I0{});
+    ld_b(smemB, 0, 0, I0{});
+    walk_a();                                                      // image 1: staged behind the K-steps js = 0, 1 of image 0
+    // one K-step, column tap js (compile-time: the three taps of an image are unrolled, nothing in here branches)
+    auto k_step = [&](auto js_tag) {
+        constexpr int js = decltype(js_tag)::value;
+        constexpr int jsn = js == S - 1 ? 0 : js + 1;
+        const char *A = smemA + sA * H2S_AEXT, *B = smemB + sB * BSZ;
+        ld_b(B, 0, 1, I1{});
+        __builtin_amdgcn_sched_barrier(0);
+        mm_row(I0{}, I0{}, I0{}, I0{});
+        walk_b();                                                  // weight tile t + 1 into the other stage (read last in K-step t - 1)
+        dma_b(sB ^ 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mm_row(I0{}, I0{}, I0{}, I1{});
+        if constexpr (TN > 1) dma_b(sB ^ 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm_row(I0{}, I0{}, I0{}, I2{});
+        if constexpr (TN > 2) dma_b(sB ^ 1, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mm_row(I0{}, I0{}, I0{}, I3{});
+        if constexpr (TN > 3) dma_b(sB ^ 1, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        ld_a(A, js_tag, I1{}, I1{});
+        ld_b(B, 1, 0, I0{});
+        __builtin_amdgcn_sched_barrier(0);
+        mm(I0{}, I1{}, I1{});
+        ld_b(B, 1, 1, I1{});
+        __builtin_amdgcn_sched_barrier(0);
+        mm(I1{}, I0{}, I0{});
+        // everything staged so far has landed (the weight tile of K-step t + 1; the image pieces issued one K-step ago); every
+        // fragment read of this K-step is back
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int sAn = js == S - 1 ? sA ^ 1 : sA;
+        sB ^= 1;
+        ld_a(smemA + sAn * H2S_AEXT, std::integral_constant<int, jsn>{}, I0{}, I0{});
+        ld_b(smemB + sB * BSZ, 0, 0, I0{});
+        __builtin_amdgcn_sched_barrier(0);
+        // the next image goes into the stage the PREVIOUS image was read from, its five piece slots spread over the K-steps of the
+        // first S - 1 column taps (slot j behind tap (j (S - 1)) / 5: at most three per K-step) - each has a whole K-step to land
+        constexpr auto at = [](int j) { return (j * (S - 1)) / 5; };
+        constexpr int first = at(0) == js ? 0 : at(1) == js ? 1 : at(2) == js ? 2 : at(3) == js ? 3 : at(4) == js ? 4 : 5;
+        mm_row(I1{}, I1{}, I1{}, I0{});
+        if constexpr (first < 5) dma_ax(sA ^ 1, std::integral_constant<int, first < 5 ? first : 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mm_row(I1{}, I1{}, I1{}, I1{});
+        if constexpr (first + 1 < 5 && at(first + 1 < 5 ? first + 1 : 4) == js) dma_ax(sA ^ 1, std::integral_constant<int, first + 1 < 5 ? first + 1 : 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mm_row(I1{}, I1{}, I1{}, I2{});
+        if constexpr (first + 2 < 5 && at(first + 2 < 5 ? first + 2 : 4) == js) dma_ax(sA ^ 1, std::integral_constant<int, first + 2 < 5 ? first + 2 : 0>{});
+        if constexpr (js == S - 1) walk_a();
+        __builtin_amdgcn_sched_barrier(0);
+        mm_row(I1{}, I1{}, I1{}, I3{});
+        __builtin_amdgcn_sched_barrier(0);
+        sA = sAn;
+    };
+    for (int u = 0; u < nsuper; ++u) {
+        k_step(I0{});
+        k_step(I1{});
+        k_step(I2{});
+        if constexpr (S > 3) {
+            k_step(I3{});
+            k_step(I4{});
+        }
+        if constexpr (S > 5) {
+            k_step(std::integral_constant<int, 5>{});
+            k_step(std::integral_constant<int, 6>{});
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // trailing (zero-filling) DMAs must not outlive the block's LDS
+
+    // which of the tile's 256 rows are real output pixels, and which: one division per row here instead of one per stored element.
+    // The table sits behind the epilogue's own LDS use (8 staging patches + 256 flags)
+    __builtin_amdgcn_s_barrier();                                 // ... of every wave
+    int *s_pix = reinterpret_cast<int *>(smem + 8 * 32 * 64 * TN + 256);
+    if (tid < H2_BM) {
+        const int m = m0 + tid;
+        const int owp = m % OWp, t = m / OWp;
+        s_pix[tid] = (m < Mp && owp < g.OW) ? t * g.OW + owp : -1;
+    }
+    const int npix = g.ng * g.OH * g.OW;
+    h2_epilogue<ElemBF16, TN, true>(acc_unused, acc16, g, epi, out, smem, m0, n0, grp,
+                                    [&](int m) { return s_pix[m - m0] >= 0; },
+                                    [&](int m) -> size_t { return ((size_t)grp * npix + (size_t)s_pix[m - m0]) * g.Ncols; });
+}
+
+template <int TN, int S>
+__global__ __launch_bounds__(512, 2) void conv_h2s_kernel(const unsigned short *__restrict__ act, const unsigned short *__restrict__ wgt,
+                                                          void *__restrict__ out, H2Geom g, H2Epi epi, size_t act_group_stride)
+{
+    __shared__ __attribute__((aligned(1024))) char smem[2 * H2S_AEXT + 2 * 64 * TN * H2_ROWB + 8 * 1024];   // + the waves' dummy patches
+    conv_h2s_body<TN, S>(act, wgt, out, g, epi, act_group_stride, smem);
 }
 
 template <int TN, int NSTAGE, int CBK, bool PARITY, bool MF16 = false>
@@ -1120,7 +1410,24 @@ static int launch_h2(const mqConvDesc *d, const void *act, const void *w, void *
     static const bool ns2 = getenv("MQGAN_H2_NS2") != nullptr;      // experiment: TN = 2 on a two-stage ring (A/B of the ring depth)
 #define MQ_H2_TN(PAR_) do { if (TN == 4) MQ_H2_CB(4, 2, PAR_); else if (TN == 3) MQ_H2_CB(3, 2, PAR_); \
                             else if (TN == 2) { if (ns2) MQ_H2_CB(2, 2, PAR_); else MQ_H2_CB(2, 3, PAR_); } else MQ_H2_CB(1, 2, PAR_); } while (0)
-    if (parity) MQ_H2_TN(true);
+    // three stride-1 column taps on 64-channel chunks: the shared-row kernel (one activation image per (chunk, tap row))
+    const bool no_share = getenv("MQGAN_H2_NO_SHARE") != nullptr;      // read per call: tests switch it
+    bool shared_rows = false;
+    if constexpr (!ET::F32)
+        shared_rows = mf16 && !no_share && !parity && g.CB == 64 && (g.S == 3 || g.S == 5 || g.S == 7) && g.sw == 1 && g.dw == 1 &&
+                      g.sh == 1 && TN >= 2 && (int64_t)ng * g.OH * (g.OW + g.S - 1) < 0x7FFFFF00ll;
+    if (shared_rows) {
+        if constexpr (!ET::F32) {
+            g.nMt = (int)cdiv((int64_t)ng * g.OH * (g.OW + g.S - 1), H2_BM);
+            grid = dim3((unsigned)(g.nMt * g.nNt), d->groups);
+#define MQ_H2S(TN_, S_) do { kname("conv_h2s_kernel<%d, %d>", TN_, S_); hipLaunchKernelGGL((conv_h2s_kernel<TN_, S_>), grid, block, 0, st, reinterpret_cast<const unsigned short *>(act), \
+                                        reinterpret_cast<const unsigned short *>(w), out, g, epi, act_gs); } while (0)
+#define MQ_H2S_TN(S_) do { if (TN == 4) MQ_H2S(4, S_); else if (TN == 3) MQ_H2S(3, S_); else MQ_H2S(2, S_); } while (0)
+            if (g.S == 3) MQ_H2S_TN(3); else if (g.S == 5) MQ_H2S_TN(5); else MQ_H2S_TN(7);
+#undef MQ_H2S_TN
+#undef MQ_H2S
+        }
+    } else if (parity) MQ_H2_TN(true);
     else MQ_H2_TN(false);
 #undef MQ_H2_TN
 #undef MQ_H2_CB

@@ -1371,3 +1371,64 @@ def test_weight_prep_channel_blocked_layout(env):
             exp_c[:, ((k // 16) * RS + rs) * 16 + k % 16] = wn[k, :, rs]
     np.testing.assert_array_equal(wk.cpu().numpy().reshape(K, -1), exp_k)
     np.testing.assert_array_equal(wc.cpu().numpy().reshape(Cc, -1), exp_c)
+
+
+H2S_CASES = [  # N, H, W, C, K, R, S (3 when absent), groups: stride-1 column taps on 64-channel chunks -> conv_h2s_kernel<TN, S>
+    dict(N=2, H=20, W=37, C=64, K=128, R=3, G=1),       # TN = 2; 37 + 2 columns: tiles straddle image rows and images
+    dict(N=1, H=9, W=50, C=128, K=192, R=3, G=1),       # TN = 3, two chunks
+    dict(N=2, H=33, W=18, C=192, K=256, R=3, G=1),      # TN = 4, three chunks, narrow image (20 padded columns)
+    dict(N=4, H=1, W=300, C=64, K=128, R=1, G=2),       # one tap row (1 x 3), two groups, last tile ragged
+    dict(N=1, H=130, W=144, C=64, K=96, R=3, G=1),      # the config-3 image width; K = 96 pads the column tile
+    dict(N=8, H=4, W=70, C=128, K=256, R=3, S=5, G=8),  # (3 x 5): the band discriminators' second layer, one group per band
+    dict(N=1, H=2, W=260, C=128, K=128, R=1, S=7, G=1), # seven taps: 262-row image, one piece slot per K-step
+]
+
+
+@pytest.mark.parametrize("c", H2S_CASES, ids=lambda c: "N{N}H{H}W{W}C{C}K{K}R{R}g{G}".format(**c) + f"S{c.get('S', 3)}")
+def test_h2_shared_row_kernel_is_bit_identical(env, monkeypatch, c):
+    """conv_h2s_kernel (one activation image per (chunk, tap row), the three column taps read it at row offsets 0 / 1 / 2) against
+    conv_h2_kernel (one activation tile per tap): same reduction order, same MFMAs - forward (bias, LeakyReLU + mask epilogue, f32
+    and bf16 output) and input gradient (plain and gated) must agree bit for bit, and the forward must match float64."""
+    ops = env
+    torch.manual_seed(3)
+    N, H, W, Cc, K, R, G = (c[k] for k in ("N", "H", "W", "C", "K", "R", "G"))
+    S = c.get("S", 3)
+    d = ops.conv_desc(N, H, W, Cc, K, R, S, pad=(R // 2, S // 2), groups=G, precision="bf16")
+    x = torch.randn(N, H, W, Cc, device=DEV).bfloat16()
+    w = (torch.randn(G * K, Cc, R, S, device=DEV) * 0.1).bfloat16().float()            # bf16-representable: the image is exact
+    b = torch.randn(G * K, device=DEV)
+    dy = torch.randn(N, H, W, K, device=DEV).bfloat16()
+    wk, wc = zip(*(ops.weight_prep(w[g * K:(g + 1) * K].contiguous(), None, True) for g in range(G)))
+    wk, wc = torch.cat(wk, 0), torch.cat(wc, 0)
+    wh, wth = ops.h2_weight_image(d, wk, False), ops.h2_weight_image(d, wc, True)
+    mask = (torch.rand(N, W, device=DEV) < 0.2).to(torch.uint8)              # True = padded column (time axis = W here)
+    dmap = (H * W, W, W)
+
+    def run():
+        last = lambda: ops.L().mq_last_kernel().decode()
+        y = ops.conv_fprop_h2(d, x, wh, b)
+        kf = last()
+        y32 = ops.conv_fprop_h2(d, x, wh, b, out_dtype=torch.float32)
+        yl = ops.conv_fprop_h2(d, x, wh, b, mask, dmap, act=2, slope=0.2)
+        dx = ops.conv_dgrad_h2(d, dy, wth)
+        kd = last()
+        dxg = ops.conv_dgrad_h2(d, dy, wth, gate=(x, mask, dmap, 0.2))
+        torch.cuda.synchronize()
+        return (y, y32, yl, dx, dxg), kf, kd
+    shared, kf_s, kd_s = run()
+    monkeypatch.setenv("MQGAN_H2_NO_SHARE", "1")
+    plain, kf_p, kd_p = run()
+    monkeypatch.delenv("MQGAN_H2_NO_SHARE")
+    assert kf_s.startswith("conv_h2s_kernel<") and kf_p.startswith("conv_h2_kernel<"), (kf_s, kf_p)
+    if Cc >= 128:            # the input gradient's column tile is C wide: narrower than 128 stays on the per-tap kernel
+        assert kd_s.startswith("conv_h2s_kernel<") and kd_p.startswith("conv_h2_kernel<"), (kd_s, kd_p)
+    for name, a, bb in zip(("y", "y f32", "y leaky+mask", "dx", "dx gated"), shared, plain):
+        assert torch.equal(a, bb), f"{name}: shared-row kernel differs from the per-tap kernel (max {float((a.float() - bb.float()).abs().max()):.3e})"
+    # and the pair is not wrong together: float64 convolution of the same bf16 operands
+    xr = x.double().cpu().permute(0, 3, 1, 2)
+    outs = []
+    for g in range(G):
+        wg = w[g * K:(g + 1) * K].double().cpu()
+        outs.append(F.conv2d(xr[g * (N // G):(g + 1) * (N // G)], wg, b[g * K:(g + 1) * K].double().cpu(), padding=(R // 2, S // 2)))
+    ref = torch.cat(outs, 0).permute(0, 2, 3, 1)
+    assert_rel(shared[1], ref, 2e-5, "f32 output against float64")
