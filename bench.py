@@ -240,7 +240,7 @@ def peak_of(tag):
     """Dense MFMA peak of the engine a conv kernel instantiation runs on (MI355X_MICROARCH.md)."""
     if "_x3_" in tag:
         return PEAK_BF16_MFMA_TFLOPS / 6      # the split engine spends 6 bf16 MFMAs per f32 product block
-    if "bf16" in tag or "_h2_" in tag or "_h_" in tag:
+    if "bf16" in tag or "_h2_" in tag or "_h2s_" in tag or "_h_" in tag:
         return PEAK_BF16_MFMA_TFLOPS
     return PEAK_F32_MFMA_TFLOPS
 

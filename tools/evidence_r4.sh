@@ -6,7 +6,10 @@ set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/ev4
 mkdir -p $O
+# usage: tools/evidence_r4.sh [profiles|paths]   (no argument: both; one gpurun call holds at most 20 minutes)
+WHAT=${1:-all}
 cd /tmp && export TMPDIR=/tmp
+if [ "$WHAT" != paths ]; then
 echo "== kernel stats, config 2 f32 $(date +%T)"; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c2 -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-vq --no-alt --no-configs > $O/c2_under_rocprof.json 2> $O/c2.err || { echo FAILED c2; tail -3 $O/c2.err; exit 1; }
 echo "== kernel stats, config 3 bf16 $(date +%T)"; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3 -- python3 $R/bench.py --config hifimusic --precision bf16 --steps 3 --warmup 2 --no-cpu-baseline --no-vq --no-alt > $O/c3_under_rocprof.json 2> $O/c3.err || { echo FAILED c3; tail -3 $O/c3.err; exit 1; }
 echo "== pmc traffic $(date +%T)"; bash $R/tools/pmc_traffic.sh 2>&1 | tee $O/pmc_traffic.log || { echo FAILED traffic; tail -5 $O/pmc_traffic.log; exit 1; }
@@ -22,6 +25,8 @@ for k, v in b.items():
 a["_note"] = "per-launch averages; kernels without 'run' were measured in the config-2 f32 bench, those with 'run' in the named pass"
 json.dump(a, open("$O/pmc_traffic.json", "w"), indent=1, sort_keys=True)
 PY
+fi
+[ "$WHAT" = profiles ] && { echo DONE profiles $(date +%T); exit 0; }
 cd $R
 echo "== one forced RCCL rank $(date +%T)"; timeout -k 10 300 python3 bench.py --steps 5 --warmup 2 --force-collectives --no-cpu-baseline --no-vq --no-alt --no-configs > $O/rccl_forced_1rank_bench.json 2> $O/rccl.err || { echo FAILED rccl; tail -5 $O/rccl.err; exit 1; }
 echo "== two gloo ranks on this GPU $(date +%T)"; MQGAN_BENCH_SHARE_GPU=1 timeout -k 10 400 python3 bench.py --gpus 2 --steps 3 --warmup 1 --batch 8 --no-cpu-baseline --no-vq --no-alt --no-configs > $O/gloo_2rank_rehearsal_bench.json 2> $O/gloo2.err || { echo FAILED gloo2; tail -5 $O/gloo2.err; exit 1; }
