@@ -161,6 +161,10 @@ int mq_conv_dgrad_h(const mqConvDesc *desc_host, const uint16_t *dy_bf16, const 
  *                       rows (mask index of row m: (m / d1) * d2 + m % d3), as mq_conv_fprop_leaky.  y is bf16
  *                       (out_f32 = 0) or f32 (out_f32 = 1).
  *   mq_conv_dgrad_h2  : dx = conv_transpose(dy), dx bf16 or f32; strided layers run by stride parity.
+ *                       Layers with 3, 5 or 7 stride-1 taps along the columns on whole 64-channel chunks (C % 64 == 0 forward,
+ *                       K % 64 == 0 backward; stride 1 both ways, column dilation 1, >= 128 output columns) take
+ *                       conv_h2s_kernel: one activation image per (chunk, tap row) for all column taps, results bit-identical to
+ *                       the per-tap kernel (MQGAN_H2_NO_SHARE=1 in the environment selects that one for A/B runs).
  *   mq_conv_wgrad_h2  : dw_krsc (f32, the layout mq_weight_prep_bwd reads) and, if dbias != NULL, dbias (f32) from
  *                       bf16 x and dy; split-K over pixels with a deterministic slab reduction. */
 int mq_h2_supported(const mqConvDesc *desc_host);
