@@ -15,6 +15,19 @@ namespace mq {
 // s / 2 = sigmoid(2 h) for s = 1 + tanh h (common.h: aptx_s = 2 * this): the kernels below take the exact factors 2 and 0.5 of
 // aptx(h) = s * 0.5 * h and of its derivative out by hand - same roundings in the same order, fewer multiplications
 __device__ __forceinline__ float aptx_half(float h) { return __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * h)); }
+// The same for two pixels at once, on the packed f32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two results per
+// issue slot; exp2 and rcp stay one per value).  __expf(x) is exp2(x * log2 e); -2 h * log2 e = h * (-2 log2 e) exactly (a power
+// of two moves through the rounding), so the values are those of aptx_half bit for bit.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 aptx_half2(f32x2 h)
+{
+    const f32x2 t = h * splat2(-2.0f * 1.44269504088896340736f);
+    const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + splat2(1.0f);
+    return f32x2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+}
+__device__ __forceinline__ float and_mask(float v, uint32_t m) { return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & m); }
 
 // Dropout of the hidden vector.  r3 drew the keep decisions from Philox4x32-7 in the forward AND again in the backward kernel: 28
 // quarter-rate integer multiplications per 8 hidden units - as many issue slots as the arithmetic of those units (exp + rcp
@@ -35,7 +48,7 @@ struct DropStream {
         s = s ? s : 0x6d2b79f5u;                                   // xorshift has no zero state
         w = mix((uint32_t)(seed >> 32) ^ lo ^ 0xc2b2ae35u);
     }
-    __device__ __forceinline__ uint32_t next()                     // two 16-bit uniforms
+    __device__ __forceinline__ uint32_t next()                     // 32 random bits: one bit plane of 32 decisions
     {
         s ^= s << 13; s ^= s >> 17; s ^= s << 5;
         w += 0x9E3779B9u;
@@ -44,12 +57,13 @@ struct DropStream {
 };
 
 constexpr int CB_TT = 4;     // time steps per block tile
-constexpr int CB_TM = 8;     // time steps per thread in the MLP backward (amortises the per-channel wave reductions)
+constexpr int CB_TM = 16;    // time steps per thread in the MLP backward: amortises the three per-unit wave reductions (8: 2.41 ms, 16: 2.03 ms)
 constexpr int CB_TC = 64;    // channels per block tile (fwd)
 
 // Forward.  Block tile CB_FT time steps x CB_TC channels; thread = channel c, CB_FP consecutive time steps, so the three MLP
 // weights of a hidden unit are read from LDS once for CB_FP pixels and the per-pixel chains are independent (packed f32 math).
 constexpr int CB_FT = 32, CB_FP = 8;
+template <uint32_t TC>
 __global__ __launch_bounds__(256) void cb2d_fwd_kernel(const float *__restrict__ x, const uint8_t *__restrict__ mask,
                                                        const float *__restrict__ wdw, const float *__restrict__ bdw,
                                                        const float *__restrict__ w1, const float *__restrict__ b1,
@@ -98,13 +112,19 @@ __global__ __launch_bounds__(256) void cb2d_fwd_kernel(const float *__restrict__
         if (v_save && inb[p]) v_save[pix[p]] = v[p];
         acc[p] = bias2;
     }
+    f32x2 v2[CB_FP / 2], acc2[CB_FP / 2];           // pixels 2 q, 2 q + 1 side by side
+#pragma unroll
+    for (int q = 0; q < CB_FP / 2; ++q) {
+        v2[q] = f32x2{v[2 * q], v[2 * q + 1]};
+        acc2[q] = f32x2{acc[2 * q], acc[2 * q + 1]};
+    }
     if (thresh16 == 0) {                            // eval mode: no dropout, no random numbers
         for (int k = 0; k < C0; ++k) {
-            const float wk1 = sw1[k], bk1 = sb1[k], wk2 = sw2[k];
+            const f32x2 wk1 = splat2(sw1[k]), bk1 = splat2(sb1[k]), wk2 = splat2(sw2[k]);
 #pragma unroll
-            for (int p = 0; p < CB_FP; ++p) {
-                const float h = fmaf(wk1, v[p], bk1);
-                acc[p] = fmaf(wk2, aptx_half(h) * h, acc[p]);       // = aptx_s(h) * 0.5f * h bit for bit (the factors 2 and 0.5 are exact)
+            for (int q = 0; q < CB_FP / 2; ++q) {
+                const f32x2 h = fma2(wk1, v2[q], bk1);
+                acc2[q] = fma2(wk2, aptx_half2(h) * h, acc2[q]);    // = aptx_s(h) * 0.5f * h bit for bit (the factors 2 and 0.5 are exact)
             }
         }
     } else {
@@ -113,39 +133,49 @@ __global__ __launch_bounds__(256) void cb2d_fwd_kernel(const float *__restrict__
 #pragma unroll
         for (int p = 0; p < CB_FP; ++p) rng[p].seed(seed, pix[p]);
         for (int k32 = 0; k32 < C0; k32 += 32) {
-            uint32_t dropped[CB_FP];                 // bit e set: hidden unit k32 + e of this pixel is dropped
+            // The 32 decisions of a pixel as ONE word, bit-sliced: the stream's next 16 words are the 16 bit planes (LSB first) of 32
+            // uniform 16-bit numbers u_e, and "u_e >= thresh16" (= keep) falls out of a ripple comparison against the threshold's
+            // bits, one bitwise operation per plane for all 32 units: going up from the LSB, a threshold bit of 1 keeps "greater or
+            // equal so far" only where the plane has a 1, a threshold bit of 0 sets it wherever the plane has a 1.  Same rule (drop
+            // iff u16 < thresh16, probability thresh16 / 65536), same number of random words as two 16-bit numbers per word, but
+            // half an instruction per decision where extracting, comparing and collecting the bits took six (r4).
+            uint32_t keep[CB_FP];
 #pragma unroll
-            for (int p = 0; p < CB_FP; ++p) dropped[p] = 0u;
+            for (int p = 0; p < CB_FP; ++p) keep[p] = ~0u;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                // TC: the threshold as a compile-time constant (the reference's hard-coded p = 0.1): one operation per plane
+                const uint32_t tmask = (thresh16 >> j) & 1u ? ~0u : 0u;                 // wave-uniform
+#pragma unroll
+                for (int p = 0; p < CB_FP; ++p) {
+                    const uint32_t r = rng[p].next();
+                    if constexpr (TC != 0) keep[p] = ((TC >> j) & 1u) ? (keep[p] & r) : (keep[p] | r);
+                    else keep[p] = (keep[p] & (r | ~tmask)) | (r & ~tmask);             // tmask ? keep & r : keep | r
+                }
+            }
 #pragma unroll 4
-            for (int e2 = 0; e2 < 16; ++e2) {
-                uint32_t word[CB_FP];
+            for (int e = 0; e < 32; ++e) {
+                const int k = k32 + e;
+                if (k >= C0) break;
+                const f32x2 wk1 = splat2(sw1[k]), bk1 = splat2(sb1[k]), wk2s = splat2(sw2[k] * scale);
 #pragma unroll
-                for (int p = 0; p < CB_FP; ++p) word[p] = rng[p].next();
-#pragma unroll
-                for (int hlf = 0; hlf < 2; ++hlf) {
-                    const int e = 2 * e2 + hlf, k = k32 + e;
-                    if (k >= C0) break;
-                    const float wk1 = sw1[k], bk1 = sb1[k], wk2s = sw2[k] * scale;
-#pragma unroll
-                    for (int p = 0; p < CB_FP; ++p) {
-                        const float h = fmaf(wk1, v[p], bk1);
-                        const float a = aptx_half(h) * h;
-                        // drop iff u16 < thresh16, without compare / select: the sign of (u16 - thresh16) as a mask of all ones
-                        const uint32_t u = hlf ? (word[p] >> 16) : (word[p] & 0xffffu);
-                        const uint32_t m = (uint32_t)((int32_t)(u - thresh16) >> 31);
-                        dropped[p] |= m & (1u << e);
-                        acc[p] = fmaf(wk2s, __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, a) & ~m), acc[p]);
-                    }
+                for (int q = 0; q < CB_FP / 2; ++q) {
+                    const f32x2 h = fma2(wk1, v2[q], bk1);
+                    const f32x2 a = aptx_half2(h) * h;
+                    // bit e of the pixel's word as a mask of all ones (v_bfe_i32), and-ed onto the activation
+                    const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)keep[2 * q], e, 1);
+                    const uint32_t m1 = (uint32_t)__builtin_amdgcn_sbfe((int)keep[2 * q + 1], e, 1);
+                    acc2[q] = fma2(wk2s, f32x2{and_mask(a.x, m0), and_mask(a.y, m1)}, acc2[q]);
                 }
             }
 #pragma unroll
             for (int p = 0; p < CB_FP; ++p)
-                if (inb[p]) keep_bits[(int64_t)(k32 >> 5) * npix + pix[p]] = ~dropped[p];
+                if (inb[p]) keep_bits[(int64_t)(k32 >> 5) * npix + pix[p]] = keep[p];
         }
     }
 #pragma unroll
     for (int p = 0; p < CB_FP; ++p)
-        if (inb[p]) y[pix[p]] = on[p] ? acc[p] : bias2;
+        if (inb[p]) y[pix[p]] = on[p] ? (p & 1 ? acc2[p >> 1].y : acc2[p >> 1].x) : bias2;
 }
 
 // Backward pass 1: per-pixel MLP backward.  Thread = channel c, CB_TM consecutive time steps.
@@ -193,6 +223,9 @@ __global__ __launch_bounds__(256) void cb2d_bwd_mlp_kernel(const float *__restri
             v[p] = on[p] ? v_save[pix[p]] : 0.f;
             dva[p] = 0.f;
         }
+        float gs[CB_TM];                                   // the output gradient times the dropout scale (1 without dropout), 0 off the mask
+#pragma unroll
+        for (int p = 0; p < CB_TM; ++p) gs[p] = on[p] ? g[p] * scale : 0.f;
         for (int k32 = 0; k32 < C0; k32 += 32) {
             uint32_t bits[CB_TM];
 #pragma unroll
@@ -201,23 +234,30 @@ __global__ __launch_bounds__(256) void cb2d_bwd_mlp_kernel(const float *__restri
             for (int e = 0; e < 32; ++e) {
                 const int k = k32 + e;
                 if (k >= C0) break;
-                const float wk1 = sw1[k], bk1 = sb1[k], wk2 = sw2[k];
-                float s_w2 = 0.f, s_w1 = 0.f, s_b1 = 0.f;
+                // two pixels per packed instruction (see aptx_half2); the sums over the thread's pixels run as an even and an odd chain
+                const f32x2 wk1 = splat2(sw1[k]), bk1 = splat2(sb1[k]), wk2 = splat2(sw2[k]);
+                f32x2 s_w2v = splat2(0.f), s_w1v = splat2(0.f), s_b1v = splat2(0.f);
 #pragma unroll
-                for (int p = 0; p < CB_TM; ++p) {
-                    const float h = fmaf(wk1, v[p], bk1);
-                    const float r = aptx_half(h);                              // s / 2, s = 1 + tanh h
-                    const float keep = ((bits[p] >> e) & 1u) ? scale : 0.f;    // scale = 1 without dropout
-                    const float gk = on[p] ? g[p] * keep : 0.f;
+                for (int q = 0; q < CB_TM / 2; ++q) {
+                    const f32x2 vq = f32x2{v[2 * q], v[2 * q + 1]};
+                    const f32x2 h = fma2(wk1, vq, bk1);
+                    const f32x2 r = aptx_half2(h);                             // s / 2, s = 1 + tanh h
+                    // g * scale where the unit was kept, 0 where it was dropped: bit e of the pixel's word as a mask of all ones
+                    const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)bits[2 * q], e, 1);
+                    const uint32_t m1 = (uint32_t)__builtin_amdgcn_sbfe((int)bits[2 * q + 1], e, 1);
+                    const f32x2 gk = f32x2{and_mask(gs[2 * q], m0), and_mask(gs[2 * q + 1], m1)};
                     // a = s * 0.5 * h and dh = gk * wk2 * 0.5 * (s + h * s * (2 - s)) with the exact factors of two taken out:
                     // the same roundings in the same order, five multiplications fewer
-                    const float a = r * h;
-                    const float dh = (gk * wk2) * fmaf(2.0f, a * (1.0f - r), r);
-                    s_w2 = fmaf(gk, a, s_w2);
-                    s_w1 = fmaf(dh, v[p], s_w1);
-                    s_b1 += dh;
-                    dva[p] = fmaf(dh, wk1, dva[p]);
+                    const f32x2 a = r * h;
+                    const f32x2 dh = (gk * wk2) * fma2(splat2(2.0f), a * (splat2(1.0f) - r), r);
+                    s_w2v = fma2(gk, a, s_w2v);
+                    s_w1v = fma2(dh, vq, s_w1v);
+                    s_b1v += dh;
+                    const f32x2 d2 = fma2(dh, wk1, f32x2{dva[2 * q], dva[2 * q + 1]});
+                    dva[2 * q] = d2.x;
+                    dva[2 * q + 1] = d2.y;
                 }
+                float s_w2 = s_w2v.x + s_w2v.y, s_w1 = s_w1v.x + s_w1v.y, s_b1 = s_b1v.x + s_b1v.y;
                 s_w2 = wave_sum(s_w2);
                 s_w1 = wave_sum(s_w1);
                 s_b1 = wave_sum(s_b1);
@@ -381,8 +421,14 @@ extern "C" int mq_convblock2d_fwd(const mqCb2dWeights *w, const float *x, const 
     MQ_REQUIRE(p_drop == 0.f || keep_bits, "mq_convblock2d_fwd: dropout needs the keep-bit buffer (mq_convblock2d_keep_bytes)");
     const size_t shm = (size_t)(3 * C0 + (CB_FT + 4) * (CB_TC + 4)) * sizeof(float);
     dim3 grid((unsigned)cdiv(C0, CB_TC), (unsigned)cdiv(T, CB_FT), B);
-    hipLaunchKernelGGL(cb2d_fwd_kernel, grid, dim3(256), shm, S(stream), x, mask, w->wdw, w->bdw, w->w1, w->b1, w->w2, w->b2, B, T,
-                       C0, p_drop > 0.f ? drop_thresh16(p_drop) : 0u, p_drop > 0.f ? drop_scale(p_drop) : 1.0f, seed, y, v_save, keep_bits);
+    const uint32_t th = p_drop > 0.f ? drop_thresh16(p_drop) : 0u;
+    constexpr uint32_t TH_REF = 6554u;                   // drop_thresh16(0.1f): the reference's hard-coded rate gets its own instantiation
+    if (th == TH_REF)
+        hipLaunchKernelGGL((cb2d_fwd_kernel<TH_REF>), grid, dim3(256), shm, S(stream), x, mask, w->wdw, w->bdw, w->w1, w->b1, w->w2, w->b2,
+                           B, T, C0, th, drop_scale(p_drop), seed, y, v_save, keep_bits);
+    else
+        hipLaunchKernelGGL((cb2d_fwd_kernel<0u>), grid, dim3(256), shm, S(stream), x, mask, w->wdw, w->bdw, w->w1, w->b1, w->w2, w->b2, B,
+                           T, C0, th, p_drop > 0.f ? drop_scale(p_drop) : 1.0f, seed, y, v_save, keep_bits);
     MQ_LAUNCH_CHECK("mq_convblock2d_fwd");
     return 0;
 }
