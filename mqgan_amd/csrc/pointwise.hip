@@ -93,7 +93,7 @@ __global__ void pointwise_fwd_kernel(PwParams p, const T *__restrict__ h, const 
             bool pd = false;
             if (mask) {
                 const int64_t m = e0 / p.C;
-                pd = mask[(m / p.d1) * p.d2 + (m % p.d3)] != 0;
+                pd = mask[mask_index(m, p.d1, p.d2, p.d3)] != 0;
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) pad[i] = pd;
@@ -107,7 +107,7 @@ __global__ void pointwise_fwd_kernel(PwParams p, const T *__restrict__ h, const 
                     t[i] = ld1(h, e) + (rpre ? ld1(rpre, e) : 0.f);
                     if (mask) {
                         const int64_t m = e / p.C;
-                        pad[i] = mask[(m / p.d1) * p.d2 + (m % p.d3)] != 0;
+                        pad[i] = mask[mask_index(m, p.d1, p.d2, p.d3)] != 0;
                     }
                 }
             }
@@ -175,7 +175,7 @@ __global__ void pointwise_bwd_kernel(PwParams p, const T *__restrict__ dout, con
             bool pd = false;
             if (mask) {
                 const int64_t m = e0 / p.C;
-                pd = mask[(m / p.d1) * p.d2 + (m % p.d3)] != 0;
+                pd = mask[mask_index(m, p.d1, p.d2, p.d3)] != 0;
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) { pad[i] = pd; live[i] = true; }
@@ -190,7 +190,7 @@ __global__ void pointwise_bwd_kernel(PwParams p, const T *__restrict__ dout, con
                     g[i] = ld1(dout, e);
                     if (mask) {
                         const int64_t m = e / p.C;
-                        pad[i] = mask[(m / p.d1) * p.d2 + (m % p.d3)] != 0;
+                        pad[i] = mask[mask_index(m, p.d1, p.d2, p.d3)] != 0;
                     }
                 }
             }

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void winon_output_kernel(const float *__restri
                     acc.y = acc.y > 0.f ? acc.y : acc.y * slope;
                     acc.z = acc.z > 0.f ? acc.z : acc.z * slope;
                     acc.w = acc.w > 0.f ? acc.w : acc.w * slope;
-                    if (padded && padded[(pix / d1) * d2 + pix % d3]) acc = wt::zero4();
+                    if (padded && padded[mask_index(pix, d1, d2, d3)]) acc = wt::zero4();
                 }
                 y4[pix * K4 + k4] = acc;
             }
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void winon_output_d2s_kernel(const float *__re
                     acc.y *= gv.y > 0.f ? 1.f : slope;
                     acc.z *= gv.z > 0.f ? 1.f : slope;
                     acc.w *= gv.w > 0.f ? 1.f : slope;
-                    if (padded && padded[(pix / d1) * d2 + pix % d3]) acc = wt::zero4();
+                    if (padded && padded[mask_index(pix, d1, d2, d3)]) acc = wt::zero4();
                 }
                 x4[pix * C4 + c4] = acc;
             }

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void winow_output_kernel(const float *__restri
                 v.y = v.y > 0.f ? v.y : v.y * slope;
                 v.z = v.z > 0.f ? v.z : v.z * slope;
                 v.w = v.w > 0.f ? v.w : v.w * slope;
-                if (padded && padded[(pix / d1) * d2 + pix % d3]) v = wt::zero4();
+                if (padded && padded[mask_index(pix, d1, d2, d3)]) v = wt::zero4();
             }
             y4[pix * K4 + k4] = v;
         }
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void winow_dx_kernel(const float *__restrict__
                 v.y *= gv.y > 0.f ? 1.f : slope;
                 v.z *= gv.z > 0.f ? 1.f : slope;
                 v.w *= gv.w > 0.f ? 1.f : slope;
-                if (padded && padded[(pix / d1) * d2 + pix % d3]) v = wt::zero4();
+                if (padded && padded[mask_index(pix, d1, d2, d3)]) v = wt::zero4();
             }
             x4[pix * C4 + c4] = v;
         }
