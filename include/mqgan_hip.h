@@ -263,7 +263,7 @@ typedef struct {
 } mqCb2dWeights;
 
 /* Dropout (p_drop > 0): the keep decision of every (pixel, hidden unit) is drawn once, in the forward call (a counter-seeded
- * xorshift + Weyl stream per pixel; same Bernoulli(1 - p) law as the pointwise kernels' Philox, 16 bits per decision), left as
+ * xorshift + Weyl stream per pixel; same Bernoulli(1 - p) law as the pointwise kernels' counter-based words, 16 bits per decision), left as
  * one bit each in keep_bits - mq_convblock2d_keep_bytes(B, T, C0) bytes, [C0 / 32][B * T * C0] words - and read back by the backward
  * call: nothing is drawn twice.  keep_bits may be NULL when p_drop == 0. */
 size_t mq_convblock2d_keep_bytes(int B, int T, int C0);

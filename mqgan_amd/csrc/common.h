@@ -128,19 +128,26 @@ __device__ __forceinline__ float block_sum(float v, float *red)
 }
 
 // ----------------------------------------------------------------------------- counter-based RNG for dropout
-// Philox4x32-7 (the shortest variant that passes BigCrush); key = seed, counter = (group index, stream id).
-__device__ __forceinline__ uint4 philox4x32_7(uint2 key, uint4 ctr)
+// 128 bits per group of 8 elements as a function of (seed, group index) alone - the backward pass draws the same bits again.
+// r1-r3 used Philox4x32-7: 28 quarter-rate 32-bit multiplications per group, as many issue slots as the APTx arithmetic of the
+// eight elements, which held the bf16-storage pointwise kernels (half the bytes per element) at 4.0 TB/s.  r4: the group index is
+// hashed once (two multiplications: the 'lowbias32' finaliser) into the state of an xorshift32, whose next four states + a Weyl
+// term are the four words.  Dropout needs independent-looking bits at a fixed rate, not a cryptographic stream.
+__device__ __forceinline__ uint4 drop_words(uint64_t seed, uint64_t group)
 {
-    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-#pragma unroll
-    for (int r = 0; r < 7; ++r) {
-        uint32_t hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
-        uint32_t hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
-        ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
-        key.x += W0;
-        key.y += W1;
-    }
-    return ctr;
+    auto mix = [](uint32_t x) {
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        return x;
+    };
+    uint32_t s = mix((uint32_t)group ^ (uint32_t)seed) ^ ((uint32_t)(group >> 32) * 0x9E3779B1u) ^ (uint32_t)(seed >> 32);
+    s = s ? s : 0x6d2b79f5u;                                      // xorshift has no zero state
+    uint32_t w = s * 0x9E3779B9u;
+    uint4 r;
+    s ^= s << 13; s ^= s >> 17; s ^= s << 5; w += 0x9E3779B9u; r.x = s + w;
+    s ^= s << 13; s ^= s >> 17; s ^= s << 5; w += 0x9E3779B9u; r.y = s + w;
+    s ^= s << 13; s ^= s >> 17; s ^= s << 5; w += 0x9E3779B9u; r.z = s + w;
+    s ^= s << 13; s ^= s >> 17; s ^= s << 5; w += 0x9E3779B9u; r.w = s + w;
+    return r;
 }
 
 // Dropout keep-scale for 8 consecutive elements [8*group, 8*group+8): each 32-bit word gives two
@@ -150,8 +157,7 @@ struct Drop8 {
     __device__ __forceinline__ Drop8() : r(make_uint4(~0u, ~0u, ~0u, ~0u)) {}   // keeps everything
     __device__ __forceinline__ Drop8(uint64_t seed, uint64_t group)
     {
-        r = philox4x32_7(make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)),
-                         make_uint4((uint32_t)group, (uint32_t)(group >> 32), 0x6d71u, 0u));
+        r = drop_words(seed, group);
     }
     __device__ __forceinline__ bool keep(int e, uint32_t thresh16) const
     {
