@@ -439,7 +439,8 @@ __device__ __forceinline__ void conv_h2_body(const void *__restrict__ act_v, con
         bf16x8 fa[2][4], fb[2][TN];
         // MQ_H2_ABLATE (tools/h2_ablate.sh; never in the shipped library): WRONG results on purpose, to see which traffic the loop's
         // time follows - bit 0: a quarter of the A fragment reads, bit 1: 1 / TN of the B fragment reads, bit 2: one B DMA piece per
-        // tile, bit 3: one A DMA piece per tile
+        // tile, bit 3: one A DMA piece per tile; in conv_wgrad_h2_body bit 4: one fragment read per operand and substep, bit 5: a
+        // quarter of the dy DMA, bit 6: a quarter of the x DMA
 #ifndef MQ_H2_ABLATE
 #define MQ_H2_ABLATE 0
 #endif
@@ -1004,10 +1005,17 @@ __device__ __forceinline__ void conv_wgrad_h2_body(const unsigned short *__restr
         char *sa = smem + stage * STAGE + wave * 1024;
         char *sb = sa + IMG;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
+#ifdef MQ_H2_ABLATE
+            if ((MQ_H2_ABLATE & 32) && j > 0) continue;             // ablation (tools/h2_ablate.sh): a quarter of the dy DMA
+#endif
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, lds_ptr(sa + j * 8192), 16, voA[j], soffA, 0, 0);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+#ifdef MQ_H2_ABLATE
+            if ((MQ_H2_ABLATE & 64) && j > 0) continue;             // ... a quarter of the x DMA
+#endif
             const bool ok = okB && (pixl + 16 * j) < left && (unsigned)(b_ohs[j] + tap_h) < (unsigned)g.IH &&
                             (unsigned)(b_ow[j] * g.sw + tap_w) < (unsigned)g.IW;
             const unsigned vo = ok ? (unsigned)(b_base[j] + tap_off) : OOB;
@@ -1096,9 +1104,19 @@ __device__ __forceinline__ void conv_wgrad_h2_body(const unsigned short *__restr
             for (int sx = 0; sx < 4; ++sx) {
                 bf16x8 a[NTA], b[NTB];
 #pragma unroll
-                for (int t = 0; t < NTA; ++t) a[t] = tr8(base + aad[t], 16 * sx);
+                for (int t = 0; t < NTA; ++t) {
+#ifdef MQ_H2_ABLATE
+                    if ((MQ_H2_ABLATE & 16) && t > 0) { a[t] = a[0]; continue; }      // ... one fragment read per operand
+#endif
+                    a[t] = tr8(base + aad[t], 16 * sx);
+                }
 #pragma unroll
-                for (int t = 0; t < NTB; ++t) b[t] = tr8(base + bad[t], 16 * sx);
+                for (int t = 0; t < NTB; ++t) {
+#ifdef MQ_H2_ABLATE
+                    if ((MQ_H2_ABLATE & 16) && t > 0) { b[t] = b[0]; continue; }
+#endif
+                    b[t] = tr8(base + bad[t], 16 * sx);
+                }
 #pragma unroll
                 for (int tm = 0; tm < NTA; ++tm)
 #pragma unroll
