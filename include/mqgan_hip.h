@@ -166,7 +166,9 @@ int mq_conv_dgrad_h(const mqConvDesc *desc_host, const uint16_t *dy_bf16, const 
  *                       conv_h2s_kernel: one activation image per (chunk, tap row) for all column taps, results bit-identical to
  *                       the per-tap kernel (MQGAN_H2_NO_SHARE=1 in the environment selects that one for A/B runs).
  *   mq_conv_wgrad_h2  : dw_krsc (f32, the layout mq_weight_prep_bwd reads) and, if dbias != NULL, dbias (f32) from
- *                       bf16 x and dy; split-K over pixels with a deterministic slab reduction. */
+ *                       bf16 x and dy; split-K over pixels with a deterministic slab reduction.  Layers with three stride-1
+ *                       column taps, C % 128 == 0 and K % 192 == 0 take conv_wgrad_h2s_kernel (one x image per K-step for the
+ *                       three taps; equal to the per-tap kernel within rounding; MQGAN_H2_NO_SHARE_WGRAD=1 for A/B runs). */
 int mq_h2_supported(const mqConvDesc *desc_host);
 int mq_h2_wgrad_supported(const mqConvDesc *desc_host);
 size_t mq_h2_weight_elems(const mqConvDesc *desc_host, int dgrad);

@@ -1170,6 +1170,232 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_h2_kernel(const unsigned sh
     conv_wgrad_h2_body<WM, TM, WRAPS, MF16>(x, dy, out, g, groups, smem);
 }
 
+// ------------------------------------------------------------------------------------------ shared-row weight gradient (r4)
+// conv_wgrad_h2_kernel is bound by its LDS-DMA bytes too (tools/h2_ablate.sh, bits 4-6: fragment reads -1 %, three quarters of
+// the dy DMA -10 %, of the x DMA -12..-20 %, both -22..-30 %).  For three stride-1 column taps the gathered x tiles of (tap row,
+// tap col 0..2) are one image shifted by a pixel - when the pixels are enumerated over a width padded by two, as in
+// conv_h2s_kernel; dy is zero at the two extra positions of an image row.  The block's columns are re-tiled accordingly: one tap
+// row r, one chunk of CHK = 64 CH2 channels, all three column taps = 3 CHK columns (the epilogue scatters them into the (tap,
+// channel) order of the slab).  Per 64-pixel K-step the block stages the dy tile (64 x 256 channels, 32 KB, as before) and ONE x
+// image of 66 pixels x CHK channels (17 KB at CHK = 128) instead of 64 pixels x 256 gathered columns (32 KB):
+//     64 KB per 256 x 256 x 64 products  ->  49 KB per 256 x 384 x 64:  -49 % DMA bytes per product (CHK = 128)
+// The three taps read their B fragments at pixel offsets 0, 1, 2 of the image (transposed reads address pixel rows per lane; the
+// 64-byte bank window of a row is XOR-ed with the row's low bits, on the DMA's source side and on the reads).
+// Block tile 192 output channels x (3 taps x 128 channels), 8 waves as 2 (96 rows each) x 4 (32 channels each, all taps); 32x32x16
+// (K = 192, 384, 768 at config 3: whole tiles; against the 192 x 256 tile of conv_wgrad_h2_kernel<2, 3>: 41 KB per 192 x 384 x 64
+// products instead of 56 KB per 192 x 256 x 64: -51 %).  S = 3, stride 1, column dilation 1, C % 128 == 0; pixel sums are formed in the same pixel order as conv_wgrad_h2_kernel but
+// in other groups of 16 (the zero positions shift the groups): equal within rounding, not bit for bit.
+template <int WRAPS>
+__device__ __forceinline__ void conv_wgrad_h2s_body(const unsigned short *__restrict__ x, const unsigned short *__restrict__ dy,
+                                                    float *__restrict__ out, const H2Wgrad &g, int groups, char *smem)
+{
+    constexpr int CH2 = 2, CHK = 64 * CH2;         // channels per chunk: 128
+    constexpr int BMK = 192, TMR = 3;              // rows of the block tile; 32-row tiles per wave (2 waves x 96 rows)
+    constexpr int RB = CHK * 2;                    // bytes of one x image row
+    constexpr int RPP = 1024 / RB;                 // image rows per 1 KB DMA piece
+    constexpr int NP = (66 + RPP - 1) / RPP;       // pieces of one image (17 / 9)
+    constexpr int BJ = (NP - 1) / 8;               // whole rounds of 8 pieces (2 / 1); piece 8 BJ belongs to wave 0
+    constexpr int CPR = RB / 16;                   // 16-byte chunks per image row
+    constexpr int IMGA = 64 * 512;                 // dy image: 64 pixels x 256 channels
+    constexpr int IMGB = NP * 1024;
+    constexpr int STAGE = IMGA + IMGB;
+    constexpr int NH = 1;                          // 32-channel column tiles per tap and wave (4 waves x 32 channels)
+    constexpr int NTB = 3 * NH;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 31, lh = lane >> 5;
+    const int ntile = gridDim.x;
+    const int lin = blockIdx.x + ntile * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int virt = xcd_remap(lin, ntile * gridDim.y * gridDim.z);
+    const int tile = virt % ntile, sg = virt / ntile;
+    const int grp = sg % gridDim.y, split = sg / gridDim.y;
+    const int kt = tile / g.nCt, ct = tile - kt * g.nCt;
+    const int nchunk = g.IC / CHK;
+    const int tap_r = ct / nchunk, chunk = ct - tap_r * nchunk;
+    const int k0 = kt * BMK;
+    const int OWp = g.OW + 2;
+    const int Mp = g.Mtot;                                         // pixels of a group over the padded width (host: ng OH (OW + 2))
+    const int m_begin = split * g.chunk;
+    const int m_end = min(Mp, m_begin + g.chunk);
+    const int ng = Mp / (g.OH * OWp);
+    const int row0 = m_begin / OWp;                                // first (image, output row) of the split: offsets are relative to it
+    const int img0 = row0 / g.OH;
+
+    // ---- dy slots (as conv_wgrad_h2_body: piece = wave + 8 j = pixels 2p, 2p + 1 of the step), walked over the padded width
+    const int pixl = 2 * wave + (lane >> 5);
+    const int lcA = (lane & 31) ^ ((pixl & 3) << 2);
+    const unsigned short *dyg = dy + ((size_t)grp * ng * g.OH + row0) * g.OW * g.K;
+    const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(dyg, ((size_t)ng * g.OH - row0) * g.OW * g.K * 2);
+    const int chA = 8 * lcA;
+    const bool okA = chA < BMK && k0 + chA < g.K;
+    int a_owp[4], a_idx[4];                                        // padded column; real pixel index relative to row0
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = m_begin + pixl + 16 * j;
+        const int row = q / OWp;
+        a_owp[j] = q - row * OWp;
+        a_idx[j] = (row - row0) * g.OW + a_owp[j];
+    }
+    // ---- x slots: piece = wave + 8 j (j < BJ) and piece 8 BJ (wave 0 only); lane -> image row RPP piece + lane / CPR, chunk lane % CPR
+    const unsigned short *xg = x + ((size_t)grp * ng + img0) * g.IH * g.IW * g.IC;
+    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(xg, (size_t)(ng - img0) * g.IH * g.IW * g.IC * 2);
+    const int ripB = lane / CPR;
+    auto swzB = [](int row) { return RB == 256 ? (row & 3) << 2 : ((row >> 1) & 1) << 2; };
+    const int lcB = (lane % CPR) ^ swzB(ripB);                     // RPP pieces start on multiples of 4 (8) rows
+    const int tap_h = tap_r * g.dh - g.ph;
+    const int x_const = ((tap_h * g.IW - g.pw) * g.IC + chunk * CHK + 8 * lcB) * 2;
+    int b_owp[BJ + 1], b_oh[BJ + 1], b_base[BJ + 1];
+    bool b_row_ok[BJ + 1];
+#pragma unroll
+    for (int j = 0; j <= BJ; ++j) {
+        const int piece = j < BJ ? wave + 8 * j : 8 * BJ;
+        const int e = RPP * piece + ripB;                          // image row
+        b_row_ok[j] = e < 66 && (j < BJ || wave == 0);
+        const int q = m_begin + e;
+        const int row = q / OWp;
+        b_owp[j] = q - row * OWp;
+        const int n = row / g.OH;
+        b_oh[j] = row - n * g.OH;
+        b_base[j] = ((((n - img0) * g.IH + b_oh[j]) * g.IW + b_owp[j]) * g.IC) * 2;
+    }
+    int left = m_end - m_begin;                                    // pixels of this split from the staged step's first one on
+    auto issue = [&](int stage) {
+        char *sa = smem + stage * STAGE + wave * 1024;
+        char *sb = smem + stage * STAGE + IMGA;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = okA && (pixl + 16 * j) < left && a_owp[j] < g.OW;
+            const unsigned vo = ok ? (unsigned)((a_idx[j] * g.K + k0 + chA) * 2) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, lds_ptr(sa + j * 8192), 16, vo, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j <= BJ; ++j) {
+            const bool ok = b_row_ok[j] && (unsigned)(b_oh[j] + tap_h) < (unsigned)g.IH && (unsigned)(b_owp[j] - g.pw) < (unsigned)g.IW;
+            const unsigned vo = ok ? (unsigned)(b_base[j] + x_const) : OOB;
+            // the last piece is wave 0's; the other waves issue the same instruction out of range into a patch of their own (no branch)
+            char *dst = j < BJ ? sb + (wave + 8 * j) * 1024 : (wave == 0 ? sb + 8 * BJ * 1024 : smem + 2 * STAGE + wave * 1024);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, lds_ptr(dst), 16, vo, 0, 0, 0);
+        }
+        // advance by 64 positions of the padded enumeration
+        left -= 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a_owp[j] += 64;
+            a_idx[j] += 64;
+#pragma unroll
+            for (int i = 0; i < WRAPS; ++i) {
+                const bool w1 = a_owp[j] >= OWp;
+                a_owp[j] -= w1 ? OWp : 0;
+                a_idx[j] -= w1 ? 2 : 0;                              // next row: + OW, column - (OW + 2)
+            }
+        }
+#pragma unroll
+        for (int j = 0; j <= BJ; ++j) {
+            b_owp[j] += 64;
+            b_base[j] += 64 * g.IC * 2;
+#pragma unroll
+            for (int i = 0; i < WRAPS; ++i) {
+                const bool w1 = b_owp[j] >= OWp;
+                b_owp[j] -= w1 ? OWp : 0;
+                b_oh[j] += w1 ? 1 : 0;
+                b_base[j] += w1 ? (g.IW - OWp) * g.IC * 2 : 0;
+                const bool w2 = b_oh[j] >= g.OH;
+                b_oh[j] -= w2 ? g.OH : 0;
+                b_base[j] += w2 ? (g.IH - g.OH) * g.IW * g.IC * 2 : 0;
+            }
+        }
+    };
+
+    f32x16 acc[TMR][NTB];
+#pragma unroll
+    for (int a = 0; a < TMR; ++a)
+#pragma unroll
+        for (int b = 0; b < NTB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // transposed-read lane constants (conv_wgrad_h2_body, 32x32x16): lane 4 q + p of a 16-lane group addresses pixel row q,
+    // channels 4 p .. 4 p + 3; group gsel = (lane >> 4) & 1 -> channels + 16, lane half lh -> pixels + 8
+    const int trq = (lane & 15) >> 2, trp = lane & 3, gsel = (lane >> 4) & 1;
+    int aad[TMR], bad[3][NH];
+#pragma unroll
+    for (int t = 0; t < TMR; ++t) {
+        const int chan = wm * 96 + t * 32 + 16 * gsel + 4 * trp;
+        aad[t] = (8 * lh + trq) * 512 + ((((chan * 2) >> 4) ^ (trq << 2)) << 4) + ((chan * 2) & 15);
+    }
+#pragma unroll
+    for (int sft = 0; sft < 3; ++sft)
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const int chan = wn * 32 + h * 32 + 16 * gsel + 4 * trp;
+            const int row = 8 * lh + trq + sft;                      // + 16 sx, + 4: multiples of 4 leave the swizzle alone
+            bad[sft][h] = IMGA + row * RB + ((((chan * 2) >> 4) ^ swzB(row)) << 4) + ((chan * 2) & 15);
+        }
+    const int nsteps = (m_end - m_begin + 63) / 64;
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    auto tr8 = [&](const char *p0, int row_off, int rowb) {         // 8 pixels of one channel per lane: two transposed reads
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)lds_ptr(p0 + row_off * rowb));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)lds_ptr(p0 + (row_off + 4) * rowb));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto compute = [&](int stage) {
+        const char *base = smem + stage * STAGE;
+#pragma unroll
+        for (int sx = 0; sx < 4; ++sx) {
+            bf16x8 a[TMR], b[NTB];
+#pragma unroll
+            for (int t = 0; t < TMR; ++t) a[t] = tr8(base + aad[t], 16 * sx, 512);
+#pragma unroll
+            for (int sft = 0; sft < 3; ++sft)
+#pragma unroll
+                for (int h = 0; h < NH; ++h) b[sft * NH + h] = tr8(base + bad[sft][h], 16 * sx, RB);
+#pragma unroll
+            for (int tm = 0; tm < TMR; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < NTB; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+        }
+    };
+    int st_c = 0;
+    for (int t = 0; t < nsteps; ++t) {
+        issue(st_c ^ 1);                 // past the end of the split: dy out of range (zeros); the x image is whatever follows
+        compute(st_c);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        st_c ^= 1;
+    }
+
+    // slab [split][group][K][RSC]; the tile's columns (tap col s, channel) go to (tap, channel) of the channel-blocked filter layout
+    float *o = out + ((size_t)split * groups + grp) * (size_t)g.K * g.RSC;
+    const int cbs = chan_block(g.IC);
+#pragma unroll
+    for (int sft = 0; sft < 3; ++sft)
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const int tap = tap_r * 3 + sft;
+            const int col = kidx(tap, chunk * CHK + wn * 32 + h * 32 + li, g.RS, cbs);
+#pragma unroll
+            for (int tm = 0; tm < TMR; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = k0 + wm * 96 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (row < g.K) o[(size_t)row * g.RSC + col] = acc[tm][sft * NH + h][r];
+                }
+        }
+}
+
+template <int WRAPS>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_h2s_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ dy,
+                                                                float *__restrict__ out, H2Wgrad g, int groups)
+{
+    constexpr int NP = 17;                                          // 66 image rows of 256 bytes in 1 KB pieces
+    __shared__ __attribute__((aligned(1024))) char smem[2 * (64 * 512 + NP * 1024) + 8 * 1024];
+    conv_wgrad_h2s_body<WRAPS>(x, dy, out, g, groups, smem);
+}
+
 // out[i] = sum_k slabs[k][i] in the fixed order k = 0, 1, ... (deterministic)
 __global__ void h2_slab_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ out, size_t n4, int splits)
 {
@@ -1591,12 +1817,60 @@ extern "C" int mq_h2_wgrad_supported(const mqConvDesc *d)
     return h2_wgrad_ok(d) ? 1 : 0;
 }
 
+// the shared-row kernel's layers and plan: pixels over the padded width, tiles of 192 rows x (tap row, 128-channel chunk)
+static bool h2_wgrad_shared_shape(const mqConvDesc *d)
+{
+    return d->S == 3 && d->stride_w == 1 && d->stride_h == 1 && d->dil_w == 1 && d->C % 128 == 0 && d->K % 192 == 0 && d->Q >= 14;
+}
+static void h2_wgrad_plan_shared(const mqConvDesc *d, H2Wgrad &g)
+{
+    const int ng = d->N / d->groups;
+    g.OH = d->P; g.OW = d->Q; g.IH = d->H; g.IW = d->W; g.IC = d->C;
+    g.S = d->S; g.sh = d->stride_h; g.sw = d->stride_w; g.ph = d->pad_h; g.pw = d->pad_w; g.dh = d->dil_h; g.dw = d->dil_w;
+    g.Mtot = ng * d->P * (d->Q + 2);
+    g.K = d->K;
+    g.RS = d->R * d->S;
+    g.RSC = g.RS * d->C;
+    g.nKt = (int)cdiv(g.K, 192);
+    g.nCt = d->R * (d->C / 128);
+    const int64_t tiles = (int64_t)g.nKt * g.nCt * d->groups;
+    const int64_t slots = 256;
+    int64_t max_splits = cdiv(g.Mtot, 64 * 16);
+    if (max_splits > 512) max_splits = 512;
+    if (max_splits < 1) max_splits = 1;
+    int64_t lo = slots / tiles, hi = 4 * slots / tiles + 1;
+    if (lo < 1) lo = 1;
+    if (lo > max_splits) lo = max_splits;
+    if (hi > max_splits) hi = max_splits;
+    int64_t splits = lo;
+    double best = -1.0;
+    for (int64_t sp = lo; sp <= hi; ++sp) {
+        const int64_t blocks = tiles * sp;
+        const double rounds = (double)cdiv(blocks, slots);
+        const double score = (double)blocks / (rounds * (double)slots) - 0.004 * rounds;
+        if (score > best + 1e-12) { best = score; splits = sp; }
+    }
+    {   // 32-bit byte offsets inside one split (dy relative to the split's first row, x to its first image)
+        const int64_t pq = (int64_t)d->P * (d->Q + 2);
+        const int64_t img = 2 * std::max((int64_t)d->H * d->W * d->C, (int64_t)d->P * d->Q * (int64_t)d->K);
+        while (splits < max_splits && (cdiv(cdiv(g.Mtot, splits), pq) + 2) * img >= 0x7FFFFFF0ll) ++splits;
+    }
+    const int64_t chunk = cdiv(cdiv(g.Mtot, splits), 64) * 64;
+    g.chunk = (int)chunk;
+    g.splits = (int)cdiv(g.Mtot, chunk);
+}
+
 extern "C" size_t mq_conv_wgrad_h2_workspace(const mqConvDesc *d)
 {
     if (!mq_h2_wgrad_supported(d)) return 0;
     H2Wgrad g;
     int wm, tm;
     h2_wgrad_plan(d, g, wm, tm);
+    if (h2_wgrad_shared_shape(d)) {
+        H2Wgrad gs;                                  // either kernel may run (MQGAN_H2_NO_SHARE[_WGRAD]): room for the larger slab set
+        h2_wgrad_plan_shared(d, gs);
+        if (gs.splits > g.splits) g.splits = gs.splits;
+    }
     const size_t slabs = g.splits > 1 ? (size_t)g.splits * d->groups * g.K * g.RSC * sizeof(float) : 0;
     return slabs + (size_t)1024 * d->groups * g.K * sizeof(float);          // + column-sum partials of the bias gradient
 }
@@ -1610,8 +1884,10 @@ extern "C" int mq_conv_wgrad_h2(const mqConvDesc *d, const uint16_t *x, const ui
     MQ_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)dw % 16 == 0, "mq_conv_wgrad_h2: 16-byte alignment");
     MQ_REQUIRE(workspace_bytes >= mq_conv_wgrad_h2_workspace(d), "mq_conv_wgrad_h2: workspace too small");
     H2Wgrad g;
-    int wm, tm;
-    h2_wgrad_plan(d, g, wm, tm);
+    int wm = 0, tm = 0;
+    const bool shared = h2_wgrad_shared_shape(d) && getenv("MQGAN_H2_NO_SHARE") == nullptr && getenv("MQGAN_H2_NO_SHARE_WGRAD") == nullptr;
+    if (shared) h2_wgrad_plan_shared(d, g);
+    else h2_wgrad_plan(d, g, wm, tm);
     hipStream_t st = S(stream);
     const size_t n = (size_t)d->groups * g.K * g.RSC;
     float *target = g.splits > 1 ? reinterpret_cast<float *>(workspace) : dw;
@@ -1624,7 +1900,10 @@ extern "C" int mq_conv_wgrad_h2(const mqConvDesc *d, const uint16_t *x, const ui
 #define MQ_WH2(WM_, TM_, WR_) do { kname("conv_wgrad_h2_kernel<%d, %d, %d, %s>", WM_, TM_, WR_, tf(mf16)); if (mf16) hipLaunchKernelGGL((conv_wgrad_h2_kernel<WM_, TM_, WR_, true>), grid, block, 0, st, x, dy, target, g, d->groups); \
                                    else hipLaunchKernelGGL((conv_wgrad_h2_kernel<WM_, TM_, WR_, false>), grid, block, 0, st, x, dy, target, g, d->groups); } while (0)
 #define MQ_WH(WM_, TM_) do { if (wraps == 1) MQ_WH2(WM_, TM_, 1); else MQ_WH2(WM_, TM_, 4); } while (0)
-    if (wm == 4) MQ_WH(4, 2);
+    if (shared) {
+        if (d->Q + 2 >= 64) { kname("conv_wgrad_h2s_kernel<%d>", 1); hipLaunchKernelGGL((conv_wgrad_h2s_kernel<1>), grid, block, 0, st, x, dy, target, g, d->groups); }
+        else { kname("conv_wgrad_h2s_kernel<%d>", 4); hipLaunchKernelGGL((conv_wgrad_h2s_kernel<4>), grid, block, 0, st, x, dy, target, g, d->groups); }
+    } else if (wm == 4) MQ_WH(4, 2);
     else if (tm == 3) MQ_WH(2, 3);
     else MQ_WH(2, 2);
 #undef MQ_WH
@@ -1637,7 +1916,7 @@ extern "C" int mq_conv_wgrad_h2(const mqConvDesc *d, const uint16_t *x, const ui
     }
     if (dbias) {
         for (int grp = 0; grp < d->groups; ++grp) {
-            const int64_t rows = g.Mtot;
+            const int64_t rows = (int64_t)(d->N / d->groups) * d->P * d->Q;      // real pixels (the shared-row plan counts padded ones)
             const int cols = g.K;
             int64_t want = cdiv(4096, cdiv(cols, 128));              // ~4096 blocks in total: 16 per CU
             if (want > rows / 64) want = rows / 64;

@@ -39,6 +39,11 @@ H2_CASES = [
     dict(N=1, H=5, W=37, C=64, K=32, R=3, S=3, pad=(2, 2), dil=(2, 2)),                       # dilation
     dict(N=1, H=1, W=70, C=128, K=160, R=1, S=7, pad=(0, 6), out_hw=(1, 70)),                 # causal 1-D, ragged N tile
     dict(N=3, H=30, W=90, C=64, K=64, R=3, S=3, pad=(1, 1)),                                  # Q >= 64: one-wrap pixel walk
+    # the shared-row weight gradient (conv_wgrad_h2s_kernel: C % 128 == 0, K % 192 == 0, three stride-1 column taps); the 384 -> 768
+    # case above takes it too
+    dict(N=2, H=6, W=144, C=128, K=192, R=3, S=3, pad=(1, 1)),                                # one-wrap walk over the padded width
+    dict(N=4, H=1, W=200, C=128, K=192, R=1, S=3, pad=(0, 1), groups=2),                      # one tap row, two groups
+    dict(N=1, H=30, W=37, C=256, K=384, R=3, S=3, pad=(1, 1)),                                # two row tiles, two chunks, 39 columns
 ]
 
 
@@ -96,6 +101,8 @@ def test_h2_fprop_dgrad_wgrad_vs_float64(env, c):
     assert_rel(dx16.float(), x.grad, 4e-3, "dgrad (bf16 out)")
     if ops.h2_wgrad_supported(desc):
         dw, db = ops.conv_wgrad_h2(desc, xh, rh, tuple(wk.shape), True)
+        shared = c["S"] == 3 and c.get("stride", (1, 1)) == (1, 1) and c.get("dil", (1, 1))[1] == 1 and c["C"] % 128 == 0 and c["K"] % 192 == 0
+        assert ops.L().mq_last_kernel().decode().startswith("conv_wgrad_h2s_kernel" if shared else "h2_colsum") or not shared
         # bring dw (KRSC, channel-blocked) back to the reference layout through the weight-prep backward
         G = c.get("groups", 1)
         dws = []
