@@ -47,12 +47,18 @@ def synthetic_batches(B, T, mel, n, device, rank):
 
 
 def kernel_build_id():
-    """Hash of the conv kernel sources: ties a PMC traffic file to the build it was measured on."""
+    """Hash of the conv kernel sources: ties a PMC traffic file to the build it was measured on.  Comments and blank lines do not
+    count (a corrected remark must not orphan the counters): '//' to the end of the line outside string literals, '/* */' blocks."""
     import hashlib
+    import re
     h = hashlib.sha256()
     for f in ("gemm_core.h", "igemm.hip", "igemm_h2.hip", "winogradn.hip", "plan.cpp", "wino1d.hip", "winow.hip", "wino_tables.h", "common.h"):
-        with open(os.path.join(ROOT, "mqgan_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
+        with open(os.path.join(ROOT, "mqgan_amd", "csrc", f), "r") as fh:
+            text = re.sub(r"/\*.*?\*/", "", fh.read(), flags=re.S)
+        for line in text.splitlines():
+            line = re.sub(r'//(?=(?:[^"]*"[^"]*")*[^"]*$).*', "", line).rstrip()
+            if line.strip():
+                h.update(line.encode() + b"\n")
     return h.hexdigest()[:16]
 
 

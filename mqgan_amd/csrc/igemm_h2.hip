@@ -627,8 +627,8 @@ __device__ __forceinline__ void conv_h2_body(const void *__restrict__ act_v, con
 }
 
 // ------------------------------------------------------------------------------------------ shared-row variant (r4)
-// What the loop above is bound by (tools/h2_ablate.sh): its time follows the bytes the LDS-DMA moves (a quarter of the
-// DMA: -24..-33 %), not the fragment reads (30 % of them: -9..-12 %).  For filters with three stride-1 taps along the columns the
+// What the loop above is bound by (tools/h2_ablate.sh): its time follows the bytes the LDS-DMA moves (with a quarter of
+// the DMA left: -22..-26 %), not the fragment reads (with 30 % of them left: -8..-9 %).  For filters with three stride-1 taps along the columns the
 // three activation tiles of (chunk, tap row, tap col 0..2) are ONE tile shifted by a pixel - if the GEMM's rows enumerate the
 // output pixels over a width padded by two (n, oh, owp), owp in [0, OW + 2): row q + 1 is then always the pixel to the right, the
 // two extra positions per image row read the zero padding that a real neighbour needs, and their own outputs are never stored
