@@ -1,5 +1,6 @@
 // Shared device/host helpers for libmqgan_hip.so (gfx950 only).
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdint.h>
@@ -51,11 +52,15 @@ inline hipStream_t S(mqStream s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// grid for a grid-stride elementwise kernel: enough blocks to fill 256 CUs x 8, no more
+// grid for a grid-stride elementwise kernel.  Until r4 the grid stopped at 256 CUs x 8 blocks ("enough to fill the chip"): one
+// resident set of waves, each looping.  Measured in r4: streaming kernels run FASTER as many short-lived blocks than as few
+// looping ones (FSQ 4.9 -> 5.8 TB/s at 32 k blocks; the config-2 step 189-192 -> 186.9 ms at a cap of 8 k or 32 k blocks), so the
+// cap is 256 x 128 now (it only bounds the launch for huge tensors; MQGAN_EW_CAP overrides it for A/B runs).
 inline int ew_grid(int64_t work_items, int block)
 {
     int64_t g = cdiv(work_items, block);
-    if (g > 256 * 8) g = 256 * 8;
+    static const int64_t cap = getenv("MQGAN_EW_CAP") ? atoll(getenv("MQGAN_EW_CAP")) : 256 * 128;
+    if (g > cap) g = cap;
     if (g < 1) g = 1;
     return (int)g;
 }
