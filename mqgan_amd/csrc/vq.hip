@@ -461,7 +461,7 @@ extern "C" int mq_fsq_forward(const mqFsqDesc *desc, const float *z, int64_t n, 
     MQ_REQUIRE(z && n > 0 && (codes || idx), "mq_fsq_forward: bad arguments");
     if (p.d == 4 && (uintptr_t)z % 16 == 0 && (uintptr_t)codes % 16 == 0) {
         // two vectors per thread and one block per 512 vectors: 5.8 TB/s at 16.7 M vectors; four per thread on 2,048 looping blocks
-        // (r1-r3) 4.9, eight per thread 4.7, plain instead of non-temporal stores -5 % (tools/fsq_variants.py, r4)
+        // (r1-r3) 4.9, eight per thread 4.7, plain instead of non-temporal stores -5 % (tools/fsq_micro.py, r4)
         hipLaunchKernelGGL((fsq_forward_kernel<4, 2, true>), dim3((unsigned)std::min<int64_t>(cdiv(n, 512), 1 << 20)), dim3(256), 0, S(stream),
                            z, n, p, codes, idx);
         MQ_LAUNCH_CHECK("mq_fsq_forward");
