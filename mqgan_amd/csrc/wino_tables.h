@@ -108,6 +108,14 @@ template <int M> __device__ __forceinline__ constexpr float at(int i, int j)
 }
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// acc += c * v for clang extended vectors (winogradn.hip's channel vectors): elementwise, packed where the width allows
+template <class V> __device__ __forceinline__ void axpyv(V &acc, float c, V v)
+{
+    if (c == 0.f) return;
+    if (c == 1.f) { acc += v; return; }
+    if (c == -1.f) { acc -= v; return; }
+    acc += c * v;
+}
 // acc += c * v with the constant known after unrolling: zero terms vanish, +-1 become adds
 __device__ __forceinline__ void axpy(float4 &acc, float c, float4 v)
 {

@@ -23,6 +23,17 @@
 
 namespace mq {
 
+// Channels per thread ("C4" / "K4" in the kernels below count these channel groups).  Through r3 every transform carried FOUR
+// channels (float4) through its tile: 233-256 vector registers, one wave per SIMD.  r4 measured TWO (8-byte accesses, half the
+// registers, two to four waves per SIMD, twice the blocks) kernel by kernel: the INPUT transforms gain (winon_input 324 -> 272 us =
+// 6.1 TB/s, the polyphase one 385 -> 362), the kernels that store pixels or two streams lose (output 231 -> 242, dy pass 357 -> 388,
+// polyphase output 582 -> 664) - so the input transforms take two, the others stay at four.
+constexpr int WN_VW = 4, WN_IW = 2;
+typedef float wvec __attribute__((ext_vector_type(WN_VW)));
+typedef float ivec __attribute__((ext_vector_type(WN_IW)));
+template <class V> __device__ __forceinline__ V vzero() { V z = {}; return z; }
+__device__ __forceinline__ wvec wzero() { return vzero<wvec>(); }
+
 __device__ __forceinline__ void wn_tile_of(int64_t i, int C4, int tw, int th, int &c4, int64_t &tile, int &tj, int &ti, int64_t &n)
 {
     c4 = (int)(i % C4);
@@ -34,35 +45,35 @@ __device__ __forceinline__ void wn_tile_of(int64_t i, int C4, int tw, int th, in
 }
 
 // v = Bh^T d Bw, stored position-major: V4[(xi * tiles + tile) * C4 + c4], xi = NPW a + b
-template <int MH, int MW>
-__device__ __forceinline__ void wn_input_tf_store(const float4 (&d)[MH + 2][MW + 2], float4 *__restrict__ V4, int64_t tiles, int64_t tile, int C4,
+template <int MH, int MW, class V>
+__device__ __forceinline__ void wn_input_tf_store(const V (&d)[MH + 2][MW + 2], V *__restrict__ V4, int64_t tiles, int64_t tile, int C4,
                                                   int c4)
 {
     constexpr int NPH = MH + 2, NPW = MW + 2;
-    float4 t[NPH][NPW];
+    V t[NPH][NPW];
 #pragma unroll
     for (int b = 0; b < NPW; ++b)
 #pragma unroll
         for (int i = 0; i < NPH; ++i) {
-            float4 a = wt::zero4();
+            V a = vzero<V>();
 #pragma unroll
-            for (int k = 0; k < NPH; ++k) wt::axpy(a, wt::bt<MH>(i, k), d[k][b]);
+            for (int k = 0; k < NPH; ++k) wt::axpyv(a, wt::bt<MH>(i, k), d[k][b]);
             t[i][b] = a;
         }
 #pragma unroll
     for (int i = 0; i < NPH; ++i)
 #pragma unroll
         for (int j = 0; j < NPW; ++j) {
-            float4 a = wt::zero4();
+            V a = vzero<V>();
 #pragma unroll
-            for (int k = 0; k < NPW; ++k) wt::axpy(a, wt::bt<MW>(j, k), t[i][k]);
+            for (int k = 0; k < NPW; ++k) wt::axpyv(a, wt::bt<MW>(j, k), t[i][k]);
             V4[((int64_t)(NPW * i + j) * tiles + tile) * C4 + c4] = a;
         }
 }
 
-template <int MH, int MW>
-__device__ __forceinline__ void wn_load_window(const float4 *__restrict__ x4, int64_t n, int H, int W, int C4, int c4, int ti, int tj,
-                                               float4 (&d)[MH + 2][MW + 2])
+template <int MH, int MW, class V>
+__device__ __forceinline__ void wn_load_window(const V *__restrict__ x4, int64_t n, int H, int W, int C4, int c4, int ti, int tj,
+                                               V (&d)[MH + 2][MW + 2])
 {
 #pragma unroll
     for (int a = 0; a < MH + 2; ++a) {
@@ -70,7 +81,7 @@ __device__ __forceinline__ void wn_load_window(const float4 *__restrict__ x4, in
 #pragma unroll
         for (int b = 0; b < MW + 2; ++b) {
             const int w = MW * tj - 1 + b;
-            d[a][b] = (h >= 0 && h < H && w >= 0 && w < W) ? x4[((n * H + h) * W + w) * C4 + c4] : wt::zero4();
+            d[a][b] = (h >= 0 && h < H && w >= 0 && w < W) ? x4[((n * H + h) * W + w) * C4 + c4] : vzero<V>();
         }
     }
 }
@@ -81,13 +92,13 @@ __global__ __launch_bounds__(256) void winon_input_kernel(const float *__restric
                                                           float *__restrict__ V)
 {
     const int64_t tiles = N * th * tw, total = tiles * C4;
-    const float4 *x4 = reinterpret_cast<const float4 *>(x);
-    float4 *V4 = reinterpret_cast<float4 *>(V);
+    const ivec *x4 = reinterpret_cast<const ivec *>(x);
+    ivec *V4 = reinterpret_cast<ivec *>(V);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         int c4, tj, ti;
         int64_t tile, n;
         wn_tile_of(i, C4, tw, th, c4, tile, tj, ti, n);
-        float4 d[MH + 2][MW + 2];
+        ivec d[MH + 2][MW + 2];
         wn_load_window<MH, MW>(x4, n, H, W, C4, c4, ti, tj, d);
         wn_input_tf_store<MH, MW>(d, V4, tiles, tile, C4, c4);
     }
@@ -101,12 +112,12 @@ __global__ __launch_bounds__(256) void winon_dy_fused_kernel(const float *__rest
                                                              float *__restrict__ Z, float *__restrict__ V, float *__restrict__ partial)
 {
     constexpr int NPH = MH + 2, NPW = MW + 2;
-    __shared__ float4 s_sum[256];
+    __shared__ wvec s_sum[256];
     const int64_t tiles = N * th * tw, total = tiles * K4;
-    const float4 *y4 = reinterpret_cast<const float4 *>(dy);
-    float4 *Z4 = reinterpret_cast<float4 *>(Z);
-    float4 *V4 = reinterpret_cast<float4 *>(V);
-    float4 bsum = wt::zero4();
+    const wvec *y4 = reinterpret_cast<const wvec *>(dy);
+    wvec *Z4 = reinterpret_cast<wvec *>(Z);
+    wvec *V4 = reinterpret_cast<wvec *>(V);
+    wvec bsum = wzero();
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         int k4, tj, ti;
         int64_t tile, n;
@@ -114,26 +125,26 @@ __global__ __launch_bounds__(256) void winon_dy_fused_kernel(const float *__rest
         // the 8 x 8 window of F(6x6) and the intermediate of Z do not fit the register file together: there this kernel reads
         // the tile's own 36 outputs only and V' comes from winon_input_kernel (mq_winon_dy_fused launches both)
         constexpr bool SHARED = NPH * NPW <= 42;
-        float4 d[NPH][NPW];
+        wvec d[NPH][NPW];
         if constexpr (SHARED) wn_load_window<MH, MW>(y4, n, H, W, K4, k4, ti, tj, d);
         {   // Z = Ah y Aw^T, y = the tile's own outputs where they exist (ragged last tiles): window positions 1 .. m
-            float4 t[NPH][MW];
+            wvec t[NPH][MW];
 #pragma unroll
             for (int b = 0; b < MW; ++b) {
-                float4 y[MH];
+                wvec y[MH];
 #pragma unroll
                 for (int a = 0; a < MH; ++a) {
                     const int h = MH * ti + a, w = MW * tj + b;
                     const bool in = h < H && w < W;
-                    if constexpr (SHARED) y[a] = in ? d[1 + a][1 + b] : wt::zero4();
-                    else y[a] = in ? y4[((n * H + h) * W + w) * K4 + k4] : wt::zero4();
-                    wt::axpy(bsum, 1.f, y[a]);
+                    if constexpr (SHARED) y[a] = in ? d[1 + a][1 + b] : wzero();
+                    else y[a] = in ? y4[((n * H + h) * W + w) * K4 + k4] : wzero();
+                    wt::axpyv(bsum, 1.f, y[a]);
                 }
 #pragma unroll
                 for (int i5 = 0; i5 < NPH; ++i5) {
-                    float4 a = wt::zero4();
+                    wvec a = wzero();
 #pragma unroll
-                    for (int k = 0; k < MH; ++k) wt::axpy(a, wt::at<MH>(k, i5), y[k]);
+                    for (int k = 0; k < MH; ++k) wt::axpyv(a, wt::at<MH>(k, i5), y[k]);
                     t[i5][b] = a;
                 }
             }
@@ -141,9 +152,9 @@ __global__ __launch_bounds__(256) void winon_dy_fused_kernel(const float *__rest
             for (int i5 = 0; i5 < NPH; ++i5)
 #pragma unroll
                 for (int j5 = 0; j5 < NPW; ++j5) {
-                    float4 a = wt::zero4();
+                    wvec a = wzero();
 #pragma unroll
-                    for (int k = 0; k < MW; ++k) wt::axpy(a, wt::at<MW>(k, j5), t[i5][k]);
+                    for (int k = 0; k < MW; ++k) wt::axpyv(a, wt::at<MW>(k, j5), t[i5][k]);
                     Z4[((int64_t)(NPW * i5 + j5) * tiles + tile) * K4 + k4] = a;
                 }
         }
@@ -156,28 +167,28 @@ __global__ __launch_bounds__(256) void winon_dy_fused_kernel(const float *__rest
     __syncthreads();
     const int t = threadIdx.x;
     if (t < K4) {
-        float4 acc = s_sum[t];
-        for (int j = t + K4; j < 256; j += K4) wt::axpy(acc, 1.f, s_sum[j]);
+        wvec acc = s_sum[t];
+        for (int j = t + K4; j < 256; j += K4) wt::axpyv(acc, 1.f, s_sum[j]);
         const int k4 = (int)(((int64_t)blockIdx.x * 256 + t) % K4);
-        reinterpret_cast<float4 *>(partial)[(int64_t)blockIdx.x * K4 + k4] = acc;
+        reinterpret_cast<wvec *>(partial)[(int64_t)blockIdx.x * K4 + k4] = acc;
     }
 }
 
 // s = Ah^T m  (rows), from the position-major M
 template <int MH, int MW>
-__device__ __forceinline__ void wn_output_rows(const float4 *__restrict__ M4, int64_t tiles, int64_t tile, int C4, int c4, float4 (&s)[MH][MW + 2])
+__device__ __forceinline__ void wn_output_rows(const wvec *__restrict__ M4, int64_t tiles, int64_t tile, int C4, int c4, wvec (&s)[MH][MW + 2])
 {
     constexpr int NPH = MH + 2, NPW = MW + 2;
 #pragma unroll
     for (int b = 0; b < NPW; ++b) {
-        float4 m[NPH];
+        wvec m[NPH];
 #pragma unroll
         for (int a = 0; a < NPH; ++a) m[a] = M4[((int64_t)(NPW * a + b) * tiles + tile) * C4 + c4];
 #pragma unroll
         for (int a = 0; a < MH; ++a) {
-            float4 acc = wt::zero4();
+            wvec acc = wzero();
 #pragma unroll
-            for (int k = 0; k < NPH; ++k) wt::axpy(acc, wt::at<MH>(a, k), m[k]);
+            for (int k = 0; k < NPH; ++k) wt::axpyv(acc, wt::at<MH>(a, k), m[k]);
             s[a][b] = acc;
         }
     }
@@ -193,15 +204,15 @@ __global__ __launch_bounds__(256) void winon_output_kernel(const float *__restri
 {
     constexpr int NPW = MW + 2;
     const int64_t tiles = N * th * tw, total = tiles * K4;
-    const float4 *M4 = reinterpret_cast<const float4 *>(M);
-    float4 *y4 = reinterpret_cast<float4 *>(y);
+    const wvec *M4 = reinterpret_cast<const wvec *>(M);
+    wvec *y4 = reinterpret_cast<wvec *>(y);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         int k4, tj, ti;
         int64_t tile, n;
         wn_tile_of(i, K4, tw, th, k4, tile, tj, ti, n);
-        float4 s[MH][NPW];
+        wvec s[MH][NPW];
         wn_output_rows<MH, MW>(M4, tiles, tile, K4, k4, s);
-        const float4 bv = bias ? reinterpret_cast<const float4 *>(bias)[k4] : wt::zero4();
+        const wvec bv = bias ? reinterpret_cast<const wvec *>(bias)[k4] : wzero();
 #pragma unroll
         for (int a = 0; a < MH; ++a) {
             const int h = MH * ti + a;
@@ -210,16 +221,14 @@ __global__ __launch_bounds__(256) void winon_output_kernel(const float *__restri
             for (int b = 0; b < MW; ++b) {
                 const int w = MW * tj + b;
                 if (w >= W) continue;
-                float4 acc = bv;
+                wvec acc = bv;
 #pragma unroll
-                for (int k = 0; k < NPW; ++k) wt::axpy(acc, wt::at<MW>(b, k), s[a][k]);
+                for (int k = 0; k < NPW; ++k) wt::axpyv(acc, wt::at<MW>(b, k), s[a][k]);
                 const int64_t pix = (n * H + h) * W + w;
                 if (act == 2) {
-                    acc.x = acc.x > 0.f ? acc.x : acc.x * slope;
-                    acc.y = acc.y > 0.f ? acc.y : acc.y * slope;
-                    acc.z = acc.z > 0.f ? acc.z : acc.z * slope;
-                    acc.w = acc.w > 0.f ? acc.w : acc.w * slope;
-                    if (padded && padded[mask_index(pix, d1, d2, d3)]) acc = wt::zero4();
+#pragma unroll
+                    for (int e = 0; e < WN_VW; ++e) acc[e] = acc[e] > 0.f ? acc[e] : acc[e] * slope;
+                    if (padded && padded[mask_index(pix, d1, d2, d3)]) acc = wzero();
                 }
                 y4[pix * K4 + k4] = acc;
             }
@@ -235,21 +244,21 @@ __global__ __launch_bounds__(256) void winon_input_s2d_kernel(const float *__res
 {
     const int C4p = 4 * C4, H2 = H >> 1, W2 = W >> 1;
     const int64_t tiles = N * th * tw, total = tiles * C4p;
-    const float4 *x4 = reinterpret_cast<const float4 *>(x);
-    float4 *V4 = reinterpret_cast<float4 *>(V);
+    const ivec *x4 = reinterpret_cast<const ivec *>(x);
+    ivec *V4 = reinterpret_cast<ivec *>(V);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         int c4p, tj, ti;
         int64_t tile, n;
         wn_tile_of(i, C4p, tw, th, c4p, tile, tj, ti, n);
         const int ph = c4p / C4, c4 = c4p - ph * C4, rho = ph >> 1, sigma = ph & 1;
-        float4 d[MH + 2][MW + 2];
+        ivec d[MH + 2][MW + 2];
 #pragma unroll
         for (int a = 0; a < MH + 2; ++a) {
             const int h = MH * ti - 1 + a;
 #pragma unroll
             for (int b = 0; b < MW + 2; ++b) {
                 const int w = MW * tj - 1 + b;
-                d[a][b] = (h >= 0 && h < H2 && w >= 0 && w < W2) ? x4[((n * H + 2 * h + rho) * W + 2 * w + sigma) * C4 + c4] : wt::zero4();
+                d[a][b] = (h >= 0 && h < H2 && w >= 0 && w < W2) ? x4[((n * H + 2 * h + rho) * W + 2 * w + sigma) * C4 + c4] : vzero<ivec>();
             }
         }
         wn_input_tf_store<MH, MW>(d, V4, tiles, tile, C4p, c4p);
@@ -267,14 +276,14 @@ __global__ __launch_bounds__(256) void winon_output_d2s_kernel(const float *__re
     constexpr int NPW = MW + 2;
     const int C4p = 4 * C4, H2 = H >> 1, W2 = W >> 1;
     const int64_t tiles = N * th * tw, total = tiles * C4p;
-    const float4 *M4 = reinterpret_cast<const float4 *>(M);
-    float4 *x4 = reinterpret_cast<float4 *>(dx);
+    const wvec *M4 = reinterpret_cast<const wvec *>(M);
+    wvec *x4 = reinterpret_cast<wvec *>(dx);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         int c4p, tj, ti;
         int64_t tile, n;
         wn_tile_of(i, C4p, tw, th, c4p, tile, tj, ti, n);
         const int ph = c4p / C4, c4 = c4p - ph * C4, rho = ph >> 1, sigma = ph & 1;
-        float4 s[MH][NPW];
+        wvec s[MH][NPW];
         wn_output_rows<MH, MW>(M4, tiles, tile, C4p, c4p, s);
 #pragma unroll
         for (int a = 0; a < MH; ++a) {
@@ -284,17 +293,15 @@ __global__ __launch_bounds__(256) void winon_output_d2s_kernel(const float *__re
             for (int b = 0; b < MW; ++b) {
                 const int w = MW * tj + b;
                 if (w >= W2) continue;
-                float4 acc = wt::zero4();
+                wvec acc = wzero();
 #pragma unroll
-                for (int k = 0; k < NPW; ++k) wt::axpy(acc, wt::at<MW>(b, k), s[a][k]);
+                for (int k = 0; k < NPW; ++k) wt::axpyv(acc, wt::at<MW>(b, k), s[a][k]);
                 const int64_t pix = (n * H + 2 * h + rho) * W + 2 * w + sigma;
                 if (gate) {
-                    const float4 gv = reinterpret_cast<const float4 *>(gate)[pix * C4 + c4];
-                    acc.x *= gv.x > 0.f ? 1.f : slope;
-                    acc.y *= gv.y > 0.f ? 1.f : slope;
-                    acc.z *= gv.z > 0.f ? 1.f : slope;
-                    acc.w *= gv.w > 0.f ? 1.f : slope;
-                    if (padded && padded[mask_index(pix, d1, d2, d3)]) acc = wt::zero4();
+                    const wvec gv = reinterpret_cast<const wvec *>(gate)[pix * C4 + c4];
+#pragma unroll
+                    for (int e = 0; e < WN_VW; ++e) acc[e] *= gv[e] > 0.f ? 1.f : slope;
+                    if (padded && padded[mask_index(pix, d1, d2, d3)]) acc = wzero();
                 }
                 x4[pix * C4 + c4] = acc;
             }
@@ -486,15 +493,15 @@ extern "C" int mq_winon_input_transform(const float *x, int N, int H, int W, int
 {
     if (wn_args(x, V, N, H, W, C, mh, mw, "mq_winon_input_transform")) return 1;
     const int th = (H + mh - 1) / mh, tw = (W + mw - 1) / mw;
-    const dim3 grid(ew_grid((int64_t)N * th * tw * (C / 4), 256));
-    MQ_WN_LAUNCH(winon_input_kernel, grid, x, (int64_t)N, H, W, C / 4, th, tw, V);
+    const dim3 grid(ew_grid((int64_t)N * th * tw * (C / WN_IW), 256));
+    MQ_WN_LAUNCH(winon_input_kernel, grid, x, (int64_t)N, H, W, C / WN_IW, th, tw, V);
     MQ_LAUNCH_CHECK("mq_winon_input_transform");
     return 0;
 }
 extern "C" int mq_winon_dy_fused_rows(int N, int H, int W, int K, int mh, int mw)
 {
-    if (N <= 0 || H <= 0 || W <= 0 || K <= 0 || K % 4 != 0 || K > 1024 || !wn_tile_ok(mh, mw)) return 0;
-    return wn_blocks_for((int64_t)N * ((H + mh - 1) / mh) * ((W + mw - 1) / mw) * (K / 4), K / 4);
+    if (N <= 0 || H <= 0 || W <= 0 || K <= 0 || K % 4 != 0 || K > 256 * WN_VW || !wn_tile_ok(mh, mw)) return 0;
+    return wn_blocks_for((int64_t)N * ((H + mh - 1) / mh) * ((W + mw - 1) / mw) * (K / WN_VW), K / WN_VW);
 }
 extern "C" int mq_winon_dy_fused(const float *dy, int N, int H, int W, int K, float *Z, float *Vd, float *bias_partial, int mh, int mw,
                                  mqStream stream)
@@ -502,13 +509,13 @@ extern "C" int mq_winon_dy_fused(const float *dy, int N, int H, int W, int K, fl
     if (wn_args(dy, Z, N, H, W, K, mh, mw, "mq_winon_dy_fused")) return 1;
     MQ_REQUIRE(((uintptr_t)Vd | (uintptr_t)bias_partial) % 16 == 0, "mq_winon_dy_fused: Vd / bias_partial unaligned");
     const int blocks = mq_winon_dy_fused_rows(N, H, W, K, mh, mw);
-    MQ_REQUIRE(blocks > 0 && ((int64_t)blocks * 256) % (K / 4) == 0, "mq_winon_dy_fused: shape not supported (K <= 1024)");
+    MQ_REQUIRE(blocks > 0 && ((int64_t)blocks * 256) % (K / WN_VW) == 0, "mq_winon_dy_fused: shape not supported (K <= 1024)");
     const int th = (H + mh - 1) / mh, tw = (W + mw - 1) / mw;
     const dim3 grid(blocks);
-    MQ_WN_LAUNCH(winon_dy_fused_kernel, grid, dy, (int64_t)N, H, W, K / 4, th, tw, Z, Vd, bias_partial);
+    MQ_WN_LAUNCH(winon_dy_fused_kernel, grid, dy, (int64_t)N, H, W, K / WN_VW, th, tw, Z, Vd, bias_partial);
     if (mw == 6 && Vd) {
-        const dim3 gv(ew_grid((int64_t)N * th * tw * (K / 4), 256));
-        hipLaunchKernelGGL((winon_input_kernel<6, 6>), gv, dim3(256), 0, S(stream), dy, (int64_t)N, H, W, K / 4, th, tw, Vd);
+        const dim3 gv(ew_grid((int64_t)N * th * tw * (K / WN_IW), 256));
+        hipLaunchKernelGGL((winon_input_kernel<6, 6>), gv, dim3(256), 0, S(stream), dy, (int64_t)N, H, W, K / WN_IW, th, tw, Vd);
     }
     MQ_LAUNCH_CHECK("mq_winon_dy_fused");
     return 0;
@@ -520,8 +527,8 @@ extern "C" int mq_winon_output_transform(const float *M, const float *bias, int 
     MQ_REQUIRE(!bias || (uintptr_t)bias % 16 == 0, "mq_winon_output_transform: bias must be 16-byte aligned");
     MQ_REQUIRE((act == 0 || act == 2) && (!padded || (act == 2 && d1 > 0 && d3 > 0)), "mq_winon_output_transform: act 0 or 2; a mask needs act 2");
     const int th = (H + mh - 1) / mh, tw = (W + mw - 1) / mw;
-    const dim3 grid(ew_grid((int64_t)N * th * tw * (K / 4), 256));
-    MQ_WN_LAUNCH(winon_output_kernel, grid, M, bias, (int64_t)N, H, W, K / 4, th, tw, act, slope, padded, d1, d2, d3, y);
+    const dim3 grid(ew_grid((int64_t)N * th * tw * (K / WN_VW), 256));
+    MQ_WN_LAUNCH(winon_output_kernel, grid, M, bias, (int64_t)N, H, W, K / WN_VW, th, tw, act, slope, padded, d1, d2, d3, y);
     MQ_LAUNCH_CHECK("mq_winon_output_transform");
     return 0;
 }
@@ -535,8 +542,8 @@ extern "C" int mq_winon_input_transform_s2d(const float *x, int N, int H, int W,
 {
     if (wn_s2d_args(x, V, N, H, W, C, mh, mw, "mq_winon_input_transform_s2d")) return 1;
     const int th = (H / 2 + mh - 1) / mh, tw = (W / 2 + mw - 1) / mw;
-    const dim3 grid(ew_grid((int64_t)N * th * tw * C, 256));
-    MQ_WN_LAUNCH(winon_input_s2d_kernel, grid, x, (int64_t)N, H, W, C / 4, th, tw, V);
+    const dim3 grid(ew_grid((int64_t)N * th * tw * (4 * C / WN_IW), 256));
+    MQ_WN_LAUNCH(winon_input_s2d_kernel, grid, x, (int64_t)N, H, W, C / WN_IW, th, tw, V);
     MQ_LAUNCH_CHECK("mq_winon_input_transform_s2d");
     return 0;
 }
@@ -547,8 +554,8 @@ extern "C" int mq_winon_output_transform_d2s(const float *M, int N, int H, int W
     MQ_REQUIRE(!gate || (uintptr_t)gate % 16 == 0, "mq_winon_output_transform_d2s: gate must be 16-byte aligned");
     MQ_REQUIRE(!padded_in || (gate && d1 > 0 && d3 > 0), "mq_winon_output_transform_d2s: a mask needs the gate tensor and an index map");
     const int th = (H / 2 + mh - 1) / mh, tw = (W / 2 + mw - 1) / mw;
-    const dim3 grid(ew_grid((int64_t)N * th * tw * C, 256));
-    MQ_WN_LAUNCH(winon_output_d2s_kernel, grid, M, (int64_t)N, H, W, C / 4, th, tw, gate, slope, padded_in, d1, d2, d3, dx);
+    const dim3 grid(ew_grid((int64_t)N * th * tw * (4 * C / WN_VW), 256));
+    MQ_WN_LAUNCH(winon_output_d2s_kernel, grid, M, (int64_t)N, H, W, C / WN_VW, th, tw, gate, slope, padded_in, d1, d2, d3, dx);
     MQ_LAUNCH_CHECK("mq_winon_output_transform_d2s");
     return 0;
 }
