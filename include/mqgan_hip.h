@@ -601,6 +601,7 @@ int mq_conv_fprop_planned(const mqConvPlan *plan, const float *x, const float *w
 /* Gradients from dy = the gradient with respect to the convolution's output BEFORE its activation (for a LeakyReLU layer apply
  * LeakyReLU'(y) and the mask first, mq_pointwise_bwd, unless the consumer of y already did: mq_conv_dgrad_gated's contract).
  * dx / dw / db NULL = not wanted.  x: needed by the direct form and when keep is NULL.  w_crsk: the direct input gradient only.
+ * workspace: plan->ws_backward bytes whatever subset of gradients is asked for (NULL allowed when that is 0, as in the forward).
  * gate (NULL = none): x itself when x came out of a LeakyReLU(gate_slope) + mask layer that expects the gradient with respect to
  * ITS pre-activation: dx *= x > 0 ? 1 : gate_slope, zero where gate_mask[(m / g1) * g2 + m % g3] (m = input pixel). */
 int mq_conv_backward_planned(const mqConvPlan *plan, const float *x, const void *keep, const float *w_krsc, const float *w_crsk,

@@ -136,15 +136,33 @@ __device__ __forceinline__ float block_sum(float v, float *red)
 // 128 bits per group of 8 elements as a function of (seed, group index) alone - the backward pass draws the same bits again.
 // r1-r3 used Philox4x32-7: 28 quarter-rate 32-bit multiplications per group, as many issue slots as the APTx arithmetic of the
 // eight elements, which held the bf16-storage pointwise kernels (half the bytes per element) at 4.0 TB/s.  r4: the group index is
-// hashed once (two multiplications: the 'lowbias32' finaliser) into the state of an xorshift32, whose next four states + a Weyl
-// term are the four words.  Dropout needs independent-looking bits at a fixed rate, not a cryptographic stream.
+// hashed (the 'lowbias32' finaliser) into the state of an xorshift32, whose next four states + a Weyl term are the four words.
+// Dropout needs independent-looking bits at a fixed rate, not a cryptographic stream.
+// r5: the SEED enters as two keys, each a hash of both of its words, around two hash rounds of the group index.  r4 XOR-ed the
+// seed's high word into the state AFTER the hash: xorshift is linear over GF(2), so two seeds that differed only there produced
+// streams that differed by a fixed XOR stream (the review measured a cross-seed correlation of 5.7e-3 of the decisions); and
+// with one keyed round hash(group ^ key) the mask of one seed is the mask of another under a permutation of the groups.  The keys
+// are wave-uniform (scalar unit); per group the cost is two more multiplications.
+__device__ __forceinline__ uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+struct SeedKeys {
+    uint32_t k0, k1;
+};
+__device__ __forceinline__ SeedKeys seed_keys(uint64_t seed)
+{
+    const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
+    SeedKeys k;
+    k.k0 = lo ^ mix32(hi ^ 0x85ebca6bu);
+    k.k1 = mix32(hi + mix32(lo ^ 0xc2b2ae35u));
+    return k;
+}
 __device__ __forceinline__ uint4 drop_words(uint64_t seed, uint64_t group)
 {
-    auto mix = [](uint32_t x) {
-        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-        return x;
-    };
-    uint32_t s = mix((uint32_t)group ^ (uint32_t)seed) ^ ((uint32_t)(group >> 32) * 0x9E3779B1u) ^ (uint32_t)(seed >> 32);
+    const SeedKeys key = seed_keys(seed);
+    uint32_t s = mix32(mix32((uint32_t)group ^ key.k0) + key.k1) ^ ((uint32_t)(group >> 32) * 0x9E3779B1u);
     s = s ? s : 0x6d2b79f5u;                                      // xorshift has no zero state
     uint32_t w = s * 0x9E3779B9u;
     uint4 r;

@@ -39,14 +39,13 @@ struct DropStream {
     uint32_t s, w;
     __device__ __forceinline__ void seed(uint64_t seed, int64_t pixel)
     {
-        auto mix = [](uint32_t x) {
-            x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-            return x;
-        };
+        // both words of the seed enter both halves of the state through the two keys of common.h (r4: a seed's high word only
+        // moved the Weyl term, i.e. translated every word of the stream by a constant)
+        const SeedKeys key = seed_keys(seed);
         const uint32_t lo = (uint32_t)pixel, hi = (uint32_t)((uint64_t)pixel >> 32);
-        s = mix((uint32_t)seed ^ (lo * 0x9E3779B1u) ^ mix(hi + 0x85ebca6bu));
+        s = mix32(mix32(key.k0 ^ (lo * 0x9E3779B1u) ^ mix32(hi + 0x85ebca6bu)) + key.k1);
         s = s ? s : 0x6d2b79f5u;                                   // xorshift has no zero state
-        w = mix((uint32_t)(seed >> 32) ^ lo ^ 0xc2b2ae35u);
+        w = mix32((key.k1 * 0x9E3779B9u) ^ lo ^ 0xc2b2ae35u);
     }
     __device__ __forceinline__ uint32_t next()                     // 32 random bits: one bit plane of 32 decisions
     {

@@ -405,8 +405,8 @@ extern "C" int mq_conv_backward_planned(const mqConvPlan *p, const float *x, con
 {
     MQ_REQUIRE(p && dy && w_krsc, "mq_conv_backward_planned: null argument");
     MQ_REQUIRE(!gate_mask || gate, "mq_conv_backward_planned: a gate mask needs the gate tensor");
-    MQ_REQUIRE(workspace && workspace_bytes >= p->ws_backward, "mq_conv_backward_planned: workspace of %zu bytes needed, %zu given",
-               p->ws_backward, workspace_bytes);
+    MQ_REQUIRE(p->ws_backward == 0 || (workspace && workspace_bytes >= p->ws_backward),
+               "mq_conv_backward_planned: workspace of %zu bytes needed, %zu given", p->ws_backward, workspace_bytes);
     MQ_REQUIRE(((uintptr_t)workspace | (uintptr_t)keep) % 256 == 0, "mq_conv_backward_planned: workspace and keep buffer must be 256-byte aligned");
     MQ_REQUIRE(p->form != MQ_FORM_DIRECT || !dx || w_crsk, "mq_conv_backward_planned: the direct input gradient needs the CRSK weights");
     MQ_REQUIRE(!dw || x || (keep && p->keep_bytes > 0), "mq_conv_backward_planned: the weight gradient needs the keep buffer or x");
@@ -440,7 +440,9 @@ int backward_impl(const mqConvPlan *p, const float *x, const void *keep, const f
             if (db) MQ_TRY(gemm_call(d, [&] { return mq_conv_wgrad_bias(&d, x, dy, dw, db, w, mq_conv_wgrad_bias_workspace(&d), st); }));
             else MQ_TRY(gemm_call(d, [&] { return mq_conv_wgrad(&d, x, dy, dw, w, mq_conv_wgrad_workspace(&d), st); }));
         } else if (db) {
-            float *cw = ws.take(1024 * rowsK);
+            // one group's column sums at a time: the scratch is reused, so it is 1024 x K floats whatever the group count (the
+            // sizing pass runs with dw wanted and reserves at least that much)
+            float *cw = ws.take(1024 * (size_t)d.K);
             const int64_t rows = (int64_t)(d.N / d.groups) * d.P * d.Q;
             for (int g = 0; g < d.groups; ++g) MQ_TRY(mq_colsum(dy + (size_t)g * rows * d.K, rows, d.K, db + (size_t)g * d.K, cw, st));
         }

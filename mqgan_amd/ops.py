@@ -518,8 +518,10 @@ class ConvPlannedFn(torch.autograd.Function):
         x, w_krsc = x.contiguous(), w_krsc.contiguous()
         mask, dmap, slope = (leaky[0], tuple(leaky[1]), float(leaky[2])) if leaky is not None else (None, (1, 0, 1), 0.0)
         # the keep buffer carries the transformed input (weight gradient) and, for the row / column forms, the CRSK transformed
-        # filters (input gradient); the two-dimensional forms transform the rotated filter in backward instead
-        need_keep = p.keep_bytes > 0 and (ctx.needs_input_grad[1] or (ctx.needs_input_grad[0] and p.form in (FORM_WINO1D, FORM_WINOW)))
+        # filters (input gradient); the two-dimensional forms transform the rotated filter in backward instead.  With frozen
+        # weights (the generator step's passes through the discriminators) nothing is kept: the transformed input - 1.5x the
+        # layer's input and more - would only be carried for the small transformed filters, which backward forms again
+        need_keep = p.keep_bytes > 0 and ctx.needs_input_grad[1]
         keep = _ws_bytes(p.keep_bytes, x) if need_keep else None
         ws = _ws_bytes(p.ws_fprop, x) if p.ws_fprop else None
         y = _empty((d.N, d.P, d.Q, d.K), x)
@@ -533,8 +535,9 @@ class ConvPlannedFn(torch.autograd.Function):
         ctx.pregated = bool(pregated)
         ctx.in_gate = None if in_gate is None else (tuple(in_gate[1]), float(in_gate[2]))
         direct = p.form == FORM_DIRECT
+        ctx.plan = p       # backward runs the plan forward ran with, whatever the module's switches say by then
         # what backward reads: x for the direct weight gradient, as the gate tensor, or to transform again without a keep buffer
-        need_x = direct or in_gate is not None or keep is None
+        need_x = in_gate is not None or (ctx.needs_input_grad[1] and (direct or keep is None))
         ctx.save_for_backward(x if need_x else None, keep, w_krsc, w_crsk if direct else None,
                               y if (leaky is not None and not pregated) else None, mask, None if in_gate is None else in_gate[0])
         return y
@@ -543,7 +546,7 @@ class ConvPlannedFn(torch.autograd.Function):
     def backward(ctx, dout):
         x, keep, w_krsc, w_crsk, y, mask, mask_in = ctx.saved_tensors
         d = _desc_from_key(ctx.key)
-        p = conv_plan(d, ctx.leaky_cfg is not None)
+        p = ctx.plan
         dy = dout.contiguous()
         if ctx.leaky_cfg is not None and not ctx.pregated:
             dmap, slope = ctx.leaky_cfg
@@ -566,12 +569,12 @@ class ConvPlannedFn(torch.autograd.Function):
         dw = _empty(ctx.w_shape, dy) if want_dw else None
         db = _empty((d.groups * d.K,), dy) if want_db else None
         gmask, gdmap, gslope = (mask_in, ctx.in_gate[0], ctx.in_gate[1]) if ctx.in_gate is not None else (None, (1, 0, 1), 1.0)
-        ws = _ws_bytes(p.ws_backward, dy)
+        ws = _ws_bytes(p.ws_backward, dy) if p.ws_backward else None
         _planned_call(ctx.key, lambda: check(
             L().mq_conv_backward_planned(C.byref(p), fptr(x, True), ptr(keep, torch.uint8, True), fptr(w_krsc), fptr(w_crsk, True), fptr(dy),
                                          fptr(x, True) if ctx.in_gate is not None else None, gslope, ptr(gmask, torch.uint8, True),
                                          gdmap[0], gdmap[1], gdmap[2], fptr(dx, True), fptr(dw, True), fptr(db, True),
-                                         ptr(ws, torch.uint8), p.ws_backward, stream()), "mq_conv_backward_planned"))
+                                         ptr(ws, torch.uint8, True), p.ws_backward, stream()), "mq_conv_backward_planned"))
         return dx, dw, None, db, None, None, None, None
 
 

@@ -318,6 +318,11 @@ def _se_masked(P, prefix, x, padded_mask):
     return x * e.view(B, C, 1, 1)
 
 
+# parity tests: a list here collects, per discriminator layer run with adopted ``gates``, how many adopted branches differ from the
+# sign of this implementation's own pre-activation and how large those pre-activations are (see patch_discriminator)
+GATE_STATS = None
+
+
 def patch_discriminator(P: Params, prefix: str, x: torch.Tensor, lengths: torch.Tensor, strides, training: bool,
                         return_features=False, gates=None):
     """discriminators.py:196-242.  x (B, T, F) -> logits (B,1,H,W), patch_mask (True = VALID)[, features].
@@ -339,9 +344,19 @@ def patch_discriminator(P: Params, prefix: str, x: torch.Tensor, lengths: torch.
         kh, kw = w.shape[-2:]
         sh, sw = strides[i]
         out = F.conv2d(out, w, P[prefix + f"convs.{i}.bias"], stride=(sh, sw), padding=((kh - 1) // 2, (kw - 1) // 2))
+        pre = out
         out = F.leaky_relu(out, 0.2) if gates is None else torch.where(gates[i], out, 0.2 * out)
         if sh > 1 or sw > 1:
             padded = F.max_pool2d(padded.float(), kernel_size=(sh, sw), stride=(sh, sw), ceil_mode=True).bool()
+        if gates is not None and GATE_STATS is not None:
+            # how far the adopted branches are from this implementation's own (sign of its own pre-activation), on valid frames:
+            # a shared branch may differ only where the pre-activation is within rounding of zero, and only on a handful of elements
+            with torch.no_grad():
+                valid = ~padded.expand_as(pre)
+                differ = ((pre > 0) != gates[i]) & valid & (pre != 0)
+                rms = float(pre[valid].double().pow(2).mean().sqrt()) if bool(valid.any()) else 0.0
+                GATE_STATS.append({"prefix": prefix, "layer": i, "valid": int(valid.sum()), "differ": int(differ.sum()), "rms": rms,
+                                   "max_abs_pre_where_differ": float(pre[differ].abs().max()) if bool(differ.any()) else 0.0})
         out = out.masked_fill(padded, 0.0)
         if return_features and 2 <= i <= n - 2:                                       # :104-108
             feats.append((out, padded))

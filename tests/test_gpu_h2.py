@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-from gpu_util import DEV, assert_rel  # noqa: E402
+from gpu_util import DEV, assert_elem, assert_rel  # noqa: E402
 from test_gpu_kernels import _torch_conv  # noqa: E402
 
 BF16 = torch.bfloat16
@@ -116,6 +116,9 @@ def test_h2_fprop_dgrad_wgrad_vs_float64(env, c):
                                              c["C"], c["R"] * c["S"], fptr(dv), None, stream()), "mq_weight_prep_bwd")
             dws.append(dv.view(c["K"], c["C"], c["R"], c["S"]))
         assert_rel(torch.cat(dws, 0), w.grad, 2e-5, "wgrad")
+        # the shared-row kernel's failure modes are LOCAL (the two zero positions per padded row, the per-tap scatter of its
+        # epilogue): every tap on its own, and no element off by more than the accumulation's rounding tail
+        assert_elem(torch.cat(dws, 0), w.grad, 2e-5, 2e-4, "wgrad " + ("(shared rows)" if shared else "(per tap)"), taps=True)
         assert_rel(db, b.grad, 2e-5, "bias grad")
     else:
         assert desc.Q < 16

@@ -29,6 +29,8 @@ CASES = [
      "winograd-rows"),
     ("decoder causal k7", dict(N=2, H=1, W=45, C=128, K=128, R=1, S=7, P=1, Q=45, stride_h=1, stride_w=1, pad_h=0, pad_w=6), False, "winograd-columns"),
     ("patch-D 3x3 s(2,1)", dict(N=2, H=9, W=22, C=128, K=128, R=3, S=3, P=5, Q=22, stride_h=2, stride_w=1, pad_h=1, pad_w=1), True, "winograd-columns"),
+    # a layer no reduced form takes, with batch groups: the direct form's bias-only call sums one group at a time
+    ("narrow band layer g4", dict(N=8, H=10, W=36, C=32, K=48, R=3, S=3, P=10, Q=18, stride_h=1, stride_w=2, pad_h=1, pad_w=1, groups=4), True, "direct"),
 ]
 
 
@@ -85,6 +87,23 @@ def test_planned_calls_through_ctypes_equal_the_direct_form(lib, name, kw, leaky
         torch.cuda.synchronize()
         assert bool((guard == 0x5A).all()), f"{leg}: a planned call wrote past the end of its workspace"
         out[leg] = (y, dx, dw, db)
+        # every subset of the gradients out of the same plan.ws_backward bytes (round 4 advice: the direct form's bias-only call
+        # carved groups x more scratch than the plan had sized)
+        for want in ("dx", "dw", "db"):
+            ws.fill_(0xFF)
+            sub = {"dx": None, "dw": None, "db": None}
+            sub[want] = torch.full_like({"dx": x, "dw": w_krsc, "db": bias}[want], float("nan"))
+            rc = L.mq_conv_backward_planned(C.byref(p), P(x), P(keep), P(w_krsc), P(w_crsk), P(dy), P(x) if gate else None, 0.2,
+                                            P(gmask) if gate else None, d.H * d.W, d.W, d.W, P(sub["dx"]), P(sub["dw"]), P(sub["db"]),
+                                            P(ws), nws, st)
+            assert rc == 0, f"{leg} {want} only: {L.mq_last_error()}"
+            torch.cuda.synchronize()
+            assert bool((guard == 0x5A).all()), f"{leg} {want} only: a planned call wrote past the end of its workspace"
+            full = {"dx": dx, "dw": dw, "db": db}[want]
+            if want == "dx":
+                assert torch.equal(sub[want], full), f"{leg}: dx alone differs from dx with the other gradients"
+            else:       # the bias sums may come from another pass (dy's column sums instead of the transform's partial sums)
+                assert_elem(sub[want], full, 2e-6, 2e-5, f"plan ctypes {name} {leg} {want} alone")
     for leg in ("planned", "planned-no-keep"):
         for nm, a, b in zip(("y", "dx", "dw", "db"), out[leg], out["direct"]):
             assert_elem(a, b, 2e-5, 2e-4, f"plan ctypes {name} {leg} {nm}")
