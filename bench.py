@@ -81,6 +81,79 @@ def pmc_traffic(kernel_tag):
     return e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
 
 
+HBM_FAMILIES = {"winograd_transforms": ("winon_", "wino1d_", "winow_"),
+                "pointwise_pool_upcat": ("pointwise_", "avgpool_", "upcat_"),
+                "fsq": ("fsq_",)}
+
+
+def pmc_family_bytes():
+    """Per step and per family of HBM-bound kernels (HBM_FAMILIES: kernel-name prefixes), the HBM-side bytes of the last committed
+    PMC pass (same file, same source-hash rule as pmc_traffic): sum over the family's kernels of bytes per launch x launches per
+    step.  The pass's step count comes from its own adam_kernel launches (two per step).  Also the bytes of the two-dimensional
+    Winograd layers as a whole - their transforms plus the dense 1x1 instantiations of the GEMM kernels, which only those layers
+    launch with more than a few MB - for the wasted-traffic ratio.  (None, source) when there is no valid pass."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    src = os.path.relpath(files[-1], ROOT)
+    with open(files[-1]) as f:
+        t = json.load(f)
+    if t.get("_build") != kernel_build_id():
+        return None, src + " (stale: measured on other kernel sources)"
+    adam = t.get("adam_kernel")
+    if not adam or not adam.get("launches"):
+        return None, src + " (no adam_kernel entry: step count unknown)"
+    steps = adam["launches"] / 2.0
+    per_step = lambda e: (e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"]) * e["launches"] / steps
+    out = {fam: 0.0 for fam in HBM_FAMILIES}
+    wino2d = 0.0
+    for name, e in t.items():
+        if name.startswith("_") or "run" in e:
+            continue
+        for fam, prefixes in HBM_FAMILIES.items():
+            if name.startswith(prefixes):
+                out[fam] += per_step(e)
+        if name.startswith("winon_") or (name.startswith(("conv_nt_kernel<", "conv_wgrad_kernel<")) and name.rstrip(">").endswith(", 4")):
+            wino2d += per_step(e)
+    out["_wino2d_layers"] = wino2d
+    return out, src
+
+
+def hbm_bound_of(tr, batches, lens, steps=2):
+    """The HBM-bound half of the step ('HBM roof for FSQ streaming and the fused passes'), measured AFTER the timed
+    region on `steps` further optimisation steps: HIP events on the launch stream around every launch of the Winograd transforms
+    (through mq_set_pass_hook), the pointwise / pool / upsample-concat passes and the FSQ kernels in situ (ops.pass_timing) give
+    ms per step per family; GB per step per family come from the committed PMC pass (null when it was taken on other kernel
+    sources, as `traffic`); TB/s and the fraction of the 8 TB/s peak follow.  wasted_traffic_ratio: bytes the two-dimensional
+    Winograd layers (refiner 3x3, patch discriminator 5x5 / stride 2) moved - transforms and Winograd-domain GEMMs, PMC - over
+    the bytes a fused layer would have to move (every activation tensor a pass reads or writes, once; reported by the library)."""
+    from mqgan_amd import ops
+    with ops.pass_timing() as t:
+        for i in range(steps):
+            tr.train_step(batches[i % len(batches)], lens)
+        torch.cuda.synchronize()
+    summ = t.summary()
+    fam_bytes, src = pmc_family_bytes()
+    out = {"bound": "hbm", "peak": PEAK_HBM_GBS / 1e3, "unit": "TB/s", "traffic_source": src, "steps_measured": steps, "families": {}}
+    for fam in HBM_FAMILIES:
+        v = summ.get(fam)
+        if not v:
+            continue
+        ms = v["ms"] / steps
+        gb = None if fam_bytes is None else fam_bytes[fam] / 1e9
+        out["families"][fam] = {"ms_per_step": ms, "launches_per_step": v["launches"] / steps, "GB_per_step": gb,
+                                "achieved": None if gb is None else gb / ms, "frac": None if gb is None else gb / ms / (PEAK_HBM_GBS / 1e3)}
+    alg = sum(b for f, b in t.layer_bytes.items() if f in ("winograd2d", "polyphase-winograd2d")) / steps
+    out["winograd2d_layers"] = {"algorithmic_GB_per_step": alg / 1e9,
+                                "moved_GB_per_step": None if fam_bytes is None else fam_bytes["_wino2d_layers"] / 1e9,
+                                "wasted_traffic_ratio": None if (fam_bytes is None or alg <= 0) else fam_bytes["_wino2d_layers"] / alg,
+                                "note": "moved: PMC bytes of winon_* and of the dense 1x1 GEMM instantiations; algorithmic: x + y (forward), "
+                                        "dy + dx + x (backward) of every such layer, once each"}
+    out["all_reduced_form_layers_algorithmic_GB_per_step"] = sum(t.layer_bytes.values()) / steps / 1e9
+    return out
+
+
 def time_events(fn, iters):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
@@ -663,11 +736,14 @@ def main():
                                                         force=args.force_collectives)
     host_ms = host_ms_per_step(tr, batches, lens)
     finite = all(np.isfinite(float(v)) for v in last.values())
+    hbm = hbm_bound_of(tr, batches, lens)          # every rank steps (the step holds collectives); rank 0 reports
 
     if rank == 0:
         frames = world * B * T * args.steps
         step_peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "fp32x3": PEAK_BF16_MFMA_TFLOPS / 6}[args.precision]
         roof = roofline_of(timer, args.steps, elapsed, step_peak)
+        roof["hbm_bound"] = hbm
+        roof["wasted_traffic_ratio"] = (hbm.get("winograd2d_layers") or {}).get("wasted_traffic_ratio")
         line = {"metric": METRIC, "value": frames / elapsed, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16 convs (f32 accumulate, bf16 activation storage) / f32 VQ",

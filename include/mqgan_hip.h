@@ -611,6 +611,12 @@ int mq_conv_backward_planned(const mqConvPlan *plan, const float *x, const void 
  * the launch's algorithmic flop count - bench.py records HIP events on the launch stream from it.  NULL switches it off. */
 typedef void (*mqLaunchHook)(int phase, double flops, const char *kernel);
 void mq_set_launch_hook(mqLaunchHook hook);
+/* The HBM-bound half of the same calls ("HBM roof for ... the fused passes"): called before (phase 0) and after
+ * (phase 1) every transform launch of the reduced forms with family = "winograd_transforms", and once per planned call of a reduced
+ * form with phase 2, bytes = the layer's ALGORITHMIC activation bytes for that pass (each activation tensor it reads or writes,
+ * once: x + y forward; dy + dx + x backward) and family = mq_form_name(form) - what bench.py's wasted-traffic ratio divides by. */
+typedef void (*mqPassHook)(int phase, double bytes, const char *family);
+void mq_set_pass_hook(mqPassHook hook);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MQGAN_HIP_LIB: load another build of the same ABI (kernel experiments); the default is the in-tree library
 LIB_PATH = os.environ.get("MQGAN_HIP_LIB") or os.path.join(_HERE, "libmqgan_hip.so")
 _lib = None
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class MqganHipError(RuntimeError):
@@ -44,6 +44,7 @@ class ConvPlan(C.Structure):
 
 FORM_DIRECT, FORM_WINO2D, FORM_S2D, FORM_WINO1D, FORM_WINOW = range(5)
 LaunchHook = C.CFUNCTYPE(None, C.c_int, C.c_double, C.c_char_p)
+PassHook = C.CFUNCTYPE(None, C.c_int, C.c_double, C.c_char_p)
 
 
 class Cb2dWeights(C.Structure):
@@ -191,6 +192,7 @@ SIGNATURES = {
     "mq_conv_fprop_planned": (_I, [C.POINTER(ConvPlan), _P, _P, _P, _I, _F, _P, _L, _L, _L, _P, _P, _P, _Z, _P]),
     "mq_conv_backward_planned": (_I, [C.POINTER(ConvPlan), _P, _P, _P, _P, _P, _P, _F, _P, _L, _L, _L, _P, _P, _P, _P, _Z, _P]),
     "mq_set_launch_hook": (None, [LaunchHook]),
+    "mq_set_pass_hook": (None, [PassHook]),
     "mq_sumsq": (_I, [_P, _L, _P, _P, _P]),
     "mq_multi_gather": (_I, [_P, _I, _L, _P, _P]),
     "mq_multi_gather_args": (_I, [_P, _I, _P, _P]),

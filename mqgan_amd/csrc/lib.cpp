@@ -19,6 +19,8 @@ thread_local char g_kernel[128] = "";
 // 8: mq_conv_plan / mq_conv_fprop_planned / mq_conv_backward_planned (the algorithm choice and the Winograd / polyphase / nested
 //    sequences behind the ABI, csrc/plan.cpp), mq_set_launch_hook; mq_winon_* take the 3 x 3 tile as well - mq_wino3_* and the
 //    F(2x2, 3x3) functions mq_wino_* are gone
-extern "C" int mq_abi_version(void) { return 8; }
+// 9: mq_set_pass_hook (HIP-event timing of the transform passes, algorithmic bytes per reduced-form layer); the screened codebook
+//    search is two launches with every bf16 score formed once (same entry points, d <= 512)
+extern "C" int mq_abi_version(void) { return 9; }
 extern "C" const char *mq_last_error(void) { return mq::g_err; }
 extern "C" const char *mq_last_kernel(void) { return mq::g_kernel; }

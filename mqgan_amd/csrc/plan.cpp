@@ -20,6 +20,7 @@ namespace {
 using mq::fail;
 
 mqLaunchHook g_hook = nullptr;
+mqPassHook g_pass = nullptr;
 
 inline size_t al(size_t n) { return (n + 255) & ~(size_t)255; }
 inline int cdivi(int a, int b) { return (a + b - 1) / b; }
@@ -189,6 +190,20 @@ void keep_layout(const mqConvPlan &p, const Sizes &s, size_t *v_floats, size_t *
         }                                                                                                         \
     } while (0)
 
+// one HBM-bound transform launch of a reduced form, bracketed for the pass hook (bench.py times the family with HIP events)
+#define MQ_PASS(call)                                                      \
+    do {                                                                   \
+        if (!dry && g_pass) g_pass(0, 0.0, "winograd_transforms");         \
+        MQ_TRY(call);                                                      \
+        if (!dry && g_pass) g_pass(1, 0.0, "winograd_transforms");         \
+    } while (0)
+// the layer's ALGORITHMIC activation bytes for this pass (what a fused kernel would have to move: every activation tensor the
+// pass reads or writes, once), reported once per planned call of a reduced form
+#define MQ_LAYER_BYTES(bytes)                                              \
+    do {                                                                   \
+        if (!dry && g_pass) g_pass(2, (double)(bytes), mq_form_name(p->form)); \
+    } while (0)
+
 // one GEMM launch, reported to the launch hook (bench.py's live HIP-event timing) with its algorithmic flops
 template <class F>
 int gemm_call(const mqConvDesc &g, F &&f)
@@ -210,6 +225,7 @@ int backward_impl(const mqConvPlan *p, const float *x, const void *keep, const f
 
 // ---------------------------------------------------------------------------------------------------- C ABI
 extern "C" void mq_set_launch_hook(mqLaunchHook hook) { g_hook = hook; }
+extern "C" void mq_set_pass_hook(mqPassHook hook) { g_pass = hook; }
 
 extern "C" void mq_plan_cfg_default(mqPlanCfg *c)
 {
@@ -332,6 +348,7 @@ int fprop_impl(const mqConvPlan *p, const float *x, const float *w_krsc, const f
         else MQ_TRY(mq_conv_fprop(&d, x, w_krsc, bias, y, st));
         return 0;
     }
+    MQ_LAYER_BYTES(4.0 * ((double)d.N * d.H * d.W * d.C + (double)d.N * d.P * d.Q * d.K));
     const Sizes s = sizes_of(*p);
     size_t kv = 0, kuc = 0;
     keep_layout(*p, s, &kv, &kuc);
@@ -345,26 +362,26 @@ int fprop_impl(const mqConvPlan *p, const float *x, const float *w_krsc, const f
     switch (p->form) {
     case MQ_FORM_WINO2D: {
         float *V = keeping ? keepV : ws.take(s.V), *U = ws.take(s.U), *M = ws.take(s.M);
-        MQ_TRY(mq_winon_input_transform(x, d.N, d.H, d.W, d.C, V, mh, mw, st));
-        MQ_TRY(mq_winon_weight_transform(w_krsc, d.K, d.C, 0, U, mh, mw, st));
+        MQ_PASS(mq_winon_input_transform(x, d.N, d.H, d.W, d.C, V, mh, mw, st));
+        MQ_PASS(mq_winon_weight_transform(w_krsc, d.K, d.C, 0, U, mh, mw, st));
         MQ_TRY(gemm_call(p->gemm, [&] { return mq_conv_fprop(&p->gemm, V, U, nullptr, M, st); }));
-        MQ_TRY(mq_winon_output_transform(M, bias, d.N, d.H, d.W, d.K, act, slope, mask, d1, d2, d3, y, mh, mw, st));
+        MQ_PASS(mq_winon_output_transform(M, bias, d.N, d.H, d.W, d.K, act, slope, mask, d1, d2, d3, y, mh, mw, st));
         return 0;
     }
     case MQ_FORM_S2D: {
         float *V = keeping ? keepV : ws.take(s.V), *U = ws.take(s.U), *M = ws.take(s.M);
-        MQ_TRY(mq_winon_input_transform_s2d(x, d.N, d.H, d.W, d.C, V, mh, mw, st));
-        MQ_TRY(mq_winon_weight_transform_s2d(w_krsc, d.K, d.C, 0, U, mh, mw, st));
+        MQ_PASS(mq_winon_input_transform_s2d(x, d.N, d.H, d.W, d.C, V, mh, mw, st));
+        MQ_PASS(mq_winon_weight_transform_s2d(w_krsc, d.K, d.C, 0, U, mh, mw, st));
         MQ_TRY(gemm_call(p->gemm, [&] { return mq_conv_fprop(&p->gemm, V, U, nullptr, M, st); }));
-        MQ_TRY(mq_winon_output_transform(M, bias, d.N, d.P, d.Q, d.K, act, slope, mask, d1, d2, d3, y, mh, mw, st));
+        MQ_PASS(mq_winon_output_transform(M, bias, d.N, d.P, d.Q, d.K, act, slope, mask, d1, d2, d3, y, mh, mw, st));
         return 0;
     }
     case MQ_FORM_WINOW: {
         float *V = keeping ? keepV : ws.take(s.V), *U = ws.take(s.U), *Uc = keeping ? keepUc : ws.take(s.Uc), *M = ws.take(s.M);
-        MQ_TRY(mq_winow_weight_transform(w_krsc, d.groups, d.K, d.C, d.R, d.S, U, Uc, st));
-        MQ_TRY(mq_winow_input_transform(x, d.N, d.H, d.W, d.C, d.S, d.Q, d.pad_w, V, st));
+        MQ_PASS(mq_winow_weight_transform(w_krsc, d.groups, d.K, d.C, d.R, d.S, U, Uc, st));
+        MQ_PASS(mq_winow_input_transform(x, d.N, d.H, d.W, d.C, d.S, d.Q, d.pad_w, V, st));
         MQ_TRY(gemm_call(p->gemm, [&] { return mq_conv_fprop(&p->gemm, V, U, nullptr, M, st); }));
-        MQ_TRY(mq_winow_output_transform(M, bias, d.N, d.P, d.Q, d.K, d.S, d.groups, act, slope, mask, d1, d2, d3, y, st));
+        MQ_PASS(mq_winow_output_transform(M, bias, d.N, d.P, d.Q, d.K, d.S, d.groups, act, slope, mask, d1, d2, d3, y, st));
         return 0;
     }
     case MQ_FORM_WINO1D: {
@@ -372,19 +389,19 @@ int fprop_impl(const mqConvPlan *p, const float *x, const float *w_krsc, const f
         const mqConvDesc &g = p->gemm;
         float *V = (keeping && !p->nested) ? keepV : ws.take(s.V), *U = ws.take(s.U), *Uc = (keeping && !p->nested) ? keepUc : ws.take(s.Uc);
         float *M = ws.take(s.M);
-        MQ_TRY(mq_wino1d_input_transform(x, d.N, d.H, d.W, d.C, m, V, st));
-        MQ_TRY(mq_wino1d_weight_transform(w_krsc, d.groups, d.K, d.C, d.S, m, U, Uc, st));
+        MQ_PASS(mq_wino1d_input_transform(x, d.N, d.H, d.W, d.C, m, V, st));
+        MQ_PASS(mq_wino1d_weight_transform(w_krsc, d.groups, d.K, d.C, d.S, m, U, Uc, st));
         if (p->nested) {      // the row convolutions themselves as F(m', S) along the columns
             const mqConvDesc &h = p->inner;
             float *V2 = keeping ? keepV : ws.take(s.V2), *U2 = ws.take(s.U2), *Uc2 = keeping ? keepUc : ws.take(s.Uc2), *M2 = ws.take(s.M2);
-            MQ_TRY(mq_winow_weight_transform(U, g.groups, g.K, g.C, g.R, g.S, U2, Uc2, st));
-            MQ_TRY(mq_winow_input_transform(V, g.N, g.H, g.W, g.C, g.S, g.Q, g.pad_w, V2, st));
+            MQ_PASS(mq_winow_weight_transform(U, g.groups, g.K, g.C, g.R, g.S, U2, Uc2, st));
+            MQ_PASS(mq_winow_input_transform(V, g.N, g.H, g.W, g.C, g.S, g.Q, g.pad_w, V2, st));
             MQ_TRY(gemm_call(h, [&] { return mq_conv_fprop(&h, V2, U2, nullptr, M2, st); }));
-            MQ_TRY(mq_winow_output_transform(M2, nullptr, g.N, g.P, g.Q, g.K, g.S, g.groups, 0, 0.f, nullptr, 1, 0, 1, M, st));
+            MQ_PASS(mq_winow_output_transform(M2, nullptr, g.N, g.P, g.Q, g.K, g.S, g.groups, 0, 0.f, nullptr, 1, 0, 1, M, st));
         } else {
             MQ_TRY(gemm_call(g, [&] { return mq_conv_fprop(&g, V, U, nullptr, M, st); }));
         }
-        MQ_TRY(mq_wino1d_output_transform(M, bias, d.N, d.H, d.Q, d.K, d.groups, m, act, slope, mask, d1, d2, d3, y, st));
+        MQ_PASS(mq_wino1d_output_transform(M, bias, d.N, d.H, d.Q, d.K, d.groups, m, act, slope, mask, d1, d2, d3, y, st));
         return 0;
     }
     default: return fail("mq_conv_fprop_planned: unknown form %d", p->form);
@@ -448,6 +465,7 @@ int backward_impl(const mqConvPlan *p, const float *x, const void *keep, const f
         }
         return 0;
     }
+    MQ_LAYER_BYTES(4.0 * ((double)d.N * d.P * d.Q * d.K + ((dx ? 1.0 : 0.0) + (dw ? 1.0 : 0.0)) * (double)d.N * d.H * d.W * d.C));
     const Sizes s = sizes_of(*p);
     size_t kv = 0, kuc = 0;
     keep_layout(*p, s, &kv, &kuc);
@@ -476,32 +494,32 @@ int backward_impl(const mqConvPlan *p, const float *x, const void *keep, const f
         const size_t m0 = ws.mark();
         float *Vd = need_Vd ? ws.take(s.M) : nullptr;
         // one pass over dy: Z = A dY A^T (weight gradient), Vd = B^T dy B (input gradient), per-block column sums (bias)
-        if (need_Z) MQ_TRY(mq_winon_dy_fused(dy, d.N, GH, GW, d.K, Z, Vd, part, mh, mw, st));
-        else if (need_Vd) MQ_TRY(mq_winon_input_transform(dy, d.N, GH, GW, d.K, Vd, mh, mw, st));
+        if (need_Z) MQ_PASS(mq_winon_dy_fused(dy, d.N, GH, GW, d.K, Z, Vd, part, mh, mw, st));
+        else if (need_Vd) MQ_PASS(mq_winon_input_transform(dy, d.N, GH, GW, d.K, Vd, mh, mw, st));
         if (dx) {
             float *Ut = ws.take(s.U), *Mt = ws.take((size_t)p->npos * p->tiles * cin);
             const mqConvDesc gt = wino2d_desc(d.N, GH, GW, d.K, cin, mh, mw, d.precision);
-            if (s2d) MQ_TRY(mq_winon_weight_transform_s2d(w_krsc, d.K, d.C, 1, Ut, mh, mw, st));
-            else MQ_TRY(mq_winon_weight_transform(w_krsc, d.K, d.C, 1, Ut, mh, mw, st));
+            if (s2d) MQ_PASS(mq_winon_weight_transform_s2d(w_krsc, d.K, d.C, 1, Ut, mh, mw, st));
+            else MQ_PASS(mq_winon_weight_transform(w_krsc, d.K, d.C, 1, Ut, mh, mw, st));
             MQ_TRY(gemm_call(gt, [&] { return mq_conv_fprop(&gt, Vd, Ut, nullptr, Mt, st); }));
-            if (s2d) MQ_TRY(mq_winon_output_transform_d2s(Mt, d.N, d.H, d.W, d.C, gate, gate_slope, gate_mask, g1, g2, g3, dx, mh, mw, st));
-            else MQ_TRY(mq_winon_output_transform(Mt, nullptr, d.N, d.H, d.W, d.C, 0, 0.f, nullptr, 1, 0, 1, dx, mh, mw, st));
+            if (s2d) MQ_PASS(mq_winon_output_transform_d2s(Mt, d.N, d.H, d.W, d.C, gate, gate_slope, gate_mask, g1, g2, g3, dx, mh, mw, st));
+            else MQ_PASS(mq_winon_output_transform(Mt, nullptr, d.N, d.H, d.W, d.C, 0, 0.f, nullptr, 1, 0, 1, dx, mh, mw, st));
         }
         ws.rewind(m0);
         if (dw) {
             const float *V = keepV;
             if (!V) {
                 float *Vn = ws.take(s.V);
-                if (s2d) MQ_TRY(mq_winon_input_transform_s2d(x, d.N, d.H, d.W, d.C, Vn, mh, mw, st));
-                else MQ_TRY(mq_winon_input_transform(x, d.N, d.H, d.W, d.C, Vn, mh, mw, st));
+                if (s2d) MQ_PASS(mq_winon_input_transform_s2d(x, d.N, d.H, d.W, d.C, Vn, mh, mw, st));
+                else MQ_PASS(mq_winon_input_transform(x, d.N, d.H, d.W, d.C, Vn, mh, mw, st));
                 V = Vn;
             }
             float *P = ws.take(s.U);
             const size_t nb = mq_conv_wgrad_workspace(&p->gemm);
             void *w = ws.take_bytes(nb);
             MQ_TRY(gemm_call(p->gemm, [&] { return mq_conv_wgrad(&p->gemm, V, Z, P, w, nb, st); }));
-            if (s2d) MQ_TRY(mq_winon_wgrad_inverse_s2d(P, d.K, d.C, dw, mh, mw, st));
-            else MQ_TRY(mq_winon_wgrad_inverse(P, d.K, d.C, dw, mh, mw, st));
+            if (s2d) MQ_PASS(mq_winon_wgrad_inverse_s2d(P, d.K, d.C, dw, mh, mw, st));
+            else MQ_PASS(mq_winon_wgrad_inverse(P, d.K, d.C, dw, mh, mw, st));
         }
         if (db) MQ_TRY(bias_from(part, need_part ? prow : 0));
         return 0;
@@ -511,16 +529,16 @@ int backward_impl(const mqConvPlan *p, const float *x, const void *keep, const f
         const mqConvDesc &g = p->gemm;
         const size_t prow = db ? mq_winow_dy_rows(d.N, d.P, d.Q, d.K, d.S, d.groups) : 0;
         float *Z = ws.take(s.M), *part = prow ? ws.take(prow * rowsK) : nullptr;
-        MQ_TRY(mq_winow_dy_transform(dy, d.N, d.P, d.Q, d.K, d.S, d.groups, Z, part, st));
+        MQ_PASS(mq_winow_dy_transform(dy, d.N, d.P, d.Q, d.K, d.S, d.groups, Z, part, st));
         const size_t m0 = ws.mark();
         const float *V = keepV, *Uc = keepUc;
         if ((dx && !Uc) || (dw && !V)) {           // no keep buffer: transform again
             float *U = ws.take(s.U), *Ucn = ws.take(s.Uc);
-            MQ_TRY(mq_winow_weight_transform(w_krsc, d.groups, d.K, d.C, d.R, d.S, U, Ucn, st));
+            MQ_PASS(mq_winow_weight_transform(w_krsc, d.groups, d.K, d.C, d.R, d.S, U, Ucn, st));
             Uc = Ucn;
             if (dw) {
                 float *Vn = ws.take(s.V);
-                MQ_TRY(mq_winow_input_transform(x, d.N, d.H, d.W, d.C, d.S, d.Q, d.pad_w, Vn, st));
+                MQ_PASS(mq_winow_input_transform(x, d.N, d.H, d.W, d.C, d.S, d.Q, d.pad_w, Vn, st));
                 V = Vn;
             }
         }
@@ -528,7 +546,7 @@ int backward_impl(const mqConvPlan *p, const float *x, const void *keep, const f
         if (dx) {
             float *dV = ws.take(s.V);
             MQ_TRY(gemm_call(g, [&] { return mq_conv_dgrad(&g, Z, Uc, dV, st); }));
-            MQ_TRY(mq_winow_dx_transform(dV, d.N, d.H, d.W, d.C, d.S, d.Q, d.pad_w, gate, gate_slope, gate_mask, g1, g2, g3, dx, st));
+            MQ_PASS(mq_winow_dx_transform(dV, d.N, d.H, d.W, d.C, d.S, d.Q, d.pad_w, gate, gate_slope, gate_mask, g1, g2, g3, dx, st));
         }
         ws.rewind(m1);
         if (dw) {
@@ -536,7 +554,7 @@ int backward_impl(const mqConvPlan *p, const float *x, const void *keep, const f
             const size_t nb = mq_conv_wgrad_workspace(&g);
             void *w = ws.take_bytes(nb);
             MQ_TRY(gemm_call(g, [&] { return mq_conv_wgrad(&g, V, Z, dU, w, nb, st); }));
-            MQ_TRY(mq_winow_wgrad_inverse(dU, d.groups, d.K, d.C, d.R, d.S, dw, st));
+            MQ_PASS(mq_winow_wgrad_inverse(dU, d.groups, d.K, d.C, d.R, d.S, dw, st));
         }
         (void)m0;
         if (db) MQ_TRY(bias_from(part, prow));
@@ -548,27 +566,27 @@ int backward_impl(const mqConvPlan *p, const float *x, const void *keep, const f
         const mqConvDesc &g = p->gemm, &h = p->inner;
         const size_t prow = db ? mq_wino1d_dy_rows(d.N, d.H, d.Q, d.K, d.groups, m) : 0;
         float *Z = ws.take(s.M), *part = prow ? ws.take(prow * rowsK) : nullptr;
-        MQ_TRY(mq_wino1d_dy_transform(dy, d.N, d.H, d.Q, d.K, d.groups, m, Z, part, st));
+        MQ_PASS(mq_wino1d_dy_transform(dy, d.N, d.H, d.Q, d.K, d.groups, m, Z, part, st));
         float *Z2 = nullptr;
         if (p->nested) {
             Z2 = ws.take(s.M2);
-            MQ_TRY(mq_winow_dy_transform(Z, g.N, g.P, g.Q, g.K, g.S, g.groups, Z2, nullptr, st));
+            MQ_PASS(mq_winow_dy_transform(Z, g.N, g.P, g.Q, g.K, g.S, g.groups, Z2, nullptr, st));
         }
         const float *V = keepV, *Uc = keepUc;              // nested: the column-transformed ones
         if ((dx && !Uc) || (dw && !V)) {
             float *U1 = ws.take(s.U), *Uc1 = ws.take(s.Uc), *V1 = nullptr;
-            MQ_TRY(mq_wino1d_weight_transform(w_krsc, d.groups, d.K, d.C, d.S, m, U1, Uc1, st));
+            MQ_PASS(mq_wino1d_weight_transform(w_krsc, d.groups, d.K, d.C, d.S, m, U1, Uc1, st));
             if (dw) {
                 V1 = ws.take(s.V);
-                MQ_TRY(mq_wino1d_input_transform(x, d.N, d.H, d.W, d.C, m, V1, st));
+                MQ_PASS(mq_wino1d_input_transform(x, d.N, d.H, d.W, d.C, m, V1, st));
             }
             if (p->nested) {
                 float *U2 = ws.take(s.U2), *Uc2 = ws.take(s.Uc2);
-                MQ_TRY(mq_winow_weight_transform(U1, g.groups, g.K, g.C, g.R, g.S, U2, Uc2, st));
+                MQ_PASS(mq_winow_weight_transform(U1, g.groups, g.K, g.C, g.R, g.S, U2, Uc2, st));
                 Uc = Uc2;
                 if (dw) {
                     float *V2 = ws.take(s.V2);
-                    MQ_TRY(mq_winow_input_transform(V1, g.N, g.H, g.W, g.C, g.S, g.Q, g.pad_w, V2, st));
+                    MQ_PASS(mq_winow_input_transform(V1, g.N, g.H, g.W, g.C, g.S, g.Q, g.pad_w, V2, st));
                     V = V2;
                 }
             } else {
@@ -582,11 +600,11 @@ int backward_impl(const mqConvPlan *p, const float *x, const void *keep, const f
             if (p->nested) {
                 float *dV2 = ws.take(s.V2);
                 MQ_TRY(gemm_call(h, [&] { return mq_conv_dgrad(&h, Z2, Uc, dV2, st); }));
-                MQ_TRY(mq_winow_dx_transform(dV2, g.N, g.H, g.W, g.C, g.S, g.Q, g.pad_w, nullptr, 1.f, nullptr, 1, 0, 1, dV, st));
+                MQ_PASS(mq_winow_dx_transform(dV2, g.N, g.H, g.W, g.C, g.S, g.Q, g.pad_w, nullptr, 1.f, nullptr, 1, 0, 1, dV, st));
             } else {
                 MQ_TRY(gemm_call(g, [&] { return mq_conv_dgrad(&g, Z, Uc, dV, st); }));
             }
-            MQ_TRY(mq_wino1d_dx_transform(dV, d.N, d.H, d.W, d.C, m, gate, gate_slope, gate_mask, g1, g2, g3, dx, st));
+            MQ_PASS(mq_wino1d_dx_transform(dV, d.N, d.H, d.W, d.C, m, gate, gate_slope, gate_mask, g1, g2, g3, dx, st));
         }
         ws.rewind(m1);
         if (dw) {
@@ -596,13 +614,13 @@ int backward_impl(const mqConvPlan *p, const float *x, const void *keep, const f
                 const size_t nb = mq_conv_wgrad_workspace(&h);
                 void *w = ws.take_bytes(nb);
                 MQ_TRY(gemm_call(h, [&] { return mq_conv_wgrad(&h, V, Z2, dU2, w, nb, st); }));
-                MQ_TRY(mq_winow_wgrad_inverse(dU2, g.groups, g.K, g.C, g.R, g.S, dU, st));
+                MQ_PASS(mq_winow_wgrad_inverse(dU2, g.groups, g.K, g.C, g.R, g.S, dU, st));
             } else {
                 const size_t nb = mq_conv_wgrad_workspace(&g);
                 void *w = ws.take_bytes(nb);
                 MQ_TRY(gemm_call(g, [&] { return mq_conv_wgrad(&g, V, Z, dU, w, nb, st); }));
             }
-            MQ_TRY(mq_wino1d_wgrad_inverse(dU, d.groups, d.K, d.C, d.S, m, dw, st));
+            MQ_PASS(mq_wino1d_wgrad_inverse(dU, d.groups, d.K, d.C, d.S, m, dw, st));
         }
         if (db) MQ_TRY(bias_from(part, prow));
         return 0;

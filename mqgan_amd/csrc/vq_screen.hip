@@ -5,33 +5,43 @@
 // Definition (oracle/vq_ref.c):  dist(n,k) = fmaf(-2, dot(n,k), cn(k)),  dot = sequential f32 fma chain over d,
 //                                idx(n) = argmin_k dist(n,k), lowest k on ties, NaN counts as -inf.
 //
-// 1. prep      x -> bf16 copy xh (RNE) and, per row, a bound B2(n) = 2 E(n) with  |score(n,k) - dist(n,k)| <= E(n)  for
-//              EVERY k (proof below); rows for which no finite bound exists (NaN / inf / huge) are marked for step 4.
-// 2. screen    score(n,k) = fmaf(-2, <xh_n, ch_k> on the bf16 MFMA, cn(k)) for all (n,k): 16x the f32 matrix rate.  The
-//              GEMM is formed TRANSPOSED (A = code tile, B = row tile), so one lane holds 32 codes of ONE row per 64 x 64
-//              wave tile and row-wise work is lane-local.  Pass 1 keeps g(n) = min_k score(n,k) (atomicMin); pass 2 forms
-//              the same scores again and puts every (n,k) with score <= g(n) + B2(n) into one of the row's SC_SLOTS
-//              candidate slots (per-row atomic counter: no contended global counter); what does not fit there (rows with
-//              many near-ties) goes to a shared overflow list.
-// 3. re-rank   every candidate gets its exact distance (the oracle's sequential fma chain, one lane per candidate) and
-//              goes into the same packed (distance, index) atomicMin as the f32 kernel: minimum distance, lowest index
-//              on ties.
-// 4. fallback  marked rows (and every row, should the overflow list itself overflow) are searched exhaustively with the
-//              exact chain, a block per row - slow, rare, exact.
+// Round 5: every bf16 score is formed ONCE and the search is TWO launches (r3-r4: five launches, every score formed twice -
+// one pass for the row minima, one to emit the candidates against them).
 //
-// Why the winner is always a candidate.  Let k* be the oracle's answer for row n.  Then
-//   score(k*) <= dist(k*) + E <= dist(k) + E <= score(k) + 2E for all k, so score(k*) <= g + 2E = g + B2: appended.
-// Every code with dist == dist(k*) satisfies the same inequalities, so the lowest such index is among the re-ranked
-// candidates too; all other candidates have a larger exact distance.  (Both passes compute bit-identical scores: same
-// tiles, same MFMA order.)
+// 1. screen (l2_screen_kernel)   a(n,k) = -cn(k)/2 + <xh_n, ch_k> on the bf16 MFMA, the norm term being the accumulator's initial
+//              value (the MFMA's C operand: no distance epilogue), so that score(n,k) = -2 a(n,k) and the best code has the LARGEST
+//              a.  The block converts its 64 rows of x to bf16 itself (f32 loads -> v_cvt_pk_bf16_f32 -> swizzled LDS image that
+//              stays resident for the whole block; the row norms the bound needs come out of the same loads) and streams 256-code
+//              tiles of the prepared bf16 codebook through a two-stage LDS-DMA ring: half the DMA bytes per MFMA of the r3
+//              kernel, which re-streamed the x tile for every code tile.  The GEMM is formed TRANSPOSED (A = codes, B = rows):
+//              a lane holds 32 codes of ONE row per wave tile, so row-wise work is lane-local.  After every code tile a lane takes
+//              the running maximum of its row (its own codes, the other lane half by one DPP exchange, the other three waves
+//              through an LDS word that is read one tile late - any value ever written there is a lower bound of the final maximum)
+//              and appends every code with  a >= running maximum - E(n)  to a PRIVATE list (row, wave, lane half): plain stores,
+//              a register counter, no atomics.  A single pass over-collects - the first tiles are compared against a maximum that
+//              still rises: ~c H(tiles) entries per row instead of c, c = 2-4 - and the re-rank drops what the final maximum
+//              excludes before it spends a chain on it.
+// 2. re-rank (l2_rerank_kernel)  a block per 64 rows: the lists' entries are filtered against the FINAL maximum, the survivors
+//              (2-4 per row) get their exact distance (the oracle's sequential fma chain, one lane per survivor, survivors
+//              compacted so that the lanes of a wave are all busy) and meet in a packed (distance, index) minimum per row in LDS -
+//              minimum distance, lowest index on ties; the block then writes idx / best_dist itself (no unpack launch).  Rows that
+//              have no error bound (NaN / inf / huge), a list that ran over or more survivors than the block's pair table holds
+//              are searched exhaustively with the exact chain by the same block - slow, rare, exact.
+//
+// Why the winner is always a candidate.  Let k* be the oracle's answer for row n and E(n) a bound with
+// |score(n,k) - dist(n,k)| <= E(n) for EVERY k.  Then score(k*) <= dist(k*) + E <= dist(k) + E <= score(k) + 2E for all k, i.e.
+// a(k*) >= a(k) - E for all k, so a(k*) >= g - E for the final maximum g and for every running maximum (each is <= g): appended,
+// and kept by the filter.  Every code with dist == dist(k*) satisfies the same inequalities, so the lowest such index is among
+// the re-ranked survivors too; all other survivors have a larger exact distance.
 //
 // The bound.  bf16 has 8 significant bits: |xh - x| <= 2^-8 |x|, so |xh ch - x c| <= (2^-7 + 2^-16) |x c| per term; bf16
-// products are exact in f32; the MFMA's f32 accumulation and the oracle's chain each err by at most D 2^-23 sum|x c|
-// (any summation order).  With sum|x_i c_i| <= |x| |c| (Cauchy-Schwarz):
-//   |dot_bf16 - dot_chain| <= delta |x_n| max_k|c_k|,   delta = 1.02 * 2^-7 + D * 2^-21,
-//   E(n) = 2.02 delta |x_n| cmax + 2^-20 cmax^2 + 1e-30   (the last two: final fmaf roundings, flushed denormals).
-// |x_n| and cmax are taken 0.1 % high to cover their own rounding.  Rows with |x_n| or cmax above 1e18 or not finite
-// have no bound (products may overflow): step 4.
+// products are exact in f32; the MFMA's f32 accumulation of [-cn/2, p_1 .. p_D] errs by at most D 2^-23 (cn/2 + sum|x c|) and
+// the oracle's chain by at most D 2^-24 sum|x c| (any summation order; the MFMA is given twice the IEEE figure).  Doubled for
+// the score, with sum|x_i c_i| <= |x| |c| (Cauchy-Schwarz):
+//   E(n) = 2.02 delta |x_n| cmax + (2^-20 + D 2^-23) cmax^2 + 1e-30,   delta = 1.02 * 2^-7 + D * 2^-21
+// (the cmax^2 term: the norm inside the accumulation and the oracle's final fmaf rounding; 1e-30: flushed denormals).  |x_n| and
+// cmax are taken 0.1 % high to cover their own rounding.  Rows with |x_n| or cmax above 1e18 or not finite have no bound
+// (products may overflow): exhaustive search.
 #include <stdlib.h>
 
 #include "gemm_core.h"
@@ -41,12 +51,16 @@ namespace mq {
 typedef __attribute__((address_space(3))) void lds_void_s;
 __device__ __forceinline__ lds_void_s *lds_ptr_s(const void *p) { return reinterpret_cast<lds_void_s *>(reinterpret_cast<uintptr_t>(p)); }
 
-constexpr int SC_CT = 128;            // codes per block tile (2 waves x 64)
-constexpr int SC_RT = 128;            // rows per block tile (2 waves x 64)
+constexpr int SC_CT = 256;            // codes per block tile (4 waves x 64)
+constexpr int SC_RT = 64;             // rows per block (two 32-row MFMA tiles per wave)
 constexpr int SC_ROWB = 128;          // bytes per LDS row: 64 bf16 k's
-constexpr int SC_OP = 128 * SC_ROWB;  // one operand tile of a stage
-constexpr int SC_STAGE = 2 * SC_OP;
-constexpr int SC_SLOTS = 8;           // candidate slots per row; further candidates of a row go to a shared overflow list
+constexpr int SC_STAGE = SC_CT * SC_ROWB;     // one code tile of a K-step: 32 KB
+constexpr int SC_XCHUNK = SC_RT * SC_ROWB;    // the x image of one K-step: 8 KB
+constexpr int SC_LISTS = 8;           // private lists per (row, code split): 4 waves x 2 lane halves
+constexpr int SC_PL = 8;              // entries per private list; a longer list sends its row to the exhaustive search
+constexpr int RR_ROWS = 64;           // rows per re-rank block
+constexpr int RR_CAP = 1024;          // survivors a re-rank block holds
+constexpr int RR_PER_ROW = 16;        // ... and per row; rows with more are searched exhaustively
 
 __device__ __forceinline__ unsigned ord_f32(float v)
 {
@@ -63,22 +77,16 @@ __device__ __forceinline__ unsigned long long pack_di(float dist, int idx)
     return ((unsigned long long)ord_f32(dist) << 32) | (unsigned)idx;
 }
 
-// ------------------------------------------------------------------------------------------ 1. prep
-// one wave per row of src [rows][d]: bf16 copy, |row|^2.  MODE 0: x rows (bound, per-row state); MODE 1: codebook rows
-// (max |c|^2 over the codes).
-template <int MODE>
-__global__ __launch_bounds__(256) void l2_screen_prep_kernel(const float *__restrict__ src, int64_t rows, int d,
-                                                             unsigned short *__restrict__ dst_h, const float *__restrict__ cmax2,
-                                                             float *__restrict__ bound2, unsigned *__restrict__ amin,
-                                                             unsigned long long *__restrict__ packed, uint2 *__restrict__ rowcnt,
-                                                             unsigned *__restrict__ counters, unsigned *__restrict__ cmax2_bits)
+// ------------------------------------------------------------------------------------------ codebook side (once per codebook)
+// one wave per code: bf16 copy, max |c|^2 over the codes
+__global__ __launch_bounds__(256) void l2_screen_cbprep_kernel(const float *__restrict__ src, int rows, int d,
+                                                               unsigned short *__restrict__ dst_h, unsigned *__restrict__ cmax2_bits)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (MODE == 0 && blockIdx.x == 0 && threadIdx.x < 4) counters[threadIdx.x] = 0u;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float *s = src + row * d;
-    unsigned short *o = dst_h + row * d;
+    const float *s = src + (size_t)row * d;
+    unsigned short *o = dst_h + (size_t)row * d;
     float ss = 0.f;
     for (int t = lane * 4; t < d; t += 256) {
         const float4 v = *reinterpret_cast<const float4 *>(s + t);
@@ -89,128 +97,173 @@ __global__ __launch_bounds__(256) void l2_screen_prep_kernel(const float *__rest
         *reinterpret_cast<uint2 *>(o + t) = pack_bf16x4(v);
     }
     ss = wave_sum(ss);
-    if (lane != 0) return;
-    if (MODE == 1) {
-        // NaN orders above +inf as an unsigned pattern: a non-finite code poisons the bound of every row (-> fallback)
-        atomicMax(cmax2_bits, __builtin_bit_cast(unsigned, ss));
+    // NaN orders above +inf as an unsigned pattern: a non-finite code poisons the bound of every row (-> exhaustive search)
+    if (lane == 0) atomicMax(cmax2_bits, __builtin_bit_cast(unsigned, ss));
+}
+
+// sequential-chain code norms (the oracle's cn) and the accumulator seeds -cn / 2, padded to a multiple of the code tile with
+// -inf (a padded code never rises above anything)
+__global__ void l2_screen_norms_kernel(const float *__restrict__ c, int k, int k_pad, int d, float *__restrict__ cn,
+                                       float *__restrict__ cnh)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= k_pad) return;
+    if (j >= k) {
+        cn[j] = INFINITY;
+        cnh[j] = -INFINITY;
         return;
     }
-    const float nx = sqrtf(ss) * 1.001f;
-    const float cm = sqrtf(cmax2[0]) * 1.001f;
-    const float delta = 1.02f * 0.0078125f + (float)d * 4.76837158203125e-07f;        // 2^-7, 2^-21
-    const float e = 2.02f * delta * nx * cm + 9.5367431640625e-07f * cm * cm + 1e-30f;
-    const bool ok = nx < 1e18f && cm < 1e18f && e < 1e30f;                              // false for NaN too
-    bound2[row] = ok ? 2.f * e : -INFINITY;
-    amin[row] = 0xFFFFFFFFu;
-    packed[row] = ~0ull;
-    rowcnt[row] = make_uint2(0u, 0u);                  // candidates appended, candidates re-ranked
+    float acc = 0.f;
+    for (int t = 0; t < d; ++t) acc = __fmaf_rn(c[(size_t)j * d + t], c[(size_t)j * d + t], acc);
+    cn[j] = acc;
+    cnh[j] = -0.5f * acc;
 }
 
-// pads the code norms to a multiple of the code tile with +inf (a padded code never scores below anything)
-__global__ void l2_screen_cnpad_kernel(float *__restrict__ cn, int k, int k_pad)
+// ------------------------------------------------------------------------------------------ 1. screen
+// grid (row tiles of 64, code splits), 256 threads = 4 waves; wave w owns codes [64 w, +64) x all 64 rows of every 256-code tile
+// as 2 x 2 MFMA tiles of 32 x 32 (v_mfma_f32_32x32x16_bf16, A = codes, B = rows).  LDS: the block's x image (NK K-steps of 64
+// rows x 128 bytes, 16-byte chunks XOR-swizzled with (row >> 1) & 7, written once by the prologue) + a ring of two code stages
+// filled by LDS-DMA (lane-linear destination: the swizzle is applied to the per-lane SOURCE address).
+template <int NK>
+__global__ __launch_bounds__(256) void l2_screen_kernel(const float *__restrict__ x, const unsigned short *__restrict__ ch,
+                                                        const float *__restrict__ cnh, const float *__restrict__ cmax2, int64_t n, int k,
+                                                        int d, int tiles_per_split, int splits, uint2 *__restrict__ cand,
+                                                        unsigned char *__restrict__ cntb, float *__restrict__ rmax,
+                                                        float *__restrict__ bound, unsigned *__restrict__ exhaustive_rows)
 {
-    const int i = k + blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < k_pad) cn[i] = INFINITY;
-}
-
-// ------------------------------------------------------------------------------------------ 2. screen
-// grid (row tiles, code splits), 256 threads = 4 waves: wave (wc, wr) owns codes [64 wc, +64) x rows [64 wr, +64) of the
-// block tile as 2 x 2 MFMA tiles of 32 x 32 (v_mfma_f32_32x32x16_bf16, A = codes, B = rows).  Both operand tiles
-// (128 x 64 k's, 128-byte rows, 16-byte chunks XOR-swizzled with (row >> 1) & 7) are staged by LDS-DMA into a ring of two
-// stages; the x tile is re-streamed from L2 for every code tile (D <= 512: 128 KB per block, it stays in L2).
-// Two passes over the same GEMM (it runs at 16x the f32 rate, so twice is still cheap):
-//   EMIT = false: the per-row minimum score -> amin (atomicMin on the order-preserving integer image);
-//   EMIT = true : every (row, code) with score <= amin[row] + B2[row] is appended to the candidate list - with the FINAL
-//                 minimum as reference that is the candidate set itself (1-3 entries per row on random data), where a
-//                 single pass could only compare against a running minimum and appended 30-300 per row.
-// Appending is aggregated per wave and code tile (one atomicAdd for all of the wave's candidates).
-template <bool EMIT>
-__global__ __launch_bounds__(256, 2) void l2_screen_kernel(const unsigned short *__restrict__ xh, const unsigned short *__restrict__ ch,
-                                                           const float *__restrict__ cn_pad, const float *__restrict__ bound2,
-                                                           int64_t n, int k, int d, int tiles_per_split, unsigned *__restrict__ amin,
-                                                           int *__restrict__ cand, uint2 *__restrict__ rowcnt,
-                                                           unsigned long long *__restrict__ ovf, unsigned *__restrict__ counters,
-                                                           unsigned ovf_cap)
-{
-    __shared__ __attribute__((aligned(1024))) char smem[2 * SC_STAGE];
+    __shared__ __attribute__((aligned(1024))) char smem[NK * SC_XCHUNK + 2 * SC_STAGE];
+    __shared__ float s_rm[4][SC_RT];
+    __shared__ float s_e[SC_RT];
+    char *xs = smem, *cs = smem + NK * SC_XCHUNK;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wc = wave >> 1, wr = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
     const int64_t m0 = (int64_t)blockIdx.x * SC_RT;
+    const int split = blockIdx.y;
     const int ntiles = (k + SC_CT - 1) / SC_CT;
-    const int t_begin = blockIdx.y * tiles_per_split;
+    const int t_begin = split * tiles_per_split;
     const int t_end = min(ntiles, t_begin + tiles_per_split);
     const int nk = (d + 63) >> 6;
     const int total = nk * (t_end - t_begin);
-    if (total <= 0) return;
+    if (total <= 0) return;                                   // block-uniform
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *exhaustive_rows = 0u;      // the re-rank launch counts them
 
-    // ---- DMA slots: piece p = wave + 4 j covers tile rows 8p .. 8p+7; lane -> row 8p + (lane >> 3), physical chunk lane & 7
+    // ---- code tile DMA: piece p = wave + 4 j covers tile rows 8p .. 8p+7; lane -> row 8p + (lane >> 3), physical chunk lane & 7
     const int lc = (lane & 7) ^ ((((wave & 1) << 2) | (lane >> 4)) & 7);        // logical chunk this lane has to fetch
-    const int64_t rows_here = n - m0 < SC_RT ? n - m0 : SC_RT;
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(xh + m0 * d, (size_t)rows_here * d * 2);
     const int64_t code0 = (int64_t)t_begin * SC_CT;
     const int64_t codes_here = min((int64_t)k, (int64_t)t_end * SC_CT) - code0;
     const __amdgpu_buffer_rsrc_t rc = make_rsrc(ch + code0 * d, (size_t)codes_here * d * 2);
-    unsigned rowoff[4];
+    unsigned rowoff[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) rowoff[j] = (unsigned)(8 * (wave + 4 * j) + (lane >> 3)) * (unsigned)d * 2u + (unsigned)lc * 16u;
+    for (int j = 0; j < 8; ++j) rowoff[j] = (unsigned)(8 * (wave + 4 * j) + (lane >> 3)) * (unsigned)d * 2u + (unsigned)lc * 16u;
     auto issue = [&](int it) {
         const int tile = it / nk, ks = it - tile * nk;
         const bool kv = ks * 64 + lc * 8 < d;
-        const unsigned koff = (unsigned)ks * 128u;
-        const unsigned toff = (unsigned)tile * (unsigned)(SC_CT * 2) * (unsigned)d;
-        char *st = smem + (it & 1) * SC_STAGE;
+        const unsigned off = (unsigned)ks * 128u + (unsigned)tile * (unsigned)(SC_CT * 2) * (unsigned)d;
+        char *st = cs + (it & 1) * SC_STAGE;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, lds_ptr_s(st + (wave + 4 * j) * 1024), 16,
-                                                     kv ? rowoff[j] + koff + toff : OOB, 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, lds_ptr_s(st + SC_OP + (wave + 4 * j) * 1024), 16,
-                                                     kv ? rowoff[j] + koff : OOB, 0, 0, 0);
+        for (int j = 0; j < 8; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, lds_ptr_s(st + (wave + 4 * j) * 1024), 16, kv ? rowoff[j] + off : OOB, 0, 0, 0);
     };
+    issue(0);
+
+    // ---- prologue: the block's rows of x -> bf16 LDS image (zeros beyond n and beyond d), |x_n|^2 out of the same loads.
+    //      Item i = (row r, 16-byte chunk c of the padded row): the NK * 8 chunks of a row sit in neighbouring lanes.
+    constexpr int CPR = NK * 8;                               // chunks per padded row (<= 64: a row never straddles waves)
+    const int cpr = d >> 3;
+    s_rm[tid >> 6][tid & 63] = -INFINITY;
+    for (int i = tid; i < SC_RT * CPR; i += 256) {
+        const int r = i / CPR, c = i - r * CPR;
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        if (m0 + r < n && c < cpr) {
+            const float *src = x + (m0 + r) * d + c * 8;
+            v0 = *reinterpret_cast<const float4 *>(src);
+            v1 = *reinterpret_cast<const float4 *>(src + 4);
+        }
+        float ss = v0.x * v0.x;
+        ss = fmaf(v0.y, v0.y, ss); ss = fmaf(v0.z, v0.z, ss); ss = fmaf(v0.w, v0.w, ss);
+        ss = fmaf(v1.x, v1.x, ss); ss = fmaf(v1.y, v1.y, ss); ss = fmaf(v1.z, v1.z, ss); ss = fmaf(v1.w, v1.w, ss);
+#pragma unroll
+        for (int o = 1; o < CPR; o <<= 1) ss += __shfl_xor(ss, o, 64);
+        const uint2 p0 = pack_bf16x4(v0), p1 = pack_bf16x4(v1);
+        *reinterpret_cast<uint4 *>(xs + (c >> 3) * SC_XCHUNK + r * SC_ROWB + (((c & 7) ^ ((r >> 1) & 7)) << 4)) =
+            make_uint4(p0.x, p0.y, p1.x, p1.y);
+        if (c == 0) {
+            // E(n) in the units of a = -score / 2 (header comment); NaN = no bound: nothing compares >= against it
+            const float nx = sqrtf(ss) * 1.001f;
+            const float cm = sqrtf(cmax2[0]) * 1.001f;
+            const float delta = 1.02f * 0.0078125f + (float)d * 4.76837158203125e-07f;        // 2^-7, 2^-21
+            const float e2 = 2.02f * delta * nx * cm + (9.5367431640625e-07f + (float)d * 1.1920928955078125e-07f) * cm * cm + 1e-30f;
+            const bool ok = nx < 1e18f && cm < 1e18f && e2 < 1e30f;                           // false for NaN too
+            const float e = ok ? 0.5f * e2 : __builtin_nanf("");
+            s_e[r] = e;
+            if (split == 0 && m0 + r < n) bound[m0 + r] = e;
+        }
+    }
 
     // ---- fragment addresses: lane (li, lh) reads chunk (2 s + lh) ^ ((li >> 1) & 7) of row li of a 32-row MFMA tile
     const int sw = (li >> 1) & 7;
     int foff[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) foff[s] = li * SC_ROWB + ((((2 * s) ^ (lh ^ sw)) & 7) << 4);
-    const int a_base = (wc * 64) * SC_ROWB, b_base = SC_OP + (wr * 64) * SC_ROWB;
+    const int a_base = (wave * 64) * SC_ROWB;
 
+    // accumulator seeds of a code tile: lane (li, lh) holds codes cbase + tm*32 + 8 (r >> 2) + 4 lh + (r & 3) -> float4 per (tm, r >> 2)
+    float4 seed[2][4];
+    auto load_seeds = [&](int tile) {
+        const int cbase = (t_begin + tile) * SC_CT + wave * 64;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) seed[tm][q] = *reinterpret_cast<const float4 *>(cnh + cbase + tm * 32 + 8 * q + 4 * lh);
+    };
     f32x16 acc[2][2];
+    auto seed_acc = [&]() {
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+        for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    float rm[2], thr[2];
+                for (int tn = 0; tn < 2; ++tn) {
+                    acc[tm][tn][4 * q + 0] = seed[tm][q].x;
+                    acc[tm][tn][4 * q + 1] = seed[tm][q].y;
+                    acc[tm][tn][4 * q + 2] = seed[tm][q].z;
+                    acc[tm][tn][4 * q + 3] = seed[tm][q].w;
+                }
+    };
+    load_seeds(0);
+    seed_acc();
+    if (nk * 1 < total) load_seeds(1);                        // the next tile's seeds travel while this tile multiplies
+
+    float rm[2], ebound[2];
+    int cnt[2];
     bool rvalid[2];
-    int64_t rown[2];
+    int64_t lbase[2];
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
-        rown[tn] = m0 + wr * 64 + tn * 32 + li;
-        rvalid[tn] = rown[tn] < n;
-        rm[tn] = INFINITY;
-        // rows without a bound: B2 = -inf and amin was never written (its image reads back as NaN): nothing compares <= thr
-        thr[tn] = (EMIT && rvalid[tn]) ? unord_f32(amin[rown[tn]]) + bound2[rown[tn]] : -INFINITY;
+        const int64_t row = m0 + tn * 32 + li;
+        rvalid[tn] = row < n;
+        rm[tn] = -INFINITY;
+        cnt[tn] = 0;
+        lbase[tn] = ((row * splits + split) * SC_LISTS + wave * 2 + lh) * SC_PL;
     }
 
-    issue(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    __syncthreads();
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) ebound[tn] = s_e[tn * 32 + li];
     int tile = 0, ks = 0;
     for (int it = 0; it < total; ++it) {
         if (it + 1 < total) issue(it + 1);
-        const char *st = smem + (it & 1) * SC_STAGE;
+        const char *st = cs + (it & 1) * SC_STAGE;
+        const char *xk = xs + ks * SC_XCHUNK;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             bf16x8 fa[2], fb[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 fa[t] = *reinterpret_cast<const bf16x8 *>(st + a_base + t * 32 * SC_ROWB + foff[s]);
-                fb[t] = *reinterpret_cast<const bf16x8 *>(st + b_base + t * 32 * SC_ROWB + foff[s]);
+                fb[t] = *reinterpret_cast<const bf16x8 *>(xk + t * 32 * SC_ROWB + foff[s]);
             }
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm)
@@ -219,102 +272,62 @@ __global__ __launch_bounds__(256, 2) void l2_screen_kernel(const unsigned short 
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
         }
         if (++ks == nk) {
-            // ---- fold the finished code tile.  Lane (li, lh) holds, for row tn*32 + li, the codes
-            //      cbase + tm*32 + 8 (r >> 2) + 4 lh + (r & 3): norms as float4 per (tm, r >> 2)
-            const int cbase = (t_begin + tile) * SC_CT + wc * 64;
-            float4 cnv[2][4];
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    cnv[tm][q] = *reinterpret_cast<const float4 *>(cn_pad + cbase + tm * 32 + 8 * q + 4 * lh);
-            auto cn_of = [&](int tm, int r) {
-                const float4 v = cnv[tm][r >> 2];
-                return (r & 3) == 0 ? v.x : (r & 3) == 1 ? v.y : (r & 3) == 2 ? v.z : v.w;
-            };
+            // ---- fold the finished code tile: running maximum of the row, candidates into the lane's private list
+            const int cbase = (t_begin + tile) * SC_CT + wave * 64;
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn) {
-                float tmin = INFINITY;
+                float tmax = -INFINITY;
 #pragma unroll
                 for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) tmin = fminf(tmin, fmaf(-2.0f, acc[tm][tn][r], cn_of(tm, r)));
-                if constexpr (!EMIT) {
-                    rm[tn] = fminf(rm[tn], tmin);
-                } else if (__any(tmin <= thr[tn])) {                 // wave-uniform: at large K most wave tiles hold no candidate
-                    // Four codes at a time: one test of their minimum, the per-code tests only where that passes.  A lane
-                    // first collects its candidates in registers (up to four; more is rare and goes out one by one), then
-                    // reserves their slots with ONE atomic: a returning atomic per candidate serialised ~6 round trips per
-                    // wave and tile.
-                    int c0 = 0, c1 = 0, c2 = 0, c3 = 0, cnt = 0;
-                    auto put = [&](int code) {
-                        const unsigned slot = atomicAdd(&rowcnt[rown[tn]].x, 1u);
-                        if (slot < (unsigned)SC_SLOTS) {
-                            cand[rown[tn] * SC_SLOTS + slot] = code;
-                        } else {
-                            const unsigned pos = atomicAdd(&counters[0], 1u);
-                            if (pos < ovf_cap) ovf[pos] = ((unsigned long long)rown[tn] << 32) | (unsigned)code;
-                        }
-                    };
+                    for (int r = 0; r < 16; r += 2) tmax = fmaxf(tmax, fmaxf(acc[tm][tn][r], acc[tm][tn][r + 1]));
+                float m = fmaxf(tmax, __shfl_xor(tmax, 32, 64));                 // all 64 codes of this wave's slice
+                rm[tn] = fmaxf(rm[tn], m);
+                const int rl = tn * 32 + li;
+                // what the other waves had reached a tile ago (any value ever written there is <= the final maximum)
+                float shared = fmaxf(fmaxf(s_rm[0][rl], s_rm[1][rl]), fmaxf(s_rm[2][rl], s_rm[3][rl]));
+                rm[tn] = fmaxf(rm[tn], shared);
+                if (lh == 0) s_rm[wave][rl] = rm[tn];
+                const float thr = rm[tn] - ebound[tn];                            // NaN for rows without a bound
+                if (__any(tmax >= thr && rvalid[tn])) {                           // wave-uniform
 #pragma unroll
                     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            float dv[4];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) dv[e] = fmaf(-2.0f, acc[tm][tn][4 * q + e], cn_of(tm, 4 * q + e));
-                            if (fminf(fminf(dv[0], dv[1]), fminf(dv[2], dv[3])) <= thr[tn]) {
+                            const float a0 = acc[tm][tn][4 * q], a1 = acc[tm][tn][4 * q + 1], a2 = acc[tm][tn][4 * q + 2],
+                                        a3 = acc[tm][tn][4 * q + 3];
+                            if (fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)) >= thr && rvalid[tn]) {
+                                const float av[4] = {a0, a1, a2, a3};
 #pragma unroll
                                 for (int e = 0; e < 4; ++e)
-                                    if (dv[e] <= thr[tn] && dv[e] < INFINITY) {       // +inf: padded codes
-                                        const int code = cbase + tm * 32 + 8 * q + 4 * lh + e;
-                                        if (cnt >= 4) put(code);
-                                        c0 = cnt == 0 ? code : c0;
-                                        c1 = cnt == 1 ? code : c1;
-                                        c2 = cnt == 2 ? code : c2;
-                                        c3 = cnt == 3 ? code : c3;
-                                        ++cnt;
+                                    if (av[e] >= thr && av[e] > -INFINITY) {      // -inf: padded codes
+                                        if (cnt[tn] < SC_PL)
+                                            cand[lbase[tn] + cnt[tn]] = make_uint2((unsigned)(cbase + tm * 32 + 8 * q + 4 * lh + e),
+                                                                                   __builtin_bit_cast(unsigned, av[e]));
+                                        ++cnt[tn];
                                     }
                             }
                         }
-                    if (cnt > 0) {
-                        const int nreg = cnt < 4 ? cnt : 4;
-                        const unsigned base = atomicAdd(&rowcnt[rown[tn]].x, (unsigned)nreg);
-                        const int cs[4] = {c0, c1, c2, c3};
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (j < nreg) {
-                                const unsigned slot = base + (unsigned)j;
-                                if (slot < (unsigned)SC_SLOTS) {
-                                    cand[rown[tn] * SC_SLOTS + slot] = cs[j];
-                                } else {
-                                    const unsigned pos = atomicAdd(&counters[0], 1u);
-                                    if (pos < ovf_cap) ovf[pos] = ((unsigned long long)rown[tn] << 32) | (unsigned)cs[j];
-                                }
-                            }
-                    }
                 }
-#pragma unroll
-                for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
             }
+            seed_acc();
             ks = 0;
             ++tile;
+            if ((tile + 1) * nk < total) load_seeds(tile + 1);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
-    if constexpr (!EMIT) {
+    // ---- list lengths (saturating) and the split's row maxima
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const float m = fminf(rm[tn], __shfl_xor(rm[tn], 32, 64));
-            if (lh == 0 && rvalid[tn] && bound2[rown[tn]] > -INFINITY) atomicMin(&amin[rown[tn]], ord_f32(m));
-        }
-    }
+    for (int tn = 0; tn < 2; ++tn)
+        if (rvalid[tn]) cntb[lbase[tn] / SC_PL] = (unsigned char)(cnt[tn] > 255 ? 255 : cnt[tn]);
+    __syncthreads();
+    if (tid < SC_RT && m0 + tid < n)
+        rmax[(m0 + tid) * splits + split] = fmaxf(fmaxf(s_rm[0][tid], s_rm[1][tid]), fmaxf(s_rm[2][tid], s_rm[3][tid]));
 }
 
-// ------------------------------------------------------------------------------------------ 3 + 4. re-rank, fallback
+// ------------------------------------------------------------------------------------------ 2. re-rank, fallback
 // dist(n,k) of the definition: the sequential f32 fma chain over d, then fmaf(-2, dot, cn).  One lane per pair.  The chain is
 // a dependent fma per element and the rows come from L2 / HBM with microseconds of latency, so the two rows are streamed
 // through a register ring of four stages of 16 floats each: 24 loads stay in flight while one stage's 16 chain steps run
@@ -371,65 +384,82 @@ __device__ __forceinline__ float exact_dist(const float *__restrict__ xr, const 
     return dist != dist ? -INFINITY : dist;
 }
 
-// Three block ranges.  [0, slot_blocks): one lane per (row, slot) - the lanes of a row are neighbours, their x loads
-// coincide.  [slot_blocks, slot_blocks + ovf_blocks): the overflow list, grid-stride.  The remaining blocks: one block per
-// 64 rows, exhaustive exact search of the rows that have no bound or (defensively) no candidate at all - and of every row
-// if the overflow list ran over.  Results meet in packed[row] (atomicMin); l2_screen_unpack_kernel splits them.  (Having
-// the last candidate of a row publish it instead needs a device-scope fence per candidate: 40 k L2 write-backs cost more
-// than the extra launch.)
-__device__ __forceinline__ void rerank_one(const float *__restrict__ x, const float *__restrict__ cb, const float *__restrict__ cn_pad,
-                                           int64_t row, int code, int d, unsigned long long *__restrict__ packed)
-{
-    const float dist = exact_dist(x + row * d, cb + (int64_t)code * d, d, cn_pad[code]);
-    atomicMin(&packed[row], pack_di(dist, code));
-}
 
-__global__ __launch_bounds__(256) void l2_rerank_kernel(const float *__restrict__ x, const float *__restrict__ cb,
-                                                        const float *__restrict__ cn_pad, const float *__restrict__ bound2,
-                                                        const int *__restrict__ cand, uint2 *__restrict__ rowcnt,
-                                                        const unsigned long long *__restrict__ ovf, const unsigned *__restrict__ counters,
-                                                        unsigned ovf_cap, int64_t n, int k, int d, int slot_blocks, int ovf_blocks,
-                                                        unsigned long long *__restrict__ packed)
+// A block per RR_ROWS rows.  (a) the rows' state: final maximum over the code splits, bound, list lengths; (b) every list entry
+// against the final maximum, survivors compacted into an LDS table (LDS atomics: a counter per block and per row); (c) one lane
+// per survivor runs the exact chain and puts (distance, index) into the row's packed minimum in LDS; (d) rows without a bound,
+// with a list that ran over, with more survivors than the table takes or - defensively - with none are searched exhaustively
+// by the whole block, one after the other; (e) idx / best_dist.
+__global__ __launch_bounds__(256) void l2_rerank_kernel(const float *__restrict__ x, const float *__restrict__ cb, const float *__restrict__ cn,
+                                                        const uint2 *__restrict__ cand, const unsigned char *__restrict__ cntb,
+                                                        const float *__restrict__ rmax, const float *__restrict__ bound, int64_t n, int k,
+                                                        int d, int splits, int32_t *__restrict__ idx, float *__restrict__ best_dist,
+                                                        unsigned *__restrict__ exhaustive_rows)
 {
-    const unsigned n_ovf = counters[0];
-    const bool all_exhaustive = n_ovf > ovf_cap;
-    if ((int)blockIdx.x < slot_blocks) {
-        if (all_exhaustive) return;
-        const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-        const int64_t row = i / SC_SLOTS;
-        const int slot = (int)(i - row * SC_SLOTS);
-        if (row >= n) return;
-        if (slot >= (int)rowcnt[row].x) return;
-        rerank_one(x, cb, cn_pad, row, cand[row * SC_SLOTS + slot], d, packed);
-        return;
-    }
-    if ((int)blockIdx.x < slot_blocks + ovf_blocks) {
-        if (all_exhaustive) return;
-        for (unsigned e = (blockIdx.x - slot_blocks) * 256u + threadIdx.x; e < n_ovf; e += (unsigned)ovf_blocks * 256u) {
-            const unsigned long long key = ovf[e];
-            rerank_one(x, cb, cn_pad, (int64_t)(key >> 32), (int)(key & 0xffffffffu), d, packed);
+    __shared__ unsigned long long s_best[RR_ROWS];
+    __shared__ float s_thr[RR_ROWS];
+    __shared__ unsigned s_rowcnt[RR_ROWS];
+    __shared__ unsigned s_exh[RR_ROWS];
+    __shared__ unsigned s_np;
+    __shared__ uint2 s_pair[RR_CAP];
+    __shared__ unsigned long long s_red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * RR_ROWS;
+    if (tid < RR_ROWS) {
+        const int64_t row = r0 + tid;
+        float g = -INFINITY, e = __builtin_nanf("");
+        if (row < n) {
+            e = bound[row];
+            for (int s = 0; s < splits; ++s) g = fmaxf(g, rmax[row * splits + s]);
         }
-        return;
+        s_thr[tid] = g - e;                          // NaN: no bound
+        s_best[tid] = ~0ull;
+        s_rowcnt[tid] = 0u;
+        s_exh[tid] = (row < n && !(g - e == g - e)) ? 1u : 0u;
     }
-    __shared__ unsigned long long s_todo;
-    __shared__ unsigned long long s_best[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t r0 = (int64_t)(blockIdx.x - slot_blocks - ovf_blocks) * 64;
-    if (wave == 0) {
-        const int64_t myrow = r0 + lane;
-        const bool need = myrow < n && (all_exhaustive || !(bound2[myrow] > -INFINITY) || rowcnt[myrow].x == 0u);
-        const unsigned long long m = __ballot(need);
-        if (lane == 0) s_todo = m;
+    if (tid == 0) s_np = 0u;
+    __syncthreads();
+    // ---- (b) lists -> survivors.  One thread per (row, list), its <= SC_PL entries are 64 contiguous bytes
+    const int lists = splits * SC_LISTS;
+    for (int i = tid; i < RR_ROWS * lists; i += 256) {
+        const int rl = i / lists, l = i - rl * lists;
+        const int64_t row = r0 + rl;
+        if (row >= n) continue;
+        const float thr = s_thr[rl];
+        if (!(thr == thr)) continue;
+        const int64_t L = row * lists + l;
+        const unsigned c = cntb[L];
+        if (c > (unsigned)SC_PL) {
+            s_exh[rl] = 1u;
+            continue;
+        }
+        for (unsigned j = 0; j < c; ++j) {
+            const uint2 ent = cand[L * SC_PL + j];
+            if (__builtin_bit_cast(float, ent.y) >= thr) {
+                const unsigned inrow = atomicAdd(&s_rowcnt[rl], 1u);
+                const unsigned pos = inrow < (unsigned)RR_PER_ROW ? atomicAdd(&s_np, 1u) : (unsigned)RR_CAP;
+                if (pos < (unsigned)RR_CAP) s_pair[pos] = make_uint2((unsigned)rl, ent.x);
+                else s_exh[rl] = 1u;
+            }
+        }
     }
     __syncthreads();
-    unsigned long long todo = s_todo;
-    while (todo) {                                                     // block-uniform
-        const int b = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const int64_t row = r0 + b;
+    // ---- (c) exact chains, one lane per survivor
+    const unsigned np = min(s_np, (unsigned)RR_CAP);
+    for (unsigned p = tid; p < np; p += 256) {
+        const uint2 pr = s_pair[p];
+        const float dist = exact_dist(x + (r0 + pr.x) * d, cb + (int64_t)pr.y * d, d, cn[pr.y]);
+        atomicMin(&s_best[pr.x], pack_di(dist, (int)pr.y));
+    }
+    __syncthreads();
+    // ---- (d) exhaustive rows (block-uniform loop)
+    for (int rl = 0; rl < RR_ROWS; ++rl) {
+        const int64_t row = r0 + rl;
+        if (row >= n) break;
+        if (!(s_exh[rl] != 0u || s_rowcnt[rl] == 0u)) continue;
         unsigned long long best = ~0ull;
-        for (int code = threadIdx.x; code < k; code += 256) {
-            const unsigned long long p = pack_di(exact_dist(x + row * d, cb + (int64_t)code * d, d, cn_pad[code]), code);
+        for (int code = tid; code < k; code += 256) {
+            const unsigned long long p = pack_di(exact_dist(x + row * d, cb + (int64_t)code * d, d, cn[code]), code);
             best = p < best ? p : best;
         }
 #pragma unroll
@@ -437,41 +467,27 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(const float *__restrict_
             const unsigned long long o = __shfl_xor(best, off, 64);
             best = o < best ? o : best;
         }
-        if (lane == 0) s_best[wave] = best;
+        if (lane == 0) s_red[wave] = best;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int w = 1; w < 4; ++w) best = s_best[w] < best ? s_best[w] : best;
-            packed[row] = best;                                       // no candidate of this row is re-ranked elsewhere
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w) best = s_red[w] < best ? s_red[w] : best;
+            s_best[rl] = best;                       // the exhaustive answer covers whatever the survivors had found
+            atomicAdd(exhaustive_rows, 1u);
         }
         __syncthreads();
     }
-}
-
-__global__ void l2_screen_unpack_kernel(const unsigned long long *__restrict__ packed, int64_t n, int32_t *__restrict__ idx,
-                                        float *__restrict__ dist)
-{
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const unsigned long long p = packed[i];
-        idx[i] = (int32_t)(p & 0xffffffffu);
-        if (dist) dist[i] = unord_f32((unsigned)(p >> 32));
+    // ---- (e)
+    if (tid < RR_ROWS && r0 + tid < n) {
+        const unsigned long long p = s_best[tid];
+        idx[r0 + tid] = (int32_t)(p & 0xffffffffu);
+        if (best_dist) best_dist[r0 + tid] = unord_f32((unsigned)(p >> 32));
     }
 }
 
-// sequential-chain code norms (the oracle's cn), written into the padded array
-__global__ void l2_screen_norms_kernel(const float *__restrict__ c, int k, int d, float *__restrict__ cn)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= k) return;
-    float acc = 0.f;
-    for (int t = 0; t < d; ++t) acc = __fmaf_rn(c[(size_t)j * d + t], c[(size_t)j * d + t], acc);
-    cn[j] = acc;
-}
-
 struct ScreenLayout {              // byte offsets inside the prepared-codebook blob and the workspace
-    size_t cn, cmax2, ch, blob;
-    size_t packed, amin, bound2, rowcnt, counters, xh, cand, ovf, ws;
-    unsigned ovf_cap;
-    int k_pad;
+    size_t cn, cnh, cmax2, ch, blob;
+    size_t cand, cntb, rmax, bound, counters, ws;
+    int k_pad, splits, tiles_per_split;
 };
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 static ScreenLayout screen_layout(int64_t n, int k, int d)
@@ -479,21 +495,24 @@ static ScreenLayout screen_layout(int64_t n, int k, int d)
     ScreenLayout L;
     L.k_pad = (int)(cdiv(k, SC_CT) * SC_CT);
     L.cn = 0;
-    L.cmax2 = al256((size_t)L.k_pad * 4);
+    L.cnh = al256((size_t)L.k_pad * 4);
+    L.cmax2 = L.cnh + al256((size_t)L.k_pad * 4);
     L.ch = L.cmax2 + 256;
     L.blob = L.ch + al256((size_t)k * d * 2);
+    // code splits: one block per CU and round when the rows alone do not fill the chip (a block keeps 64 rows of x resident)
+    const int64_t row_tiles = cdiv(n > 0 ? n : 1, SC_RT);
+    const int ntiles = (int)cdiv(k, SC_CT);
+    int splits = (int)cdiv(256, row_tiles);
+    if (splits > ntiles) splits = ntiles;
+    if (splits < 1) splits = 1;
+    L.tiles_per_split = (int)cdiv(ntiles, splits);
+    L.splits = (int)cdiv(ntiles, L.tiles_per_split);
     size_t o = 0;
-    L.packed = o; o += al256((size_t)n * 8);
-    L.amin = o; o += al256((size_t)n * 4);
-    L.bound2 = o; o += al256((size_t)n * 4);
-    L.rowcnt = o; o += al256((size_t)n * 8);
-    L.xh = o; o += al256((size_t)n * d * 2);
-    L.cand = o; o += al256((size_t)n * SC_SLOTS * 4);
+    L.cand = o; o += al256((size_t)n * L.splits * SC_LISTS * SC_PL * 8);
+    L.cntb = o; o += al256((size_t)n * L.splits * SC_LISTS);
+    L.rmax = o; o += al256((size_t)n * L.splits * 4);
+    L.bound = o; o += al256((size_t)n * 4);
     L.counters = o; o += 256;
-    int64_t cap = 4 * n + 4096;
-    if (cap > 0x7FFFFFF0ll) cap = 0x7FFFFFF0ll;
-    L.ovf_cap = (unsigned)cap;
-    L.ovf = o; o += al256((size_t)cap * 8);
     L.ws = o;
     return L;
 }
@@ -504,8 +523,8 @@ using namespace mq;
 
 static bool screen_shape_ok(int64_t n, int k, int d)
 {
-    return n >= 0 && n < ((int64_t)1 << 31) && k > 0 && d > 0 && d % 8 == 0 && (int64_t)SC_RT * d * 2 < 0x7FFFFFF0ll &&
-           (int64_t)k * d * 2 < 0xFFFFFFF0ll;
+    // d <= 512: the block's x image (64 rows x d bf16) stays resident in LDS next to the two code stages
+    return n >= 0 && n < ((int64_t)1 << 31) && k > 0 && d > 0 && d % 8 == 0 && d <= 512 && (int64_t)k * d * 4 < 0xFFFFFFF0ll;
 }
 
 extern "C" int mq_l2_screen_supported(int64_t n, int k, int d) { return screen_shape_ok(n, k, d) ? 1 : 0; }
@@ -520,19 +539,17 @@ extern "C" size_t mq_l2_screen_workspace(int64_t n, int k, int d)
 extern "C" int mq_l2_screen_prepare(const float *codebook, int k, int d, void *prepared, mqStream stream)
 {
     MQ_REQUIRE(codebook && prepared, "mq_l2_screen_prepare: null pointer");
-    MQ_REQUIRE(screen_shape_ok(0, k, d), "mq_l2_screen_prepare: need k > 0, d %% 8 == 0, k * d * 2 < 4 GiB (k=%d, d=%d)", k, d);
+    MQ_REQUIRE(screen_shape_ok(0, k, d), "mq_l2_screen_prepare: need k > 0, d %% 8 == 0, d <= 512, k * d * 4 < 4 GiB (k=%d, d=%d)", k, d);
     MQ_REQUIRE((uintptr_t)codebook % 16 == 0 && (uintptr_t)prepared % 256 == 0, "mq_l2_screen_prepare: alignment (codebook 16, blob 256)");
     const ScreenLayout L = screen_layout(0, k, d);
     char *b = reinterpret_cast<char *>(prepared);
-    float *cn = reinterpret_cast<float *>(b + L.cn);
     unsigned *cmax2 = reinterpret_cast<unsigned *>(b + L.cmax2);
     hipError_t e = hipMemsetAsync(cmax2, 0, 16, S(stream));
     MQ_REQUIRE(e == hipSuccess, "mq_l2_screen_prepare: memset failed: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(l2_screen_norms_kernel, dim3((unsigned)cdiv(k, 256)), dim3(256), 0, S(stream), codebook, k, d, cn);
-    if (L.k_pad > k)
-        hipLaunchKernelGGL(l2_screen_cnpad_kernel, dim3((unsigned)cdiv(L.k_pad - k, 128)), dim3(128), 0, S(stream), cn, k, L.k_pad);
-    hipLaunchKernelGGL(l2_screen_prep_kernel<1>, dim3((unsigned)cdiv(k, 4)), dim3(256), 0, S(stream), codebook, (int64_t)k, d,
-                       reinterpret_cast<unsigned short *>(b + L.ch), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, cmax2);
+    hipLaunchKernelGGL(l2_screen_norms_kernel, dim3((unsigned)cdiv(L.k_pad, 256)), dim3(256), 0, S(stream), codebook, k, L.k_pad, d,
+                       reinterpret_cast<float *>(b + L.cn), reinterpret_cast<float *>(b + L.cnh));
+    hipLaunchKernelGGL(l2_screen_cbprep_kernel, dim3((unsigned)cdiv(k, 4)), dim3(256), 0, S(stream), codebook, k, d,
+                       reinterpret_cast<unsigned short *>(b + L.ch), cmax2);
     MQ_LAUNCH_CHECK("mq_l2_screen_prepare");
     return 0;
 }
@@ -550,62 +567,56 @@ extern "C" int mq_l2_argmin_screened(const float *x, const float *codebook, cons
     MQ_REQUIRE(workspace_bytes >= L.ws, "mq_l2_argmin_screened: workspace too small (%zu < %zu)", workspace_bytes, L.ws);
     const char *pb = reinterpret_cast<const char *>(prepared);
     const float *cn = reinterpret_cast<const float *>(pb + L.cn);
+    const float *cnh = reinterpret_cast<const float *>(pb + L.cnh);
     const float *cmax2 = reinterpret_cast<const float *>(pb + L.cmax2);
     const unsigned short *ch = reinterpret_cast<const unsigned short *>(pb + L.ch);
     char *w = reinterpret_cast<char *>(workspace);
-    unsigned long long *packed = reinterpret_cast<unsigned long long *>(w + L.packed);
-    unsigned *amin = reinterpret_cast<unsigned *>(w + L.amin);
-    float *bound2 = reinterpret_cast<float *>(w + L.bound2);
-    uint2 *rowcnt = reinterpret_cast<uint2 *>(w + L.rowcnt);
-    unsigned short *xh = reinterpret_cast<unsigned short *>(w + L.xh);
-    int *cand = reinterpret_cast<int *>(w + L.cand);
+    uint2 *cand = reinterpret_cast<uint2 *>(w + L.cand);
+    unsigned char *cntb = reinterpret_cast<unsigned char *>(w + L.cntb);
+    float *rmax = reinterpret_cast<float *>(w + L.rmax);
+    float *bound = reinterpret_cast<float *>(w + L.bound);
     unsigned *counters = reinterpret_cast<unsigned *>(w + L.counters);
-    unsigned long long *ovf = reinterpret_cast<unsigned long long *>(w + L.ovf);
     hipStream_t st = S(stream);
-    hipLaunchKernelGGL(l2_screen_prep_kernel<0>, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, st, x, n, d, xh, cmax2, bound2, amin, packed,
-                       rowcnt, counters, nullptr);
-    const int row_tiles = (int)cdiv(n, SC_RT);
-    const int ntiles = (int)cdiv(k, SC_CT);
-    int splits = (int)cdiv(1024, row_tiles);            // about two rounds of 2 blocks per CU
-    if (splits > ntiles) splits = ntiles;
-    if (splits < 1) splits = 1;
-    const int tps = (int)cdiv(ntiles, splits);
-    splits = (int)cdiv(ntiles, tps);
-    hipLaunchKernelGGL(l2_screen_kernel<false>, dim3(row_tiles, splits), dim3(256), 0, st, xh, ch, cn, bound2, n, k, d, tps, amin, cand,
-                       rowcnt, ovf, counters, L.ovf_cap);
-    hipLaunchKernelGGL(l2_screen_kernel<true>, dim3(row_tiles, splits), dim3(256), 0, st, xh, ch, cn, bound2, n, k, d, tps, amin, cand,
-                       rowcnt, ovf, counters, L.ovf_cap);
-    const int slot_blocks = (int)cdiv(n * SC_SLOTS, 256), ovf_blocks = 64;
-    const int fb_blocks = (int)cdiv(n, 64);
-    hipLaunchKernelGGL(l2_rerank_kernel, dim3(slot_blocks + ovf_blocks + fb_blocks), dim3(256), 0, st, x, codebook, cn, bound2, cand, rowcnt,
-                       ovf, counters, L.ovf_cap, n, k, d, slot_blocks, ovf_blocks, packed);
-    hipLaunchKernelGGL(l2_screen_unpack_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, st, packed, n, idx, best_dist);
+    const dim3 grid((unsigned)cdiv(n, SC_RT), (unsigned)L.splits);
+    const int nk = (d + 63) / 64;
+#define MQ_SCREEN(NK_) hipLaunchKernelGGL((l2_screen_kernel<NK_>), grid, dim3(256), 0, st, x, ch, cnh, cmax2, n, k, d, L.tiles_per_split, \
+                                          L.splits, cand, cntb, rmax, bound, counters)
+    if (nk <= 1) MQ_SCREEN(1);
+    else if (nk <= 2) MQ_SCREEN(2);
+    else if (nk <= 4) MQ_SCREEN(4);
+    else MQ_SCREEN(8);
+#undef MQ_SCREEN
+    hipLaunchKernelGGL(l2_rerank_kernel, dim3((unsigned)cdiv(n, RR_ROWS)), dim3(256), 0, st, x, codebook, cn, cand, cntb, rmax, bound, n, k, d,
+                       L.splits, idx, best_dist, counters);
     MQ_LAUNCH_CHECK("mq_l2_argmin_screened");
     return 0;
 }
 
-// candidates appended / slots available in the last call that used `workspace` (diagnostics; synchronises the stream)
+// diagnostics of the last call that used `workspace` (synchronises the stream): entries the screening pass appended to the private
+// lists, list entries available, rows that were searched exhaustively
 extern "C" int mq_l2_screen_stats(const void *workspace, int64_t n, int k, int d, uint64_t *appended, uint64_t *slots,
                                   uint64_t *rows_over, mqStream stream)
 {
     MQ_REQUIRE(workspace && appended && slots && rows_over && n > 0 && screen_shape_ok(n, k, d), "mq_l2_screen_stats: bad arguments");
     const ScreenLayout L = screen_layout(n, k, d);
-    uint2 *h = reinterpret_cast<uint2 *>(malloc((size_t)n * 8));
+    const size_t nl = (size_t)n * L.splits * SC_LISTS;
+    unsigned char *h = reinterpret_cast<unsigned char *>(malloc(nl + 4));
     MQ_REQUIRE(h != nullptr, "mq_l2_screen_stats: out of host memory");
-    hipError_t e = hipMemcpyAsync(h, reinterpret_cast<const char *>(workspace) + L.rowcnt, (size_t)n * 8, hipMemcpyDeviceToHost, S(stream));
+    const char *w = reinterpret_cast<const char *>(workspace);
+    hipError_t e = hipMemcpyAsync(h, w + L.cntb, nl, hipMemcpyDeviceToHost, S(stream));
+    if (e == hipSuccess) e = hipMemcpyAsync(h + nl, w + L.counters, 4, hipMemcpyDeviceToHost, S(stream));
     if (e == hipSuccess) e = hipStreamSynchronize(S(stream));
     if (e != hipSuccess) {
         free(h);
         return ::mq::fail("mq_l2_screen_stats: copy failed: %s", hipGetErrorString(e));
     }
-    uint64_t a = 0, o = 0;
-    for (int64_t i = 0; i < n; ++i) {
-        a += h[i].x;
-        o += h[i].x > (unsigned)SC_SLOTS ? h[i].x - SC_SLOTS : 0;
-    }
+    uint64_t a = 0;
+    for (size_t i = 0; i < nl; ++i) a += h[i];
+    unsigned over = 0;
+    memcpy(&over, h + nl, 4);
     free(h);
     *appended = a;
-    *slots = (uint64_t)n * SC_SLOTS;
-    *rows_over = o > L.ovf_cap ? (uint64_t)n : 0;      // overflow list ran over: every row was searched exhaustively
+    *slots = (uint64_t)nl * SC_PL;
+    *rows_over = over;
     return 0;
 }

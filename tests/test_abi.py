@@ -42,7 +42,7 @@ def test_library_exports_every_declared_symbol(built):
     for name, nargs in d.items():
         assert hasattr(lib, name), name
         assert len(_lib.SIGNATURES[name][1]) == nargs, (name, nargs, len(_lib.SIGNATURES[name][1]))
-    assert lib.mq_abi_version() == 8 == _lib.ABI_VERSION
+    assert lib.mq_abi_version() == 9 == _lib.ABI_VERSION
     # nm agrees (extern "C", no mangling)
     syms = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     for name in d:

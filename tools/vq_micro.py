@@ -40,4 +40,6 @@ for k, d in ((8192, 512), (2048, 512), (1024, 256)):
     e.record()
     torch.cuda.synchronize()
     ms = s.elapsed_time(e) / 10
-    print(f"l2_argmin_screened rows {rows} codes {k} d {d}: {ms:.4f} ms  {2.0 * rows * k * d / ms / 1e9:.1f} TF/s (algorithmic)", flush=True)
+    emitted, cap, over = ops.l2_screen_stats(ws2, rows, k, d)
+    print(f"l2_argmin_screened rows {rows} codes {k} d {d}: {ms:.4f} ms  {2.0 * rows * k * d / ms / 1e9:.1f} TF/s (algorithmic); "
+          f"{emitted / rows:.2f} list entries per row of {cap // rows}, {over} rows searched exhaustively", flush=True)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised soak of the screened codebook search against the f32 kernel (both on the GPU, so it is fast): random shapes
-(rows 1..40000, codes 1..9000, d a multiple of 8 up to 768), random scales, a few NaN / huge rows, repeated launches on the same
+(rows 1..40000, codes 1..9000, d a multiple of 8 up to 512: what the screened search takes), random scales, a few NaN / huge rows, repeated launches on the same
 workspace.  Any difference in indices or distances is a bug (the LDS-DMA staging of l2_screen_kernel is the kind of code where a
 missing wait shows up once in a thousand tiles).  usage: python tools/vq_soak.py [cases] [seed]"""
 import os
@@ -21,7 +21,7 @@ bad = 0
 for c in range(cases):
     n = int(rng.choice([1, 7, 127, 128, 129, 1000, 4096, 16384, int(rng.integers(1, 40000))]))
     k = int(rng.choice([1, 5, 127, 128, 129, 1000, 1024, 2048, int(rng.integers(1, 9000))]))
-    d = 8 * int(rng.choice([1, 3, 8, 9, 32, 64, int(rng.integers(1, 97))]))
+    d = 8 * int(rng.choice([1, 3, 8, 9, 32, 64, int(rng.integers(1, 65))]))
     sx, sc = float(10.0 ** rng.uniform(-6, 6)), float(10.0 ** rng.uniform(-6, 6))
     x = torch.randn(n, d, device="cuda") * sx
     cb = torch.randn(k, d, device="cuda") * sc
