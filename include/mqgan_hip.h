@@ -70,16 +70,18 @@ size_t mq_l2_argmin_workspace(int64_t n);
 int mq_l2_argmin(const float *x, const float *codebook, const float *cnorm, int64_t n, int k, int d, int32_t *idx,
                  float *best_dist, void *workspace, mqStream stream);
 /* The same search, same results bit for bit (indices AND best distances), past the f32-MFMA roof (csrc/vq_screen.hip;
- * SURVEY.md 8d "bf16 candidate scoring + exact fp32 re-rank"): every (row, code) pair is scored on the bf16 matrix pipe,
- * pairs within a proven error bound of the row's minimum score become candidates, candidates get the exact k-ordered f32
- * distance of the definition above; rows without a finite bound (NaN / inf / |x| |c| beyond 1e18) are searched exhaustively
- * in exact arithmetic.  Needs d % 8 == 0 (mq_l2_screen_supported).
+ * SURVEY.md 8d "bf16 candidate scoring + exact fp32 re-rank"): every (row, code) pair is scored ONCE on the bf16 matrix pipe
+ * (three launches: x -> bf16 + per-row error bound; scores with the code norm as the accumulator's initial value, every code
+ * within the proven bound of the row's RUNNING best appended to a private list; lists filtered against the final best, the
+ * survivors re-ranked with the exact k-ordered f32 distance of the definition above, idx / best_dist written); rows without a
+ * finite bound (NaN / inf / |x| |c| beyond 1e18) or with an overrun list are searched exhaustively in exact arithmetic.  Needs
+ * d % 8 == 0 (mq_l2_screen_supported).
  *   prepared : per-codebook blob of mq_l2_screen_codebook_bytes(k, d) bytes, 256-byte aligned, filled once per codebook by
- *              mq_l2_screen_prepare (code norms, bf16 copy, max norm)
- *   workspace: mq_l2_screen_workspace(n, k, d) bytes, 256-byte aligned (bf16 copy of x, 8 candidate slots per row and a
- *              shared overflow list of 4 n + 4096 entries)
- * mq_l2_screen_stats (synchronises `stream`): candidates appended by the last call on that workspace, in-row slots
- * available, and the number of rows searched exhaustively because the overflow list ran over (0 or n; still exact). */
+ *              mq_l2_screen_prepare (code norms, accumulator seeds -norm / 2, bf16 copy, max norm)
+ *   workspace: mq_l2_screen_workspace(n, k, d) bytes, 256-byte aligned (bf16 copy of x; 4 private lists of 16 entries per row
+ *              and code split; per-row bound and running best)
+ * mq_l2_screen_stats (synchronises `stream`): entries the last call on that workspace appended to its lists, list entries
+ * available, and the number of rows it searched exhaustively (still exact). */
 int mq_l2_screen_supported(int64_t n, int k, int d);
 size_t mq_l2_screen_codebook_bytes(int k, int d);
 size_t mq_l2_screen_workspace(int64_t n, int k, int d);

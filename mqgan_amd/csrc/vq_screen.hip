@@ -5,23 +5,26 @@
 // Definition (oracle/vq_ref.c):  dist(n,k) = fmaf(-2, dot(n,k), cn(k)),  dot = sequential f32 fma chain over d,
 //                                idx(n) = argmin_k dist(n,k), lowest k on ties, NaN counts as -inf.
 //
-// Round 5: every bf16 score is formed ONCE and the search is TWO launches (r3-r4: five launches, every score formed twice -
+// Round 5: every bf16 score is formed ONCE and the search is THREE launches (r3-r4: five launches, every score formed twice -
 // one pass for the row minima, one to emit the candidates against them).
 //
-// 1. screen (l2_screen_kernel)   a(n,k) = -cn(k)/2 + <xh_n, ch_k> on the bf16 MFMA, the norm term being the accumulator's initial
+// 1. prep   (l2_screen_prep_kernel)   x -> bf16 copy xh (RNE) and, per row, the bound E(n) (below); NaN marks rows without one.
+// 2. screen (l2_screen_kernel)   a(n,k) = -cn(k)/2 + <xh_n, ch_k> on the bf16 MFMA, the norm term being the accumulator's initial
 //              value (the MFMA's C operand: no distance epilogue), so that score(n,k) = -2 a(n,k) and the best code has the LARGEST
-//              a.  The block converts its 64 rows of x to bf16 itself (f32 loads -> v_cvt_pk_bf16_f32 -> swizzled LDS image that
-//              stays resident for the whole block; the row norms the bound needs come out of the same loads) and streams 256-code
-//              tiles of the prepared bf16 codebook through a two-stage LDS-DMA ring: half the DMA bytes per MFMA of the r3
-//              kernel, which re-streamed the x tile for every code tile.  The GEMM is formed TRANSPOSED (A = codes, B = rows):
-//              a lane holds 32 codes of ONE row per wave tile, so row-wise work is lane-local.  After every code tile a lane takes
-//              the running maximum of its row (its own codes, the other lane half by one DPP exchange, the other three waves
-//              through an LDS word that is read one tile late - any value ever written there is a lower bound of the final maximum)
-//              and appends every code with  a >= running maximum - E(n)  to a PRIVATE list (row, wave, lane half): plain stores,
-//              a register counter, no atomics.  A single pass over-collects - the first tiles are compared against a maximum that
-//              still rises: ~c H(tiles) entries per row instead of c, c = 2-4 - and the re-rank drops what the final maximum
-//              excludes before it spends a chain on it.
-// 2. re-rank (l2_rerank_kernel)  a block per 64 rows: the lists' entries are filtered against the FINAL maximum, the survivors
+//              a.  The GEMM is formed TRANSPOSED (A = 128-code tile, B = 128-row tile, both staged by LDS-DMA into 128-byte
+//              swizzled rows, two stages, two blocks per CU: 64 KB of loads in flight per CU is what the L2 -> LDS path needs to
+//              run at its rate): a lane holds 32 codes of ONE row per wave tile, so row-wise work is lane-local.  After every
+//              code tile a lane takes the running maximum of its row (its own codes, the other lane half by one DPP exchange, the
+//              other code half of the block through an LDS word that is read one tile late - any value ever written there is a
+//              lower bound of the final maximum) and appends every code with  a >= running maximum - E(n)  to a PRIVATE list
+//              (row, code split, wave column, lane half): plain stores, a register counter, no atomics.  A single pass
+//              over-collects - the first tiles are compared against a maximum that still rises: ~c H(tiles) entries per row
+//              instead of c, c = 2-4 - and the re-rank drops what the final maximum excludes before it spends a chain on it.
+//              (Tried first and measured: the block's x rows converted in-kernel and kept resident in LDS, 256-code tiles of the
+//              codebook streamed past them - one launch fewer, half the DMA bytes per tile; but at 64-128 KB of LDS for the image
+//              only ONE stage of 32 KB is in flight per CU and every K-step waits out the DMA latency: 303 us at 8192 x 512 against
+//              ~130 us for this structure.  Bytes in flight decide, not bytes moved.)
+// 3. re-rank (l2_rerank_kernel)  a block per 64 rows: the lists' entries are filtered against the FINAL maximum, the survivors
 //              (2-4 per row) get their exact distance (the oracle's sequential fma chain, one lane per survivor, survivors
 //              compacted so that the lanes of a wave are all busy) and meet in a packed (distance, index) minimum per row in LDS -
 //              minimum distance, lowest index on ties; the block then writes idx / best_dist itself (no unpack launch).  Rows that
@@ -51,15 +54,16 @@ namespace mq {
 typedef __attribute__((address_space(3))) void lds_void_s;
 __device__ __forceinline__ lds_void_s *lds_ptr_s(const void *p) { return reinterpret_cast<lds_void_s *>(reinterpret_cast<uintptr_t>(p)); }
 
-constexpr int SC_CT = 256;            // codes per block tile (4 waves x 64)
-constexpr int SC_RT = 64;             // rows per block (two 32-row MFMA tiles per wave)
+constexpr int SC_CT = 128;            // codes per block tile (2 waves x 64)
+constexpr int SC_RT = 128;            // rows per block tile (2 waves x 64)
 constexpr int SC_ROWB = 128;          // bytes per LDS row: 64 bf16 k's
-constexpr int SC_STAGE = SC_CT * SC_ROWB;     // one code tile of a K-step: 32 KB
-constexpr int SC_XCHUNK = SC_RT * SC_ROWB;    // the x image of one K-step: 8 KB
-constexpr int SC_LISTS = 8;           // private lists per (row, code split): 4 waves x 2 lane halves
-constexpr int SC_PL = 8;              // entries per private list; a longer list sends its row to the exhaustive search
+constexpr int SC_OP = 128 * SC_ROWB;  // one operand tile of a stage
+constexpr int SC_STAGE = 2 * SC_OP;
+constexpr int SC_LISTS = 4;           // private lists per (row, code split): 2 wave columns x 2 lane halves
+constexpr int SC_PL = 16;             // entries per private list (64 bytes would overflow once per ~10^4 rows at 8192 codes); a longer list sends its row to the exhaustive search
 constexpr int RR_ROWS = 64;           // rows per re-rank block
 constexpr int RR_CAP = 1024;          // survivors a re-rank block holds
+constexpr int RR_STAGE = 2 * 64 * 128;  // one stage of a wave's staging ring: 64 pairs x 32 f32 of the code row + of the x row
 constexpr int RR_PER_ROW = 16;        // ... and per row; rows with more are searched exhaustively
 
 __device__ __forceinline__ unsigned ord_f32(float v)
@@ -119,24 +123,55 @@ __global__ void l2_screen_norms_kernel(const float *__restrict__ c, int k, int k
     cnh[j] = -0.5f * acc;
 }
 
-// ------------------------------------------------------------------------------------------ 1. screen
-// grid (row tiles of 64, code splits), 256 threads = 4 waves; wave w owns codes [64 w, +64) x all 64 rows of every 256-code tile
-// as 2 x 2 MFMA tiles of 32 x 32 (v_mfma_f32_32x32x16_bf16, A = codes, B = rows).  LDS: the block's x image (NK K-steps of 64
-// rows x 128 bytes, 16-byte chunks XOR-swizzled with (row >> 1) & 7, written once by the prologue) + a ring of two code stages
-// filled by LDS-DMA (lane-linear destination: the swizzle is applied to the per-lane SOURCE address).
-template <int NK>
-__global__ __launch_bounds__(256) void l2_screen_kernel(const float *__restrict__ x, const unsigned short *__restrict__ ch,
-                                                        const float *__restrict__ cnh, const float *__restrict__ cmax2, int64_t n, int k,
-                                                        int d, int tiles_per_split, int splits, uint2 *__restrict__ cand,
-                                                        unsigned char *__restrict__ cntb, float *__restrict__ rmax,
-                                                        float *__restrict__ bound, unsigned *__restrict__ exhaustive_rows)
+// ------------------------------------------------------------------------------------------ 1. prep (x side, every call)
+// one wave per row: bf16 copy, |x_n|^2 -> E(n) in the units of a = -score / 2 (header comment); NaN = no bound
+__global__ __launch_bounds__(256) void l2_screen_prep_kernel(const float *__restrict__ x, int64_t rows, int d,
+                                                             unsigned short *__restrict__ xh, const float *__restrict__ cmax2,
+                                                             float *__restrict__ bound, unsigned *__restrict__ gmax,
+                                                             unsigned *__restrict__ exhaustive_rows)
 {
-    __shared__ __attribute__((aligned(1024))) char smem[NK * SC_XCHUNK + 2 * SC_STAGE];
-    __shared__ float s_rm[4][SC_RT];
-    __shared__ float s_e[SC_RT];
-    char *xs = smem, *cs = smem + NK * SC_XCHUNK;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *exhaustive_rows = 0u;          // the re-rank launch counts them
+    if (row >= rows) return;
+    const float *s = x + row * d;
+    unsigned short *o = xh + row * d;
+    float ss = 0.f;
+    for (int t = lane * 4; t < d; t += 256) {
+        const float4 v = *reinterpret_cast<const float4 *>(s + t);
+        ss = fmaf(v.x, v.x, ss);
+        ss = fmaf(v.y, v.y, ss);
+        ss = fmaf(v.z, v.z, ss);
+        ss = fmaf(v.w, v.w, ss);
+        *reinterpret_cast<uint2 *>(o + t) = pack_bf16x4(v);
+    }
+    ss = wave_sum(ss);
+    if (lane != 0) return;
+    const float nx = sqrtf(ss) * 1.001f;
+    const float cm = sqrtf(cmax2[0]) * 1.001f;
+    const float delta = 1.02f * 0.0078125f + (float)d * 4.76837158203125e-07f;        // 2^-7, 2^-21
+    const float e2 = 2.02f * delta * nx * cm + (9.5367431640625e-07f + (float)d * 1.1920928955078125e-07f) * cm * cm + 1e-30f;
+    const bool ok = nx < 1e18f && cm < 1e18f && e2 < 1e30f;                           // false for NaN too
+    bound[row] = ok ? 0.5f * e2 : __builtin_nanf("");
+    gmax[row] = ord_f32(-INFINITY);                    // the row's running maximum, shared by the code splits (atomicMax)
+}
+
+// ------------------------------------------------------------------------------------------ 2. screen
+// grid (row tiles, code splits), 256 threads = 4 waves: wave (wc, wr) owns codes [64 wc, +64) x rows [64 wr, +64) of the
+// block tile as 2 x 2 MFMA tiles of 32 x 32 (v_mfma_f32_32x32x16_bf16, A = codes, B = rows).  Both operand tiles
+// (128 x 64 k's, 128-byte rows, 16-byte chunks XOR-swizzled with (row >> 1) & 7) are staged by LDS-DMA into a ring of two
+// stages (lane-linear destination: the swizzle is applied to the per-lane SOURCE address); the x tile is re-streamed from L2
+// for every code tile (D <= 512: 128 KB per block, it stays in L2).
+__global__ __launch_bounds__(256, 2) void l2_screen_kernel(const unsigned short *__restrict__ xh, const unsigned short *__restrict__ ch,
+                                                           const float *__restrict__ cnh, const float *__restrict__ bound, int64_t n, int k,
+                                                           int d, int tiles_per_split, int splits, uint2 *__restrict__ cand,
+                                                           unsigned char *__restrict__ cntb, unsigned *__restrict__ gmax)
+{
+    __shared__ __attribute__((aligned(1024))) char smem[2 * SC_STAGE];
+    __shared__ float s_rm[2][SC_RT];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave >> 1, wr = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
     const int64_t m0 = (int64_t)blockIdx.x * SC_RT;
     const int split = blockIdx.y;
@@ -145,73 +180,47 @@ __global__ __launch_bounds__(256) void l2_screen_kernel(const float *__restrict_
     const int t_end = min(ntiles, t_begin + tiles_per_split);
     const int nk = (d + 63) >> 6;
     const int total = nk * (t_end - t_begin);
-    if (total <= 0) return;                                   // block-uniform
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *exhaustive_rows = 0u;      // the re-rank launch counts them
+    if (total <= 0) return;                                   // block-uniform (the layout gives every split a tile)
 
-    // ---- code tile DMA: piece p = wave + 4 j covers tile rows 8p .. 8p+7; lane -> row 8p + (lane >> 3), physical chunk lane & 7
+    // ---- DMA slots: piece p = wave + 4 j covers tile rows 8p .. 8p+7; lane -> row 8p + (lane >> 3), physical chunk lane & 7
     const int lc = (lane & 7) ^ ((((wave & 1) << 2) | (lane >> 4)) & 7);        // logical chunk this lane has to fetch
+    const int64_t rows_here = n - m0 < SC_RT ? n - m0 : SC_RT;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(xh + m0 * d, (size_t)rows_here * d * 2);
     const int64_t code0 = (int64_t)t_begin * SC_CT;
     const int64_t codes_here = min((int64_t)k, (int64_t)t_end * SC_CT) - code0;
     const __amdgpu_buffer_rsrc_t rc = make_rsrc(ch + code0 * d, (size_t)codes_here * d * 2);
-    unsigned rowoff[8];
+    unsigned rowoff[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) rowoff[j] = (unsigned)(8 * (wave + 4 * j) + (lane >> 3)) * (unsigned)d * 2u + (unsigned)lc * 16u;
+    for (int j = 0; j < 4; ++j) rowoff[j] = (unsigned)(8 * (wave + 4 * j) + (lane >> 3)) * (unsigned)d * 2u + (unsigned)lc * 16u;
     auto issue = [&](int it) {
         const int tile = it / nk, ks = it - tile * nk;
         const bool kv = ks * 64 + lc * 8 < d;
-        const unsigned off = (unsigned)ks * 128u + (unsigned)tile * (unsigned)(SC_CT * 2) * (unsigned)d;
-        char *st = cs + (it & 1) * SC_STAGE;
+        const unsigned koff = (unsigned)ks * 128u;
+        const unsigned toff = (unsigned)tile * (unsigned)(SC_CT * 2) * (unsigned)d;
+        char *st = smem + (it & 1) * SC_STAGE;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, lds_ptr_s(st + (wave + 4 * j) * 1024), 16, kv ? rowoff[j] + off : OOB, 0, 0, 0);
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, lds_ptr_s(st + (wave + 4 * j) * 1024), 16,
+                                                     kv ? rowoff[j] + koff + toff : OOB, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, lds_ptr_s(st + SC_OP + (wave + 4 * j) * 1024), 16,
+                                                     kv ? rowoff[j] + koff : OOB, 0, 0, 0);
     };
     issue(0);
-
-    // ---- prologue: the block's rows of x -> bf16 LDS image (zeros beyond n and beyond d), |x_n|^2 out of the same loads.
-    //      Item i = (row r, 16-byte chunk c of the padded row): the NK * 8 chunks of a row sit in neighbouring lanes.
-    constexpr int CPR = NK * 8;                               // chunks per padded row (<= 64: a row never straddles waves)
-    const int cpr = d >> 3;
-    s_rm[tid >> 6][tid & 63] = -INFINITY;
-    for (int i = tid; i < SC_RT * CPR; i += 256) {
-        const int r = i / CPR, c = i - r * CPR;
-        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-        if (m0 + r < n && c < cpr) {
-            const float *src = x + (m0 + r) * d + c * 8;
-            v0 = *reinterpret_cast<const float4 *>(src);
-            v1 = *reinterpret_cast<const float4 *>(src + 4);
-        }
-        float ss = v0.x * v0.x;
-        ss = fmaf(v0.y, v0.y, ss); ss = fmaf(v0.z, v0.z, ss); ss = fmaf(v0.w, v0.w, ss);
-        ss = fmaf(v1.x, v1.x, ss); ss = fmaf(v1.y, v1.y, ss); ss = fmaf(v1.z, v1.z, ss); ss = fmaf(v1.w, v1.w, ss);
-#pragma unroll
-        for (int o = 1; o < CPR; o <<= 1) ss += __shfl_xor(ss, o, 64);
-        const uint2 p0 = pack_bf16x4(v0), p1 = pack_bf16x4(v1);
-        *reinterpret_cast<uint4 *>(xs + (c >> 3) * SC_XCHUNK + r * SC_ROWB + (((c & 7) ^ ((r >> 1) & 7)) << 4)) =
-            make_uint4(p0.x, p0.y, p1.x, p1.y);
-        if (c == 0) {
-            // E(n) in the units of a = -score / 2 (header comment); NaN = no bound: nothing compares >= against it
-            const float nx = sqrtf(ss) * 1.001f;
-            const float cm = sqrtf(cmax2[0]) * 1.001f;
-            const float delta = 1.02f * 0.0078125f + (float)d * 4.76837158203125e-07f;        // 2^-7, 2^-21
-            const float e2 = 2.02f * delta * nx * cm + (9.5367431640625e-07f + (float)d * 1.1920928955078125e-07f) * cm * cm + 1e-30f;
-            const bool ok = nx < 1e18f && cm < 1e18f && e2 < 1e30f;                           // false for NaN too
-            const float e = ok ? 0.5f * e2 : __builtin_nanf("");
-            s_e[r] = e;
-            if (split == 0 && m0 + r < n) bound[m0 + r] = e;
-        }
-    }
+    if (tid < SC_RT) { s_rm[0][tid] = -INFINITY; s_rm[1][tid] = -INFINITY; }
 
     // ---- fragment addresses: lane (li, lh) reads chunk (2 s + lh) ^ ((li >> 1) & 7) of row li of a 32-row MFMA tile
     const int sw = (li >> 1) & 7;
     int foff[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) foff[s] = li * SC_ROWB + ((((2 * s) ^ (lh ^ sw)) & 7) << 4);
-    const int a_base = (wave * 64) * SC_ROWB;
+    const int a_base = (wc * 64) * SC_ROWB, b_base = SC_OP + (wr * 64) * SC_ROWB;
 
     // accumulator seeds of a code tile: lane (li, lh) holds codes cbase + tm*32 + 8 (r >> 2) + 4 lh + (r & 3) -> float4 per (tm, r >> 2)
     float4 seed[2][4];
     auto load_seeds = [&](int tile) {
-        const int cbase = (t_begin + tile) * SC_CT + wave * 64;
+        const int cbase = (t_begin + tile) * SC_CT + wc * 64;
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -232,38 +241,36 @@ __global__ __launch_bounds__(256) void l2_screen_kernel(const float *__restrict_
                 }
     };
     load_seeds(0);
-    seed_acc();
-    if (nk * 1 < total) load_seeds(1);                        // the next tile's seeds travel while this tile multiplies
-
-    float rm[2], ebound[2];
+    float rm[2], ebound[2], seen[2];
     int cnt[2];
     bool rvalid[2];
-    int64_t lbase[2];
+    int64_t lbase[2], grow[2];
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
-        const int64_t row = m0 + tn * 32 + li;
+        const int64_t row = m0 + wr * 64 + tn * 32 + li;
         rvalid[tn] = row < n;
         rm[tn] = -INFINITY;
         cnt[tn] = 0;
-        lbase[tn] = ((row * splits + split) * SC_LISTS + wave * 2 + lh) * SC_PL;
+        lbase[tn] = ((row * splits + split) * SC_LISTS + wc * 2 + lh) * SC_PL;
+        ebound[tn] = rvalid[tn] ? bound[row] : __builtin_nanf("");                // NaN: nothing compares >= against it
+        grow[tn] = rvalid[tn] ? row : m0;
+        seen[tn] = -INFINITY;
     }
-
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    seed_acc();
+    if (nk < total) load_seeds(1);                            // the next tile's seeds travel while this tile multiplies
     __syncthreads();
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) ebound[tn] = s_e[tn * 32 + li];
     int tile = 0, ks = 0;
     for (int it = 0; it < total; ++it) {
         if (it + 1 < total) issue(it + 1);
-        const char *st = cs + (it & 1) * SC_STAGE;
-        const char *xk = xs + ks * SC_XCHUNK;
+        const char *st = smem + (it & 1) * SC_STAGE;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             bf16x8 fa[2], fb[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 fa[t] = *reinterpret_cast<const bf16x8 *>(st + a_base + t * 32 * SC_ROWB + foff[s]);
-                fb[t] = *reinterpret_cast<const bf16x8 *>(xk + t * 32 * SC_ROWB + foff[s]);
+                fb[t] = *reinterpret_cast<const bf16x8 *>(st + b_base + t * 32 * SC_ROWB + foff[s]);
             }
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm)
@@ -273,7 +280,7 @@ __global__ __launch_bounds__(256) void l2_screen_kernel(const float *__restrict_
         }
         if (++ks == nk) {
             // ---- fold the finished code tile: running maximum of the row, candidates into the lane's private list
-            const int cbase = (t_begin + tile) * SC_CT + wave * 64;
+            const int cbase = (t_begin + tile) * SC_CT + wc * 64;
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn) {
                 float tmax = -INFINITY;
@@ -281,22 +288,24 @@ __global__ __launch_bounds__(256) void l2_screen_kernel(const float *__restrict_
                 for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) tmax = fmaxf(tmax, fmaxf(acc[tm][tn][r], acc[tm][tn][r + 1]));
-                float m = fmaxf(tmax, __shfl_xor(tmax, 32, 64));                 // all 64 codes of this wave's slice
-                rm[tn] = fmaxf(rm[tn], m);
-                const int rl = tn * 32 + li;
-                // what the other waves had reached a tile ago (any value ever written there is <= the final maximum)
-                float shared = fmaxf(fmaxf(s_rm[0][rl], s_rm[1][rl]), fmaxf(s_rm[2][rl], s_rm[3][rl]));
-                rm[tn] = fmaxf(rm[tn], shared);
-                if (lh == 0) s_rm[wave][rl] = rm[tn];
+                const float m = fmaxf(tmax, __shfl_xor(tmax, 32, 64));           // all 64 codes of this wave's slice
+                const int rl = wr * 64 + tn * 32 + li;
+                // what the other code half of this block had reached a tile ago, and what the other code splits had published in
+                // the row's global word (any value ever written to either is <= the final maximum, stale reads included)
+                rm[tn] = fmaxf(fmaxf(rm[tn], m), fmaxf(s_rm[wc ^ 1][rl], seen[tn]));
+                if (lh == 0) {
+                    s_rm[wc][rl] = rm[tn];
+                    if (splits > 1 && rvalid[tn] && m > seen[tn]) atomicMax(&gmax[grow[tn]], ord_f32(rm[tn]));
+                }
                 const float thr = rm[tn] - ebound[tn];                            // NaN for rows without a bound
-                if (__any(tmax >= thr && rvalid[tn])) {                           // wave-uniform
+                if (__any(tmax >= thr)) {                                         // wave-uniform
 #pragma unroll
                     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const float a0 = acc[tm][tn][4 * q], a1 = acc[tm][tn][4 * q + 1], a2 = acc[tm][tn][4 * q + 2],
                                         a3 = acc[tm][tn][4 * q + 3];
-                            if (fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)) >= thr && rvalid[tn]) {
+                            if (fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)) >= thr) {
                                 const float av[4] = {a0, a1, a2, a3};
 #pragma unroll
                                 for (int e = 0; e < 4; ++e)
@@ -314,20 +323,23 @@ __global__ __launch_bounds__(256) void l2_screen_kernel(const float *__restrict_
             ks = 0;
             ++tile;
             if ((tile + 1) * nk < total) load_seeds(tile + 1);
+            if (splits > 1) {                                                     // what the other splits have reached: used at the next fold
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) seen[tn] = fmaxf(seen[tn], unord_f32(*reinterpret_cast<volatile const unsigned *>(gmax + grow[tn])));
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
-    // ---- list lengths (saturating) and the split's row maxima
+    // ---- list lengths (saturating) and the row maxima
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
         if (rvalid[tn]) cntb[lbase[tn] / SC_PL] = (unsigned char)(cnt[tn] > 255 ? 255 : cnt[tn]);
     __syncthreads();
-    if (tid < SC_RT && m0 + tid < n)
-        rmax[(m0 + tid) * splits + split] = fmaxf(fmaxf(s_rm[0][tid], s_rm[1][tid]), fmaxf(s_rm[2][tid], s_rm[3][tid]));
+    if (tid < SC_RT && m0 + tid < n) atomicMax(&gmax[m0 + tid], ord_f32(fmaxf(s_rm[0][tid], s_rm[1][tid])));
 }
 
-// ------------------------------------------------------------------------------------------ 2. re-rank, fallback
+// ------------------------------------------------------------------------------------------ 3. re-rank, fallback
 // dist(n,k) of the definition: the sequential f32 fma chain over d, then fmaf(-2, dot, cn).  One lane per pair.  The chain is
 // a dependent fma per element and the rows come from L2 / HBM with microseconds of latency, so the two rows are streamed
 // through a register ring of four stages of 16 floats each: 24 loads stay in flight while one stage's 16 chain steps run
@@ -392,7 +404,7 @@ __device__ __forceinline__ float exact_dist(const float *__restrict__ xr, const 
 // by the whole block, one after the other; (e) idx / best_dist.
 __global__ __launch_bounds__(256) void l2_rerank_kernel(const float *__restrict__ x, const float *__restrict__ cb, const float *__restrict__ cn,
                                                         const uint2 *__restrict__ cand, const unsigned char *__restrict__ cntb,
-                                                        const float *__restrict__ rmax, const float *__restrict__ bound, int64_t n, int k,
+                                                        const unsigned *__restrict__ gmax, const float *__restrict__ bound, int64_t n, int k,
                                                         int d, int splits, int32_t *__restrict__ idx, float *__restrict__ best_dist,
                                                         unsigned *__restrict__ exhaustive_rows)
 {
@@ -403,6 +415,7 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(const float *__restrict_
     __shared__ unsigned s_np;
     __shared__ uint2 s_pair[RR_CAP];
     __shared__ unsigned long long s_red[4];
+    __shared__ __attribute__((aligned(1024))) char s_ring[4 * 2 * RR_STAGE];      // per wave: two stages of (64 pairs x 128 B) x {code, x}
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t r0 = (int64_t)blockIdx.x * RR_ROWS;
     if (tid < RR_ROWS) {
@@ -410,7 +423,7 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(const float *__restrict_
         float g = -INFINITY, e = __builtin_nanf("");
         if (row < n) {
             e = bound[row];
-            for (int s = 0; s < splits; ++s) g = fmaxf(g, rmax[row * splits + s]);
+            g = unord_f32(gmax[row]);
         }
         s_thr[tid] = g - e;                          // NaN: no bound
         s_best[tid] = ~0ull;
@@ -419,37 +432,133 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(const float *__restrict_
     }
     if (tid == 0) s_np = 0u;
     __syncthreads();
-    // ---- (b) lists -> survivors.  One thread per (row, list), its <= SC_PL entries are 64 contiguous bytes
+    // ---- (b) lists -> survivors.  One thread per (row, list): the first two entries of every list are requested before any is
+    // looked at (lists hold 1-2 entries on average; a loop of dependent count -> entry loads per thread was 16 us of this kernel)
     const int lists = splits * SC_LISTS;
-    for (int i = tid; i < RR_ROWS * lists; i += 256) {
-        const int rl = i / lists, l = i - rl * lists;
-        const int64_t row = r0 + rl;
-        if (row >= n) continue;
-        const float thr = s_thr[rl];
-        if (!(thr == thr)) continue;
-        const int64_t L = row * lists + l;
-        const unsigned c = cntb[L];
-        if (c > (unsigned)SC_PL) {
-            s_exh[rl] = 1u;
-            continue;
+    for (int i0 = tid; i0 < RR_ROWS * lists; i0 += 4 * 256) {
+        int rl_[4], c_[4];
+        int64_t L_[4];
+        uint2 e0_[4], e1_[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * 256;
+            const bool v = i < RR_ROWS * lists;
+            rl_[u] = v ? i / lists : 0;
+            const int64_t row = r0 + rl_[u];
+            L_[u] = (v && row < n) ? row * lists + (i - rl_[u] * lists) : -1;
         }
-        for (unsigned j = 0; j < c; ++j) {
-            const uint2 ent = cand[L * SC_PL + j];
-            if (__builtin_bit_cast(float, ent.y) >= thr) {
-                const unsigned inrow = atomicAdd(&s_rowcnt[rl], 1u);
-                const unsigned pos = inrow < (unsigned)RR_PER_ROW ? atomicAdd(&s_np, 1u) : (unsigned)RR_CAP;
-                if (pos < (unsigned)RR_CAP) s_pair[pos] = make_uint2((unsigned)rl, ent.x);
-                else s_exh[rl] = 1u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c_[u] = L_[u] >= 0 ? (int)cntb[L_[u]] : 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            e0_[u] = c_[u] > 0 ? cand[L_[u] * SC_PL] : make_uint2(0u, 0u);
+            e1_[u] = c_[u] > 1 ? cand[L_[u] * SC_PL + 1] : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (c_[u] == 0) continue;
+            const int rl = rl_[u];
+            const float thr = s_thr[rl];
+            if (!(thr == thr)) continue;
+            if (c_[u] > SC_PL) {
+                s_exh[rl] = 1u;
+                continue;
+            }
+            for (int j = 0; j < c_[u]; ++j) {
+                const uint2 ent = j == 0 ? e0_[u] : j == 1 ? e1_[u] : cand[L_[u] * SC_PL + j];
+                if (__builtin_bit_cast(float, ent.y) >= thr) {
+                    const unsigned inrow = atomicAdd(&s_rowcnt[rl], 1u);
+                    const unsigned pos = inrow < (unsigned)RR_PER_ROW ? atomicAdd(&s_np, 1u) : (unsigned)RR_CAP;
+                    if (pos < (unsigned)RR_CAP) s_pair[pos] = make_uint2((unsigned)rl, ent.x);
+                    else s_exh[rl] = 1u;
+                }
             }
         }
     }
     __syncthreads();
-    // ---- (c) exact chains, one lane per survivor
-    const unsigned np = min(s_np, (unsigned)RR_CAP);
-    for (unsigned p = tid; p < np; p += 256) {
-        const uint2 pr = s_pair[p];
-        const float dist = exact_dist(x + (r0 + pr.x) * d, cb + (int64_t)pr.y * d, d, cn[pr.y]);
-        atomicMin(&s_best[pr.x], pack_di(dist, (int)pr.y));
+    // ---- (c) exact chains, one lane per survivor, operands staged through LDS by LDS-DMA.
+    // A lane that fetched its own two rows from global memory touched a different cache line per lane and instruction, each line
+    // four times (16 bytes at a time): 23-33 us at 16,384 rows - the texture addresser, not the chain, was the cost.  Here a wave
+    // stages 32 elements of the code row and of the x row of each of its 64 pairs per step: 8 + 8 instructions of 1 KB, 8 lanes on
+    // each pair's 128 bytes (whole lines), into a wave-private ring of two stages; the lane of pair p then reads its 128-byte
+    // slots back (16-byte parts XOR-swizzled with p & 7, applied to the per-lane SOURCE part as the DMA writes lane-linear) and
+    // runs the 32 chain steps while the next stage lands.  No block barrier: a wave waits for its own DMAs only.
+    {
+        const unsigned np = min(s_np, (unsigned)RR_CAP);
+        const __amdgpu_buffer_rsrc_t rcb = make_rsrc(cb, (size_t)k * d * 4);
+        const int64_t rows_here = n - r0 < RR_ROWS ? n - r0 : RR_ROWS;
+        const __amdgpu_buffer_rsrc_t rxb = make_rsrc(x + r0 * d, (size_t)rows_here * d * 4);
+        char *ring = s_ring + wave * (2 * RR_STAGE);
+        const int nch = (d + 31) >> 5;
+        const int sub = lane >> 3, part = (lane & 7) ^ (sub & 7);      // this lane's pair within a DMA instruction, logical 16-byte part
+        for (unsigned b0 = 0; b0 < np; b0 += 256) {                    // block-uniform
+            const unsigned pbase = b0 + wave * 64;
+            if (pbase >= np) continue;                                 // wave-uniform
+            // the 8 pairs this lane fetches for (instruction i covers pairs 8 i .. 8 i + 7 of the wave's 64)
+            unsigned coff[8], xoff[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const unsigned q = pbase + 8 * i + sub;
+                const uint2 pr = q < np ? s_pair[q] : make_uint2(0u, 0u);
+                coff[i] = q < np ? pr.y * (unsigned)d * 4u + (unsigned)part * 16u : OOB;
+                xoff[i] = q < np ? pr.x * (unsigned)d * 4u + (unsigned)part * 16u : OOB;
+            }
+            auto issue = [&](int ch) {
+                char *st = ring + (ch & 1) * RR_STAGE;
+                const bool pv = ch * 32 + part * 4 < d;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rcb, lds_ptr_s(st + i * 1024), 16,
+                                                             (pv && coff[i] != OOB) ? coff[i] + (unsigned)ch * 128u : OOB, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rxb, lds_ptr_s(st + 8192 + i * 1024), 16,
+                                                             (pv && xoff[i] != OOB) ? xoff[i] + (unsigned)ch * 128u : OOB, 0, 0, 0);
+            };
+            const unsigned me = pbase + lane;
+            const uint2 mine = me < np ? s_pair[me] : make_uint2(0u, 0u);
+            float acc = 0.f;
+            issue(0);
+            // No branch inside the loop: at the join of a branch the compiler drains its wait counters (vmcnt(0) in front of every
+            // LDS read - measured: 30-56 us for this kernel, every stage paying the full DMA latency).  So the DMA of stage
+            // ch + 1 is issued unconditionally (past the end of the rows its offsets are out of range: it writes zeros into the
+            // free stage) and all eight 16-byte parts are chained unconditionally: parts past d are zeros on both sides, and
+            // fma(0, 0, acc) == acc.
+            for (int ch = 0; ch < nch; ++ch) {
+                issue(ch + 1);
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                 // stage ch landed, ch + 1 in flight
+                // LDS reads as inline asm: in front of a C++ load from LDS the compiler waits for EVERY LDS-DMA in flight
+                // (vmcnt(0) - it cannot tell the landed stage from the one just requested), which made every stage pay the whole DMA
+                // latency (30-56 us for this kernel).  The wait that matters is the counted one above.
+                const unsigned sb = (unsigned)reinterpret_cast<uintptr_t>(ring + (ch & 1) * RR_STAGE + lane * 128);
+                f32x4v c4[8], x4[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned a = sb + (unsigned)((j ^ (lane & 7)) << 4);
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(c4[j]) : "v"(a));
+                    asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(x4[j]) : "v"(a));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(c4[0]), "+v"(c4[1]), "+v"(c4[2]), "+v"(c4[3]), "+v"(c4[4]), "+v"(c4[5]), "+v"(c4[6]), "+v"(c4[7]),
+                               "+v"(x4[0]), "+v"(x4[1]), "+v"(x4[2]), "+v"(x4[3]), "+v"(x4[4]), "+v"(x4[5]), "+v"(x4[6]), "+v"(x4[7])
+                             :
+                             : "memory");
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    acc = __fmaf_rn(x4[j][0], c4[j][0], acc);
+                    acc = __fmaf_rn(x4[j][1], c4[j][1], acc);
+                    acc = __fmaf_rn(x4[j][2], c4[j][2], acc);
+                    acc = __fmaf_rn(x4[j][3], c4[j][3], acc);
+                }
+                // (the reads above are back - their values were just used - before the next iteration's DMA overwrites this stage)
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the trailing zero-fill must not outlive the batch
+            if (me < np) {
+                float dist = __fmaf_rn(-2.0f, acc, cn[mine.y]);
+                dist = dist != dist ? -INFINITY : dist;
+                atomicMin(&s_best[mine.x], pack_di(dist, (int)mine.y));
+            }
+        }
     }
     __syncthreads();
     // ---- (d) exhaustive rows (block-uniform loop)
@@ -486,7 +595,7 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(const float *__restrict_
 
 struct ScreenLayout {              // byte offsets inside the prepared-codebook blob and the workspace
     size_t cn, cnh, cmax2, ch, blob;
-    size_t cand, cntb, rmax, bound, counters, ws;
+    size_t cand, cntb, gmax, bound, counters, xh, ws;
     int k_pad, splits, tiles_per_split;
 };
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -499,10 +608,11 @@ static ScreenLayout screen_layout(int64_t n, int k, int d)
     L.cmax2 = L.cnh + al256((size_t)L.k_pad * 4);
     L.ch = L.cmax2 + 256;
     L.blob = L.ch + al256((size_t)k * d * 2);
-    // code splits: one block per CU and round when the rows alone do not fill the chip (a block keeps 64 rows of x resident)
+    // code splits: one round of 2 blocks per CU (every block of a launch has the same work); fewer splits = longer private lists
+    // of one running maximum each, i.e. less over-collection
     const int64_t row_tiles = cdiv(n > 0 ? n : 1, SC_RT);
     const int ntiles = (int)cdiv(k, SC_CT);
-    int splits = (int)cdiv(256, row_tiles);
+    int splits = (int)cdiv(512, row_tiles);
     if (splits > ntiles) splits = ntiles;
     if (splits < 1) splits = 1;
     L.tiles_per_split = (int)cdiv(ntiles, splits);
@@ -510,9 +620,10 @@ static ScreenLayout screen_layout(int64_t n, int k, int d)
     size_t o = 0;
     L.cand = o; o += al256((size_t)n * L.splits * SC_LISTS * SC_PL * 8);
     L.cntb = o; o += al256((size_t)n * L.splits * SC_LISTS);
-    L.rmax = o; o += al256((size_t)n * L.splits * 4);
+    L.gmax = o; o += al256((size_t)n * 4);
     L.bound = o; o += al256((size_t)n * 4);
     L.counters = o; o += 256;
+    L.xh = o; o += al256((size_t)n * d * 2);
     L.ws = o;
     return L;
 }
@@ -523,8 +634,8 @@ using namespace mq;
 
 static bool screen_shape_ok(int64_t n, int k, int d)
 {
-    // d <= 512: the block's x image (64 rows x d bf16) stays resident in LDS next to the two code stages
-    return n >= 0 && n < ((int64_t)1 << 31) && k > 0 && d > 0 && d % 8 == 0 && d <= 512 && (int64_t)k * d * 4 < 0xFFFFFFF0ll;
+    return n >= 0 && n < ((int64_t)1 << 31) && k > 0 && d > 0 && d % 8 == 0 && (int64_t)SC_RT * d * 2 < 0x7FFFFFF0ll &&
+           (int64_t)k * d * 4 < 0xFFFFFFF0ll;
 }
 
 extern "C" int mq_l2_screen_supported(int64_t n, int k, int d) { return screen_shape_ok(n, k, d) ? 1 : 0; }
@@ -539,7 +650,7 @@ extern "C" size_t mq_l2_screen_workspace(int64_t n, int k, int d)
 extern "C" int mq_l2_screen_prepare(const float *codebook, int k, int d, void *prepared, mqStream stream)
 {
     MQ_REQUIRE(codebook && prepared, "mq_l2_screen_prepare: null pointer");
-    MQ_REQUIRE(screen_shape_ok(0, k, d), "mq_l2_screen_prepare: need k > 0, d %% 8 == 0, d <= 512, k * d * 4 < 4 GiB (k=%d, d=%d)", k, d);
+    MQ_REQUIRE(screen_shape_ok(0, k, d), "mq_l2_screen_prepare: need k > 0, d %% 8 == 0, k * d * 4 < 4 GiB (k=%d, d=%d)", k, d);
     MQ_REQUIRE((uintptr_t)codebook % 16 == 0 && (uintptr_t)prepared % 256 == 0, "mq_l2_screen_prepare: alignment (codebook 16, blob 256)");
     const ScreenLayout L = screen_layout(0, k, d);
     char *b = reinterpret_cast<char *>(prepared);
@@ -573,20 +684,15 @@ extern "C" int mq_l2_argmin_screened(const float *x, const float *codebook, cons
     char *w = reinterpret_cast<char *>(workspace);
     uint2 *cand = reinterpret_cast<uint2 *>(w + L.cand);
     unsigned char *cntb = reinterpret_cast<unsigned char *>(w + L.cntb);
-    float *rmax = reinterpret_cast<float *>(w + L.rmax);
+    unsigned *gmax = reinterpret_cast<unsigned *>(w + L.gmax);
     float *bound = reinterpret_cast<float *>(w + L.bound);
     unsigned *counters = reinterpret_cast<unsigned *>(w + L.counters);
     hipStream_t st = S(stream);
-    const dim3 grid((unsigned)cdiv(n, SC_RT), (unsigned)L.splits);
-    const int nk = (d + 63) / 64;
-#define MQ_SCREEN(NK_) hipLaunchKernelGGL((l2_screen_kernel<NK_>), grid, dim3(256), 0, st, x, ch, cnh, cmax2, n, k, d, L.tiles_per_split, \
-                                          L.splits, cand, cntb, rmax, bound, counters)
-    if (nk <= 1) MQ_SCREEN(1);
-    else if (nk <= 2) MQ_SCREEN(2);
-    else if (nk <= 4) MQ_SCREEN(4);
-    else MQ_SCREEN(8);
-#undef MQ_SCREEN
-    hipLaunchKernelGGL(l2_rerank_kernel, dim3((unsigned)cdiv(n, RR_ROWS)), dim3(256), 0, st, x, codebook, cn, cand, cntb, rmax, bound, n, k, d,
+    unsigned short *xh = reinterpret_cast<unsigned short *>(w + L.xh);
+    hipLaunchKernelGGL(l2_screen_prep_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, st, x, n, d, xh, cmax2, bound, gmax, counters);
+    hipLaunchKernelGGL(l2_screen_kernel, dim3((unsigned)cdiv(n, SC_RT), (unsigned)L.splits), dim3(256), 0, st, xh, ch, cnh, bound, n, k, d,
+                       L.tiles_per_split, L.splits, cand, cntb, gmax);
+    hipLaunchKernelGGL(l2_rerank_kernel, dim3((unsigned)cdiv(n, RR_ROWS)), dim3(256), 0, st, x, codebook, cn, cand, cntb, gmax, bound, n, k, d,
                        L.splits, idx, best_dist, counters);
     MQ_LAUNCH_CHECK("mq_l2_argmin_screened");
     return 0;

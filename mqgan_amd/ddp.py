@@ -10,6 +10,13 @@ Design (MI355X-first, not a port of torch DDP):
     accumulated (post-accumulate-grad hooks, i.e. while backward is still running; the collective
     runs on the process group's own HIP stream), and waits for all of them before the clip/Adam
     kernels read the arena;
+  * the buckets TAPER towards the front of the arena (r5): the gradients of the first-registered
+    layers become ready when backward ends, so whatever is still queued on the collective stream at
+    that moment is exposed - no compute is left to hide it.  A bucket therefore takes at most half
+    of what remains in front of it (never more than ``bucket_bytes``, never less than
+    ``tail_bytes`` = 1 MiB): ..., 32, 16, 8, 4, 2, 1 MiB.  The last-ready bucket is the smallest,
+    and the ones launched in the last stretch of backward shrink with the time left to hide them
+    (r4 cut equal 32 MiB buckets and left the remainder - 9.4 MiB for the generator - to the end);
   * parameters that never receive a gradient (``hidden_proj.*``: its only consumer is detached,
     reference preencoder.py:413-415) do not block a bucket: whatever is still pending is flushed by
     ``finish()``.
@@ -141,7 +148,7 @@ class FlatArena:
 
 class GradReducer:
     def __init__(self, arena: FlatArena, process_group=None, bucket_bytes: int = 32 << 20, average: bool = False, comm=None,
-                 force: bool = False):
+                 force: bool = False, tail_bytes: int = 1 << 20):
         """``force``: hooks, per-bucket arena fill and asynchronous all-reduces even in a process group of ONE rank (the sum
         is then the identity) - lets a one-GPU box execute the production RCCL path end to end."""
         self.arena = arena
@@ -155,16 +162,21 @@ class GradReducer:
         self.bucket_members = []               # positions in arena.params, per bucket
         self.param_bucket = {}
         cap = max(1, bucket_bytes // 4)
+        floor = max(1, min(cap, tail_bytes // 4))
         end = arena.numel
         cur_start, members = end, []
         index_of = {id(p): i for i, p in enumerate(arena.params)}
         self._index_of = index_of
+        # tapering: a bucket that ends at `end` closes once it holds min(cap, max(floor, end / 2)) elements - half of what is
+        # left in front of it (the arena starts at 0), so the bucket sizes fall geometrically towards the last-ready gradients
+        want = min(cap, max(floor, end // 2))
         for p, o in reversed(list(zip(arena.params, arena.offsets))):
             cur_start = o
             members.append(p)
-            if end - cur_start >= cap:
+            if end - cur_start >= want:
                 self._add_bucket(cur_start, end, members)
                 end, members = cur_start, []
+                want = min(cap, max(floor, end // 2))
         if members:
             self._add_bucket(cur_start, end, members)
         self._pending = [0] * len(self.buckets)
@@ -199,6 +211,23 @@ class GradReducer:
         self._pending = [n for (_, _, n) in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._handles = []
+        self._last_launch_event = None
+
+    def tail_ms(self) -> float:
+        """Mean time on the compute stream between the launch of a step's LAST bucket (its gradients had just become ready) and the
+        end of finish()'s waits - what clip / Adam waited for behind the end of backward.  Measured while the communicator's
+        StallClock is enabled; synchronises; resets."""
+        pairs, self._tail_pairs = getattr(self, "_tail_pairs", []), []
+        if not pairs:
+            return 0.0
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in pairs) / len(pairs)
+
+    @property
+    def last_bucket_bytes(self) -> int:
+        """Size of the bucket whose gradients are ready last (the front of the arena)."""
+        s, e, _ = self.buckets[-1]
+        return 4 * (e - s)
 
     def _launch(self, b):
         s, e, _ = self.buckets[b]
@@ -208,6 +237,10 @@ class GradReducer:
             print(f"[ddp rank {dist.get_rank(self.pg)}] launch bucket {b} of {len(self.buckets)} [{s}:{e}) from "
                   f"{threading.current_thread().name}", file=sys.stderr, flush=True)
         self.arena.gather(self.bucket_members[b])      # gather mode: the bucket's gradients move into the arena now
+        if self.clock is not None and self.clock.enabled and self.arena.flat_grad.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)   # overwritten by every launch: what is left is the step's last one
+            ev.record()
+            self._last_launch_event = ev
         if self._drain_first:
             torch.cuda.current_stream().synchronize()
         if self._blocking:
@@ -248,6 +281,13 @@ class GradReducer:
                 import sys
                 print(f"[ddp rank {dist.get_rank(self.pg)}] handle {i} of {len(self._handles)} done", file=sys.stderr, flush=True)
         self._handles = []
+        if getattr(self, "_last_launch_event", None) is not None:
+            done = torch.cuda.Event(enable_timing=True)
+            done.record()
+            if not hasattr(self, "_tail_pairs"):
+                self._tail_pairs = []
+            self._tail_pairs.append((self._last_launch_event, done))
+            self._last_launch_event = None
         if self.average:
             self.arena.flat_grad.mul_(1.0 / self.world)
 

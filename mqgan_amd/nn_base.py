@@ -174,13 +174,74 @@ def conv1d(x: torch.Tensor, p: ConvParams, causal: bool, dilation: int = 1) -> t
     return ops.conv(x.view(B, 1, T, cin), w_krsc, w_crsk, p.bias, d).view(B, T, p.cout)
 
 
+def pad_channels(c: int) -> int:
+    """Channel count a tensor of ``c`` channels is STORED with inside the bf16-storage refiner: the next multiple of 64 when c is
+    a multiple of 16 above 64 that is not one already (hifimusic's 96-channel level -> 128), else c.  The bf16-storage kernels
+    walk the reduction in 64-channel chunks whose pixels are whole 128-byte lines; with 96 channels they fall back to 32-channel
+    chunks (half lines, two taps per K-step) and ran at 0.16-0.26 of the bf16 peak (profiles/r4_c3_*).  The extra channels hold
+    zeros: zero filter rows produce them, APTx(0) = 0 and dropout keep them, zero filter columns ignore them - the level costs
+    a third more multiplications and runs 1.6x faster for it."""
+    if ops.ACT_BF16 and ops.H2_PAD_CHANNELS and c > 64 and c % 16 == 0 and c % 64 != 0:
+        return (c + 63) // 64 * 64
+    return c
+
+
+def _pad_filters(w_krsc, w_crsk, bias, cin_segments, cout_pad):
+    """Zero-padded copies of the effective filters: input channels segment by segment ((real, stored) pairs in tensor order - a
+    concatenated input has one pair per part), output channels at the end.  KRSC rows are channel-blocked [C / 16][RS][16] and CRSK
+    rows [K / 16][RS][16], so whole 16-channel blocks of zeros go in; autograd slices the padded weight gradient back."""
+    K, RS, C = w_krsc.shape
+    assert sum(r for r, _ in cin_segments) == C and all(r % 16 == 0 and s % 16 == 0 for r, s in cin_segments if s != r)
+    Cp = sum(s for _, s in cin_segments)
+    wk = w_krsc.view(K, C // 16, RS, 16) if Cp != C else w_krsc
+    if Cp != C:
+        parts, pos = [], 0
+        for real, stored in cin_segments:
+            parts.append(wk[:, pos // 16:(pos + real) // 16])
+            if stored > real:
+                parts.append(wk.new_zeros(K, (stored - real) // 16, RS, 16))
+            pos += real
+        wk = torch.cat(parts, 1).reshape(K, RS, Cp)
+    if cout_pad > K:
+        wk = torch.cat([wk, wk.new_zeros(cout_pad - K, RS, Cp)], 0)
+    wc = None
+    if w_crsk is not None:
+        wc = w_crsk
+        if cout_pad > K:
+            assert K % 16 == 0 and cout_pad % 16 == 0
+            wc = torch.cat([wc.view(C, K // 16, RS, 16), wc.new_zeros(C, (cout_pad - K) // 16, RS, 16)], 1).reshape(C, RS, cout_pad)
+        if Cp != C:
+            parts, pos = [], 0
+            for real, stored in cin_segments:
+                parts.append(wc[pos:pos + real])
+                if stored > real:
+                    parts.append(wc.new_zeros(stored - real, RS, wc.shape[2]))
+                pos += real
+            wc = torch.cat(parts, 0)
+        wc = wc.contiguous()
+    b = bias
+    if bias is not None and cout_pad > K:
+        b = torch.cat([bias, bias.new_zeros(cout_pad - K)])
+    return wk.contiguous(), wc, b
+
+
 def conv2d(x: torch.Tensor, p: ConvParams, stride=(1, 1), pad: Optional[Tuple[int, int]] = None, need_dx: bool = True,
-           power_iteration: bool = False) -> torch.Tensor:
-    """x (N, H, W, Cin) -> (N, P, Q, Cout), padding (k-1)//2 per dim unless given."""
+           power_iteration: bool = False, cin_segments=None, cout_pad: Optional[int] = None) -> torch.Tensor:
+    """x (N, H, W, Cin) -> (N, P, Q, Cout), padding (k-1)//2 per dim unless given.
+
+    ``cin_segments`` / ``cout_pad`` (pad_channels): x is stored with more channels than the layer has - zeros - and / or the
+    output is to be: the filters are zero-padded to match ((real, stored) pairs per part of x, in order)."""
     N, H, W, cin = x.shape
     kh, kw = p.ksize
     if pad is None:
         pad = ((kh - 1) // 2, (kw - 1) // 2)
     w_krsc, w_crsk = p.effective(need_crsk=need_dx, power_iteration=power_iteration)
-    d = ops.conv_desc(N, H, W, cin, p.cout, kh, kw, stride=tuple(stride), pad=pad)
-    return ops.conv(x, w_krsc, w_crsk, p.bias, d)
+    bias, cout = p.bias, p.cout
+    if cin_segments is not None or (cout_pad is not None and cout_pad != p.cout):
+        segs = cin_segments if cin_segments is not None else [(p.cin, p.cin)]
+        cout = cout_pad if cout_pad is not None else p.cout
+        if any(r != s for r, s in segs) or cout != p.cout:
+            w_krsc, w_crsk, bias = _pad_filters(w_krsc, w_crsk, bias, segs, cout)
+        assert sum(s for _, s in segs) == cin, (segs, cin)
+    d = ops.conv_desc(N, H, W, cin, cout, kh, kw, stride=tuple(stride), pad=pad)
+    return ops.conv(x, w_krsc, w_crsk, bias, d)

@@ -168,6 +168,9 @@ class conv_precision:
 # two convolutions is a bf16 tensor - what the reference's autocast region stores (train.py:220, 523) - and the layers
 # whose shapes allow it run on the LDS-DMA kernels of csrc/igemm_h2.hip.  Off by default (f32 tensors everywhere).
 ACT_BF16 = False
+# inside the bf16-storage refiner, tensors whose channel count is a multiple of 16 above 64 but not of 64 are stored zero-padded
+# to the next multiple of 64 (nn_base.pad_channels); MQGAN_H2_PAD=0 switches it off for A/B runs
+H2_PAD_CHANNELS = os.environ.get("MQGAN_H2_PAD", "1") != "0"
 # what the caller asked for (Trainer: training.precision == "bf16"); the modules that support bf16 storage (UNetRefiner,
 # the discriminators) switch ACT_BF16 on for their own body and hand f32 tensors back at their boundary
 ACT_BF16_REQUESTED = False
@@ -1548,7 +1551,7 @@ def l2_argmin_screened(x: torch.Tensor, codebook: torch.Tensor, prepared: Option
 
 
 def l2_screen_stats(workspace: torch.Tensor, n, k, d):
-    """(candidates appended, slots available, rows that overflowed their slots) of the last screened search on
+    """(list entries appended, list entries available, rows searched exhaustively) of the last screened search on
     ``workspace``; synchronises the stream."""
     import ctypes as _C
     a, sl, ov = _C.c_uint64(0), _C.c_uint64(0), _C.c_uint64(0)

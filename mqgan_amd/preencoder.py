@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from . import ops
 from .attentions import APTx, ResidualBlock1D
-from .nn_base import ConvParams, conv2d, linear
+from .nn_base import ConvParams, conv2d, linear, pad_channels
 from .quantizer import FSQ
 
 
@@ -43,17 +43,19 @@ class ConvBlock(nn.Module):
         self.p_drop = dropout
         self.match = c_in == c_out
 
-    def forward(self, x, mask, input_is_masked=False, need_dx=True):
-        """x (N, T, F, C); mask uint8 (N, T)."""
+    def forward(self, x, mask, input_is_masked=False, need_dx=True, cin_segments=None):
+        """x (N, T, F, C); mask uint8 (N, T).  With bf16 storage the block's tensors may carry zero channels beyond the layer's
+        own (nn_base.pad_channels): ``cin_segments`` = (real, stored) channels per part of x, the output has pad_channels(c_out)."""
         Fq = x.shape[2]
         dmap = (Fq, 1, 1)
         b, g = self.act.params()
         x = ops.to_storage(x)                                      # bf16 tensors between the convs when storage is on
         if not input_is_masked:
             x = ops.pointwise(x, mask=mask, mask_post=True, dmap=dmap)
-        y = ops.to_storage(conv2d(x, self.conv1, need_dx=need_dx))
+        cp = pad_channels(self.conv1.cout)
+        y = ops.to_storage(conv2d(x, self.conv1, need_dx=need_dx, cin_segments=cin_segments, cout_pad=cp))
         y = ops.pointwise(y, act=ops.ACT_APTX, beta=b, gamma=g, p_drop=self.p_drop, training=self.training)
-        y = ops.to_storage(conv2d(y, self.conv2))
+        y = ops.to_storage(conv2d(y, self.conv2, cin_segments=[(self.conv2.cin, cp)], cout_pad=cp))
         return ops.pointwise(y, act=ops.ACT_APTX, beta=b, gamma=g, p_drop=self.p_drop, training=self.training,
                              r_post=x if self.match else None, mask=mask, mask_post=True, dmap=dmap)
 
@@ -67,13 +69,14 @@ class DownBlock(nn.Module):
         m = ops.mask_pool(mask, 2, ceil_mode=False)                # padding stays padded (:63-65)
         fused = ops.mask_fusable(x.shape[-1])                      # the block's entry masked_fill rides on the pooling pass
         x = ops.AvgPoolT2Fn.apply(x, m if fused else None)         # time / 2 (preencoder.py:108)
-        return self.conv(x, m, input_is_masked=fused), m
+        return self.conv(x, m, input_is_masked=fused, cin_segments=[(self.conv.conv1.cin, x.shape[-1])]), m
 
 
 class UpBlock(nn.Module):
     def __init__(self, c_in, c_skip, c_out):
         super().__init__()
         self.conv = ConvBlock(c_in + c_skip, c_out)
+        self.c_in, self.c_skip = c_in, c_skip
 
     def forward(self, x, skip, mask):
         m = ops.mask_upsample2(mask)                               # :68-70
@@ -82,8 +85,9 @@ class UpBlock(nn.Module):
         if dt > 0:                                                 # crop_to_match (:73-82); never hit when T % 2^depth == 0
             skip = skip[:, dt // 2: dt // 2 + t_up].contiguous()
         fused = ops.mask_fusable(x.shape[-1], skip.shape[-1])
+        segs = [(self.c_in, x.shape[-1]), (self.c_skip, skip.shape[-1])]       # either part may be stored zero-padded
         x = ops.UpCatFn.apply(x, skip, m if fused else None)       # nearest x2 in time + channel concat (:124-129), masked
-        return self.conv(x, m, input_is_masked=fused), m
+        return self.conv(x, m, input_is_masked=fused, cin_segments=segs), m
 
 
 class UNetRefiner(nn.Module):
@@ -123,11 +127,11 @@ class UNetRefiner(nn.Module):
         for down in self.downs:
             skips.append(x)
             x, cur = down(x, cur)
-        x = self.mid(x, cur, input_is_masked=True)
+        x = self.mid(x, cur, input_is_masked=True, cin_segments=[(self.mid.conv1.cin, x.shape[-1])])
         for up in self.ups:
             x, cur = up(x, skips.pop(), cur)
         # x is already masked with `cur` by the last block, so apply_mask(x, cur_mask) (:191) is a no-op
-        out = ops.to_f32(conv2d(x, self.post)).view(B, T0 + pad, Fq)
+        out = ops.to_f32(conv2d(x, self.post, cin_segments=[(self.post.cin, x.shape[-1])])).view(B, T0 + pad, Fq)
         if pad:
             out = out[:, :T0].contiguous()
         out = ops.pointwise(out, mask=x_mask, mask_post=True)      # (:197-198)

@@ -41,7 +41,7 @@ def _worker(rank, world, port, out_q, gather=False):
         net = Net()
         arena = FlatArena([net], gather=gather)
         broadcast_arena(arena)
-        red = GradReducer(arena, bucket_bytes=1024)  # several buckets
+        red = GradReducer(arena, bucket_bytes=1024, tail_bytes=64)  # several buckets, tapering towards the front of the arena
         assert len(red.buckets) >= 3
         launched_during_backward = []
         orig = red._launch
@@ -105,6 +105,32 @@ def test_bucketed_allreduce_world2(gather):
     i = [id(p) for p in arena.params].index(id(net.unused.weight))
     o = arena.offsets[i]
     assert float(g0[0][o:o + net.unused.weight.numel()].abs().max()) == 0.0
+
+
+def test_buckets_taper_towards_the_last_ready_gradients():
+    """Bucket geometry (pure host logic): the buckets tile the gradient arena without gaps in reverse registration order, none is
+    larger than the cap plus one tensor, each closes at half of what is left in front of it, and the bucket at the FRONT of the
+    arena - the first layers, whose gradients are ready when backward ends, so its all-reduce is never hidden - is the smallest."""
+    from mqgan_amd.ddp import FlatArena, GradReducer
+    net = torch.nn.Sequential(*[torch.nn.Linear(64, 64) for _ in range(40)])           # 40 x (4096 + 64) floats = 166,400
+    arena = FlatArena([net])
+    cap, tail = 16384 * 4, 1024 * 4                                                    # bytes
+    red = GradReducer(arena, bucket_bytes=cap, tail_bytes=tail)
+    sizes = [e - s for (s, e, _) in red.buckets]
+    assert red.buckets[0][1] == arena.numel and red.buckets[-1][0] == 0
+    for (s0, _, _), (_, e1, _) in zip(red.buckets, red.buckets[1:]):
+        assert e1 == s0                                                                # contiguous, back to front
+    biggest = 4096
+    assert max(sizes) <= cap // 4 + biggest
+    for (s, e, _), n in zip(red.buckets[:-1], sizes):
+        want = min(cap // 4, max(tail // 4, e // 2))
+        assert want <= n <= want + biggest, (s, e, n, want)
+    assert sizes[-1] == min(sizes) and sizes[-1] <= tail // 4 + biggest, sizes
+    assert red.last_bucket_bytes == 4 * sizes[-1]
+    assert sum(len(m) for m in red.bucket_members) == len(arena.params)
+    # r4's geometry for comparison: equal caps leave an arbitrary remainder to the end
+    flat = GradReducer(arena, bucket_bytes=cap, tail_bytes=cap)
+    assert len(red.buckets) > len(flat.buckets)
 
 
 def test_arena_survives_load_state_dict_and_zero_grad():

@@ -254,3 +254,49 @@ def test_bf16_storage_train_step_tracks_fp32(env, use_fm):
         for k in ("loss_d", "loss_g_total", "loss_recon_pre", "loss_recon_post", "loss_gan") + (("loss_fm",) if use_fm else ()):
             np.testing.assert_allclose(a[k], b[k], rtol=3e-2, atol=1e-4, err_msg=f"step {s_} {k}")
         np.testing.assert_allclose([a["ng"], a["nd"]], [b["ng"], b["nd"]], rtol=6e-2, err_msg=f"step {s_} norms")
+
+
+def test_bf16_refiner_zero_padded_channel_storage(env, monkeypatch):
+    """hifimusic's refiner has a 96-channel level (reference preencoder.py:134-202 with refiner_base_channels 96): under bf16
+    storage its tensors are kept with 128 channels, the last 32 zero (nn_base.pad_channels), so that the bf16-storage kernels
+    walk 64-channel chunks of whole 128-byte lines.  The padded run must equal the unpadded one up to the bf16 rounding both
+    carry (same products, another summation order), in the output and in EVERY parameter gradient; both must track the f32
+    refiner; and the padded run must really have taken the 64-channel-chunk kernels on that level."""
+    ops = env
+    from mqgan_amd.preencoder import UNetRefiner
+    torch.manual_seed(0)
+    m = UNetRefiner(1, base_ch=96, depth=2, dropout=0.1, input_out_channels=[40, 32]).to(DEV).eval()
+    B, T, Fq = 2, 64, 40
+    x = torch.randn(B, T, Fq, 1, device=DEV)
+    mask = torch.zeros(B, T, dtype=torch.uint8, device=DEV)
+    mask[1, 45:] = 1
+    r = torch.randn(B, T, 32, device=DEV)
+    runs = {}
+    for tag, storage, pad in (("f32", False, True), ("padded", True, True), ("unpadded", True, False)):
+        monkeypatch.setattr(ops, "H2_PAD_CHANNELS", pad)
+        for p in m.parameters():
+            p.grad = None
+        timer = ops.KernelTimer()
+        ops.TIMER = timer
+        try:
+            with ops.conv_precision("bf16" if storage else "f32"), ops.request_act_storage(storage):
+                out = m(x, mask)
+                (out * r).sum().backward()
+        finally:
+            ops.TIMER = None
+        torch.cuda.synchronize()
+        runs[tag] = (out.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None},
+                     set(timer.summary().keys()))
+    assert runs["padded"][0].shape == runs["f32"][0].shape == (B, T, 32)
+    assert len(runs["padded"][1]) == len(runs["f32"][1]) > 20
+    assert_rel(runs["padded"][0], runs["unpadded"][0], 1e-2, "output, padded vs unpadded storage")
+    assert_rel(runs["padded"][0], runs["f32"][0], 3e-2, "output, padded bf16 vs f32")
+    for k, gref in runs["f32"][1].items():
+        if float(gref.norm()) == 0.0:
+            continue
+        assert tuple(runs["padded"][1][k].shape) == tuple(gref.shape), k              # gradients come back in the layer's own shape
+        assert_rel(runs["padded"][1][k], runs["unpadded"][1][k], 3e-2, f"grad {k}, padded vs unpadded storage")
+        assert_rel(runs["padded"][1][k], gref, 6e-2, f"grad {k}, padded bf16 vs f32")
+    chunk32 = lambda names: {n for n in names if n.startswith("conv_h2_kernel<") and ", 32, " in n}
+    assert chunk32(runs["unpadded"][2]), runs["unpadded"][2]                          # 96 channels: 32-channel chunks
+    assert not chunk32(runs["padded"][2]), runs["padded"][2]                          # 128 stored channels: 64-channel chunks only
