@@ -540,6 +540,14 @@ int mq_multi_gather(const int64_t *table_dev, int n_tensors, int64_t total_block
  * the stream (what the data-parallel gradient exchange uses; train.py:140-197 makes shapes, hence addresses, vary per step). */
 int mq_multi_gather_args(const int64_t *table_host, int n_tensors, float *dst, mqStream stream);
 
+/* PROTOTYPE (csrc/winofused.hip, tools/winofused_micro.py; never chosen by mq_conv_plan): the 3x3 / stride-1 / pad-1 convolution
+ * of the refiner's 64-channel level (preencoder.py:86-102) as F(4x5, 3x3) in ONE kernel - input transform in the MFMA's operand
+ * registers, all 42 positions of a tile in one lane's accumulators, output transform lane-local; no V / M tensors in HBM.  U: the
+ * transformed filters of mq_winon_weight_transform(w_krsc, K, C, 0, U, 4, 5); Ut: scratch of 42 * C * K floats; K % 16 == 0,
+ * K <= 64, C % 4 == 0. */
+int mq_winofused_fprop(const float *x, const float *U, const float *bias, int N, int H, int W, int C, int K, float *Ut, float *y,
+                       mqStream stream);
+
 /* ------------------------------------------------------------------ algorithm choice and planned execution (csrc/plan.cpp)
  * WHICH form a convolution layer takes is decided behind this ABI: direct implicit GEMM, or one of the reduced-multiplication
  * forms above and below - by the rule the Python package applies itself (mqgan_amd.ops calls mq_conv_plan; there is one copy of

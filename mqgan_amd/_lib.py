@@ -191,6 +191,7 @@ SIGNATURES = {
     "mq_conv_plan": (_I, [C.POINTER(ConvDesc), _I, C.POINTER(PlanCfg), C.POINTER(ConvPlan)]),
     "mq_conv_fprop_planned": (_I, [C.POINTER(ConvPlan), _P, _P, _P, _I, _F, _P, _L, _L, _L, _P, _P, _P, _Z, _P]),
     "mq_conv_backward_planned": (_I, [C.POINTER(ConvPlan), _P, _P, _P, _P, _P, _P, _F, _P, _L, _L, _L, _P, _P, _P, _P, _Z, _P]),
+    "mq_winofused_fprop": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "mq_set_launch_hook": (None, [LaunchHook]),
     "mq_set_pass_hook": (None, [PassHook]),
     "mq_sumsq": (_I, [_P, _L, _P, _P, _P]),

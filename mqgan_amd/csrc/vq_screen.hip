@@ -63,7 +63,8 @@ constexpr int SC_LISTS = 4;           // private lists per (row, code split): 2 
 constexpr int SC_PL = 16;             // entries per private list (64 bytes would overflow once per ~10^4 rows at 8192 codes); a longer list sends its row to the exhaustive search
 constexpr int RR_ROWS = 64;           // rows per re-rank block
 constexpr int RR_CAP = 1024;          // survivors a re-rank block holds
-constexpr int RR_STAGE = 2 * 64 * 128;  // one stage of a wave's staging ring: 64 pairs x 32 f32 of the code row + of the x row
+constexpr int RR_STAGE = 2 * 64 * 64;   // one stage of a wave's staging ring: 64 pairs x 16 f32 of the code row + of the x row
+constexpr int RR_NS = 4;                // ring depth (a power of two)
 constexpr int RR_PER_ROW = 16;        // ... and per row; rows with more are searched exhaustively
 
 __device__ __forceinline__ unsigned ord_f32(float v)
@@ -409,35 +410,31 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(const float *__restrict_
                                                         unsigned *__restrict__ exhaustive_rows)
 {
     __shared__ unsigned long long s_best[RR_ROWS];
-    __shared__ float s_thr[RR_ROWS];
     __shared__ unsigned s_rowcnt[RR_ROWS];
     __shared__ unsigned s_exh[RR_ROWS];
     __shared__ unsigned s_np;
+    __shared__ unsigned long long s_todo;
     __shared__ uint2 s_pair[RR_CAP];
     __shared__ unsigned long long s_red[4];
-    __shared__ __attribute__((aligned(1024))) char s_ring[4 * 2 * RR_STAGE];      // per wave: two stages of (64 pairs x 128 B) x {code, x}
+    __shared__ __attribute__((aligned(1024))) char s_ring[4 * RR_NS * RR_STAGE];  // per wave: four stages of (64 pairs x 64 B) x {code, x}
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t r0 = (int64_t)blockIdx.x * RR_ROWS;
     if (tid < RR_ROWS) {
-        const int64_t row = r0 + tid;
-        float g = -INFINITY, e = __builtin_nanf("");
-        if (row < n) {
-            e = bound[row];
-            g = unord_f32(gmax[row]);
-        }
-        s_thr[tid] = g - e;                          // NaN: no bound
         s_best[tid] = ~0ull;
         s_rowcnt[tid] = 0u;
-        s_exh[tid] = (row < n && !(g - e == g - e)) ? 1u : 0u;
+        s_exh[tid] = 0u;
     }
     if (tid == 0) s_np = 0u;
     __syncthreads();
-    // ---- (b) lists -> survivors.  One thread per (row, list): the first two entries of every list are requested before any is
-    // looked at (lists hold 1-2 entries on average; a loop of dependent count -> entry loads per thread was 16 us of this kernel)
+    // ---- (a) + (b) lists -> survivors.  One thread per (row, list); everything a thread needs first - the row's final maximum and
+    // bound, the list's length - is requested at once, then the first two entries of every list (lists hold 1-2 entries on
+    // average), before anything is looked at: a kernel of 64-row blocks is a string of memory latencies, and r5's first version
+    // spent 16 us of them one after the other.
     const int lists = splits * SC_LISTS;
     for (int i0 = tid; i0 < RR_ROWS * lists; i0 += 4 * 256) {
         int rl_[4], c_[4];
         int64_t L_[4];
+        float thr_[4];
         uint2 e0_[4], e1_[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -448,7 +445,10 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(const float *__restrict_
             L_[u] = (v && row < n) ? row * lists + (i - rl_[u] * lists) : -1;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) c_[u] = L_[u] >= 0 ? (int)cntb[L_[u]] : 0;
+        for (int u = 0; u < 4; ++u) {
+            c_[u] = L_[u] >= 0 ? (int)cntb[L_[u]] : 0;
+            thr_[u] = L_[u] >= 0 ? unord_f32(gmax[r0 + rl_[u]]) - bound[r0 + rl_[u]] : 0.f;      // NaN: no bound
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             e0_[u] = c_[u] > 0 ? cand[L_[u] * SC_PL] : make_uint2(0u, 0u);
@@ -456,11 +456,10 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(const float *__restrict_
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (c_[u] == 0) continue;
+            if (L_[u] < 0) continue;
             const int rl = rl_[u];
-            const float thr = s_thr[rl];
-            if (!(thr == thr)) continue;
-            if (c_[u] > SC_PL) {
+            const float thr = thr_[u];
+            if (!(thr == thr) || c_[u] > SC_PL) {                   // no bound, or the list ran over: exhaustive search
                 s_exh[rl] = 1u;
                 continue;
             }
@@ -479,93 +478,102 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(const float *__restrict_
     // ---- (c) exact chains, one lane per survivor, operands staged through LDS by LDS-DMA.
     // A lane that fetched its own two rows from global memory touched a different cache line per lane and instruction, each line
     // four times (16 bytes at a time): 23-33 us at 16,384 rows - the texture addresser, not the chain, was the cost.  Here a wave
-    // stages 32 elements of the code row and of the x row of each of its 64 pairs per step: 8 + 8 instructions of 1 KB, 8 lanes on
-    // each pair's 128 bytes (whole lines), into a wave-private ring of two stages; the lane of pair p then reads its 128-byte
-    // slots back (16-byte parts XOR-swizzled with p & 7, applied to the per-lane SOURCE part as the DMA writes lane-linear) and
-    // runs the 32 chain steps while the next stage lands.  No block barrier: a wave waits for its own DMAs only.
+    // stages 16 elements of the code row and of the x row of each of its 64 pairs per step - 4 + 4 instructions of 1 KB, four lanes
+    // on each pair's 64 bytes - into a wave-private ring of FOUR stages, three of them in flight (the chain is a string of DMA
+    // latencies: with one stage in flight every 32 elements cost a whole latency, 26 us; what is in flight decides); the lane of
+    // pair p reads its 64-byte slots back (16-byte parts XOR-swizzled with (p >> 2) & 3, applied to the per-lane SOURCE part, as
+    // the DMA writes lane-linear) and runs the 16 chain steps.  No block barrier: a wave waits for its own DMAs only.
     {
         const unsigned np = min(s_np, (unsigned)RR_CAP);
         const __amdgpu_buffer_rsrc_t rcb = make_rsrc(cb, (size_t)k * d * 4);
         const int64_t rows_here = n - r0 < RR_ROWS ? n - r0 : RR_ROWS;
         const __amdgpu_buffer_rsrc_t rxb = make_rsrc(x + r0 * d, (size_t)rows_here * d * 4);
-        char *ring = s_ring + wave * (2 * RR_STAGE);
-        const int nch = (d + 31) >> 5;
-        const int sub = lane >> 3, part = (lane & 7) ^ (sub & 7);      // this lane's pair within a DMA instruction, logical 16-byte part
+        char *ring = s_ring + wave * (RR_NS * RR_STAGE);
+        const int nch = (d + 15) >> 4;
+        const int sub = lane >> 2, part = (lane & 3) ^ ((lane >> 4) & 3);   // this lane's pair within a DMA instruction, logical 16-byte part
         for (unsigned b0 = 0; b0 < np; b0 += 256) {                    // block-uniform
             const unsigned pbase = b0 + wave * 64;
             if (pbase >= np) continue;                                 // wave-uniform
-            // the 8 pairs this lane fetches for (instruction i covers pairs 8 i .. 8 i + 7 of the wave's 64)
-            unsigned coff[8], xoff[8];
+            // the 4 pairs this lane fetches for (instruction i covers pairs 16 i .. 16 i + 15 of the wave's 64)
+            unsigned coff[4], xoff[4];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const unsigned q = pbase + 8 * i + sub;
+            for (int i = 0; i < 4; ++i) {
+                const unsigned q = pbase + 16 * i + sub;
                 const uint2 pr = q < np ? s_pair[q] : make_uint2(0u, 0u);
                 coff[i] = q < np ? pr.y * (unsigned)d * 4u + (unsigned)part * 16u : OOB;
                 xoff[i] = q < np ? pr.x * (unsigned)d * 4u + (unsigned)part * 16u : OOB;
             }
             auto issue = [&](int ch) {
-                char *st = ring + (ch & 1) * RR_STAGE;
-                const bool pv = ch * 32 + part * 4 < d;
+                char *st = ring + (ch & (RR_NS - 1)) * RR_STAGE;
+                const bool pv = ch * 16 + part * 4 < d;
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
+                for (int i = 0; i < 4; ++i)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rcb, lds_ptr_s(st + i * 1024), 16,
-                                                             (pv && coff[i] != OOB) ? coff[i] + (unsigned)ch * 128u : OOB, 0, 0, 0);
+                                                             (pv && coff[i] != OOB) ? coff[i] + (unsigned)ch * 64u : OOB, 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rxb, lds_ptr_s(st + 8192 + i * 1024), 16,
-                                                             (pv && xoff[i] != OOB) ? xoff[i] + (unsigned)ch * 128u : OOB, 0, 0, 0);
+                for (int i = 0; i < 4; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rxb, lds_ptr_s(st + 4096 + i * 1024), 16,
+                                                             (pv && xoff[i] != OOB) ? xoff[i] + (unsigned)ch * 64u : OOB, 0, 0, 0);
             };
             const unsigned me = pbase + lane;
             const uint2 mine = me < np ? s_pair[me] : make_uint2(0u, 0u);
+            const float cnk = cn[mine.y];                           // travels while the chain runs
             float acc = 0.f;
             issue(0);
-            // No branch inside the loop: at the join of a branch the compiler drains its wait counters (vmcnt(0) in front of every
-            // LDS read - measured: 30-56 us for this kernel, every stage paying the full DMA latency).  So the DMA of stage
-            // ch + 1 is issued unconditionally (past the end of the rows its offsets are out of range: it writes zeros into the
-            // free stage) and all eight 16-byte parts are chained unconditionally: parts past d are zeros on both sides, and
+            issue(1);
+            issue(2);
+            // No branch inside the loop (at the join of a branch the compiler drains its wait counters): the DMA of stage ch + 3 is
+            // issued unconditionally - past the end of the rows its offsets are out of range and it writes zeros into the free
+            // stage - and all four 16-byte parts are chained unconditionally: parts past d are zeros on both sides, and
             // fma(0, 0, acc) == acc.
             for (int ch = 0; ch < nch; ++ch) {
-                issue(ch + 1);
-                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                 // stage ch landed, ch + 1 in flight
+                issue(ch + 3);
+                asm volatile("s_waitcnt vmcnt(24)" ::: "memory");                 // stage ch landed, three later ones in flight
                 // LDS reads as inline asm: in front of a C++ load from LDS the compiler waits for EVERY LDS-DMA in flight
-                // (vmcnt(0) - it cannot tell the landed stage from the one just requested), which made every stage pay the whole DMA
-                // latency (30-56 us for this kernel).  The wait that matters is the counted one above.
-                const unsigned sb = (unsigned)reinterpret_cast<uintptr_t>(ring + (ch & 1) * RR_STAGE + lane * 128);
-                f32x4v c4[8], x4[8];
+                // (vmcnt(0) - it cannot tell the landed stage from the ones just requested), which made every stage pay the
+                // whole DMA latency.  The wait that matters is the counted one above.
+                const unsigned sb = (unsigned)reinterpret_cast<uintptr_t>(ring + (ch & (RR_NS - 1)) * RR_STAGE + lane * 64);
+                f32x4v c4[4], x4[4];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const unsigned a = sb + (unsigned)((j ^ (lane & 7)) << 4);
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned a = sb + (unsigned)((j ^ ((lane >> 2) & 3)) << 4);
                     asm volatile("ds_read_b128 %0, %1" : "=v"(c4[j]) : "v"(a));
-                    asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(x4[j]) : "v"(a));
+                    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(x4[j]) : "v"(a));
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(c4[0]), "+v"(c4[1]), "+v"(c4[2]), "+v"(c4[3]), "+v"(c4[4]), "+v"(c4[5]), "+v"(c4[6]), "+v"(c4[7]),
-                               "+v"(x4[0]), "+v"(x4[1]), "+v"(x4[2]), "+v"(x4[3]), "+v"(x4[4]), "+v"(x4[5]), "+v"(x4[6]), "+v"(x4[7])
+                             : "+v"(c4[0]), "+v"(c4[1]), "+v"(c4[2]), "+v"(c4[3]), "+v"(x4[0]), "+v"(x4[1]), "+v"(x4[2]), "+v"(x4[3])
                              :
                              : "memory");
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < 4; ++j) {
                     acc = __fmaf_rn(x4[j][0], c4[j][0], acc);
                     acc = __fmaf_rn(x4[j][1], c4[j][1], acc);
                     acc = __fmaf_rn(x4[j][2], c4[j][2], acc);
                     acc = __fmaf_rn(x4[j][3], c4[j][3], acc);
                 }
-                // (the reads above are back - their values were just used - before the next iteration's DMA overwrites this stage)
+                // (the reads above are back - their values were just used - before the next iteration's DMA overwrites stage ch - 1 ... )
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the trailing zero-fill must not outlive the batch
             if (me < np) {
-                float dist = __fmaf_rn(-2.0f, acc, cn[mine.y]);
+                float dist = __fmaf_rn(-2.0f, acc, cnk);
                 dist = dist != dist ? -INFINITY : dist;
                 atomicMin(&s_best[mine.x], pack_di(dist, (int)mine.y));
             }
         }
     }
     __syncthreads();
-    // ---- (d) exhaustive rows (block-uniform loop)
-    for (int rl = 0; rl < RR_ROWS; ++rl) {
+    // ---- (d) exhaustive rows: a 64-bit mask first (the common case is an empty one), then a block-uniform loop over its bits
+    if (wave == 0) {
+        const bool need = r0 + lane < n && (s_exh[lane] != 0u || s_rowcnt[lane] == 0u);
+        const unsigned long long mask = __ballot(need);
+        if (lane == 0) s_todo = mask;
+    }
+    __syncthreads();
+    unsigned long long todo = s_todo;
+    while (todo) {
+        const int rl = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
         const int64_t row = r0 + rl;
-        if (row >= n) break;
-        if (!(s_exh[rl] != 0u || s_rowcnt[rl] == 0u)) continue;
         unsigned long long best = ~0ull;
         for (int code = tid; code < k; code += 256) {
             const unsigned long long p = pack_di(exact_dist(x + row * d, cb + (int64_t)code * d, d, cn[code]), code);

@@ -175,12 +175,11 @@ def conv1d(x: torch.Tensor, p: ConvParams, causal: bool, dilation: int = 1) -> t
 
 
 def pad_channels(c: int) -> int:
-    """Channel count a tensor of ``c`` channels is STORED with inside the bf16-storage refiner: the next multiple of 64 when c is
-    a multiple of 16 above 64 that is not one already (hifimusic's 96-channel level -> 128), else c.  The bf16-storage kernels
-    walk the reduction in 64-channel chunks whose pixels are whole 128-byte lines; with 96 channels they fall back to 32-channel
-    chunks (half lines, two taps per K-step) and ran at 0.16-0.26 of the bf16 peak (profiles/r4_c3_*).  The extra channels hold
-    zeros: zero filter rows produce them, APTx(0) = 0 and dropout keep them, zero filter columns ignore them - the level costs
-    a third more multiplications and runs 1.6x faster for it."""
+    """Channel count a tensor of ``c`` channels is STORED with inside the bf16-storage refiner when ops.H2_PAD_CHANNELS is on (it
+    is off by default: measured slower, see there): the next multiple of 64 when c is a multiple of 16 above 64 that is not one
+    already (hifimusic's 96-channel level -> 128), else c.  The bf16-storage kernels walk the reduction in 64-channel chunks whose
+    pixels are whole 128-byte lines; with 96 channels they fall back to 32-channel chunks (half lines, two taps per K-step).  The
+    extra channels hold zeros: zero filter rows produce them, APTx(0) = 0 and dropout keep them, zero filter columns ignore them."""
     if ops.ACT_BF16 and ops.H2_PAD_CHANNELS and c > 64 and c % 16 == 0 and c % 64 != 0:
         return (c + 63) // 64 * 64
     return c

@@ -168,9 +168,12 @@ class conv_precision:
 # two convolutions is a bf16 tensor - what the reference's autocast region stores (train.py:220, 523) - and the layers
 # whose shapes allow it run on the LDS-DMA kernels of csrc/igemm_h2.hip.  Off by default (f32 tensors everywhere).
 ACT_BF16 = False
-# inside the bf16-storage refiner, tensors whose channel count is a multiple of 16 above 64 but not of 64 are stored zero-padded
-# to the next multiple of 64 (nn_base.pad_channels); MQGAN_H2_PAD=0 switches it off for A/B runs
-H2_PAD_CHANNELS = os.environ.get("MQGAN_H2_PAD", "1") != "0"
+# inside the bf16-storage refiner, tensors whose channel count is a multiple of 16 above 64 but not of 64 CAN be stored zero-padded
+# to the next multiple of 64 (nn_base.pad_channels; MQGAN_H2_PAD=1).  Off by default - a recorded negative result: hifimusic's
+# 96-channel level as 128 stored channels moves its layers from the 32-channel-chunk kernels (0.43-0.64 PF/s) to the shared-row
+# kernels, but at two 64-column tiles those reach only 0.82 PF/s on a third more multiplications: config 3 189.6-189.8 ms/step
+# against 187.3-188.4 without (alternating runs in one call, profiles/r5_c3_pad_ab.txt)
+H2_PAD_CHANNELS = os.environ.get("MQGAN_H2_PAD", "0") == "1"
 # what the caller asked for (Trainer: training.precision == "bf16"); the modules that support bf16 storage (UNetRefiner,
 # the discriminators) switch ACT_BF16 on for their own body and hand f32 tensors back at their boundary
 ACT_BF16_REQUESTED = False

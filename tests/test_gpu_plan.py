@@ -112,3 +112,28 @@ def test_planned_calls_through_ctypes_equal_the_direct_form(lib, name, kw, leaky
     if leaky:
         assert float(out["planned"][0][-1, :, d.Q // 2:].abs().max()) == 0.0        # padded output frames
         assert float(out["planned"][1][-1, :, d.W // 2:].abs().max()) == 0.0        # padded input frames of the gated gradient
+
+
+def test_fused_winograd_prototype_matches_float64(lib):
+    """csrc/winofused.hip (round-5 prototype, never chosen by mq_conv_plan): F(4x5, 3x3) with both transforms inside the GEMM kernel,
+    on a ragged image (H, W not multiples of the tile) with 64 output channels - against a float64 convolution at the bounds the
+    separate Winograd sequence meets (relative L2 2e-5, no element off by more than 1e-4 of the rms), first / last rows and
+    columns on their own."""
+    _lib, L = lib
+    torch.manual_seed(5)
+    N, H, W, Cc, K = 3, 22, 33, 48, 64
+    x = torch.randn(N, H, W, Cc, device=DEV)
+    w = torch.randn(K, Cc, 3, 3, device=DEV) / (3 * Cc ** 0.5)
+    bias = torch.randn(K, device=DEV)
+    from mqgan_amd import ops
+    wk, _ = ops.weight_prep(w, None, False)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    U = torch.empty(42 * K * Cc, device=DEV)
+    assert L.mq_winon_weight_transform(P(wk), K, Cc, 0, P(U), 4, 5, st) == 0, L.mq_last_error()
+    Ut = torch.full_like(U, float("nan"))
+    y = torch.full((N, H, W, K), float("nan"), device=DEV)
+    assert L.mq_winofused_fprop(P(x), P(U), P(bias), N, H, W, Cc, K, P(Ut), P(y), st) == 0, L.mq_last_error()
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2).cpu(), w.double().cpu(), bias.double().cpu(), padding=1).permute(0, 2, 3, 1)
+    assert_elem(y, ref, 2e-5, 1e-4, "fused Winograd prototype", edges=(1, 2, 1, 3))
+    assert L.mq_winofused_fprop(P(x), P(U), P(bias), N, H, W, Cc, 80, P(Ut), P(y), st) != 0            # K > 64: refused, not mis-run
