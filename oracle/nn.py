@@ -343,6 +343,7 @@ def patch_discriminator(P: Params, prefix: str, x: torch.Tensor, lengths: torch.
         w = sn_weight(P, prefix + f"convs.{i}.", training)
         kh, kw = w.shape[-2:]
         sh, sw = strides[i]
+        inp = out
         out = F.conv2d(out, w, P[prefix + f"convs.{i}.bias"], stride=(sh, sw), padding=((kh - 1) // 2, (kw - 1) // 2))
         pre = out
         out = F.leaky_relu(out, 0.2) if gates is None else torch.where(gates[i], out, 0.2 * out)
@@ -355,7 +356,12 @@ def patch_discriminator(P: Params, prefix: str, x: torch.Tensor, lengths: torch.
                 valid = ~padded.expand_as(pre)
                 differ = ((pre > 0) != gates[i]) & valid & (pre != 0)
                 rms = float(pre[valid].double().pow(2).mean().sqrt()) if bool(valid.any()) else 0.0
+                # the scale rounding errors of this layer live on: the largest sum of |x| |w| (+ |b|) of an output element (a layer
+                # whose terms cancel - the first one, on nearly constant mel frames - has pre-activations far smaller than that)
+                terms = F.conv2d(inp.detach().abs(), w.detach().abs(), P[prefix + f"convs.{i}.bias"].detach().abs(), stride=(sh, sw),
+                                 padding=((kh - 1) // 2, (kw - 1) // 2))
                 GATE_STATS.append({"prefix": prefix, "layer": i, "valid": int(valid.sum()), "differ": int(differ.sum()), "rms": rms,
+                                   "terms": float(terms.max()),
                                    "max_abs_pre_where_differ": float(pre[differ].abs().max()) if bool(differ.any()) else 0.0})
         out = out.masked_fill(padded, 0.0)
         if return_features and 2 <= i <= n - 2:                                       # :104-108
