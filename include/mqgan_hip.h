@@ -599,6 +599,11 @@ typedef struct {
     mqConvDesc inner;         /* nested: the column form's convolution */
     size_t keep_bytes, ws_fprop, ws_backward;
     double flops;             /* 2 x multiplications of one forward pass in this form */
+    int keep_filters_only;    /* set by the CALLER on its copy of the plan (mq_conv_plan leaves 0): the keep buffer handed to the planned
+                               * calls holds the transformed CRSK filters only and is keep_uc_bytes large - for passes whose weights get no
+                               * gradient (the generator step through the discriminators): the transformed input, 1.5x the layer's input
+                               * and more, is then not carried from forward to backward; ignored where keep_uc_bytes == 0 */
+    size_t keep_uc_bytes;     /* row / column forms: bytes of the transformed CRSK filters inside the keep buffer; 0 for the other forms */
 } mqConvPlan;
 void mq_plan_cfg_default(mqPlanCfg *cfg);
 const char *mq_form_name(int form);

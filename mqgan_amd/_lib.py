@@ -39,7 +39,8 @@ class PlanCfg(C.Structure):
 class ConvPlan(C.Structure):
     _fields_ = [("form", C.c_int), ("mh", C.c_int), ("mw", C.c_int), ("nested", C.c_int), ("leaky", C.c_int), ("npos", C.c_int),
                 ("tiles", C.c_int64), ("desc", ConvDesc), ("gemm", ConvDesc), ("inner", ConvDesc), ("keep_bytes", C.c_size_t),
-                ("ws_fprop", C.c_size_t), ("ws_backward", C.c_size_t), ("flops", C.c_double)]
+                ("ws_fprop", C.c_size_t), ("ws_backward", C.c_size_t), ("flops", C.c_double), ("keep_filters_only", C.c_int),
+                ("keep_uc_bytes", C.c_size_t)]
 
 
 FORM_DIRECT, FORM_WINO2D, FORM_S2D, FORM_WINO1D, FORM_WINOW = range(5)

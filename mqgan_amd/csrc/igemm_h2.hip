@@ -942,9 +942,66 @@ struct H2Wgrad {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
+
+// ---- bias gradient inside the weight-gradient kernels (r5).  db[k] = sum over the pixels of dy[pixel][k]: the dy tile of every
+// K-step is in LDS anyway (64 pixels x 256 channels, 512-byte rows, 16-byte chunk index XORed with the row's swizzle), so the
+// blocks of column tile 0 - one per (split, group, row tile) - add it up on the vector unit: thread (chunk c = tid & 31, pixel
+// group tid >> 5) reads 4 pixels x 8 channels per K-step.  r2-r4 read dy a second time from HBM for this (h2_colsum_*: 4.0 ms of
+// the config-3 step, 67 launches).  The reads are inline asm: in front of a C++ load from LDS the compiler waits for every
+// LDS-DMA in flight (vmcnt(0)), which would make exactly these blocks pay the DMA latency of the NEXT tile in every K-step.
+template <bool MF16>
+__device__ __forceinline__ void h2_dy_colsum_step(const char *img, float (&bs)[8])
+{
+    const int c16 = threadIdx.x & 31, pg = threadIdx.x >> 5;
+    u32x4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = pg * 4 + i;
+        const int swz = ((p & 3) << 2) | (MF16 ? (((p >> 3) & 1) << 1) : 0);
+        const unsigned a = (unsigned)reinterpret_cast<uintptr_t>(img + p * 512 + ((c16 ^ swz) << 4));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(v[i]) : "v"(a));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : : "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            bs[2 * e] += __builtin_bit_cast(float, v[i][e] << 16);
+            bs[2 * e + 1] += __builtin_bit_cast(float, v[i][e] & 0xFFFF0000u);
+        }
+}
+// after the K loop (every wave past its last barrier, LDS free): the 16 pixel groups' sums of a channel are added in a fixed order
+// and go to the (split, group) row of the bias slab
+__device__ __forceinline__ void h2_dy_colsum_store(const float (&bs)[8], char *smem, float *__restrict__ bias_row, int k0, int bmk, int K)
+{
+    float *sp = reinterpret_cast<float *>(smem);                   // [16 pixel groups][256 channels]
+    const int c16 = threadIdx.x & 31, pg = threadIdx.x >> 5;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sp[pg * 256 + c16 * 8 + e] = bs[e];
+    __syncthreads();
+    const int ch = threadIdx.x;
+    if (ch < bmk && k0 + ch < K) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += sp[q * 256 + ch];
+        bias_row[k0 + ch] = t;
+    }
+}
+// db[i] = sum over the splits of the bias slab, fixed order
+__global__ void h2_bias_reduce_kernel(const float *__restrict__ slab, int splits, int n, float *__restrict__ db)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float t = 0.f;
+    for (int k = 0; k < splits; ++k) t += slab[(size_t)k * n + i];
+    db[i] = t;
+}
+
 template <int WM, int TM, int WRAPS, bool MF16>
 __device__ __forceinline__ void conv_wgrad_h2_body(const unsigned short *__restrict__ x, const unsigned short *__restrict__ dy,
-                                                   float *__restrict__ out, const H2Wgrad &g, int groups, char *smem)
+                                                   float *__restrict__ out, float *__restrict__ bias_slab, const H2Wgrad &g, int groups,
+                                                   char *smem)
 {
     constexpr int WN = 8 / WM, TNW = WM;           // wave grid and 32-column tiles per wave (WN * 32 * TNW = 256)
     constexpr int BMK = WM * 32 * TM;
@@ -1126,13 +1183,17 @@ __device__ __forceinline__ void conv_wgrad_h2_body(const unsigned short *__restr
         }
     };
     int st_c = 0;
+    const bool sum_dy = bias_slab != nullptr && ct == 0;           // block-uniform
+    float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < nsteps; ++t) {
         issue(st_c ^ 1);                 // past the end of the split: every lane is out of range, the DMA writes zeros
         compute(st_c);
+        if (sum_dy) h2_dy_colsum_step<MF16>(smem + st_c * STAGE, bs);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         st_c ^= 1;
     }
+    if (sum_dy) h2_dy_colsum_store(bs, smem, bias_slab + ((size_t)split * groups + grp) * g.K, k0, BMK, g.K);
 
     // slab [split][group][K][RSC], columns scattered into the channel-blocked filter layout (common.h: kidx)
     float *o = out + ((size_t)split * groups + grp) * (size_t)g.K * g.RSC;
@@ -1164,10 +1225,10 @@ __device__ __forceinline__ void conv_wgrad_h2_body(const unsigned short *__restr
 
 template <int WM, int TM, int WRAPS, bool MF16>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_h2_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ dy,
-                                                               float *__restrict__ out, H2Wgrad g, int groups)
+                                                               float *__restrict__ out, float *__restrict__ bias_slab, H2Wgrad g, int groups)
 {
     __shared__ __attribute__((aligned(1024))) char smem[2 * 2 * 64 * 512];
-    conv_wgrad_h2_body<WM, TM, WRAPS, MF16>(x, dy, out, g, groups, smem);
+    conv_wgrad_h2_body<WM, TM, WRAPS, MF16>(x, dy, out, bias_slab, g, groups, smem);
 }
 
 // ------------------------------------------------------------------------------------------ shared-row weight gradient (r4)
@@ -1187,7 +1248,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_h2_kernel(const unsigned sh
 // in other groups of 16 (the zero positions shift the groups): equal within rounding, not bit for bit.
 template <int WRAPS>
 __device__ __forceinline__ void conv_wgrad_h2s_body(const unsigned short *__restrict__ x, const unsigned short *__restrict__ dy,
-                                                    float *__restrict__ out, const H2Wgrad &g, int groups, char *smem)
+                                                    float *__restrict__ out, float *__restrict__ bias_slab, const H2Wgrad &g, int groups,
+                                                    char *smem)
 {
     constexpr int CH2 = 2, CHK = 64 * CH2;         // channels per chunk: 128
     constexpr int BMK = 192, TMR = 3;              // rows of the block tile; 32-row tiles per wave (2 waves x 96 rows)
@@ -1360,13 +1422,17 @@ __device__ __forceinline__ void conv_wgrad_h2s_body(const unsigned short *__rest
         }
     };
     int st_c = 0;
+    const bool sum_dy = bias_slab != nullptr && ct == 0;           // block-uniform; dy is zero at the padded positions
+    float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < nsteps; ++t) {
         issue(st_c ^ 1);                 // past the end of the split: dy out of range (zeros); the x image is whatever follows
         compute(st_c);
+        if (sum_dy) h2_dy_colsum_step<false>(smem + st_c * STAGE, bs);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         st_c ^= 1;
     }
+    if (sum_dy) h2_dy_colsum_store(bs, smem, bias_slab + ((size_t)split * groups + grp) * g.K, k0, BMK, g.K);
 
     // slab [split][group][K][RSC]; the tile's columns (tap col s, channel) go to (tap, channel) of the channel-blocked filter layout
     float *o = out + ((size_t)split * groups + grp) * (size_t)g.K * g.RSC;
@@ -1389,11 +1455,12 @@ __device__ __forceinline__ void conv_wgrad_h2s_body(const unsigned short *__rest
 
 template <int WRAPS>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_h2s_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ dy,
-                                                                float *__restrict__ out, H2Wgrad g, int groups)
+                                                                float *__restrict__ out, float *__restrict__ bias_slab, H2Wgrad g,
+                                                                int groups)
 {
     constexpr int NP = 17;                                          // 66 image rows of 256 bytes in 1 KB pieces
     __shared__ __attribute__((aligned(1024))) char smem[2 * (64 * 512 + NP * 1024) + 8 * 1024];
-    conv_wgrad_h2s_body<WRAPS>(x, dy, out, g, groups, smem);
+    conv_wgrad_h2s_body<WRAPS>(x, dy, out, bias_slab, g, groups, smem);
 }
 
 // out[i] = sum_k slabs[k][i] in the fixed order k = 0, 1, ... (deterministic)
@@ -1893,16 +1960,20 @@ extern "C" int mq_conv_wgrad_h2(const mqConvDesc *d, const uint16_t *x, const ui
     float *target = g.splits > 1 ? reinterpret_cast<float *>(workspace) : dw;
     float *bias_ws = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + (g.splits > 1 ? (size_t)g.splits * n * sizeof(float) : 0));
     dim3 grid(g.nKt * g.nCt, d->groups, g.splits), block(512);
+    // the bias gradient rides on the dy tiles the kernel stages anyway: per-split column sums into bias_ws [splits][groups][K]
+    // (MQGAN_H2_BIAS_PASS=1: the separate column-sum passes over dy of r2-r4, for A/B runs)
+    static const bool bias_pass = getenv("MQGAN_H2_BIAS_PASS") != nullptr;
+    float *bias_slab = (dbias && !bias_pass) ? bias_ws : nullptr;
     const int wraps = d->Q >= 64 ? 1 : 4;
     // the weight gradient stays on 32x32x16: its 16x16x32 instantiation (conflict-free too) measured 3-5 % slower
     // (twice the transposed LDS reads per flop); MQGAN_H2_WG16=1 selects it for A/B runs
     static const bool mf16 = getenv("MQGAN_H2_WG16") != nullptr;
-#define MQ_WH2(WM_, TM_, WR_) do { kname("conv_wgrad_h2_kernel<%d, %d, %d, %s>", WM_, TM_, WR_, tf(mf16)); if (mf16) hipLaunchKernelGGL((conv_wgrad_h2_kernel<WM_, TM_, WR_, true>), grid, block, 0, st, x, dy, target, g, d->groups); \
-                                   else hipLaunchKernelGGL((conv_wgrad_h2_kernel<WM_, TM_, WR_, false>), grid, block, 0, st, x, dy, target, g, d->groups); } while (0)
+#define MQ_WH2(WM_, TM_, WR_) do { kname("conv_wgrad_h2_kernel<%d, %d, %d, %s>", WM_, TM_, WR_, tf(mf16)); if (mf16) hipLaunchKernelGGL((conv_wgrad_h2_kernel<WM_, TM_, WR_, true>), grid, block, 0, st, x, dy, target, bias_slab, g, d->groups); \
+                                   else hipLaunchKernelGGL((conv_wgrad_h2_kernel<WM_, TM_, WR_, false>), grid, block, 0, st, x, dy, target, bias_slab, g, d->groups); } while (0)
 #define MQ_WH(WM_, TM_) do { if (wraps == 1) MQ_WH2(WM_, TM_, 1); else MQ_WH2(WM_, TM_, 4); } while (0)
     if (shared) {
-        if (d->Q + 2 >= 64) { kname("conv_wgrad_h2s_kernel<%d>", 1); hipLaunchKernelGGL((conv_wgrad_h2s_kernel<1>), grid, block, 0, st, x, dy, target, g, d->groups); }
-        else { kname("conv_wgrad_h2s_kernel<%d>", 4); hipLaunchKernelGGL((conv_wgrad_h2s_kernel<4>), grid, block, 0, st, x, dy, target, g, d->groups); }
+        if (d->Q + 2 >= 64) { kname("conv_wgrad_h2s_kernel<%d>", 1); hipLaunchKernelGGL((conv_wgrad_h2s_kernel<1>), grid, block, 0, st, x, dy, target, bias_slab, g, d->groups); }
+        else { kname("conv_wgrad_h2s_kernel<%d>", 4); hipLaunchKernelGGL((conv_wgrad_h2s_kernel<4>), grid, block, 0, st, x, dy, target, bias_slab, g, d->groups); }
     } else if (wm == 4) MQ_WH(4, 2);
     else if (tm == 3) MQ_WH(2, 3);
     else MQ_WH(2, 2);
@@ -1914,7 +1985,11 @@ extern "C" int mq_conv_wgrad_h2(const mqConvDesc *d, const uint16_t *x, const ui
         hipLaunchKernelGGL(h2_slab_reduce_kernel, dim3(ew_grid((int64_t)n / 4, 256)), dim3(256), 0, st, target, dw, n / 4, g.splits);
         MQ_LAUNCH_CHECK("mq_conv_wgrad_h2(reduce)");
     }
-    if (dbias) {
+    if (bias_slab) {
+        const int nb = d->groups * g.K;
+        hipLaunchKernelGGL(h2_bias_reduce_kernel, dim3((unsigned)cdiv(nb, 256)), dim3(256), 0, st, bias_slab, g.splits, nb, dbias);
+        MQ_LAUNCH_CHECK("mq_conv_wgrad_h2(bias)");
+    } else if (dbias) {
         for (int grp = 0; grp < d->groups; ++grp) {
             const int64_t rows = (int64_t)(d->N / d->groups) * d->P * d->Q;      // real pixels (the shared-row plan counts padded ones)
             const int cols = g.K;

@@ -305,6 +305,7 @@ extern "C" int mq_conv_plan(const mqConvDesc *desc, int leaky, const mqPlanCfg *
     size_t v = 0, uc = 0;
     keep_layout(*p, s, &v, &uc);
     p->keep_bytes = (p->form != MQ_FORM_DIRECT && v * 4 <= ((size_t)cfg.keep_mib << 20)) ? al(v * 4) + al(uc * 4) : 0;
+    p->keep_uc_bytes = (p->form == MQ_FORM_WINO1D || p->form == MQ_FORM_WINOW) ? al(uc * 4) : 0;
     // workspace sizes: the planned paths themselves, run dry (no launches, a measuring carver) in their most demanding
     // configuration - no keep buffer, every gradient wanted
     size_t peak = 0;
@@ -342,7 +343,8 @@ int fprop_impl(const mqConvPlan *p, const float *x, const float *w_krsc, const f
     if (!mask) { d1 = 1; d2 = 0; d3 = 1; }
     const mqConvDesc &d = p->desc;
     if (peak) *peak = 0;
-    Carver ws(workspace, workspace_bytes), kp(keep, keep ? p->keep_bytes : 0);
+    const bool fonly = p->keep_filters_only != 0 && p->keep_uc_bytes > 0;      // the keep buffer holds the CRSK filters only
+    Carver ws(workspace, workspace_bytes), kp(keep, keep ? (fonly ? p->keep_uc_bytes : p->keep_bytes) : 0);
     if (p->form == MQ_FORM_DIRECT) {
         if (act == 2) MQ_TRY(mq_conv_fprop_leaky(&d, x, w_krsc, bias, mask, d1, d2, d3, slope, y, st));
         else MQ_TRY(mq_conv_fprop(&d, x, w_krsc, bias, y, st));
@@ -356,12 +358,12 @@ int fprop_impl(const mqConvPlan *p, const float *x, const float *w_krsc, const f
         Carver &c; size_t *out;
         ~PeakOut() { if (out) *out = c.peak; }
     } peak_out{ws, peak};
-    const bool keeping = keep != nullptr && p->keep_bytes > 0;
-    float *keepV = keeping ? kp.take(kv) : nullptr, *keepUc = keeping ? kp.take(kuc) : nullptr;
+    const bool keeping = keep != nullptr && (fonly || p->keep_bytes > 0);
+    float *keepV = (keeping && !fonly) ? kp.take(kv) : nullptr, *keepUc = keeping ? kp.take(kuc) : nullptr;
     const int mh = p->mh, mw = p->mw;
     switch (p->form) {
     case MQ_FORM_WINO2D: {
-        float *V = keeping ? keepV : ws.take(s.V), *U = ws.take(s.U), *M = ws.take(s.M);
+        float *V = keepV ? keepV : ws.take(s.V), *U = ws.take(s.U), *M = ws.take(s.M);
         MQ_PASS(mq_winon_input_transform(x, d.N, d.H, d.W, d.C, V, mh, mw, st));
         MQ_PASS(mq_winon_weight_transform(w_krsc, d.K, d.C, 0, U, mh, mw, st));
         MQ_TRY(gemm_call(p->gemm, [&] { return mq_conv_fprop(&p->gemm, V, U, nullptr, M, st); }));
@@ -369,7 +371,7 @@ int fprop_impl(const mqConvPlan *p, const float *x, const float *w_krsc, const f
         return 0;
     }
     case MQ_FORM_S2D: {
-        float *V = keeping ? keepV : ws.take(s.V), *U = ws.take(s.U), *M = ws.take(s.M);
+        float *V = keepV ? keepV : ws.take(s.V), *U = ws.take(s.U), *M = ws.take(s.M);
         MQ_PASS(mq_winon_input_transform_s2d(x, d.N, d.H, d.W, d.C, V, mh, mw, st));
         MQ_PASS(mq_winon_weight_transform_s2d(w_krsc, d.K, d.C, 0, U, mh, mw, st));
         MQ_TRY(gemm_call(p->gemm, [&] { return mq_conv_fprop(&p->gemm, V, U, nullptr, M, st); }));
@@ -377,7 +379,7 @@ int fprop_impl(const mqConvPlan *p, const float *x, const float *w_krsc, const f
         return 0;
     }
     case MQ_FORM_WINOW: {
-        float *V = keeping ? keepV : ws.take(s.V), *U = ws.take(s.U), *Uc = keeping ? keepUc : ws.take(s.Uc), *M = ws.take(s.M);
+        float *V = keepV ? keepV : ws.take(s.V), *U = ws.take(s.U), *Uc = keepUc ? keepUc : ws.take(s.Uc), *M = ws.take(s.M);
         MQ_PASS(mq_winow_weight_transform(w_krsc, d.groups, d.K, d.C, d.R, d.S, U, Uc, st));
         MQ_PASS(mq_winow_input_transform(x, d.N, d.H, d.W, d.C, d.S, d.Q, d.pad_w, V, st));
         MQ_TRY(gemm_call(p->gemm, [&] { return mq_conv_fprop(&p->gemm, V, U, nullptr, M, st); }));
@@ -387,13 +389,13 @@ int fprop_impl(const mqConvPlan *p, const float *x, const float *w_krsc, const f
     case MQ_FORM_WINO1D: {
         const int m = mh;
         const mqConvDesc &g = p->gemm;
-        float *V = (keeping && !p->nested) ? keepV : ws.take(s.V), *U = ws.take(s.U), *Uc = (keeping && !p->nested) ? keepUc : ws.take(s.Uc);
+        float *V = (keepV && !p->nested) ? keepV : ws.take(s.V), *U = ws.take(s.U), *Uc = (keepUc && !p->nested) ? keepUc : ws.take(s.Uc);
         float *M = ws.take(s.M);
         MQ_PASS(mq_wino1d_input_transform(x, d.N, d.H, d.W, d.C, m, V, st));
         MQ_PASS(mq_wino1d_weight_transform(w_krsc, d.groups, d.K, d.C, d.S, m, U, Uc, st));
         if (p->nested) {      // the row convolutions themselves as F(m', S) along the columns
             const mqConvDesc &h = p->inner;
-            float *V2 = keeping ? keepV : ws.take(s.V2), *U2 = ws.take(s.U2), *Uc2 = keeping ? keepUc : ws.take(s.Uc2), *M2 = ws.take(s.M2);
+            float *V2 = keepV ? keepV : ws.take(s.V2), *U2 = ws.take(s.U2), *Uc2 = keepUc ? keepUc : ws.take(s.Uc2), *M2 = ws.take(s.M2);
             MQ_PASS(mq_winow_weight_transform(U, g.groups, g.K, g.C, g.R, g.S, U2, Uc2, st));
             MQ_PASS(mq_winow_input_transform(V, g.N, g.H, g.W, g.C, g.S, g.Q, g.pad_w, V2, st));
             MQ_TRY(gemm_call(h, [&] { return mq_conv_fprop(&h, V2, U2, nullptr, M2, st); }));
@@ -426,7 +428,7 @@ extern "C" int mq_conv_backward_planned(const mqConvPlan *p, const float *x, con
                "mq_conv_backward_planned: workspace of %zu bytes needed, %zu given", p->ws_backward, workspace_bytes);
     MQ_REQUIRE(((uintptr_t)workspace | (uintptr_t)keep) % 256 == 0, "mq_conv_backward_planned: workspace and keep buffer must be 256-byte aligned");
     MQ_REQUIRE(p->form != MQ_FORM_DIRECT || !dx || w_crsk, "mq_conv_backward_planned: the direct input gradient needs the CRSK weights");
-    MQ_REQUIRE(!dw || x || (keep && p->keep_bytes > 0), "mq_conv_backward_planned: the weight gradient needs the keep buffer or x");
+    MQ_REQUIRE(!dw || x || (keep && p->keep_bytes > 0 && !p->keep_filters_only), "mq_conv_backward_planned: the weight gradient needs the full keep buffer or x");
     MQ_REQUIRE(p->form != MQ_FORM_WINO2D || !gate, "mq_conv_backward_planned: the plain 3x3 form has no gated input gradient (its layers feed APTx, not LeakyReLU)");
     return backward_impl(p, x, keep, w_krsc, w_crsk, dy, gate, gate_slope, gate_mask, g1, g2, g3, dx, dw, db, workspace, workspace_bytes, st, false,
                          nullptr);
@@ -469,9 +471,10 @@ int backward_impl(const mqConvPlan *p, const float *x, const void *keep, const f
     const Sizes s = sizes_of(*p);
     size_t kv = 0, kuc = 0;
     keep_layout(*p, s, &kv, &kuc);
-    const bool kept = keep != nullptr && p->keep_bytes > 0;
-    const float *keepV = kept ? static_cast<const float *>(keep) : nullptr;
-    const float *keepUc = kept ? reinterpret_cast<const float *>(static_cast<const char *>(keep) + al(kv * 4)) : nullptr;
+    const bool fonly = p->keep_filters_only != 0 && p->keep_uc_bytes > 0;      // the keep buffer holds the CRSK filters only
+    const bool kept = keep != nullptr && (fonly || p->keep_bytes > 0);
+    const float *keepV = (kept && !fonly) ? static_cast<const float *>(keep) : nullptr;
+    const float *keepUc = kept ? reinterpret_cast<const float *>(static_cast<const char *>(keep) + (fonly ? 0 : al(kv * 4))) : nullptr;
     const int mh = p->mh, mw = p->mw;
     float *colws = ws.take(1024 * rowsK);
     auto bias_from = [&](const float *part, size_t part_rows) -> int {

@@ -516,16 +516,19 @@ def _plan_cfg():
             int(WINO_S2D_MIN_CHANNELS), int(WINO1D_MIN_CHANNELS), int(WINO1D_TILE), int(WINOW_MIN_CHANNELS), int(WINO_KEEP_V_MIB))
 
 
-def conv_plan(d: ConvDesc, leaky: bool) -> "_lib.ConvPlan":
+def conv_plan(d: ConvDesc, leaky: bool, filters_only: bool = False) -> "_lib.ConvPlan":
     """mq_conv_plan for this descriptor under the module's current switches (cached): .form, .mh, .mw, .nested, .gemm, .flops,
-    .keep_bytes, .ws_fprop, .ws_backward.  ``leaky``: the layer is conv -> LeakyReLU -> masked_fill."""
+    .keep_bytes, .ws_fprop, .ws_backward.  ``leaky``: the layer is conv -> LeakyReLU -> masked_fill.  ``filters_only``: the copy of
+    the plan whose keep buffer holds the transformed CRSK filters alone (keep_uc_bytes; row / column forms with frozen weights)."""
     cfg = _plan_cfg()
-    key = (_desc_key(d), bool(leaky), cfg)
+    key = (_desc_key(d), bool(leaky), cfg, bool(filters_only))
     p = _PLANS.get(key)
     if p is None:
         c = _lib.PlanCfg(*cfg)
         p = _lib.ConvPlan()
         check(L().mq_conv_plan(C.byref(d), int(bool(leaky)), C.byref(c), C.byref(p)), "mq_conv_plan")
+        if filters_only:
+            p.keep_filters_only = 1
         _PLANS[key] = p
     return p
 
@@ -601,10 +604,13 @@ class ConvPlannedFn(torch.autograd.Function):
         mask, dmap, slope = (leaky[0], tuple(leaky[1]), float(leaky[2])) if leaky is not None else (None, (1, 0, 1), 0.0)
         # the keep buffer carries the transformed input (weight gradient) and, for the row / column forms, the CRSK transformed
         # filters (input gradient); the two-dimensional forms transform the rotated filter in backward instead.  With frozen
-        # weights (the generator step's passes through the discriminators) nothing is kept: the transformed input - 1.5x the
-        # layer's input and more - would only be carried for the small transformed filters, which backward forms again
+        # weights (the generator step's passes through the discriminators) only those filters are kept (the plan's filters-only
+        # copy): the transformed input - 1.5x the layer's input and more - is not carried from forward to backward for nothing
         need_keep = p.keep_bytes > 0 and ctx.needs_input_grad[1]
         keep = _ws_bytes(p.keep_bytes, x) if need_keep else None
+        if not need_keep and ctx.needs_input_grad[0] and p.keep_uc_bytes > 0:
+            p = conv_plan(d, leaky is not None, filters_only=True)
+            keep = _ws_bytes(p.keep_uc_bytes, x)
         ws = _ws_bytes(p.ws_fprop, x) if p.ws_fprop else None
         y = _empty((d.N, d.P, d.Q, d.K), x)
         _planned_call(key, lambda: check(
@@ -619,7 +625,7 @@ class ConvPlannedFn(torch.autograd.Function):
         direct = p.form == FORM_DIRECT
         ctx.plan = p       # backward runs the plan forward ran with, whatever the module's switches say by then
         # what backward reads: x for the direct weight gradient, as the gate tensor, or to transform again without a keep buffer
-        need_x = in_gate is not None or (ctx.needs_input_grad[1] and (direct or keep is None))
+        need_x = in_gate is not None or (ctx.needs_input_grad[1] and (direct or keep is None or p.keep_filters_only))
         ctx.save_for_backward(x if need_x else None, keep, w_krsc, w_crsk if direct else None,
                               y if (leaky is not None and not pregated) else None, mask, None if in_gate is None else in_gate[0])
         return y

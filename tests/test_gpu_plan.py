@@ -104,6 +104,33 @@ def test_planned_calls_through_ctypes_equal_the_direct_form(lib, name, kw, leaky
                 assert torch.equal(sub[want], full), f"{leg}: dx alone differs from dx with the other gradients"
             else:       # the bias sums may come from another pass (dy's column sums instead of the transform's partial sums)
                 assert_elem(sub[want], full, 2e-6, 2e-5, f"plan ctypes {name} {leg} {want} alone")
+    # the filters-only keep buffer (frozen weights: the generator step's passes through the discriminators): the row / column forms
+    # carry their transformed CRSK filters in keep_uc_bytes bytes and nothing else; dx must be what the full keep buffer gives
+    p = _lib.ConvPlan()
+    cfg = _lib.PlanCfg()
+    L.mq_plan_cfg_default(C.byref(cfg))
+    assert L.mq_conv_plan(C.byref(d), int(leaky), C.byref(cfg), C.byref(p)) == 0, L.mq_last_error()
+    assert (p.keep_uc_bytes > 0) == (form in ("winograd-rows", "winograd-columns")) and p.keep_filters_only == 0
+    if p.keep_uc_bytes:
+        p.keep_filters_only = 1
+        nws = (max(p.ws_fprop, p.ws_backward, 256) + 255) // 256 * 256
+        arena = torch.full((nws + 4096 + p.keep_uc_bytes + 4096,), 0xFF, dtype=torch.uint8, device=DEV)
+        ws, g1, keep, g2 = arena[:nws], arena[nws:nws + 4096], arena[nws + 4096:nws + 4096 + p.keep_uc_bytes], arena[nws + 4096 + p.keep_uc_bytes:]
+        g1.fill_(0x5A); g2.fill_(0x5A)
+        y = torch.empty(d.N, d.P, d.Q, d.K, device=DEV)
+        assert L.mq_conv_fprop_planned(C.byref(p), P(x), P(w_krsc), P(bias), 2 if leaky else 0, 0.2, P(mask) if leaky else None, d.P * d.Q, d.Q,
+                                       d.Q, P(y), P(keep), P(ws), nws, st) == 0, L.mq_last_error()
+        ws.fill_(0xFF)
+        dx = torch.full_like(x, float("nan"))
+        gate = leaky
+        assert L.mq_conv_backward_planned(C.byref(p), None, P(keep), P(w_krsc), None, P(dy), P(x) if gate else None, 0.2,
+                                          P(gmask) if gate else None, d.H * d.W, d.W, d.W, P(dx), None, None, P(ws), nws, st) == 0, L.mq_last_error()
+        torch.cuda.synchronize()
+        assert bool((g1 == 0x5A).all()) and bool((g2 == 0x5A).all()), "filters-only keep: wrote outside the workspace or the keep buffer"
+        assert torch.equal(y, out["planned"][0]) and torch.equal(dx, out["planned"][1])
+        dwn = torch.empty_like(w_krsc)          # a weight gradient cannot come out of a filters-only keep buffer without x
+        assert L.mq_conv_backward_planned(C.byref(p), None, P(keep), P(w_krsc), None, P(dy), None, 1.0, None, 1, 0, 1, None, P(dwn), None,
+                                          P(ws), nws, st) != 0
     for leg in ("planned", "planned-no-keep"):
         for nm, a, b in zip(("y", "dx", "dw", "db"), out[leg], out["direct"]):
             assert_elem(a, b, 2e-5, 2e-4, f"plan ctypes {name} {leg} {nm}")

@@ -316,8 +316,8 @@ def test_hifispeech_architecture_step_matches_oracle(monkeypatch, wino_tile, win
     show it as well as the Winograd forms).  With the branches shared, what is left is the arithmetic under test.
 
     The sharing is BOUNDED (round 4 review): per discriminator layer the oracle counts the adopted branches that differ from the
-    sign of its own pre-activation - at most 1e-5 of the valid elements over the step (measured: 17-20 of 17 M), each such pre-activation within 1e-5 of the
-    largest |x||w| sum of its layer of zero (rounding of what it was summed from; a wrong mask, a layout slip in the capture or a systematically wrong pre-activation would show as
+    sign of its own pre-activation - at most 1e-5 of the valid elements over the step (measured: 17-20 of 17 M), each such pre-activation within 2e-4 of the
+    largest |x||w| sum of its layer of zero (the tolerance its inputs are held to; a wrong mask, a layout slip in the capture or a systematically wrong pre-activation would show as
     thousands) - and the HIP losses also meet the losses of the oracle step run with its OWN branches at 1e-4.  Which forms ran
     is asserted from the plans the step asked for (form, tile, nesting per layer), not from a kernel name every path launches.
 
@@ -334,8 +334,8 @@ def test_hifispeech_architecture_step_matches_oracle(monkeypatch, wino_tile, win
     plans = []
     real_conv_plan = ops.conv_plan
 
-    def recording_conv_plan(d, leaky):
-        p = real_conv_plan(d, leaky)
+    def recording_conv_plan(d, leaky, filters_only=False):
+        p = real_conv_plan(d, leaky, filters_only)
         plans.append((d.R, d.S, d.stride_h, d.stride_w, d.C, d.K, d.H, d.W, d.groups, bool(leaky), p.form, p.mh, p.mw, p.nested))
         return p
 
@@ -378,9 +378,12 @@ def test_hifispeech_architecture_step_matches_oracle(monkeypatch, wino_tile, win
     assert n_valid > 10_000_000, n_valid
     assert n_differ <= 1e-5 * n_valid, f"{n_differ} of {n_valid} adopted LeakyReLU branches differ from the oracle's own signs"
     for g in gs:
-        # within rounding of zero: 1e-5 of the largest sum of |x| |w| + |b| of the layer (~170 f32 ulps of what the element was
-        # summed from; the first layer's terms cancel to an rms a thousand times smaller than that)
-        assert g["max_abs_pre_where_differ"] <= 1e-5 * g["terms"], \
+        # within the path's own tolerance of zero: the two pre-activations are sums over inputs that already differ by the bar the
+        # reconstructions are held to (1e-4 relative: the discriminators see the HIP generator's output in one run and the oracle's in
+        # the other), so a branch may differ where |pre-activation| <= 2e-4 of the largest sum of |x| |w| + |b| of the layer
+        # (measured: 3e-6 ... 1.0e-4; the first layer's terms cancel to an rms ten times smaller than that sum).  A wrong mask or
+        # layout would put differing branches at pre-activations of the order of the rms itself
+        assert g["max_abs_pre_where_differ"] <= 2e-4 * g["terms"], \
             f"{g['prefix']}convs.{g['layer']}: a branch differs where the oracle's pre-activation is {g['max_abs_pre_where_differ']:.2e} " \
             f"(layer rms {g['rms']:.2e}, largest sum of |x||w| {g['terms']:.2e})"
     own = _oracle_hifispeech_own_branches()
