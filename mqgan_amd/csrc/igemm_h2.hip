@@ -945,46 +945,56 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 // ---- bias gradient inside the weight-gradient kernels (r5).  db[k] = sum over the pixels of dy[pixel][k]: the dy tile of every
 // K-step is in LDS anyway (64 pixels x 256 channels, 512-byte rows, 16-byte chunk index XORed with the row's swizzle), so the
-// blocks of column tile 0 - one per (split, group, row tile) - add it up on the vector unit: thread (chunk c = tid & 31, pixel
-// group tid >> 5) reads 4 pixels x 8 channels per K-step.  r2-r4 read dy a second time from HBM for this (h2_colsum_*: 4.0 ms of
-// the config-3 step, 67 launches).  The reads are inline asm: in front of a C++ load from LDS the compiler waits for every
-// LDS-DMA in flight (vmcnt(0)), which would make exactly these blocks pay the DMA latency of the NEXT tile in every K-step.
+// blocks add it up on the vector unit.  r2-r4 read dy a second time from HBM for this (h2_colsum_*: 4.0 ms of the config-3 step,
+// 67 launches).  The work is SPREAD over the column tiles of a (split, group, row tile): column tile ct owns the 8-channel chunks
+// ct, ct + nCt, ... of the 32 - one to three chunks of 64 pixels per K-step, a 16-byte read for some of its threads.  (First
+// version: column tile 0 summed everything, 4 reads + 32 adds per thread and K-step - those blocks became the stragglers of every
+// launch and the step got 1.5 ms SLOWER than with the separate passes.)  The reads are inline asm: in front of a C++ load from
+// LDS the compiler waits for every LDS-DMA in flight (vmcnt(0)), i.e. for the NEXT tile.
+constexpr int H2_BS_MAX = 4;                      // items per thread: 32 chunks x 64 pixels / 512 threads (one column tile owns all)
 template <bool MF16>
-__device__ __forceinline__ void h2_dy_colsum_step(const char *img, float (&bs)[8])
+__device__ __forceinline__ void h2_dy_colsum_step(const char *img, int ct, int nct, float (&bs)[H2_BS_MAX][8])
 {
-    const int c16 = threadIdx.x & 31, pg = threadIdx.x >> 5;
-    u32x4 v[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int p = pg * 4 + i;
-        const int swz = ((p & 3) << 2) | (MF16 ? (((p >> 3) & 1) << 1) : 0);
-        const unsigned a = (unsigned)reinterpret_cast<uintptr_t>(img + p * 512 + ((c16 ^ swz) << 4));
-        asm volatile("ds_read_b128 %0, %1" : "=v"(v[i]) : "v"(a));
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : : "memory");
+    for (int r = 0; r < H2_BS_MAX; ++r) {
+        const int item = threadIdx.x + 512 * r;
+        const int c16 = ct + nct * (item >> 6), p = item & 63;
+        if (c16 < 32) {                                            // wave-uniform: a wave's 64 items share the chunk
+            const int swz = ((p & 3) << 2) | (MF16 ? (((p >> 3) & 1) << 1) : 0);
+            const unsigned a = (unsigned)reinterpret_cast<uintptr_t>(img + p * 512 + ((c16 ^ swz) << 4));
+            u32x4 v;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            bs[2 * e] += __builtin_bit_cast(float, v[i][e] << 16);
-            bs[2 * e + 1] += __builtin_bit_cast(float, v[i][e] & 0xFFFF0000u);
+            for (int e = 0; e < 4; ++e) {
+                bs[r][2 * e] += __builtin_bit_cast(float, v[e] << 16);
+                bs[r][2 * e + 1] += __builtin_bit_cast(float, v[e] & 0xFFFF0000u);
+            }
         }
+    }
 }
-// after the K loop (every wave past its last barrier, LDS free): the 16 pixel groups' sums of a channel are added in a fixed order
-// and go to the (split, group) row of the bias slab
-__device__ __forceinline__ void h2_dy_colsum_store(const float (&bs)[8], char *smem, float *__restrict__ bias_row, int k0, int bmk, int K)
+// after the K loop (every wave past its last barrier, LDS free): the 64 pixels' sums of a channel are added in a fixed order and go
+// to the (split, group) row of the bias slab
+__device__ __forceinline__ void h2_dy_colsum_store(const float (&bs)[H2_BS_MAX][8], char *smem, float *__restrict__ bias_row, int ct,
+                                                   int nct, int k0, int bmk, int K)
 {
-    float *sp = reinterpret_cast<float *>(smem);                   // [16 pixel groups][256 channels]
-    const int c16 = threadIdx.x & 31, pg = threadIdx.x >> 5;
+    float *sp = reinterpret_cast<float *>(smem);                   // [owned chunk][8 channels][64 pixels]
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 8; ++e) sp[pg * 256 + c16 * 8 + e] = bs[e];
+    for (int r = 0; r < H2_BS_MAX; ++r) {
+        const int item = threadIdx.x + 512 * r;
+        const int slot = item >> 6, p = item & 63;
+        if (ct + nct * slot < 32) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sp[(slot * 8 + e) * 64 + p] = bs[r][e];
+        }
+    }
     __syncthreads();
-    const int ch = threadIdx.x;
-    if (ch < bmk && k0 + ch < K) {
+    const int slot = threadIdx.x >> 3, e = threadIdx.x & 7;       // 64 slots x 8 channels >= 32 chunks
+    const int c16 = ct + nct * slot;
+    const int ch = c16 * 8 + e;
+    if (c16 < 32 && ch < bmk && k0 + ch < K) {
         float t = 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) t += sp[q * 256 + ch];
+        for (int q = 0; q < 64; ++q) t += sp[(slot * 8 + e) * 64 + q];
         bias_row[k0 + ch] = t;
     }
 }
@@ -1183,17 +1193,17 @@ __device__ __forceinline__ void conv_wgrad_h2_body(const unsigned short *__restr
         }
     };
     int st_c = 0;
-    const bool sum_dy = bias_slab != nullptr && ct == 0;           // block-uniform
-    float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool sum_dy = bias_slab != nullptr && ct < 32;           // block-uniform: column tile ct owns the chunks ct, ct + nCt, ...
+    float bs[H2_BS_MAX][8] = {};
     for (int t = 0; t < nsteps; ++t) {
         issue(st_c ^ 1);                 // past the end of the split: every lane is out of range, the DMA writes zeros
         compute(st_c);
-        if (sum_dy) h2_dy_colsum_step<MF16>(smem + st_c * STAGE, bs);
+        if (sum_dy) h2_dy_colsum_step<MF16>(smem + st_c * STAGE, ct, g.nCt, bs);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         st_c ^= 1;
     }
-    if (sum_dy) h2_dy_colsum_store(bs, smem, bias_slab + ((size_t)split * groups + grp) * g.K, k0, BMK, g.K);
+    if (sum_dy) h2_dy_colsum_store(bs, smem, bias_slab + ((size_t)split * groups + grp) * g.K, ct, g.nCt, k0, BMK, g.K);
 
     // slab [split][group][K][RSC], columns scattered into the channel-blocked filter layout (common.h: kidx)
     float *o = out + ((size_t)split * groups + grp) * (size_t)g.K * g.RSC;
@@ -1422,17 +1432,17 @@ __device__ __forceinline__ void conv_wgrad_h2s_body(const unsigned short *__rest
         }
     };
     int st_c = 0;
-    const bool sum_dy = bias_slab != nullptr && ct == 0;           // block-uniform; dy is zero at the padded positions
-    float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool sum_dy = bias_slab != nullptr && ct < 32;           // block-uniform; dy is zero at the padded positions
+    float bs[H2_BS_MAX][8] = {};
     for (int t = 0; t < nsteps; ++t) {
         issue(st_c ^ 1);                 // past the end of the split: dy out of range (zeros); the x image is whatever follows
         compute(st_c);
-        if (sum_dy) h2_dy_colsum_step<false>(smem + st_c * STAGE, bs);
+        if (sum_dy) h2_dy_colsum_step<false>(smem + st_c * STAGE, ct, g.nCt, bs);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         st_c ^= 1;
     }
-    if (sum_dy) h2_dy_colsum_store(bs, smem, bias_slab + ((size_t)split * groups + grp) * g.K, k0, BMK, g.K);
+    if (sum_dy) h2_dy_colsum_store(bs, smem, bias_slab + ((size_t)split * groups + grp) * g.K, ct, g.nCt, k0, BMK, g.K);
 
     // slab [split][group][K][RSC]; the tile's columns (tap col s, channel) go to (tap, channel) of the channel-blocked filter layout
     float *o = out + ((size_t)split * groups + grp) * (size_t)g.K * g.RSC;

@@ -38,8 +38,10 @@ hist += ["## F. Notes", ""] + L[i_note:i_39] + L[i_soak:i_4]
 hist += ["## G. The 4-rank \"hang\" of round 2", ""] + L[i_hang:i_exposed]
 hist += ["## H. Round 4's closing section: the r3 review's items, what was measured and not built, the next list", ""] + L[i_6 + 1:]
 
-new = L[:i_tab] + part("table.md") + [""] + part("steptimes.md") + [""]
-new += L[i_31:i_34] + part("s34.md") + [""] + L[i_35:i_why] + part("s36_fused.md") + [""]
+i_bf16 = find("bf16 (`training.precision: bf16`")
+new = L[:i_bf16] + part("s1_r5.md") + [""] + L[i_bf16:i_tab] + part("table.md") + [""] + part("steptimes.md") + [""]
+i_32 = find("### 3.2 GEMM engine")
+new += L[i_31:i_32] + part("s31b.md") + [""] + L[i_32:i_34] + part("s34.md") + [""] + L[i_35:i_why] + part("s36_fused.md") + [""]
 new += part("s37.md") + [""] + L[i_38:i_note] + L[i_39:i_soak] + L[i_4:i_hang] + L[i_exposed:i_host] + part("s4_r5.md") + [""] + L[i_host:i_5]
 new += L[i_5:i_6] + part("s6.md") + [""]
 text = "\n".join(new)
