@@ -183,6 +183,8 @@ class GradReducer:
         self._launched = [False] * len(self.buckets)
         self._handles = []
         self._hooks = []
+        self._last_launch_event = None         # HIP event at the launch of the step's last bucket (while the StallClock runs)
+        self._tail_pairs = []                  # (that event, event behind finish()'s waits) per step
         self.enabled = (self.world > 1 or (force and dist.is_initialized())) and self.comm is None
         # gloo with DEVICE tensors (only the one-GPU rehearsal of the multi-rank path uses it): ProcessGroupGloo stages every
         # collective through a private HIGH-PRIORITY stream that waits ON THE DEVICE for the compute stream.  With several
@@ -217,7 +219,7 @@ class GradReducer:
         """Mean time on the compute stream between the launch of a step's LAST bucket (its gradients had just become ready) and the
         end of finish()'s waits - what clip / Adam waited for behind the end of backward.  Measured while the communicator's
         StallClock is enabled; synchronises; resets."""
-        pairs, self._tail_pairs = getattr(self, "_tail_pairs", []), []
+        pairs, self._tail_pairs = self._tail_pairs, []
         if not pairs:
             return 0.0
         torch.cuda.synchronize()
@@ -281,11 +283,9 @@ class GradReducer:
                 import sys
                 print(f"[ddp rank {dist.get_rank(self.pg)}] handle {i} of {len(self._handles)} done", file=sys.stderr, flush=True)
         self._handles = []
-        if getattr(self, "_last_launch_event", None) is not None:
+        if self._last_launch_event is not None:
             done = torch.cuda.Event(enable_timing=True)
             done.record()
-            if not hasattr(self, "_tail_pairs"):
-                self._tail_pairs = []
             self._tail_pairs.append((self._last_launch_event, done))
             self._last_launch_event = None
         if self.average:
