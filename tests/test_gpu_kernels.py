@@ -843,6 +843,40 @@ def test_pointwise_eval(env, Cc, act):
         assert_rel(gd.grad, gamma.grad, 1e-4, "dgamma")
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act,p_drop", [(0, 0.0), (0, 0.1), (1, 0.0), (1, 0.1), (2, 0.0), (2, 0.1)])
+def test_pointwise_specialised_kernels_are_bit_identical_to_the_generic_ones(env, monkeypatch, dt, act, p_drop):
+    """csrc/pointwise.hip: the vector path runs kernels specialised on (activation, dropout) with multiply-high divisions for the
+    frame-mask index; MQGAN_PW_GENERIC=1 selects the run-time-switched kernels they replace.  Same arithmetic in the same order:
+    outputs, input / residual gradients and the APTx parameter gradients agree bit for bit - with both residuals, both mask
+    flags, the refiner's and the discriminators' mask maps, and divisors that are not powers of two."""
+    ops = env
+    torch.manual_seed(11)
+    for shape, dmap, mshape in (((3, 37, 5, 24), (5, 1, 1 << 30), (3, 37)), ((4, 6, 19, 40), (6 * 19, 19, 19), (4, 19)),
+                                ((2, 64, 90, 64), (90, 1, 1), (2, 64))):
+        h = torch.randn(shape, device=DEV).to(dt)
+        rp, ro, g = (torch.randn(shape, device=DEV).to(dt) for _ in range(3))
+        m = (torch.rand(mshape, device=DEV) > 0.6).to(torch.uint8)
+        beta, gamma = torch.tensor(1.1, device=DEV), torch.tensor(0.45, device=DEV)
+        res = []
+        for generic in (False, True):
+            if generic:
+                monkeypatch.setenv("MQGAN_PW_GENERIC", "1")
+            else:
+                monkeypatch.delenv("MQGAN_PW_GENERIC", raising=False)
+            ops.manual_seed(77)
+            leaves = [t.clone().requires_grad_(True) for t in (h, rp, ro)] + [beta.clone().requires_grad_(True), gamma.clone().requires_grad_(True)]
+            kw = dict(beta=leaves[3], gamma=leaves[4]) if act == 1 else {}
+            y = ops.pointwise(leaves[0], act=act, r_pre=leaves[1], r_post=leaves[2], mask=m, mask_pre=True, mask_post=True, dmap=dmap,
+                              p_drop=p_drop, training=True, **kw)
+            y.backward(g)
+            res.append([y.detach()] + [t.grad for t in leaves[:3]] + ([leaves[3].grad, leaves[4].grad] if act == 1 else []))
+        monkeypatch.delenv("MQGAN_PW_GENERIC", raising=False)
+        for a, b, name in zip(res[0], res[1], ("y", "dh", "dr_pre", "dr_post", "dbeta", "dgamma")):
+            assert torch.equal(a, b), (name, shape, dt)
+        assert res[0][0].float().abs().sum().item() > 0
+
+
 def test_pointwise_mask_mappings(env):
     ops = env
     torch.manual_seed(5)

@@ -35,3 +35,12 @@ for (kind, det), (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     dd = dict(zip(names, det))
     print(f"{kind:16s} x{n:<2d} {ms:8.2f} ms {fl / ms / 1e9:7.1f} TF  N{dd['N']} {dd['H']}x{dd['W']} C{dd['C']}->K{dd['K']} k{dd['R']}x{dd['S']} s{dd['sh']},{dd['sw']} g{dd['g']}")
 print("total conv ms", tot)
+# LAYER_FILTER="k3x5 s1,1": every launch of the matching layers, in launch order, with the kernel instantiation
+flt = os.environ.get("LAYER_FILTER")
+if flt:
+    for (tag, flops, a, b), det in zip(timer.records, timer.details):
+        dd = dict(zip(names, det))
+        shape = f"N{dd['N']} {dd['H']}x{dd['W']} C{dd['C']}->K{dd['K']} k{dd['R']}x{dd['S']} s{dd['sh']},{dd['sw']} g{dd['g']}"
+        if flt in shape:
+            ms = a.elapsed_time(b)
+            print(f"  {shape:52s} {ms:7.3f} ms {flops / ms / 1e9:7.1f} TF  {tag}")
