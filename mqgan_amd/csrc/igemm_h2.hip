@@ -79,8 +79,9 @@ struct ElemF32 { static constexpr int ESZ = 4; static constexpr bool F32 = true;
 
 // ---- epilogue of the H2 kernels: bias, activation / gate, store (f32 straight from the accumulators, bf16 transposed through a
 // per-wave LDS patch).  row_ok(m): output row m of the tile's enumeration exists;  out_index(m): element offset of its column 0.
-template <class ET, int TN, bool MF16, class RowOk, class OutIdx>
-__device__ __forceinline__ void h2_epilogue(f32x16 (&acc)[MF16 ? 1 : 2][MF16 ? 1 : TN], f32x4v (&acc16)[MF16 ? 4 : 1][MF16 ? 2 * TN : 1],
+// W16: 16-column tiles per wave (the wave tile is 16 * W16 columns wide; 2 * TN except in the 96-column kernel, where TN is unused)
+template <class ET, int TN, bool MF16, int W16, class RowOk, class OutIdx>
+__device__ __forceinline__ void h2_epilogue(f32x16 (&acc)[MF16 ? 1 : 2][MF16 ? 1 : TN], f32x4v (&acc16)[MF16 ? 4 : 1][MF16 ? W16 : 1],
                                             const H2Geom &g, const H2Epi &epi, void *__restrict__ out, char *smem, int m0, int n0, int grp,
                                             RowOk &&row_ok, OutIdx &&out_index)
 {
@@ -91,7 +92,8 @@ __device__ __forceinline__ void h2_epilogue(f32x16 (&acc)[MF16 ? 1 : 2][MF16 ? 1
     // ---- epilogue.  LDS is free once every wave's DMAs have landed and its fragment reads are back.
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    constexpr int STG_ROWB = 64 * TN;                             // bytes of one staged bf16 row: 32 * TN columns
+    static_assert(MF16 || W16 == 2 * TN, "wave tile width");
+    constexpr int STG_ROWB = 32 * W16;                            // bytes of one staged bf16 row: 16 * W16 columns
     constexpr int STG_WAVE = 32 * STG_ROWB;                       // one wave stages 32 rows (one tm) at a time
     unsigned char *padf = reinterpret_cast<unsigned char *>(smem) + 8 * STG_WAVE;
     const bool fused = epi.act == 2, gated = epi.act == 3;
@@ -115,7 +117,7 @@ __device__ __forceinline__ void h2_epilogue(f32x16 (&acc)[MF16 ? 1 : 2][MF16 ? 1
 #pragma unroll
             for (int th = 0; th < 2; ++th)
 #pragma unroll
-                for (int tn = 0; tn < 2 * TN; ++tn)
+                for (int tn = 0; tn < W16; ++tn)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         fn(th * 16 + (lane >> 4) * 4 + j, tn * 16 + (lane & 15), acc16[2 * half + th][tn][j]);
@@ -127,11 +129,11 @@ __device__ __forceinline__ void h2_epilogue(f32x16 (&acc)[MF16 ? 1 : 2][MF16 ? 1
         }
     };
     // bias of this lane's columns: column index inside the wave tile -> slot
-    constexpr int NBV = MF16 ? 2 * TN : TN;
+    constexpr int NBV = MF16 ? W16 : TN;
     float bv[NBV];
 #pragma unroll
     for (int tn = 0; tn < NBV; ++tn) {
-        const int n = n0 + wn * 32 * TN + (MF16 ? tn * 16 + (lane & 15) : tn * 32 + li);
+        const int n = n0 + wn * 16 * W16 + (MF16 ? tn * 16 + (lane & 15) : tn * 32 + li);
         bv[tn] = (epi.bias && n < g.Ncols) ? epi.bias[(size_t)grp * g.Ncols + n] : 0.f;
     }
     auto bias_of = [&](int cl) { return bv[MF16 ? cl >> 4 : cl >> 5]; };
@@ -142,7 +144,7 @@ __device__ __forceinline__ void h2_epilogue(f32x16 (&acc)[MF16 ? 1 : 2][MF16 ? 1
             constexpr int half = decltype(half_tag)::value;
             for_half(half_tag, [&](int rl, int cl, float a) {
                 const int row = wm * 64 + half * 32 + rl;
-                const int m = m0 + row, n = n0 + wn * 32 * TN + cl;
+                const int m = m0 + row, n = n0 + wn * 16 * W16 + cl;
                 if (row_ok(m) && n < g.Ncols) {
                     float v = a + bias_of(cl);
                     if (fused) {
@@ -168,7 +170,7 @@ __device__ __forceinline__ void h2_epilogue(f32x16 (&acc)[MF16 ? 1 : 2][MF16 ? 1
     char *stg = smem + wave * STG_WAVE;
     auto stage_half = [&](auto half_tag) {
         constexpr int half = decltype(half_tag)::value;
-        constexpr int CPR = 4 * TN;                                   // 16-byte chunks per row
+        constexpr int CPR = 2 * W16;                                  // 16-byte chunks per row
         constexpr int NIT = (32 * CPR + 63) / 64;
         // gated store: this lane's chunks of the gate tensor are requested before the tile is staged, so their latency
         // hides behind the LDS transpose instead of sitting in front of every store
@@ -179,7 +181,7 @@ __device__ __forceinline__ void h2_epilogue(f32x16 (&acc)[MF16 ? 1 : 2][MF16 ? 1
                 const int q = i * 64 + lane;
                 const int rl = q / CPR, c16 = q - rl * CPR;
                 const int m = m0 + wm * 64 + half * 32 + rl;
-                const int n = n0 + wn * 32 * TN + c16 * 8;
+                const int n = n0 + wn * 16 * W16 + c16 * 8;
                 gq[i] = make_uint4(0, 0, 0, 0);
                 if (rl < 32 && row_ok(m) && n < g.Ncols) gq[i] = *reinterpret_cast<const uint4 *>(epi.gate + out_index(m) + n);
             }
@@ -198,7 +200,7 @@ __device__ __forceinline__ void h2_epilogue(f32x16 (&acc)[MF16 ? 1 : 2][MF16 ? 1
             const int q = i * 64 + lane;
             const int rl = q / CPR, c16 = q - rl * CPR;
             const int m = m0 + wm * 64 + half * 32 + rl;
-            const int n = n0 + wn * 32 * TN + c16 * 8;
+            const int n = n0 + wn * 16 * W16 + c16 * 8;
             if (rl < 32 && row_ok(m) && n < g.Ncols) {
                 uint4 v = *reinterpret_cast<const uint4 *>(stg + rl * STG_ROWB + c16 * 16);
                 if (gated) {
@@ -623,7 +625,7 @@ __device__ __forceinline__ void conv_h2_body(const void *__restrict__ act_v, con
             return ((size_t)grp * Mc + m) * g.Ncols;
         }
     };
-    h2_epilogue<ET, TN, MF16>(acc, acc16, g, epi, out, smem, m0, n0, grp, [&](int m) { return m < Mc; }, out_index);
+    h2_epilogue<ET, TN, MF16, 2 * TN>(acc, acc16, g, epi, out, smem, m0, n0, grp, [&](int m) { return m < Mc; }, out_index);
 }
 
 // ------------------------------------------------------------------------------------------ shared-row variant (r4)
@@ -889,7 +891,7 @@ __device__ __forceinline__ void conv_h2s_body(const void *__restrict__ act_v, co
         s_pix[tid] = (m < Mp && owp < g.OW) ? t * g.OW + owp : -1;
     }
     const int npix = g.ng * g.OH * g.OW;
-    h2_epilogue<ElemBF16, TN, true>(acc_unused, acc16, g, epi, out, smem, m0, n0, grp,
+    h2_epilogue<ElemBF16, TN, true, 2 * TN>(acc_unused, acc16, g, epi, out, smem, m0, n0, grp,
                                     [&](int m) { return s_pix[m - m0] >= 0; },
                                     [&](int m) -> size_t { return ((size_t)grp * npix + (size_t)s_pix[m - m0]) * g.Ncols; });
 }
@@ -900,6 +902,276 @@ __global__ __launch_bounds__(512, 2) void conv_h2s_kernel(const unsigned short *
 {
     __shared__ __attribute__((aligned(1024))) char smem[2 * H2S_AEXT + 2 * 64 * TN * H2_ROWB + 8 * 1024];   // + the waves' dummy patches
     conv_h2s_body<TN, S>(act, wgt, out, g, epi, act_group_stride, smem);
+}
+
+// ------------------------------------------------------------------------------------------ shared rows on 96-channel chunks (r5)
+// The refiner's outer levels have 96 / 288 channels (hifimusic): no multiple of 64, so their 3x3 layers ran on conv_h2_kernel with
+// 32-channel chunks and a 128-column tile for 96 output channels - every activation byte staged for 96 of 128 columns, three
+// times (once per column tap): 64 useful flop per DMA byte against 155-230 on the wide levels, and 0.17-0.26 of the bf16 peak.
+// Here an LDS row is one pixel's 96-channel chunk (192 bytes), a K-step is one tap x 96 channels (three 32-deep MFMA substeps),
+// the block tile is 256 x 96 (8 waves as 4 x 64 rows by 2 x 48 columns = 4 x 3 tiles of 16 x 16: no padding column, no padding
+// channel) and the activation image is shared by the three column taps as in conv_h2s_kernel:
+//   DMA bytes per three K-steps: 48.4 KB of image + 3 x 18 KB of weights for 14.2 MFLOP = 139 flop per byte.
+// 192-byte rows put rows r and r + 4 on the same banks; the 16-byte chunk c of row R is therefore stored at chunk
+// (c + ((R >> 2) & 3)) mod 12 - any 16 consecutive rows then cover the 16 bank quads once, at every row offset (the shifted
+// reads of the column taps included).  The LDS-DMA writes whole 1 KB pieces (5 1/3 rows), so each lane derives (row, chunk) from
+// its linear chunk index once, before the loop.  The weight image is the 32-channel-chunk image the layer already has: a lane's
+// 16 bytes lie in ONE 32-channel chunk, the three chunks of a tap are RS * 64 bytes apart.
+// Reduction order (96-chunk, tap row, tap col, channel): not the order of conv_h2_kernel<.., 32, ..> - tested against float64.
+constexpr int H96_ROWB = 192, H96_NCH = 12;                      // bytes and 16-byte chunks per LDS row
+constexpr int H96_APIECES = 49, H96_AEXT = H96_APIECES * 1024;   // 258 rows x 192 B = 49,536 B in whole 1 KB pieces
+constexpr int H96_ASLOTS = 7;                                    // pieces p = wave + 8 j, j = 0 .. 6 (p < 49)
+constexpr int H96_BN = 96, H96_BPIECES = 18, H96_BSZ = H96_BPIECES * 1024, H96_BSLOTS = 3;
+// THREE weight stages: a K-step here is 36 MFMAs per wave (0.5 us per SIMD), shorter than an L2 round trip under load - with two
+// stages (tile t + 1 requested at the start of K-step t, awaited at its end) the kernel ran at 0.75 PF/s waiting for it.  Tile
+// t + 2 is requested instead and the wait at the end of a K-step leaves its three pieces in flight (counted wait).
+constexpr int H96_NSB = 3;
+
+template <int S>
+__device__ __forceinline__ void conv_h2s96_body(const void *__restrict__ act_v, const void *__restrict__ wgt_v, void *__restrict__ out,
+                                                const H2Geom &g, const H2Epi &epi, size_t act_group_stride, char *smem)
+{
+    static_assert(S == 3, "column taps");
+    // pieces beyond the image / the tile are issued out of range (zeros) into ONE shared 1 KB patch: every wave writes the same zeros
+    char *smemA = smem, *smemB = smem + 2 * H96_AEXT, *patch = smemB + H96_NSB * H96_BSZ;
+    const char *act = reinterpret_cast<const char *>(act_v);
+    const char *wgt = reinterpret_cast<const char *>(wgt_v);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int grp = blockIdx.y;
+    const int OWp = g.OW + S - 1;
+    const int Mp = g.ng * g.OH * OWp;
+    const int tile = xcd_remap(blockIdx.x, g.nMt * g.nNt);
+    const int mt = tile / g.nNt, nt = tile - mt * g.nNt;
+    const int m0 = mt * H2_BM, n0 = nt * H96_BN;
+    const int step_h = __builtin_amdgcn_readfirstlane(g.step_h);
+    const int smin = g.step_w < 0 ? (S - 1) * g.step_w : 0;
+    const int nR = __builtin_amdgcn_readfirstlane(g.nR);
+    const int nch = g.IC / 96;
+    const int RS = g.R * g.S;
+
+    // ---- DMA slots: lane L of piece p holds the linear chunk n = 64 p + L = 12 row + physical chunk
+    const int img0 = m0 / (g.OH * OWp);
+    const size_t img_elems = (size_t)g.IH * g.IW * g.IC;
+    const char *abase = act + ((size_t)grp * act_group_stride + (size_t)img0 * img_elems) * 2;
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(abase, (act_group_stride - (size_t)img0 * img_elems) * 2);
+    const char *wbase = wgt + ((size_t)grp * g.Ncols + n0) * g.Kp * 2;
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(wbase, (size_t)(g.Ncols - n0 < H96_BN ? g.Ncols - n0 : H96_BN) * g.Kp * 2);
+    int bh_[H96_ASLOTS], rowbase_[H96_ASLOTS];
+    bool rv_[H96_ASLOTS];
+#pragma unroll
+    for (int j = 0; j < H96_ASLOTS; ++j) {
+        const int pc = wave + 8 * j;
+        const int n = 64 * pc + lane;
+        const int e = n / H96_NCH, phys = n - e * H96_NCH;
+        int lc = phys - ((e >> 2) & 3);
+        lc += lc < 0 ? H96_NCH : 0;
+        const int q = m0 + e;
+        bool v = pc < H96_APIECES && e < H2_BM + S - 1 && q < Mp;
+        const int qq = v ? q : m0;
+        const int owp = qq % OWp, t = qq / OWp;
+        const int oh = t % g.OH, nimg = t / g.OH - img0;
+        const int col = owp + g.add_w + smin;
+        v = v && (unsigned)col < (unsigned)g.IW;
+        const int bh = oh * g.mul_h + g.add_h;
+        rv_[j] = v;
+        bh_[j] = bh;
+        rowbase_[j] = (((nimg * g.IH + bh) * g.IW + (v ? col : 0)) * g.IC) * 2 + lc * 16;
+    }
+    unsigned rowoffB[H96_BSLOTS];
+#pragma unroll
+    for (int j = 0; j < H96_BSLOTS; ++j) {
+        const int pc = wave + 8 * j;
+        const int n = 64 * pc + lane;
+        const int row = n / H96_NCH, phys = n - row * H96_NCH;
+        int lc = phys - ((row >> 2) & 3);
+        lc += lc < 0 ? H96_NCH : 0;
+        const bool ok = pc < H96_BPIECES && n0 + row < g.Ncols;
+        // 32-channel chunk lc >> 2 of the tap (RS * 64 bytes further per chunk in the weight image), 16-byte piece lc & 3 of it
+        rowoffB[j] = ok ? (unsigned)row * (unsigned)g.Kp * 2u + (unsigned)(lc >> 2) * (unsigned)RS * 64u + (unsigned)(lc & 3) * 16u : OOB;
+    }
+    // ---- scalar walks (as conv_h2s_body): weight tile per K-step over (96-chunk, tap row, tap col), image per (96-chunk, tap row)
+    int b_js = 0, b_jr = 0, b_ch = nR > 0 ? 0 : nch;
+    int a_jr = 0, a_ch = b_ch;
+    int bcol = 0, hoffA = 0, aoffA = 0;
+    bool kvB = false, kvA = false;
+    auto walk_b = [&]() {
+        bcol = ((3 * b_ch * RS + b_jr * g.S + b_js) * 32) * 2;
+        kvB = b_ch < nch;
+        ++b_js;
+        const bool c2 = b_js >= S;
+        b_js = c2 ? 0 : b_js;
+        b_jr += c2 ? 1 : 0;
+        const bool c3 = b_jr >= nR;
+        b_jr = c3 ? 0 : b_jr;
+        b_ch += c3 ? 1 : 0;
+    };
+    auto walk_a = [&]() {
+        hoffA = a_jr * step_h;
+        aoffA = ((hoffA * g.IW) * g.IC + a_ch * 96) * 2;
+        kvA = a_ch < nch;
+        ++a_jr;
+        const bool c3 = a_jr >= nR;
+        a_jr = c3 ? 0 : a_jr;
+        a_ch += c3 ? 1 : 0;
+    };
+    // branch-free (see conv_h2s_body): pieces beyond the image / the tile go out of range into the wave's own 1 KB patch
+    auto dma_ax = [&](int stage, auto j_tag) {
+        constexpr int j = decltype(j_tag)::value;
+        const bool ok = rv_[j] & kvA & ((unsigned)(bh_[j] + hoffA) < (unsigned)g.IH);
+        const unsigned vo = ok ? (unsigned)(rowbase_[j] + aoffA) : OOB;
+        char *dst = smemA + stage * H96_AEXT + (wave + 8 * j) * 1024;
+        if constexpr (8 * j + 7 >= H96_APIECES) dst = wave + 8 * j < H96_APIECES ? dst : patch;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, lds_ptr(dst), 16, vo, 0, 0, 0);
+    };
+    auto dma_b = [&](int stage, auto j_tag) {
+        constexpr int j = decltype(j_tag)::value;
+        const unsigned vo = ((rowoffB[j] != OOB) & kvB) ? rowoffB[j] + (unsigned)bcol : OOB;
+        char *dst = smemB + stage * H96_BSZ + (wave + 8 * j) * 1024;
+        if constexpr (8 * j + 7 >= H96_BPIECES) dst = wave + 8 * j < H96_BPIECES ? dst : patch;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, lds_ptr(dst), 16, vo, 0, 0, 0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    using I4 = std::integral_constant<int, 4>;
+    using I5 = std::integral_constant<int, 5>;
+    using I6 = std::integral_constant<int, 6>;
+
+    f32x16 acc_unused[1][1];
+    f32x4v acc16[4][3];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc16[a][b][r] = 0.f;
+
+    // ---- fragment addresses: lane (r = l & 15, q = l >> 4) holds k = 8 q .. 8 q + 7 of substep sx = logical chunk 4 sx + q of its row
+    const int r16 = lane & 15, g4 = lane >> 4;
+    auto chunk_off = [](int row, int c) { return row * H96_ROWB + (((c + ((row >> 2) & 3)) % H96_NCH) << 4); };
+    int a16t[S][3], b16[3];
+#pragma unroll
+    for (int js = 0; js < S; ++js) {
+        const int rr = wm * 64 + r16 + (g.step_w < 0 ? S - 1 - js : js);      // + 16 tt: the rotation does not change
+#pragma unroll
+        for (int sx = 0; sx < 3; ++sx) a16t[js][sx] = chunk_off(rr, 4 * sx + g4);
+    }
+#pragma unroll
+    for (int sx = 0; sx < 3; ++sx) b16[sx] = chunk_off(wn * 48 + r16, 4 * sx + g4);
+    bf16x8 fa[3][4], fb[3][3];                                      // one fragment set per substep
+    auto ld_a = [&](const char *base, auto js_tag, auto sx_tag) {
+        constexpr int js = decltype(js_tag)::value, sx = decltype(sx_tag)::value;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) fa[sx][tt] = *reinterpret_cast<const bf16x8 *>(base + a16t[js][sx] + tt * 16 * H96_ROWB);
+    };
+    auto ld_b = [&](const char *base, auto sx_tag) {
+        constexpr int sx = decltype(sx_tag)::value;
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) fb[sx][tt] = *reinterpret_cast<const bf16x8 *>(base + b16[sx] + tt * 16 * H96_ROWB);
+    };
+    auto mm_row = [&](auto sx_tag, auto tm_tag) {
+        constexpr int sx = decltype(sx_tag)::value, tm = decltype(tm_tag)::value;
+#pragma unroll
+        for (int tn = 0; tn < 3; ++tn) acc16[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[sx][tm], fb[sx][tn], acc16[tm][tn], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- prologue: image 0 and weight tile 0
+    walk_a();
+    dma_ax(0, I0{}); dma_ax(0, I1{}); dma_ax(0, I2{}); dma_ax(0, I3{}); dma_ax(0, I4{}); dma_ax(0, I5{}); dma_ax(0, I6{});
+    walk_b();
+    dma_b(0, I0{}); dma_b(0, I1{}); dma_b(0, I2{});
+    walk_b();                                                      // tile 1 is on its way before the loop starts
+    dma_b(1, I0{}); dma_b(1, I1{}); dma_b(1, I2{});
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int sA = 0, sB = 0;
+    ld_a(smemA, I0{}, I0{});
+    ld_b(smemB, I0{});
+    walk_a();                                                      // image 1: staged behind the K-steps js = 0, 1 of image 0
+    const int nsuper = nch * nR;
+    // one K-step = column tap js x 96 channels.  On entry the fragments of substep 0 are in registers; one barrier per K-step
+    auto k_step = [&](auto js_tag) {
+        constexpr int js = decltype(js_tag)::value;
+        constexpr int jsn = js == S - 1 ? 0 : js + 1;
+        const char *A = smemA + sA * H96_AEXT, *B = smemB + sB * H96_BSZ;
+        ld_a(A, js_tag, I1{});
+        ld_b(B, I1{});
+        __builtin_amdgcn_sched_barrier(0);
+        mm_row(I0{}, I0{});
+        const int sBi = sB == 0 ? 2 : sB - 1;                      // weight tile t + 2 into the stage tile t - 1 was read from
+        walk_b();
+        dma_b(sBi, I0{});
+        __builtin_amdgcn_sched_barrier(0);
+        mm_row(I0{}, I1{});
+        dma_b(sBi, I1{});
+        __builtin_amdgcn_sched_barrier(0);
+        mm_row(I0{}, I2{});
+        dma_b(sBi, I2{});
+        __builtin_amdgcn_sched_barrier(0);
+        mm_row(I0{}, I3{});
+        ld_a(A, js_tag, I2{});
+        ld_b(B, I2{});
+        __builtin_amdgcn_sched_barrier(0);
+        mm_row(I1{}, I0{}); mm_row(I1{}, I1{}); mm_row(I1{}, I2{}); mm_row(I1{}, I3{});
+        // the weight tile of K-step t + 1 and the image pieces issued one K-step ago have landed (the three pieces of tile t + 2,
+        // issued last, may still be in flight); every fragment read is back
+        asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int sAn = js == S - 1 ? sA ^ 1 : sA;
+        sB = sB == 2 ? 0 : sB + 1;
+        ld_a(smemA + sAn * H96_AEXT, std::integral_constant<int, jsn>{}, I0{});
+        ld_b(smemB + sB * H96_BSZ, I0{});
+        __builtin_amdgcn_sched_barrier(0);
+        // the next image goes into the stage the PREVIOUS image was read from: slots 0 .. 3 behind tap 0, 4 .. 6 behind tap 1, so
+        // that the last of them has the whole K-step of tap 2 to land
+        mm_row(I2{}, I0{});
+        if constexpr (js == 0) dma_ax(sA ^ 1, I0{});
+        if constexpr (js == 1) dma_ax(sA ^ 1, I4{});
+        __builtin_amdgcn_sched_barrier(0);
+        mm_row(I2{}, I1{});
+        if constexpr (js == 0) dma_ax(sA ^ 1, I1{});
+        if constexpr (js == 1) dma_ax(sA ^ 1, I5{});
+        __builtin_amdgcn_sched_barrier(0);
+        mm_row(I2{}, I2{});
+        if constexpr (js == 0) dma_ax(sA ^ 1, I2{});
+        if constexpr (js == 1) dma_ax(sA ^ 1, I6{});
+        __builtin_amdgcn_sched_barrier(0);
+        mm_row(I2{}, I3{});
+        if constexpr (js == 0) dma_ax(sA ^ 1, I3{});
+        if constexpr (js == S - 1) walk_a();
+        __builtin_amdgcn_sched_barrier(0);
+        sA = sAn;
+    };
+    for (int u = 0; u < nsuper; ++u) {
+        k_step(I0{});
+        k_step(I1{});
+        k_step(I2{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // trailing (zero-filling) DMAs must not outlive the block's LDS
+
+    __builtin_amdgcn_s_barrier();
+    int *s_pix = reinterpret_cast<int *>(smem + 8 * 32 * 32 * 3 + 256);      // behind the epilogue's 8 staging patches + 256 flags
+    if (tid < H2_BM) {
+        const int m = m0 + tid;
+        const int owp = m % OWp, t = m / OWp;
+        s_pix[tid] = (m < Mp && owp < g.OW) ? t * g.OW + owp : -1;
+    }
+    const int npix = g.ng * g.OH * g.OW;
+    h2_epilogue<ElemBF16, 1, true, 3>(acc_unused, acc16, g, epi, out, smem, m0, n0, grp,
+                                      [&](int m) { return s_pix[m - m0] >= 0; },
+                                      [&](int m) -> size_t { return ((size_t)grp * npix + (size_t)s_pix[m - m0]) * g.Ncols; });
+}
+
+template <int S>
+__global__ __launch_bounds__(512, 2) void conv_h2s96_kernel(const unsigned short *__restrict__ act, const unsigned short *__restrict__ wgt,
+                                                            void *__restrict__ out, H2Geom g, H2Epi epi, size_t act_group_stride)
+{
+    __shared__ __attribute__((aligned(1024))) char smem[2 * H96_AEXT + H96_NSB * H96_BSZ + 1024];   // + the shared dummy patch
+    conv_h2s96_body<S>(act, wgt, out, g, epi, act_group_stride, smem);
 }
 
 template <int TN, int NSTAGE, int CBK, bool PARITY, bool MF16 = false>
@@ -1737,7 +2009,23 @@ static int launch_h2(const mqConvDesc *d, const void *act, const void *w, void *
     if constexpr (!ET::F32)
         shared_rows = mf16 && !no_share && !parity && g.CB == 64 && (g.S == 3 || g.S == 5 || g.S == 7) && g.sw == 1 && g.dw == 1 &&
                       g.sh == 1 && TN >= 2 && (int64_t)ng * g.OH * (g.OW + g.S - 1) < 0x7FFFFF00ll;
-    if (shared_rows) {
+    // 96-channel chunks: the shared-row kernel on 192-byte rows with a 96-column tile (reduction channels a multiple of 96 but not
+    // of 64, output columns that 96-wide tiles pad no more than the 64 TN ones)
+    bool shared96 = false;
+    if constexpr (!ET::F32)
+        shared96 = mf16 && !no_share && getenv("MQGAN_H2_NO_96") == nullptr && !parity && g.CB == 32 && g.IC % 96 == 0 && g.S == 3 &&
+                   g.sw == 1 && g.dw == 1 && g.sh == 1 && cdiv(g.Ncols, 96) * 96 <= cdiv(g.Ncols, BN) * BN &&
+                   (int64_t)ng * g.OH * (g.OW + g.S - 1) < 0x7FFFFF00ll;
+    if (shared96) {
+        if constexpr (!ET::F32) {
+            g.nMt = (int)cdiv((int64_t)ng * g.OH * (g.OW + g.S - 1), H2_BM);
+            g.nNt = (int)cdiv(g.Ncols, H96_BN);
+            grid = dim3((unsigned)(g.nMt * g.nNt), d->groups);
+            kname("conv_h2s96_kernel<%d>", 3);
+            hipLaunchKernelGGL((conv_h2s96_kernel<3>), grid, block, 0, st, reinterpret_cast<const unsigned short *>(act),
+                               reinterpret_cast<const unsigned short *>(w), out, g, epi, act_gs);
+        }
+    } else if (shared_rows) {
         if constexpr (!ET::F32) {
             g.nMt = (int)cdiv((int64_t)ng * g.OH * (g.OW + g.S - 1), H2_BM);
             grid = dim3((unsigned)(g.nMt * g.nNt), d->groups);

@@ -44,6 +44,11 @@ H2_CASES = [
     dict(N=2, H=6, W=144, C=128, K=192, R=3, S=3, pad=(1, 1)),                                # one-wrap walk over the padded width
     dict(N=4, H=1, W=200, C=128, K=192, R=1, S=3, pad=(0, 1), groups=2),                      # one tap row, two groups
     dict(N=1, H=30, W=37, C=256, K=384, R=3, S=3, pad=(1, 1)),                                # two row tiles, two chunks, 39 columns
+    # the 96-channel shared-row kernel (conv_h2s96_kernel: reduction channels % 96 == 0 and % 64 != 0, three stride-1 column taps);
+    # the 96 -> 96 and 288 -> 96 cases above take it too (forward, and the input gradient with 3 column tiles)
+    dict(N=2, H=5, W=144, C=96, K=192, R=3, S=3, pad=(1, 1)),                                 # two column tiles; rows wrap inside a tile
+    dict(N=4, H=3, W=50, C=96, K=96, R=1, S=3, pad=(0, 1), groups=2),                         # one tap row, two groups, ragged last tile
+    dict(N=1, H=9, W=31, C=288, K=288, R=3, S=3, pad=(1, 1)),                                 # three chunks x three column tiles
 ]
 
 
@@ -88,6 +93,9 @@ def test_h2_fprop_dgrad_wgrad_vs_float64(env, c):
     assert_rel(y32, y_ref, 2e-5, "fprop (f32 out)")
     y16 = ops.conv_fprop_h2(desc, xh, w_h2, bd)
     assert y16.dtype == BF16
+    on96 = (c["S"] == 3 and c.get("stride", (1, 1)) == (1, 1) and c.get("dil", (1, 1)) [1] == 1 and c["C"] % 96 == 0 and c["C"] % 64 != 0 and
+            c["K"] % 96 == 0)
+    assert ops.L().mq_last_kernel().decode().startswith("conv_h2s96_kernel") == on96       # exactly these take the 96-channel kernel
     want16 = y_ref.detach().float().to(BF16).float()
     got16 = y16.float().cpu()
     # one bf16 ulp is <= 2^-7 of the value; the f32 accumulation error (1e-5 of the tensor's scale) can move a value
@@ -124,9 +132,10 @@ def test_h2_fprop_dgrad_wgrad_vs_float64(env, c):
         assert desc.Q < 16
 
 
-def test_h2_leaky_mask_epilogue(env):
+@pytest.mark.parametrize("c", [dict(N=4, H=6, W=40, C=64, K=96, R=3, S=3, stride=(1, 2), pad=(1, 1)),
+                               dict(N=4, H=6, W=40, C=96, K=96, R=3, S=3, pad=(1, 1))], ids=_ids)      # the second: conv_h2s96_kernel
+def test_h2_leaky_mask_epilogue(env, c):
     ops = env
-    c = dict(N=4, H=6, W=40, C=64, K=96, R=3, S=3, stride=(1, 2), pad=(1, 1))
     x, w, b, desc, wk, wc = _setup(ops, c)
     y_ref = _torch_conv(x, w, b, c)                                             # (N, P, Q, K)
     mask = torch.zeros(c["N"], desc.Q, dtype=torch.uint8)
@@ -141,6 +150,7 @@ def test_h2_leaky_mask_epilogue(env):
 
 GATE_CASES = [
     dict(N=4, H=6, W=40, C=64, K=96, R=3, S=3, pad=(1, 1)),                                   # stride 1
+    dict(N=3, H=7, W=40, C=96, K=96, R=3, S=3, pad=(1, 1)),                                   # the 96-channel shared-row kernel
     dict(N=2, H=16, W=20, C=64, K=128, R=5, S=5, stride=(2, 2), pad=(2, 2)),                  # parity classes
     dict(N=16, H=2, W=40, C=32, K=64, R=3, S=5, stride=(1, 2), pad=(1, 2), groups=8),         # 8 groups, stride (1,2)
 ]
