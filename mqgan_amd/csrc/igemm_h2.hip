@@ -50,6 +50,11 @@ struct H2Geom {
     int Kp;                    // weight row pitch in elements (multiple of 64)
     int sh, sw, ph, pw, dh, dw;
     int ng;                    // images per group
+    // conv_h2s_kernel on ONE stride-parity class of a strided input gradient (launch_h2): the taps walked are r0 + jr * rstep,
+    // s0 + js * sstep of the full filter, and row (n, oh, ow) of the class is pixel (oh * osh + oa, ow * osw + ob) of the full
+    // OHf x OWf output.  A plain launch has 0 / 1 / 0 / 1, 1 / 1 / 0 / 0 and OHf = OH, OWf = OW.
+    int tap_r0, tap_rstep, tap_s0, tap_sstep;
+    int osh, osw, oa, ob, OHf, OWf;
 };
 
 struct H2Epi {
@@ -657,7 +662,7 @@ __device__ __forceinline__ void conv_h2s_body(const void *__restrict__ act_v, co
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int grp = blockIdx.y;
-    static_assert(S == 3 || S == 5 || S == 7, "column taps");
+    static_assert(S >= 2 && S <= 7, "column taps");
     const int OWp = g.OW + S - 1;
     const int Mp = g.ng * g.OH * OWp;                             // GEMM rows over the padded width (host: nMt = ceil(Mp / 256))
     const int tile = xcd_remap(blockIdx.x, g.nMt * g.nNt);
@@ -709,7 +714,7 @@ __device__ __forceinline__ void conv_h2s_body(const void *__restrict__ act_v, co
     int bcol = 0, hoffA = 0, aoffA = 0;
     bool kvB = false, kvA = false;
     auto walk_b = [&]() {
-        bcol = ((b_ch * RS + b_jr * g.S + b_js) * 64) * 2;
+        bcol = ((b_ch * RS + (g.tap_r0 + b_jr * g.tap_rstep) * g.S + g.tap_s0 + b_js * g.tap_sstep) * 64) * 2;
         kvB = b_ch < g.nchunks;
         ++b_js;
         const bool c2 = b_js >= S;
@@ -850,6 +855,7 @@ __device__ __forceinline__ void conv_h2s_body(const void *__restrict__ act_v, co
         __builtin_amdgcn_sched_barrier(0);
         // the next image goes into the stage the PREVIOUS image was read from, its five piece slots spread over the K-steps of the
         // first S - 1 column taps (slot j behind tap (j (S - 1)) / 5: at most three per K-step) - each has a whole K-step to land
+        // (S = 2: there is only tap 0 to hide behind - slots 0 .. 2 and, doubled up, 3 and 4)
         constexpr auto at = [](int j) { return (j * (S - 1)) / 5; };
         constexpr int first = at(0) == js ? 0 : at(1) == js ? 1 : at(2) == js ? 2 : at(3) == js ? 3 : at(4) == js ? 4 : 5;
         mm_row(I1{}, I1{}, I1{}, I0{});
@@ -860,24 +866,22 @@ __device__ __forceinline__ void conv_h2s_body(const void *__restrict__ act_v, co
         __builtin_amdgcn_sched_barrier(0);
         mm_row(I1{}, I1{}, I1{}, I2{});
         if constexpr (first + 2 < 5 && at(first + 2 < 5 ? first + 2 : 4) == js) dma_ax(sA ^ 1, std::integral_constant<int, first + 2 < 5 ? first + 2 : 0>{});
-        if constexpr (js == S - 1) walk_a();
+        if constexpr (S == 2 && js == 0) dma_ax(sA ^ 1, I3{});
         __builtin_amdgcn_sched_barrier(0);
         mm_row(I1{}, I1{}, I1{}, I3{});
+        if constexpr (S == 2 && js == 0) dma_ax(sA ^ 1, I4{});
+        if constexpr (js == S - 1) walk_a();
         __builtin_amdgcn_sched_barrier(0);
         sA = sAn;
     };
     for (int u = 0; u < nsuper; ++u) {
         k_step(I0{});
         k_step(I1{});
-        k_step(I2{});
-        if constexpr (S > 3) {
-            k_step(I3{});
-            k_step(I4{});
-        }
-        if constexpr (S > 5) {
-            k_step(std::integral_constant<int, 5>{});
-            k_step(std::integral_constant<int, 6>{});
-        }
+        if constexpr (S > 2) k_step(I2{});
+        if constexpr (S > 3) k_step(I3{});
+        if constexpr (S > 4) k_step(I4{});
+        if constexpr (S > 5) k_step(std::integral_constant<int, 5>{});
+        if constexpr (S > 6) k_step(std::integral_constant<int, 6>{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // trailing (zero-filling) DMAs must not outlive the block's LDS
 
@@ -888,9 +892,10 @@ __device__ __forceinline__ void conv_h2s_body(const void *__restrict__ act_v, co
     if (tid < H2_BM) {
         const int m = m0 + tid;
         const int owp = m % OWp, t = m / OWp;
-        s_pix[tid] = (m < Mp && owp < g.OW) ? t * g.OW + owp : -1;
+        const int oh = t % g.OH, nimg = t / g.OH;
+        s_pix[tid] = (m < Mp && owp < g.OW) ? (nimg * g.OHf + oh * g.osh + g.oa) * g.OWf + owp * g.osw + g.ob : -1;
     }
-    const int npix = g.ng * g.OH * g.OW;
+    const int npix = g.ng * g.OHf * g.OWf;
     h2_epilogue<ElemBF16, TN, true, 2 * TN>(acc_unused, acc16, g, epi, out, smem, m0, n0, grp,
                                     [&](int m) { return s_pix[m - m0] >= 0; },
                                     [&](int m) -> size_t { return ((size_t)grp * npix + (size_t)s_pix[m - m0]) * g.Ncols; });
@@ -1942,6 +1947,8 @@ static int launch_h2(const mqConvDesc *d, const void *act, const void *w, void *
         g.step_h = -d->dil_h; g.step_w = -d->dil_w;
     }
     g.nR = g.R; g.nS = g.S;
+    g.tap_r0 = 0; g.tap_rstep = 1; g.tap_s0 = 0; g.tap_sstep = 1;
+    g.osh = 1; g.osw = 1; g.oa = 0; g.ob = 0; g.OHf = g.OH; g.OWf = g.OW;
     g.Mtot = ng * g.OH * g.OW;
     g.CB = ET::F32 ? 16 : (g.IC % 64 == 0 ? 64 : 32);
     g.nchunks = g.IC / g.CB;
@@ -2016,7 +2023,56 @@ static int launch_h2(const mqConvDesc *d, const void *act, const void *w, void *
         shared96 = mf16 && !no_share && getenv("MQGAN_H2_NO_96") == nullptr && !parity && g.CB == 32 && g.IC % 96 == 0 && g.S == 3 &&
                    g.sw == 1 && g.dw == 1 && g.sh == 1 && cdiv(g.Ncols, 96) * 96 <= cdiv(g.Ncols, BN) * BN &&
                    (int64_t)ng * g.OH * (g.OW + g.S - 1) < 0x7FFFFF00ll;
-    if (shared96) {
+    // strided input gradients: inside one stride-parity class the taps are a stride-1 walk over dy - every class with two or more
+    // column taps goes through the shared-row kernel on its own (class geometry in H2Geom), the others through the per-tap kernel
+    bool shared_classes = false;
+    if constexpr (!ET::F32)
+        shared_classes = mf16 && !no_share && getenv("MQGAN_H2_NO_SHARE_PARITY") == nullptr && parity && g.CB == 64 && TN >= 2 &&
+                         (int64_t)ng * g.OH * (g.OW + 8) < 0x7FFFFF00ll;
+    if (shared_classes) {
+        if constexpr (!ET::F32) {
+            const int shift_h = g.sh == 2 ? 1 : 0, shift_w = g.sw == 2 ? 1 : 0;
+            for (int c = 0; c < pi.ncls; ++c) {
+                const int64_t Mc = (int64_t)ng * pi.Ha[c] * pi.Wb[c];
+                if (Mc == 0) continue;
+                const int ns = pi.ns[c], nr = pi.nr[c];
+                const int stepw = -((pi.sstep[c] * g.dw) >> shift_w);
+                if (ns >= 2 && ns <= 4 && nr >= 1 && stepw == -1) {
+                    H2Geom gc = g;
+                    gc.OH = pi.Ha[c]; gc.OW = pi.Wb[c];
+                    gc.mul_h = 1; gc.mul_w = 1;
+                    gc.add_h = (pi.a[c] + g.ph - pi.r0[c] * g.dh) >> shift_h;
+                    gc.add_w = (pi.b[c] + g.pw - pi.s0[c] * g.dw) >> shift_w;
+                    gc.step_h = -((pi.rstep[c] * g.dh) >> shift_h);
+                    gc.step_w = stepw;
+                    gc.nR = nr; gc.nS = ns;
+                    gc.tap_r0 = pi.r0[c]; gc.tap_rstep = pi.rstep[c]; gc.tap_s0 = pi.s0[c]; gc.tap_sstep = pi.sstep[c];
+                    gc.osh = g.sh; gc.osw = g.sw; gc.oa = pi.a[c]; gc.ob = pi.b[c]; gc.OHf = g.OH; gc.OWf = g.OW;
+                    gc.nMt = (int)cdiv((int64_t)ng * gc.OH * (gc.OW + ns - 1), H2_BM);
+                    const dim3 cgrid((unsigned)(gc.nMt * gc.nNt), d->groups);
+#define MQ_H2SC(TN_, S_) do { kname("conv_h2s_kernel<%d, %d>", TN_, S_); hipLaunchKernelGGL((conv_h2s_kernel<TN_, S_>), cgrid, block, 0, st, reinterpret_cast<const unsigned short *>(act), \
+                                        reinterpret_cast<const unsigned short *>(w), out, gc, epi, act_gs); } while (0)
+#define MQ_H2SC_TN(S_) do { if (TN == 4) MQ_H2SC(4, S_); else if (TN == 3) MQ_H2SC(3, S_); else MQ_H2SC(2, S_); } while (0)
+                    if (ns == 2) MQ_H2SC_TN(2); else if (ns == 3) MQ_H2SC_TN(3); else MQ_H2SC_TN(4);
+#undef MQ_H2SC_TN
+#undef MQ_H2SC
+                } else {
+                    H2Parity p1;
+                    memset(&p1, 0, sizeof(p1));
+                    p1.ncls = 1;
+                    p1.a[0] = pi.a[c]; p1.b[0] = pi.b[c]; p1.Ha[0] = pi.Ha[c]; p1.Wb[0] = pi.Wb[c];
+                    p1.nr[0] = pi.nr[c]; p1.ns[0] = pi.ns[c]; p1.r0[0] = pi.r0[c]; p1.s0[0] = pi.s0[c];
+                    p1.rstep[0] = pi.rstep[c]; p1.sstep[0] = pi.sstep[c];
+                    p1.tile0[0] = 0; p1.tile0[1] = (int)cdiv(Mc, H2_BM);
+                    const dim3 cgrid((unsigned)(p1.tile0[1] * g.nNt), d->groups);
+#define MQ_H2P1(TN_, NS_) do { kname("conv_h2_kernel<%d, %d, 64, true, true>", TN_, NS_); hipLaunchKernelGGL((conv_h2_kernel<TN_, NS_, 64, true, true>), cgrid, block, 0, st, \
+                                        reinterpret_cast<const unsigned short *>(act), reinterpret_cast<const unsigned short *>(w), out, g, p1, epi, act_gs); } while (0)
+                    if (TN == 4) MQ_H2P1(4, 2); else if (TN == 3) MQ_H2P1(3, 2); else MQ_H2P1(2, 3);
+#undef MQ_H2P1
+                }
+            }
+        }
+    } else if (shared96) {
         if constexpr (!ET::F32) {
             g.nMt = (int)cdiv((int64_t)ng * g.OH * (g.OW + g.S - 1), H2_BM);
             g.nNt = (int)cdiv(g.Ncols, H96_BN);

@@ -49,6 +49,9 @@ H2_CASES = [
     dict(N=2, H=5, W=144, C=96, K=192, R=3, S=3, pad=(1, 1)),                                 # two column tiles; rows wrap inside a tile
     dict(N=4, H=3, W=50, C=96, K=96, R=1, S=3, pad=(0, 1), groups=2),                         # one tap row, two groups, ragged last tile
     dict(N=1, H=9, W=31, C=288, K=288, R=3, S=3, pad=(1, 1)),                                 # three chunks x three column tiles
+    # strided input gradients by stride-parity class through the shared-row kernel (64-channel chunks of dy, >= 128 columns)
+    dict(N=2, H=12, W=20, C=128, K=64, R=7, S=7, stride=(2, 2), pad=(3, 3)),                  # classes of 4 / 3 column taps
+    dict(N=2, H=9, W=21, C=128, K=128, R=3, S=3, stride=(2, 2), pad=(1, 1)),                  # 2 taps shared, 1 tap on the per-tap kernel
 ]
 
 
@@ -183,6 +186,53 @@ def test_h2_gated_dgrad_is_dgrad_then_leaky_backward(env, c, out_f32):
     nomask = ops.conv_dgrad_h2(desc, dy, wt, out_dtype=od, gate=(xin, None, dmap, 0.2))
     want2 = ops.pointwise_bwd_raw(plain, xin if not out_f32 else xin.float(), act=ops.ACT_LEAKY)
     assert torch.equal(nomask, want2)
+
+
+STRIDED_DGRAD_CASES = [
+    dict(N=2, H=16, W=20, C=128, K=64, R=7, S=7, stride=(2, 2), pad=(3, 3)),                  # 4 / 3 taps per class, TN = 2
+    dict(N=2, H=9, W=21, C=128, K=128, R=5, S=5, stride=(2, 2), pad=(2, 2)),                  # 3 / 2 taps, odd sizes
+    dict(N=16, H=2, W=40, C=192, K=64, R=3, S=5, stride=(1, 2), pad=(1, 2), groups=8),        # multibin: 8 groups, stride (1,2), TN = 3
+    dict(N=2, H=10, W=22, C=256, K=64, R=3, S=3, stride=(2, 1), pad=(1, 1)),                  # stride (2,1): classes by row, 3 taps, TN = 4
+    dict(N=2, H=8, W=16, C=128, K=64, R=3, S=3, stride=(2, 2), pad=(1, 1)),                   # 2 taps shared, the 1-tap classes per tap
+    dict(N=2, H=6, W=300, C=128, K=64, R=5, S=5, stride=(2, 2), pad=(2, 2)),                  # wide rows: several tiles per class row
+]
+
+
+@pytest.mark.parametrize("c", STRIDED_DGRAD_CASES, ids=_ids)
+@pytest.mark.parametrize("out_f32", [False, True])
+def test_h2_strided_dgrad_classes_on_shared_rows_are_bit_identical(env, monkeypatch, c, out_f32):
+    """A strided input gradient is, per stride-parity class, a stride-1 walk over dy: launch_h2 sends every class with 2 - 4 column
+    taps through conv_h2s_kernel (class geometry, scattered store) and the rest through the per-tap kernel, class by class.
+    Same reduction order, same MFMAs as the one-launch per-tap kernel (MQGAN_H2_NO_SHARE_PARITY=1): plain and gated results agree
+    bit for bit; test_h2_fprop_dgrad_wgrad_vs_float64 holds two such shapes to float64."""
+    ops = env
+    x, w, b, desc, wk, wc = _setup(ops, c)
+    torch.manual_seed(7)
+    xin = F.leaky_relu(torch.randn(c["N"], c["H"], c["W"], c["C"], device=DEV), 0.2)
+    mask = torch.zeros(c["N"], c["W"], dtype=torch.uint8, device=DEV)
+    mask[1, c["W"] // 3:] = 1
+    mask[-1, 2:] = 1
+    xin = (xin * (1 - mask[:, None, :, None].float())).to(BF16)
+    dy = torch.randn(c["N"], desc.P, desc.Q, c["K"], device=DEV).to(BF16)
+    wt = ops.h2_weight_image(desc, wc, True)
+    dmap = (c["H"] * c["W"], c["W"], c["W"])
+    od = torch.float32 if out_f32 else BF16
+
+    def run():
+        plain = ops.conv_dgrad_h2(desc, dy, wt, out_dtype=od)
+        kernel = ops.L().mq_last_kernel().decode()
+        gated = ops.conv_dgrad_h2(desc, dy, wt, out_dtype=od, gate=(xin, mask, dmap, 0.2))
+        torch.cuda.synchronize()
+        return plain, gated, kernel
+    p_s, g_s, k_s = run()
+    monkeypatch.setenv("MQGAN_H2_NO_SHARE_PARITY", "1")
+    p_p, g_p, k_p = run()
+    monkeypatch.delenv("MQGAN_H2_NO_SHARE_PARITY")
+    assert k_p.startswith("conv_h2_kernel<") and ", true, true>" in k_p, k_p
+    assert k_s.startswith("conv_h2s_kernel<") or c["S"] == 3 and c["stride"][1] == 2, k_s       # (3 taps, stride 2: the last class has one)
+    assert torch.equal(p_s, p_p), f"plain: max {float((p_s.float() - p_p.float()).abs().max()):.3e}"
+    assert torch.equal(g_s, g_p), f"gated: max {float((g_s.float() - g_p.float()).abs().max()):.3e}"
+    assert float(p_s.float().abs().sum()) > 0
 
 
 def test_h2_full_size_refiner_layer_and_addressing(env):
