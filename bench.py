@@ -47,12 +47,13 @@ def synthetic_batches(B, T, mel, n, device, rank):
 
 
 def kernel_build_id():
-    """Hash of the conv kernel sources: ties a PMC traffic file to the build it was measured on.  Comments and blank lines do not
-    count (a corrected remark must not orphan the counters): '//' to the end of the line outside string literals, '/* */' blocks."""
+    """Hash of the sources of the kernels whose traffic is quoted (convolutions, transforms, the pointwise family): ties a PMC traffic
+    file to the build it was measured on.  Comments and blank lines do not count (a corrected remark must not orphan the counters):
+    '//' to the end of the line outside string literals, '/* */' blocks."""
     import hashlib
     import re
     h = hashlib.sha256()
-    for f in ("gemm_core.h", "igemm.hip", "igemm_h2.hip", "winogradn.hip", "plan.cpp", "wino1d.hip", "winow.hip", "wino_tables.h", "common.h"):
+    for f in ("gemm_core.h", "igemm.hip", "igemm_h2.hip", "winogradn.hip", "plan.cpp", "wino1d.hip", "winow.hip", "wino_tables.h", "common.h", "pointwise.hip"):
         with open(os.path.join(ROOT, "mqgan_amd", "csrc", f), "r") as fh:
             text = re.sub(r"/\*.*?\*/", "", fh.read(), flags=re.S)
         for line in text.splitlines():
