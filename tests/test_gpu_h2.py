@@ -262,6 +262,35 @@ def test_h2_full_size_refiner_layer_and_addressing(env):
     assert float((dw - wkf.grad).abs().max()) / float(wkf.grad.pow(2).mean().sqrt()) < 3e-4      # 295k pixel terms per weight in f32
 
 
+@pytest.mark.parametrize("Cc,K", [(96, 96), (288, 96)])
+def test_h2_full_size_96_channel_level(env, Cc, K):
+    """C3's outer refiner level at full size (16 x 1024 x 144 pixels): conv_h2s96_kernel (forward, and the input gradient with 96 dy
+    channels) against the f32-tensor bf16 engine of igemm.hip on the same bf16-representable operands - both have exact products
+    and f32 accumulation - and an image copied to the end of the batch reproduces the first one (addressing of the last tile rows)."""
+    ops = env
+    torch.manual_seed(6)
+    N, H, W = 16, 1024, 144
+    x = torch.randn(N, H, W, Cc, device=DEV).to(BF16)
+    x[N - 1] = x[0]
+    w = (torch.randn(K, Cc, 3, 3, device=DEV) * 0.05).to(BF16).float()
+    wk, wc = ops.weight_prep(w, None, True)
+    d = ops.conv_desc(N, H, W, Cc, K, 3, 3, pad=(1, 1), precision="bf16")
+    y = ops.conv_fprop_h2(d, x, ops.h2_weight_image(d, wk, False), None, out_dtype=torch.float32)
+    assert ops.L().mq_last_kernel().decode().startswith("conv_h2s96_kernel")
+    assert torch.equal(y[N - 1], y[0])
+    y_old = ops.conv(x.float(), wk, wc, None, d)
+    assert float((y - y_old).abs().max()) / float(y_old.pow(2).mean().sqrt()) < 2e-5
+    del y, y_old
+    r = torch.randn(N, H, W, K, device=DEV).to(BF16)
+    r[N - 1] = r[0]
+    dx = ops.conv_dgrad_h2(d, r, ops.h2_weight_image(d, wc, True), out_dtype=torch.float32)
+    assert ops.L().mq_last_kernel().decode().startswith("conv_h2s96_kernel") == (K % 96 == 0 and K % 64 != 0)
+    assert torch.equal(dx[N - 1], dx[0])
+    xf = x.float().requires_grad_(True)
+    (ops.conv(xf, wk, wc, None, d) * r.float()).sum().backward()
+    assert float((dx - xf.grad).abs().max()) / float(xf.grad.pow(2).mean().sqrt()) < 2e-5
+
+
 MID_CFG = {
     "model": {"mel_channels": 32,
               "generator": {"channels": [32, 32, 64], "kernel_sizes": [3, 5], "fsq_levels": [8, 5, 5, 5],
