@@ -291,6 +291,17 @@ def test_h2_full_size_96_channel_level(env, Cc, K):
     assert float((dx - xf.grad).abs().max()) / float(xf.grad.pow(2).mean().sqrt()) < 2e-5
 
 
+def test_h2_random_shapes_against_float64():
+    """tools/fuzz_h2.py: 40 random layers (channel counts, taps, strides, groups, dilation, ragged sizes drawn so that every kernel
+    family of igemm_h2.hip gets its share) through fprop / dgrad / wgrad against float64: relative L2 <= 4e-5, no element further than
+    4e-4 of the tensor's rms.  The tool exits non-zero at the first case above the bound."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_h2.py"), "40", "3"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "FUZZ OK 40 cases" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "conv_h2s96_kernel<3>" in out.stdout and "conv_h2s_kernel<" in out.stdout
+
+
 MID_CFG = {
     "model": {"mel_channels": 32,
               "generator": {"channels": [32, 32, 64], "kernel_sizes": [3, 5], "fsq_levels": [8, 5, 5, 5],
