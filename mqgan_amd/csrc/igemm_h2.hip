@@ -901,7 +901,9 @@ __device__ __forceinline__ void conv_h2s_body(const void *__restrict__ act_v, co
                                     [&](int m) -> size_t { return ((size_t)grp * npix + (size_t)s_pix[m - m0]) * g.Ncols; });
 }
 
-template <int TN, int S>
+// CLASS: the launch is one stride-parity class of a strided input gradient (same code; a symbol of its own, so that a profiler's
+// per-kernel averages do not mix these quarter-size launches with the stride-1 layers of the same <TN, S>)
+template <int TN, int S, bool CLASS = false>
 __global__ __launch_bounds__(512, 2) void conv_h2s_kernel(const unsigned short *__restrict__ act, const unsigned short *__restrict__ wgt,
                                                           void *__restrict__ out, H2Geom g, H2Epi epi, size_t act_group_stride)
 {
@@ -2050,7 +2052,7 @@ static int launch_h2(const mqConvDesc *d, const void *act, const void *w, void *
                     gc.osh = g.sh; gc.osw = g.sw; gc.oa = pi.a[c]; gc.ob = pi.b[c]; gc.OHf = g.OH; gc.OWf = g.OW;
                     gc.nMt = (int)cdiv((int64_t)ng * gc.OH * (gc.OW + ns - 1), H2_BM);
                     const dim3 cgrid((unsigned)(gc.nMt * gc.nNt), d->groups);
-#define MQ_H2SC(TN_, S_) do { kname("conv_h2s_kernel<%d, %d>", TN_, S_); hipLaunchKernelGGL((conv_h2s_kernel<TN_, S_>), cgrid, block, 0, st, reinterpret_cast<const unsigned short *>(act), \
+#define MQ_H2SC(TN_, S_) do { kname("conv_h2s_kernel<%d, %d, true>", TN_, S_); hipLaunchKernelGGL((conv_h2s_kernel<TN_, S_, true>), cgrid, block, 0, st, reinterpret_cast<const unsigned short *>(act), \
                                         reinterpret_cast<const unsigned short *>(w), out, gc, epi, act_gs); } while (0)
 #define MQ_H2SC_TN(S_) do { if (TN == 4) MQ_H2SC(4, S_); else if (TN == 3) MQ_H2SC(3, S_); else MQ_H2SC(2, S_); } while (0)
                     if (ns == 2) MQ_H2SC_TN(2); else if (ns == 3) MQ_H2SC_TN(3); else MQ_H2SC_TN(4);
@@ -2085,7 +2087,7 @@ static int launch_h2(const mqConvDesc *d, const void *act, const void *w, void *
         if constexpr (!ET::F32) {
             g.nMt = (int)cdiv((int64_t)ng * g.OH * (g.OW + g.S - 1), H2_BM);
             grid = dim3((unsigned)(g.nMt * g.nNt), d->groups);
-#define MQ_H2S(TN_, S_) do { kname("conv_h2s_kernel<%d, %d>", TN_, S_); hipLaunchKernelGGL((conv_h2s_kernel<TN_, S_>), grid, block, 0, st, reinterpret_cast<const unsigned short *>(act), \
+#define MQ_H2S(TN_, S_) do { kname("conv_h2s_kernel<%d, %d, false>", TN_, S_); hipLaunchKernelGGL((conv_h2s_kernel<TN_, S_>), grid, block, 0, st, reinterpret_cast<const unsigned short *>(act), \
                                         reinterpret_cast<const unsigned short *>(w), out, g, epi, act_gs); } while (0)
 #define MQ_H2S_TN(S_) do { if (TN == 4) MQ_H2S(4, S_); else if (TN == 3) MQ_H2S(3, S_); else MQ_H2S(2, S_); } while (0)
             if (g.S == 3) MQ_H2S_TN(3); else if (g.S == 5) MQ_H2S_TN(5); else MQ_H2S_TN(7);
