@@ -85,7 +85,8 @@ struct ElemF32 { static constexpr int ESZ = 4; static constexpr bool F32 = true;
 // ---- epilogue of the H2 kernels: bias, activation / gate, store (f32 straight from the accumulators, bf16 transposed through a
 // per-wave LDS patch).  row_ok(m): output row m of the tile's enumeration exists;  out_index(m): element offset of its column 0.
 // W16: 16-column tiles per wave (the wave tile is 16 * W16 columns wide; 2 * TN except in the 96-column kernel, where TN is unused)
-template <class ET, int TN, bool MF16, int W16, class RowOk, class OutIdx>
+// NW: waves of the block (two per 64 rows of the tile: 8 for the 256-row kernels, 4 for conv_h2_small_kernel)
+template <class ET, int TN, bool MF16, int W16, int NW, class RowOk, class OutIdx>
 __device__ __forceinline__ void h2_epilogue(f32x16 (&acc)[MF16 ? 1 : 2][MF16 ? 1 : TN], f32x4v (&acc16)[MF16 ? 4 : 1][MF16 ? W16 : 1],
                                             const H2Geom &g, const H2Epi &epi, void *__restrict__ out, char *smem, int m0, int n0, int grp,
                                             RowOk &&row_ok, OutIdx &&out_index)
@@ -100,10 +101,10 @@ __device__ __forceinline__ void h2_epilogue(f32x16 (&acc)[MF16 ? 1 : 2][MF16 ? 1
     static_assert(MF16 || W16 == 2 * TN, "wave tile width");
     constexpr int STG_ROWB = 32 * W16;                            // bytes of one staged bf16 row: 16 * W16 columns
     constexpr int STG_WAVE = 32 * STG_ROWB;                       // one wave stages 32 rows (one tm) at a time
-    unsigned char *padf = reinterpret_cast<unsigned char *>(smem) + 8 * STG_WAVE;
+    unsigned char *padf = reinterpret_cast<unsigned char *>(smem) + NW * STG_WAVE;
     const bool fused = epi.act == 2, gated = epi.act == 3;
     if (fused || gated) {
-        if (tid < H2_BM) {
+        if (tid < 32 * NW) {
             const int m = m0 + tid;
             unsigned char pd = 0;
             if (epi.mask != nullptr && row_ok(m)) {
@@ -630,7 +631,159 @@ __device__ __forceinline__ void conv_h2_body(const void *__restrict__ act_v, con
             return ((size_t)grp * Mc + m) * g.Ncols;
         }
     };
-    h2_epilogue<ET, TN, MF16, 2 * TN>(acc, acc16, g, epi, out, smem, m0, n0, grp, [&](int m) { return m < Mc; }, out_index);
+    h2_epilogue<ET, TN, MF16, 2 * TN, 8>(acc, acc16, g, epi, out, smem, m0, n0, grp, [&](int m) { return m < Mc; }, out_index);
+}
+
+// ------------------------------------------------------------------------------------------ short reductions (r5)
+// The 1x1 layers at the edges of the networks (32 -> 128, 64 -> 384, 96 -> 32 channels ...) have one to four K-steps.  On
+// conv_h2_kernel a block is then a prologue, a handful of MFMAs and a 64-128 KB store, one after the other, with ONE block per CU
+// (two or three stages of a 256-row tile fill the LDS): 2.1 TB/s of a traffic that is x once + y once.  This kernel gives up the
+// ring - the K-steps it has are too few to fill one - and the latency hiding moves to the blocks: 128-row tiles, four waves, one
+// stage of (128 + 64 TN) rows = 24-48 KB, three blocks per CU at different points of their lives.  Same K order, same MFMAs and
+// the same epilogue as conv_h2_kernel: bit-identical (test_h2_small_kernel_is_bit_identical).
+constexpr int H2Q_BM = 128;
+
+template <int TN, int CBK>
+__device__ __forceinline__ void conv_h2_small_body(const void *__restrict__ act_v, const void *__restrict__ wgt_v, void *__restrict__ out,
+                                                   const H2Geom &g, const H2Epi &epi, size_t act_group_stride, char *smem)
+{
+    constexpr int BN = 64 * TN;
+    constexpr int NSUB = 128 / (CBK * 2);          // (chunk, tap) positions per K-step
+    constexpr int CPB = CBK * 2 / 16;              // 16-byte chunks per position
+    const char *act = reinterpret_cast<const char *>(act_v);
+    const char *wgt = reinterpret_cast<const char *>(wgt_v);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int grp = blockIdx.y;
+    const int tile = xcd_remap(blockIdx.x, g.nMt * g.nNt);
+    const int mt = tile / g.nNt, nt = tile - mt * g.nNt;
+    const int m0 = mt * H2Q_BM, n0 = nt * BN;
+    const int Mc = g.Mtot;
+    const int nR = __builtin_amdgcn_readfirstlane(g.nR), nS = __builtin_amdgcn_readfirstlane(g.nS);
+    const int step_h = __builtin_amdgcn_readfirstlane(g.step_h), step_w = __builtin_amdgcn_readfirstlane(g.step_w);
+
+    // ---- DMA slots (conv_h2_body with four waves: piece p = wave + 4 j covers tile rows 8 p .. 8 p + 7)
+    const int lrow = lane >> 3;
+    const int lc = (lane & 7) ^ ((((wave & 1) << 2) | (lane >> 4)) & 7);
+    const int sub = lc / CPB;
+    const int cin_b = (lc % CPB) * 16;
+    const int img0 = m0 / (g.OH * g.OW);
+    const size_t img_elems = (size_t)g.IH * g.IW * g.IC;
+    const char *abase = act + ((size_t)grp * act_group_stride + (size_t)img0 * img_elems) * 2;
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(abase, (act_group_stride - (size_t)img0 * img_elems) * 2);
+    const char *wbase = wgt + ((size_t)grp * g.Ncols + n0) * g.Kp * 2;
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(wbase, (size_t)(g.Ncols - n0 < BN ? g.Ncols - n0 : BN) * g.Kp * 2);
+    int bh_[4], bw_[4], rowbase_[4];
+    bool rv_[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + 8 * (wave + 4 * j) + lrow;
+        const bool v = m < Mc;
+        const int mm = v ? m : m0;
+        const int ow = mm % g.OW, t = mm / g.OW;
+        const int oh = t % g.OH, n = t / g.OH - img0;
+        rv_[j] = v;
+        bh_[j] = oh * g.mul_h + g.add_h;
+        bw_[j] = ow * g.mul_w + g.add_w;
+        rowbase_[j] = (((n * g.IH + bh_[j]) * g.IW + bw_[j]) * g.IC) * 2 + cin_b;
+    }
+    unsigned rowoffB[2 * TN];
+#pragma unroll
+    for (int j = 0; j < 2 * TN; ++j) {
+        const int row = 8 * (wave + 4 * j) + lrow;
+        rowoffB[j] = (n0 + row < g.Ncols) ? (unsigned)row * (unsigned)g.Kp * 2u + (unsigned)cin_b : OOB;
+    }
+    int w_js[NSUB], w_jr[NSUB], w_ch[NSUB];
+#pragma unroll
+    for (int u = 0; u < NSUB; ++u) {
+        int js = u, jr = 0, ch = (nR > 0 && nS > 0) ? 0 : g.nchunks;
+        if (nS > 0) { while (js >= nS) { js -= nS; ++jr; } }
+        if (nR > 0) { while (jr >= nR) { jr -= nR; ++ch; } }
+        w_js[u] = js; w_jr[u] = jr; w_ch[u] = ch;
+    }
+    const int RS = g.R * g.S;
+    int hoff = 0, woff = 0, aoff = 0, bcol = 0;
+    bool kv = false;
+    auto walk = [&]() {
+#pragma unroll
+        for (int u = 0; u < NSUB; ++u) {
+            const int h_u = w_jr[u] * step_h, w_u = w_js[u] * step_w;
+            const int a_u = ((h_u * g.IW + w_u) * g.IC + w_ch[u] * CBK) * 2;
+            const int b_u = ((w_ch[u] * RS + w_jr[u] * g.S + w_js[u]) * CBK) * 2;
+            const bool k_u = w_ch[u] < g.nchunks;
+            if (u == 0 || sub == u) { hoff = h_u; woff = w_u; aoff = a_u; bcol = b_u; kv = k_u; }
+#pragma unroll
+            for (int i = 0; i < NSUB; ++i) {
+                ++w_js[u];
+                const bool c2 = w_js[u] >= nS;
+                w_js[u] = c2 ? 0 : w_js[u];
+                w_jr[u] += c2 ? 1 : 0;
+                const bool c3 = w_jr[u] >= nR;
+                w_jr[u] = c3 ? 0 : w_jr[u];
+                w_ch[u] += c3 ? 1 : 0;
+            }
+        }
+    };
+    f32x16 acc_unused[1][1];
+    f32x4v acc16[4][2 * TN];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2 * TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc16[a][b][r] = 0.f;
+    const int r16 = lane & 15, g4 = lane >> 4, sw16 = (r16 >> 1) & 7;
+    int a16[2], b16[2];
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx) {
+        a16[sx] = (wm * 64 + r16) * H2_ROWB + (((4 * sx + g4) ^ sw16) << 4);
+        b16[sx] = H2Q_BM * H2_ROWB + (wn * 32 * TN + r16) * H2_ROWB + (((4 * sx + g4) ^ sw16) << 4);
+    }
+    const int npos = g.nchunks * nR * nS;
+    const int nk = (npos + NSUB - 1) / NSUB;
+    for (int t = 0; t < nk; ++t) {
+        walk();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = rv_[j] & kv & ((unsigned)(bh_[j] + hoff) < (unsigned)g.IH) & ((unsigned)(bw_[j] + woff) < (unsigned)g.IW);
+            const unsigned vo = ok ? (unsigned)(rowbase_[j] + aoff) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, lds_ptr(smem + wave * 1024 + j * 4096), 16, vo, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 2 * TN; ++j) {
+            const unsigned vo = ((rowoffB[j] != OOB) & kv) ? rowoffB[j] + (unsigned)bcol : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, lds_ptr(smem + H2Q_BM * H2_ROWB + wave * 1024 + j * 4096), 16, vo, 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+            bf16x8 fa[4], fb[2 * TN];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) fa[tt] = *reinterpret_cast<const bf16x8 *>(smem + a16[sx] + tt * 16 * H2_ROWB);
+#pragma unroll
+            for (int tt = 0; tt < 2 * TN; ++tt) fb[tt] = *reinterpret_cast<const bf16x8 *>(smem + b16[sx] + tt * 16 * H2_ROWB);
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2 * TN; ++tn)
+                    acc16[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[tm], fb[tn], acc16[tm][tn], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                              // every wave's reads are back before the next K-step's DMA lands
+    }
+    h2_epilogue<ElemBF16, TN, true, 2 * TN, 4>(acc_unused, acc16, g, epi, out, smem, m0, n0, grp, [&](int m) { return m < Mc; },
+                                               [&](int m) -> size_t { return ((size_t)grp * Mc + m) * g.Ncols; });
+}
+
+template <int TN, int CBK>
+__global__ __launch_bounds__(256, TN <= 3 ? 3 : 2) void conv_h2_small_kernel(const unsigned short *__restrict__ act, const unsigned short *__restrict__ wgt,
+                                                            void *__restrict__ out, H2Geom g, H2Epi epi, size_t act_group_stride)
+{
+    // one stage; the epilogue's four staging patches (4 x 32 x 64 TN bytes) + 128 row flags fit inside it
+    __shared__ __attribute__((aligned(1024))) char smem[(H2Q_BM + 64 * TN) * H2_ROWB + 256];
+    conv_h2_small_body<TN, CBK>(act, wgt, out, g, epi, act_group_stride, smem);
 }
 
 // ------------------------------------------------------------------------------------------ shared-row variant (r4)
@@ -896,7 +1049,7 @@ __device__ __forceinline__ void conv_h2s_body(const void *__restrict__ act_v, co
         s_pix[tid] = (m < Mp && owp < g.OW) ? (nimg * g.OHf + oh * g.osh + g.oa) * g.OWf + owp * g.osw + g.ob : -1;
     }
     const int npix = g.ng * g.OHf * g.OWf;
-    h2_epilogue<ElemBF16, TN, true, 2 * TN>(acc_unused, acc16, g, epi, out, smem, m0, n0, grp,
+    h2_epilogue<ElemBF16, TN, true, 2 * TN, 8>(acc_unused, acc16, g, epi, out, smem, m0, n0, grp,
                                     [&](int m) { return s_pix[m - m0] >= 0; },
                                     [&](int m) -> size_t { return ((size_t)grp * npix + (size_t)s_pix[m - m0]) * g.Ncols; });
 }
@@ -1168,7 +1321,7 @@ __device__ __forceinline__ void conv_h2s96_body(const void *__restrict__ act_v, 
         s_pix[tid] = (m < Mp && owp < g.OW) ? t * g.OW + owp : -1;
     }
     const int npix = g.ng * g.OH * g.OW;
-    h2_epilogue<ElemBF16, 1, true, 3>(acc_unused, acc16, g, epi, out, smem, m0, n0, grp,
+    h2_epilogue<ElemBF16, 1, true, 3, 8>(acc_unused, acc16, g, epi, out, smem, m0, n0, grp,
                                       [&](int m) { return s_pix[m - m0] >= 0; },
                                       [&](int m) -> size_t { return ((size_t)grp * npix + (size_t)s_pix[m - m0]) * g.Ncols; });
 }
@@ -2025,6 +2178,11 @@ static int launch_h2(const mqConvDesc *d, const void *act, const void *w, void *
         shared96 = mf16 && !no_share && getenv("MQGAN_H2_NO_96") == nullptr && !parity && g.CB == 32 && g.IC % 96 == 0 && g.S == 3 &&
                    g.sw == 1 && g.dw == 1 && g.sh == 1 && cdiv(g.Ncols, 96) * 96 <= cdiv(g.Ncols, BN) * BN &&
                    (int64_t)ng * g.OH * (g.OW + g.S - 1) < 0x7FFFFF00ll;
+    // one to four K-steps (the 1x1 layers at the networks' edges): no ring to fill - 128-row tiles, one stage, three blocks per CU
+    bool small_k = false;
+    if constexpr (!ET::F32)
+        small_k = mf16 && !parity && !shared_rows && !shared96 && getenv("MQGAN_H2_NO_SMALL") == nullptr &&
+                  cdiv((int64_t)g.nchunks * g.R * g.S, g.CB == 64 ? 1 : 2) <= 4;
     // strided input gradients: inside one stride-parity class the taps are a stride-1 walk over dy - every class with two or more
     // column taps goes through the shared-row kernel on its own (class geometry in H2Geom), the others through the per-tap kernel
     bool shared_classes = false;
@@ -2082,6 +2240,17 @@ static int launch_h2(const mqConvDesc *d, const void *act, const void *w, void *
             kname("conv_h2s96_kernel<%d>", 3);
             hipLaunchKernelGGL((conv_h2s96_kernel<3>), grid, block, 0, st, reinterpret_cast<const unsigned short *>(act),
                                reinterpret_cast<const unsigned short *>(w), out, g, epi, act_gs);
+        }
+    } else if (small_k) {
+        if constexpr (!ET::F32) {
+            g.nMt = (int)cdiv(g.Mtot, H2Q_BM);
+            grid = dim3((unsigned)(g.nMt * g.nNt), d->groups);
+#define MQ_H2Q(TN_, CB_) do { kname("conv_h2_small_kernel<%d, %d>", TN_, CB_); hipLaunchKernelGGL((conv_h2_small_kernel<TN_, CB_>), grid, dim3(256), 0, st, \
+                                        reinterpret_cast<const unsigned short *>(act), reinterpret_cast<const unsigned short *>(w), out, g, epi, act_gs); } while (0)
+#define MQ_H2Q_TN(CB_) do { if (TN == 4) MQ_H2Q(4, CB_); else if (TN == 3) MQ_H2Q(3, CB_); else if (TN == 2) MQ_H2Q(2, CB_); else MQ_H2Q(1, CB_); } while (0)
+            if (g.CB == 64) MQ_H2Q_TN(64); else MQ_H2Q_TN(32);
+#undef MQ_H2Q_TN
+#undef MQ_H2Q
         }
     } else if (shared_rows) {
         if constexpr (!ET::F32) {

@@ -188,6 +188,57 @@ def test_h2_gated_dgrad_is_dgrad_then_leaky_backward(env, c, out_f32):
     assert torch.equal(nomask, want2)
 
 
+SMALL_K_CASES = [
+    dict(N=8, H=3, W=100, C=32, K=128, R=1, S=1, groups=4),                                   # the multi-bin first layer: 32 -> 128, groups
+    dict(N=2, H=7, W=33, C=64, K=384, R=1, S=1),                                              # 64 -> 384: TN = 3, two column tiles
+    dict(N=1, H=9, W=50, C=96, K=32, R=1, S=1),                                               # 96 -> 32: two K-steps of 32-channel chunks, TN = 1
+    dict(N=2, H=5, W=41, C=256, K=160, R=1, S=1),                                             # four K-steps, ragged column tile
+    dict(N=3, H=1, W=70, C=64, K=64, R=1, S=3, pad=(0, 1)),                                   # 1x3 on one column tile (TN = 1: not the shared-row kernel)
+    dict(N=2, H=6, W=20, C=128, K=256, R=1, S=1, stride=(1, 2)),                              # strided forward, TN = 4
+]
+
+
+@pytest.mark.parametrize("c", SMALL_K_CASES, ids=_ids)
+def test_h2_small_kernel_is_bit_identical(env, monkeypatch, c):
+    """conv_h2_small_kernel (layers of one to four K-steps: 128-row tiles, one LDS stage, three blocks per CU) against
+    conv_h2_kernel (MQGAN_H2_NO_SMALL=1): same K order, same MFMAs, same epilogue - forward (bias; LeakyReLU + mask; f32 and bf16
+    store) and, where the layer is not strided, input gradient (plain and gated) bit for bit; the forward also against float64."""
+    ops = env
+    x, w, b, desc, wk, wc = _setup(ops, c)
+    y_ref = _torch_conv(x, w, b, c)
+    xh = x.to(DEV).to(BF16)
+    bd = b.float().to(DEV)
+    wh, wth = ops.h2_weight_image(desc, wk, False), ops.h2_weight_image(desc, wc, True)
+    mask = (torch.rand(c["N"], desc.Q, device=DEV) < 0.3).to(torch.uint8)
+    dmap = (desc.P * desc.Q, desc.Q, desc.Q)
+    torch.manual_seed(9)
+    dy = torch.randn(c["N"], desc.P, desc.Q, c["K"], device=DEV).to(BF16)
+    strided = c.get("stride", (1, 1)) != (1, 1)
+    gmask = (torch.rand(c["N"], c["W"], device=DEV) < 0.3).to(torch.uint8)
+    gmap = (c["H"] * c["W"], c["W"], c["W"])
+
+    def run():
+        outs = [ops.conv_fprop_h2(desc, xh, wh, bd, out_dtype=torch.float32)]
+        kf = ops.L().mq_last_kernel().decode()
+        outs.append(ops.conv_fprop_h2(desc, xh, wh, bd))
+        outs.append(ops.conv_fprop_h2(desc, xh, wh, bd, mask=mask, dmap=dmap, act=2, slope=0.2))
+        kd = ""
+        if not strided:
+            outs.append(ops.conv_dgrad_h2(desc, dy, wth))
+            kd = ops.L().mq_last_kernel().decode()
+            outs.append(ops.conv_dgrad_h2(desc, dy, wth, out_dtype=torch.float32, gate=(xh, gmask, gmap, 0.2)))
+        torch.cuda.synchronize()
+        return outs, kf, kd
+    small, kf_s, kd_s = run()
+    monkeypatch.setenv("MQGAN_H2_NO_SMALL", "1")
+    plain, kf_p, kd_p = run()
+    monkeypatch.delenv("MQGAN_H2_NO_SMALL")
+    assert kf_s.startswith("conv_h2_small_kernel<") and kf_p.startswith("conv_h2_kernel<"), (kf_s, kf_p)
+    for i, (a, bb) in enumerate(zip(small, plain)):
+        assert torch.equal(a, bb), f"output {i}: max {float((a.float() - bb.float()).abs().max()):.3e} ({kf_s} / {kd_s} against {kf_p} / {kd_p})"
+    assert_rel(small[0], y_ref, 2e-5, "fprop (f32 out)")
+
+
 STRIDED_DGRAD_CASES = [
     dict(N=2, H=16, W=20, C=128, K=64, R=7, S=7, stride=(2, 2), pad=(3, 3)),                  # 4 / 3 taps per class, TN = 2
     dict(N=2, H=9, W=21, C=128, K=128, R=5, S=5, stride=(2, 2), pad=(2, 2)),                  # 3 / 2 taps, odd sizes
