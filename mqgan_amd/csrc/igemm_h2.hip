@@ -1334,6 +1334,154 @@ __global__ __launch_bounds__(512, 2) void conv_h2s96_kernel(const unsigned short
     conv_h2s96_body<S>(act, wgt, out, g, epi, act_group_stride, smem);
 }
 
+// The same layers on 128-row tiles without any ring: one image of 130 rows (25 KB), one weight tile (18 KB), four waves - 44 KB, so
+// THREE blocks share a CU and hide each other's round trips, as in conv_h2_small_kernel.  conv_h2s96_kernel moves 139 flop per DMA
+// byte but, at one block per CU, reached 0.78 PF/s on 5.6 TB/s of LDS-DMA traffic - half of what the L2 delivers: it waited.  Here a
+// block stages twice the weight bytes per flop (90 flop per byte) and waits for every one of them - and nobody cares, because two
+// other blocks are computing meanwhile.  Same reduction order and MFMAs as conv_h2s96_kernel: bit-identical
+// (MQGAN_H2_96_BIG=1 selects the 256-row kernel).
+constexpr int H96Q_BM = 128, H96Q_APIECES = 25, H96Q_AEXT = H96Q_APIECES * 1024;      // 130 rows x 192 B = 24,960 B
+
+template <int S>
+__device__ __forceinline__ void conv_h2s96q_body(const void *__restrict__ act_v, const void *__restrict__ wgt_v, void *__restrict__ out,
+                                                 const H2Geom &g, const H2Epi &epi, size_t act_group_stride, char *smem)
+{
+    static_assert(S == 3, "column taps");
+    char *smemA = smem, *smemB = smem + H96Q_AEXT, *patch = smemB + H96_BSZ;
+    const char *act = reinterpret_cast<const char *>(act_v);
+    const char *wgt = reinterpret_cast<const char *>(wgt_v);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int grp = blockIdx.y;
+    const int OWp = g.OW + S - 1;
+    const int Mp = g.ng * g.OH * OWp;
+    const int tile = xcd_remap(blockIdx.x, g.nMt * g.nNt);
+    const int mt = tile / g.nNt, nt = tile - mt * g.nNt;
+    const int m0 = mt * H96Q_BM, n0 = nt * H96_BN;
+    const int step_h = __builtin_amdgcn_readfirstlane(g.step_h);
+    const int smin = g.step_w < 0 ? (S - 1) * g.step_w : 0;
+    const int nR = __builtin_amdgcn_readfirstlane(g.nR);
+    const int nch = g.IC / 96;
+    const int RS = g.R * g.S;
+    const int img0 = m0 / (g.OH * OWp);
+    const size_t img_elems = (size_t)g.IH * g.IW * g.IC;
+    const char *abase = act + ((size_t)grp * act_group_stride + (size_t)img0 * img_elems) * 2;
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(abase, (act_group_stride - (size_t)img0 * img_elems) * 2);
+    const char *wbase = wgt + ((size_t)grp * g.Ncols + n0) * g.Kp * 2;
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(wbase, (size_t)(g.Ncols - n0 < H96_BN ? g.Ncols - n0 : H96_BN) * g.Kp * 2);
+    // image pieces p = wave + 4 j, j = 0 .. 6 (p < 25); weight pieces p = wave + 4 j, j = 0 .. 4 (p < 18); see conv_h2s96_body
+    constexpr int ASL = 7, BSL = 5;
+    int bh_[ASL], rowbase_[ASL];
+    bool rv_[ASL];
+#pragma unroll
+    for (int j = 0; j < ASL; ++j) {
+        const int pc = wave + 4 * j;
+        const int n = 64 * pc + lane;
+        const int e = n / H96_NCH, phys = n - e * H96_NCH;
+        int lc = phys - ((e >> 2) & 3);
+        lc += lc < 0 ? H96_NCH : 0;
+        const int q = m0 + e;
+        bool v = pc < H96Q_APIECES && e < H96Q_BM + S - 1 && q < Mp;
+        const int qq = v ? q : m0;
+        const int owp = qq % OWp, t = qq / OWp;
+        const int oh = t % g.OH, nimg = t / g.OH - img0;
+        const int col = owp + g.add_w + smin;
+        v = v && (unsigned)col < (unsigned)g.IW;
+        rv_[j] = v;
+        bh_[j] = oh * g.mul_h + g.add_h;
+        rowbase_[j] = (((nimg * g.IH + bh_[j]) * g.IW + (v ? col : 0)) * g.IC) * 2 + lc * 16;
+    }
+    unsigned rowoffB[BSL];
+#pragma unroll
+    for (int j = 0; j < BSL; ++j) {
+        const int pc = wave + 4 * j;
+        const int n = 64 * pc + lane;
+        const int row = n / H96_NCH, phys = n - row * H96_NCH;
+        int lc = phys - ((row >> 2) & 3);
+        lc += lc < 0 ? H96_NCH : 0;
+        const bool ok = pc < H96_BPIECES && n0 + row < g.Ncols;
+        rowoffB[j] = ok ? (unsigned)row * (unsigned)g.Kp * 2u + (unsigned)(lc >> 2) * (unsigned)RS * 64u + (unsigned)(lc & 3) * 16u : OOB;
+    }
+    f32x16 acc_unused[1][1];
+    f32x4v acc16[4][3];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc16[a][b][r] = 0.f;
+    const int r16 = lane & 15, g4 = lane >> 4;
+    auto chunk_off = [](int row, int c) { return row * H96_ROWB + (((c + ((row >> 2) & 3)) % H96_NCH) << 4); };
+    int a16t[S][3], b16[3];
+#pragma unroll
+    for (int js = 0; js < S; ++js) {
+        const int rr = wm * 64 + r16 + (g.step_w < 0 ? S - 1 - js : js);
+#pragma unroll
+        for (int sx = 0; sx < 3; ++sx) a16t[js][sx] = chunk_off(rr, 4 * sx + g4);
+    }
+#pragma unroll
+    for (int sx = 0; sx < 3; ++sx) b16[sx] = chunk_off(wn * 48 + r16, 4 * sx + g4);
+
+    for (int ch = 0; ch < nch; ++ch)
+        for (int jr = 0; jr < nR; ++jr) {
+            const int hoff = jr * step_h;
+            const int aoff = ((hoff * g.IW) * g.IC + ch * 96) * 2;
+#pragma unroll
+            for (int j = 0; j < ASL; ++j) {
+                const bool ok = rv_[j] & ((unsigned)(bh_[j] + hoff) < (unsigned)g.IH);
+                const unsigned vo = ok ? (unsigned)(rowbase_[j] + aoff) : OOB;
+                char *dst = wave + 4 * j < H96Q_APIECES ? smemA + (wave + 4 * j) * 1024 : patch;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, lds_ptr(dst), 16, vo, 0, 0, 0);
+            }
+#pragma unroll
+            for (int js = 0; js < S; ++js) {
+                const unsigned bcol = (unsigned)(((3 * ch * RS + jr * g.S + js) * 32) * 2);
+#pragma unroll
+                for (int j = 0; j < BSL; ++j) {
+                    const unsigned vo = rowoffB[j] != OOB ? rowoffB[j] + bcol : OOB;
+                    char *dst = wave + 4 * j < H96_BPIECES ? smemB + (wave + 4 * j) * 1024 : patch;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, lds_ptr(dst), 16, vo, 0, 0, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int sx = 0; sx < 3; ++sx) {
+                    bf16x8 fa[4], fb[3];
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) fa[tt] = *reinterpret_cast<const bf16x8 *>(smemA + a16t[js][sx] + tt * 16 * H96_ROWB);
+#pragma unroll
+                    for (int tt = 0; tt < 3; ++tt) fb[tt] = *reinterpret_cast<const bf16x8 *>(smemB + b16[sx] + tt * 16 * H96_ROWB);
+#pragma unroll
+                    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < 3; ++tn)
+                            acc16[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[tm], fb[tn], acc16[tm][tn], 0, 0, 0);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                      // reads are back before the next weight tile (or image) lands
+            }
+        }
+    int *s_pix = reinterpret_cast<int *>(smem + 4 * 32 * 32 * 3 + 256);      // behind the epilogue's 4 staging patches + flags
+    if (tid < H96Q_BM) {
+        const int m = m0 + tid;
+        const int owp = m % OWp, t = m / OWp;
+        s_pix[tid] = (m < Mp && owp < g.OW) ? t * g.OW + owp : -1;
+    }
+    const int npix = g.ng * g.OH * g.OW;
+    h2_epilogue<ElemBF16, 1, true, 3, 4>(acc_unused, acc16, g, epi, out, smem, m0, n0, grp,
+                                         [&](int m) { return s_pix[m - m0] >= 0; },
+                                         [&](int m) -> size_t { return ((size_t)grp * npix + (size_t)s_pix[m - m0]) * g.Ncols; });
+}
+
+template <int S>
+__global__ __launch_bounds__(256, 3) void conv_h2s96q_kernel(const unsigned short *__restrict__ act, const unsigned short *__restrict__ wgt,
+                                                             void *__restrict__ out, H2Geom g, H2Epi epi, size_t act_group_stride)
+{
+    __shared__ __attribute__((aligned(1024))) char smem[H96Q_AEXT + H96_BSZ + 1024];
+    conv_h2s96q_body<S>(act, wgt, out, g, epi, act_group_stride, smem);
+}
+
 template <int TN, int NSTAGE, int CBK, bool PARITY, bool MF16 = false>
 __global__ __launch_bounds__(512, 2) void conv_h2_kernel(const unsigned short *__restrict__ act, const unsigned short *__restrict__ wgt,
                                                          void *__restrict__ out, H2Geom g, H2Parity pi, H2Epi epi,
@@ -2234,12 +2382,19 @@ static int launch_h2(const mqConvDesc *d, const void *act, const void *w, void *
         }
     } else if (shared96) {
         if constexpr (!ET::F32) {
-            g.nMt = (int)cdiv((int64_t)ng * g.OH * (g.OW + g.S - 1), H2_BM);
+            const bool big = getenv("MQGAN_H2_96_BIG") != nullptr;        // A/B runs and the identity test: the 256-row kernel
+            g.nMt = (int)cdiv((int64_t)ng * g.OH * (g.OW + g.S - 1), big ? H2_BM : H96Q_BM);
             g.nNt = (int)cdiv(g.Ncols, H96_BN);
             grid = dim3((unsigned)(g.nMt * g.nNt), d->groups);
-            kname("conv_h2s96_kernel<%d>", 3);
-            hipLaunchKernelGGL((conv_h2s96_kernel<3>), grid, block, 0, st, reinterpret_cast<const unsigned short *>(act),
-                               reinterpret_cast<const unsigned short *>(w), out, g, epi, act_gs);
+            if (big) {
+                kname("conv_h2s96_kernel<%d>", 3);
+                hipLaunchKernelGGL((conv_h2s96_kernel<3>), grid, block, 0, st, reinterpret_cast<const unsigned short *>(act),
+                                   reinterpret_cast<const unsigned short *>(w), out, g, epi, act_gs);
+            } else {
+                kname("conv_h2s96q_kernel<%d>", 3);
+                hipLaunchKernelGGL((conv_h2s96q_kernel<3>), grid, dim3(256), 0, st, reinterpret_cast<const unsigned short *>(act),
+                                   reinterpret_cast<const unsigned short *>(w), out, g, epi, act_gs);
+            }
         }
     } else if (small_k) {
         if constexpr (!ET::F32) {

@@ -98,7 +98,7 @@ def test_h2_fprop_dgrad_wgrad_vs_float64(env, c):
     assert y16.dtype == BF16
     on96 = (c["S"] == 3 and c.get("stride", (1, 1)) == (1, 1) and c.get("dil", (1, 1)) [1] == 1 and c["C"] % 96 == 0 and c["C"] % 64 != 0 and
             c["K"] % 96 == 0)
-    assert ops.L().mq_last_kernel().decode().startswith("conv_h2s96_kernel") == on96       # exactly these take the 96-channel kernel
+    assert ops.L().mq_last_kernel().decode().startswith("conv_h2s96") == on96       # exactly these take the 96-channel kernel
     want16 = y_ref.detach().float().to(BF16).float()
     got16 = y16.float().cpu()
     # one bf16 ulp is <= 2^-7 of the value; the f32 accumulation error (1e-5 of the tensor's scale) can move a value
@@ -239,6 +239,41 @@ def test_h2_small_kernel_is_bit_identical(env, monkeypatch, c):
     assert_rel(small[0], y_ref, 2e-5, "fprop (f32 out)")
 
 
+@pytest.mark.parametrize("c", [dict(N=2, H=20, W=33, C=96, K=96, R=3, S=3, pad=(1, 1)), dict(N=1, H=9, W=31, C=288, K=288, R=3, S=3, pad=(1, 1)),
+                               dict(N=4, H=3, W=50, C=96, K=96, R=1, S=3, pad=(0, 1), groups=2), dict(N=2, H=5, W=144, C=96, K=192, R=3, S=3, pad=(1, 1))],
+                         ids=_ids)
+def test_h2_96_channel_kernels_agree_bit_for_bit(env, monkeypatch, c):
+    """conv_h2s96q_kernel (128-row tiles, no ring, three blocks per CU: the default) against conv_h2s96_kernel (256-row tiles, double
+    image buffer, three weight stages: MQGAN_H2_96_BIG=1): same reduction order, same MFMAs, same epilogue - forward (f32, bf16,
+    LeakyReLU + mask) and input gradient (plain, gated) bit for bit."""
+    ops = env
+    x, w, b, desc, wk, wc = _setup(ops, c)
+    xh, bd = x.to(DEV).to(BF16), b.float().to(DEV)
+    wh, wth = ops.h2_weight_image(desc, wk, False), ops.h2_weight_image(desc, wc, True)
+    mask = (torch.rand(c["N"], desc.Q, device=DEV) < 0.3).to(torch.uint8)
+    dmap = (desc.P * desc.Q, desc.Q, desc.Q)
+    torch.manual_seed(12)
+    dy = torch.randn(c["N"], desc.P, desc.Q, c["K"], device=DEV).to(BF16)
+
+    def run():
+        outs = [ops.conv_fprop_h2(desc, xh, wh, bd, out_dtype=torch.float32)]
+        name = ops.L().mq_last_kernel().decode()
+        outs.append(ops.conv_fprop_h2(desc, xh, wh, bd))
+        outs.append(ops.conv_fprop_h2(desc, xh, wh, bd, mask=mask, dmap=dmap, act=2, slope=0.2))
+        if c["K"] % 96 == 0 and c["K"] % 64 != 0:                  # the input gradient reduces over K
+            outs.append(ops.conv_dgrad_h2(desc, dy, wth))
+            outs.append(ops.conv_dgrad_h2(desc, dy, wth, out_dtype=torch.float32, gate=(xh, mask, dmap, 0.2)))
+        torch.cuda.synchronize()
+        return outs, name
+    small, k_s = run()
+    monkeypatch.setenv("MQGAN_H2_96_BIG", "1")
+    big, k_b = run()
+    monkeypatch.delenv("MQGAN_H2_96_BIG")
+    assert k_s.startswith("conv_h2s96q_kernel<") and k_b.startswith("conv_h2s96_kernel<"), (k_s, k_b)
+    for i, (a, bb) in enumerate(zip(small, big)):
+        assert torch.equal(a, bb), f"output {i}: max {float((a.float() - bb.float()).abs().max()):.3e}"
+
+
 STRIDED_DGRAD_CASES = [
     dict(N=2, H=16, W=20, C=128, K=64, R=7, S=7, stride=(2, 2), pad=(3, 3)),                  # 4 / 3 taps per class, TN = 2
     dict(N=2, H=9, W=21, C=128, K=128, R=5, S=5, stride=(2, 2), pad=(2, 2)),                  # 3 / 2 taps, odd sizes
@@ -328,7 +363,7 @@ def test_h2_full_size_96_channel_level(env, Cc, K):
     wk, wc = ops.weight_prep(w, None, True)
     d = ops.conv_desc(N, H, W, Cc, K, 3, 3, pad=(1, 1), precision="bf16")
     y = ops.conv_fprop_h2(d, x, ops.h2_weight_image(d, wk, False), None, out_dtype=torch.float32)
-    assert ops.L().mq_last_kernel().decode().startswith("conv_h2s96_kernel")
+    assert ops.L().mq_last_kernel().decode().startswith("conv_h2s96")
     assert torch.equal(y[N - 1], y[0])
     y_old = ops.conv(x.float(), wk, wc, None, d)
     assert float((y - y_old).abs().max()) / float(y_old.pow(2).mean().sqrt()) < 2e-5
@@ -336,7 +371,7 @@ def test_h2_full_size_96_channel_level(env, Cc, K):
     r = torch.randn(N, H, W, K, device=DEV).to(BF16)
     r[N - 1] = r[0]
     dx = ops.conv_dgrad_h2(d, r, ops.h2_weight_image(d, wc, True), out_dtype=torch.float32)
-    assert ops.L().mq_last_kernel().decode().startswith("conv_h2s96_kernel") == (K % 96 == 0 and K % 64 != 0)
+    assert ops.L().mq_last_kernel().decode().startswith("conv_h2s96") == (K % 96 == 0 and K % 64 != 0)
     assert torch.equal(dx[N - 1], dx[0])
     xf = x.float().requires_grad_(True)
     (ops.conv(xf, wk, wc, None, d) * r.float()).sum().backward()
@@ -351,7 +386,7 @@ def test_h2_random_shapes_against_float64():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_h2.py"), "40", "3"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "FUZZ OK 40 cases" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
-    assert "conv_h2s96_kernel<3>" in out.stdout and "conv_h2s_kernel<" in out.stdout
+    assert "conv_h2s96q_kernel<3>" in out.stdout and "conv_h2s_kernel<" in out.stdout
 
 
 MID_CFG = {
