@@ -326,7 +326,7 @@ def peak_of(tag):
     """Dense MFMA peak of the engine a conv kernel instantiation runs on (MI355X_MICROARCH.md)."""
     if "_x3_" in tag:
         return PEAK_BF16_MFMA_TFLOPS / 6      # the split engine spends 6 bf16 MFMAs per f32 product block
-    if "bf16" in tag or "_h2_" in tag or "_h2s_" in tag or "_h_" in tag:
+    if "bf16" in tag or "_h2" in tag or "_h_" in tag:          # conv_h2_*, conv_h2s_*, conv_h2s96*_kernel, conv_wgrad_h2*
         return PEAK_BF16_MFMA_TFLOPS
     return PEAK_F32_MFMA_TFLOPS
 

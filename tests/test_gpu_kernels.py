@@ -1453,9 +1453,10 @@ def test_h2_shared_row_kernel_is_bit_identical(env, monkeypatch, c):
     monkeypatch.setenv("MQGAN_H2_NO_SHARE", "1")
     plain, kf_p, kd_p = run()
     monkeypatch.delenv("MQGAN_H2_NO_SHARE")
-    assert kf_s.startswith("conv_h2s_kernel<") and kf_p.startswith("conv_h2_kernel<"), (kf_s, kf_p)
+    per_tap = ("conv_h2_kernel<", "conv_h2_small_kernel<")      # the ring kernel, or its ring-free form for one to four K-steps
+    assert kf_s.startswith("conv_h2s_kernel<") and kf_p.startswith(per_tap), (kf_s, kf_p)
     if Cc >= 128:            # the input gradient's column tile is C wide: narrower than 128 stays on the per-tap kernel
-        assert kd_s.startswith("conv_h2s_kernel<") and kd_p.startswith("conv_h2_kernel<"), (kd_s, kd_p)
+        assert kd_s.startswith("conv_h2s_kernel<") and kd_p.startswith(per_tap), (kd_s, kd_p)
     for name, a, bb in zip(("y", "y f32", "y leaky+mask", "dx", "dx gated"), shared, plain):
         assert torch.equal(a, bb), f"{name}: shared-row kernel differs from the per-tap kernel (max {float((a.float() - bb.float()).abs().max()):.3e})"
     # and the pair is not wrong together: float64 convolution of the same bf16 operands
