@@ -1518,6 +1518,7 @@ struct H2Wgrad {
     int Mtot, K, RSC, RS;
     int nKt, nCt;
     int splits, chunk;         // pixels per split (multiple of 64)
+    int pipe;                  // conv_wgrad_h2_kernel<2, 2, *>: fragments of substep s + 1 requested before the MFMAs of substep s
 };
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -1745,6 +1746,32 @@ __device__ __forceinline__ void conv_wgrad_h2_body(const unsigned short *__restr
 #pragma unroll
                     for (int tn = 0; tn < NTB; ++tn)
                         acc16[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[tm], b[tn], acc16[tm][tn], 0, 0, 0);
+            }
+        } else if (WM == 2 && TM == 2 && g.pipe) {
+            // Two fragment sets - only where the registers are: <2, 2> runs at 234 with them, <2, 3> spilled 93 registers and
+            // quadrupled its time when it got them, <4, 2> sits at 252 without.  The compiler's own order
+            // requests the fragments of substep s + 1 behind the last-but-one MFMA of substep s - an LDS round trip exposed four
+            // times per K-step, and the two waves of a SIMD reach it together.  Here the next set is requested first.
+            bf16x8 a[2][NTA], b[2][NTB];
+#pragma unroll
+            for (int t = 0; t < NTA; ++t) a[0][t] = tr8(base + aad[t], 0);
+#pragma unroll
+            for (int t = 0; t < NTB; ++t) b[0][t] = tr8(base + bad[t], 0);
+#pragma unroll
+            for (int sx = 0; sx < 4; ++sx) {
+                if (sx < 3) {
+#pragma unroll
+                    for (int t = 0; t < NTA; ++t) a[(sx + 1) & 1][t] = tr8(base + aad[t], 16 * (sx + 1));
+#pragma unroll
+                    for (int t = 0; t < NTB; ++t) b[(sx + 1) & 1][t] = tr8(base + bad[t], 16 * (sx + 1));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tm = 0; tm < NTA; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < NTB; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sx & 1][tm], b[sx & 1][tn], acc[tm][tn], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {
 #pragma unroll
@@ -2644,6 +2671,7 @@ extern "C" int mq_conv_wgrad_h2(const mqConvDesc *d, const uint16_t *x, const ui
     // (MQGAN_H2_BIAS_PASS=1: the separate column-sum passes over dy of r2-r4, for A/B runs)
     static const bool bias_pass = getenv("MQGAN_H2_BIAS_PASS") != nullptr;
     float *bias_slab = (dbias && !bias_pass) ? bias_ws : nullptr;
+    g.pipe = getenv("MQGAN_H2_WGRAD_NOPIPE") == nullptr;              // read per call: A/B runs
     const int wraps = d->Q >= 64 ? 1 : 4;
     // the weight gradient stays on 32x32x16: its 16x16x32 instantiation (conflict-free too) measured 3-5 % slower
     // (twice the transposed LDS reads per flop); MQGAN_H2_WG16=1 selects it for A/B runs
