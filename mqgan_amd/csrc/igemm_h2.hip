@@ -1774,28 +1774,28 @@ __device__ __forceinline__ void conv_wgrad_h2_body(const unsigned short *__restr
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
-            // No registers for a second set (<2, 3> spilled 93 with one, <4, 2> sits at 252): ONE set, refilled in place.  A row
-            // fragment a[tm] is dead after its NTB MFMAs, so the next substep's a[tm] is requested right behind them and has the
-            // remaining rows of MFMAs to arrive; only the NTB column fragments are requested at the end of a substep.
-            bf16x8 a[NTA], b[NTB];
-#pragma unroll
-            for (int t = 0; t < NTA; ++t) a[t] = tr8(base + aad[t], 0);
-#pragma unroll
-            for (int t = 0; t < NTB; ++t) b[t] = tr8(base + bad[t], 0);
 #pragma unroll
             for (int sx = 0; sx < 4; ++sx) {
+                bf16x8 a[NTA], b[NTB];
 #pragma unroll
-                for (int tm = 0; tm < NTA; ++tm) {
+                for (int t = 0; t < NTA; ++t) {
+#ifdef MQ_H2_ABLATE
+                    if ((MQ_H2_ABLATE & 16) && t > 0) { a[t] = a[0]; continue; }      // ... one fragment read per operand
+#endif
+                    a[t] = tr8(base + aad[t], 16 * sx);
+                }
+#pragma unroll
+                for (int t = 0; t < NTB; ++t) {
+#ifdef MQ_H2_ABLATE
+                    if ((MQ_H2_ABLATE & 16) && t > 0) { b[t] = b[0]; continue; }
+#endif
+                    b[t] = tr8(base + bad[t], 16 * sx);
+                }
+#pragma unroll
+                for (int tm = 0; tm < NTA; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < NTB; ++tn)
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
-                    if (sx < 3) a[tm] = tr8(base + aad[tm], 16 * (sx + 1));
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (sx < 3) {
-#pragma unroll
-                    for (int t = 0; t < NTB; ++t) b[t] = tr8(base + bad[t], 16 * (sx + 1));
-                }
             }
         }
     };
@@ -2022,28 +2022,20 @@ __device__ __forceinline__ void conv_wgrad_h2s_body(const unsigned short *__rest
     };
     auto compute = [&](int stage) {
         const char *base = smem + stage * STAGE;
-        bf16x8 a[TMR], b[NTB];
-        auto ld_b = [&](int sx) {
+#pragma unroll
+        for (int sx = 0; sx < 4; ++sx) {
+            bf16x8 a[TMR], b[NTB];
+#pragma unroll
+            for (int t = 0; t < TMR; ++t) a[t] = tr8(base + aad[t], 16 * sx, 512);
 #pragma unroll
             for (int sft = 0; sft < 3; ++sft)
 #pragma unroll
                 for (int h = 0; h < NH; ++h) b[sft * NH + h] = tr8(base + bad[sft][h], 16 * sx, RB);
-        };
-        // one fragment set refilled in place (see conv_wgrad_h2_body): a[tm] of the next substep behind its own MFMAs
 #pragma unroll
-        for (int t = 0; t < TMR; ++t) a[t] = tr8(base + aad[t], 0, 512);
-        ld_b(0);
-#pragma unroll
-        for (int sx = 0; sx < 4; ++sx) {
-#pragma unroll
-            for (int tm = 0; tm < TMR; ++tm) {
+            for (int tm = 0; tm < TMR; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < NTB; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
-                if (sx < 3) a[tm] = tr8(base + aad[tm], 16 * (sx + 1), 512);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (sx < 3) ld_b(sx + 1);
         }
     };
     int st_c = 0;
