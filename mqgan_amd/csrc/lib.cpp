@@ -20,7 +20,8 @@ thread_local char g_kernel[128] = "";
 //    sequences behind the ABI, csrc/plan.cpp), mq_set_launch_hook; mq_winon_* take the 3 x 3 tile as well - mq_wino3_* and the
 //    F(2x2, 3x3) functions mq_wino_* are gone
 // 9: mq_set_pass_hook (HIP-event timing of the transform passes, algorithmic bytes per reduced-form layer); the screened codebook
-//    search is two launches with every bf16 score formed once (same entry points, d <= 512)
+//    search is three launches with every bf16 score formed once (same entry points; any d % 8 == 0 - tuned for d <= 512, where a
+//    block's x tile stays in L2; longer rows are tested, not tuned)
 extern "C" int mq_abi_version(void) { return 9; }
 extern "C" const char *mq_last_error(void) { return mq::g_err; }
 extern "C" const char *mq_last_kernel(void) { return mq::g_kernel; }

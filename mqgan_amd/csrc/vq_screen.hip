@@ -33,18 +33,25 @@
 //
 // Why the winner is always a candidate.  Let k* be the oracle's answer for row n and E(n) a bound with
 // |score(n,k) - dist(n,k)| <= E(n) for EVERY k.  Then score(k*) <= dist(k*) + E <= dist(k) + E <= score(k) + 2E for all k, i.e.
-// a(k*) >= a(k) - E for all k, so a(k*) >= g - E for the final maximum g and for every running maximum (each is <= g): appended,
-// and kept by the filter.  Every code with dist == dist(k*) satisfies the same inequalities, so the lowest such index is among
+// (score = -2 a)  a(k*) >= a(k) - E for all k, so a(k*) >= g - E for the final maximum g and for every running maximum (each is
+// <= g): appended, and kept by the filter.  The threshold in a-units is therefore the WHOLE score bound E, not half of it: r5
+// stored E / 2 (the 2 of "2E" and the 2 of "score = -2a" cancel; they were applied twice) and passed every random test because
+// Cauchy-Schwarz leaves random data 10-30x inside the bound - tests/vq_adversarial.py builds the rows that sit at 0.6-0.67 E.  Every code with dist == dist(k*) satisfies the same inequalities, so the lowest such index is among
 // the re-ranked survivors too; all other survivors have a larger exact distance.
 //
-// The bound.  bf16 has 8 significant bits: |xh - x| <= 2^-8 |x|, so |xh ch - x c| <= (2^-7 + 2^-16) |x c| per term; bf16
-// products are exact in f32; the MFMA's f32 accumulation of [-cn/2, p_1 .. p_D] errs by at most D 2^-23 (cn/2 + sum|x c|) and
-// the oracle's chain by at most D 2^-24 sum|x c| (any summation order; the MFMA is given twice the IEEE figure).  Doubled for
-// the score, with sum|x_i c_i| <= |x| |c| (Cauchy-Schwarz):
-//   E(n) = 2.02 delta |x_n| cmax + (2^-20 + D 2^-23) cmax^2 + 1e-30,   delta = 1.02 * 2^-7 + D * 2^-21
-// (the cmax^2 term: the norm inside the accumulation and the oracle's final fmaf rounding; 1e-30: flushed denormals).  |x_n| and
-// cmax are taken 0.1 % high to cover their own rounding.  Rows with |x_n| or cmax above 1e18 or not finite have no bound
-// (products may overflow): exhaustive search.
+// The bound (r6: from the rounding residuals the prep kernels measure, not from bf16's worst case).  With ex = x - xh and
+// ec = c - ch (both exact in f32: xh is x with its low significand bits rounded away),
+//   <x, c> - <xh, ch> = <ex, c> + <xh, ec>   exactly, so   |...| <= |ex_n| |c_k| + |xh_n| |ec_k|   (Cauchy-Schwarz, twice).
+// bf16 products are exact in f32; the MFMA's f32 accumulation of [-cn/2, p_1 .. p_D] errs by at most D 2^-23 (cn/2 + sum|xh ch|),
+// the oracle's chain by at most D 2^-24 sum|x c| (any summation order; the MFMA is given twice the IEEE figure), its final fmaf
+// by 2^-24 (cn + 2 |x||c|).  Doubled for the score:
+//   E(n) = 2.02 (|ex_n| cmax + |xh_n| ecmax) + 2.02 D 2^-21 |x_n| cmax + (2^-20 + D 2^-23) cmax^2 + 1e-30
+// with cmax = max_k |c_k|, ecmax = max_k |ec_k| (1e-30: flushed denormals; every norm is taken 0.1 % high to cover its own
+// rounding, |xh_n| as 1.004 |x_n|).  r3-r5 used the worst case |ex| <= 2^-8 |x|, |ec| <= 2^-8 |c|, i.e. 2.02 * 1.02 * 2^-7 |x| cmax:
+// random data rounds with an rms residual of 0.41 * 2^-8, so the measured norms give a bound 2.2x smaller (1.5-1.9 survivors per
+// row where the worst-case bound has 2.4-4) and lose nothing where the worst case is real (tests/vq_adversarial.py: residuals at
+// half an ulp in every component - there the two bounds agree and the winner trails the best score by 0.69 E).  Rows with |x_n| or
+// cmax above 1e18 or not finite have no bound (products may overflow): exhaustive search.
 #include <stdlib.h>
 
 #include "gemm_core.h"
@@ -65,7 +72,7 @@ constexpr int RR_ROWS = 64;           // rows per re-rank block
 constexpr int RR_CAP = 1024;          // survivors a re-rank block holds
 constexpr int RR_STAGE = 2 * 64 * 64;   // one stage of a wave's staging ring: 64 pairs x 16 f32 of the code row + of the x row
 constexpr int RR_NS = 4;                // ring depth (a power of two)
-constexpr int RR_PER_ROW = 16;        // ... and per row; rows with more are searched exhaustively
+constexpr int RR_PER_ROW = 32;        // ... and per row; rows with more are searched exhaustively
 
 __device__ __forceinline__ unsigned ord_f32(float v)
 {
@@ -82,6 +89,14 @@ __device__ __forceinline__ unsigned long long pack_di(float dist, int idx)
     return ((unsigned long long)ord_f32(dist) << 32) | (unsigned)idx;
 }
 
+// |v - bf16(v)|^2 of four elements (the difference is exact in f32; inf - inf and NaN give NaN, which poisons the bound as it must)
+__device__ __forceinline__ float residual_sq(float4 v, uint2 h)
+{
+    const float e0 = v.x - __builtin_bit_cast(float, h.x << 16), e1 = v.y - __builtin_bit_cast(float, h.x & 0xffff0000u);
+    const float e2 = v.z - __builtin_bit_cast(float, h.y << 16), e3 = v.w - __builtin_bit_cast(float, h.y & 0xffff0000u);
+    return fmaf(e0, e0, fmaf(e1, e1, fmaf(e2, e2, e3 * e3)));
+}
+
 // ------------------------------------------------------------------------------------------ codebook side (once per codebook)
 // one wave per code: bf16 copy, max |c|^2 over the codes
 __global__ __launch_bounds__(256) void l2_screen_cbprep_kernel(const float *__restrict__ src, int rows, int d,
@@ -92,18 +107,24 @@ __global__ __launch_bounds__(256) void l2_screen_cbprep_kernel(const float *__re
     if (row >= rows) return;
     const float *s = src + (size_t)row * d;
     unsigned short *o = dst_h + (size_t)row * d;
-    float ss = 0.f;
+    float ss = 0.f, se = 0.f;
     for (int t = lane * 4; t < d; t += 256) {
         const float4 v = *reinterpret_cast<const float4 *>(s + t);
         ss = fmaf(v.x, v.x, ss);
         ss = fmaf(v.y, v.y, ss);
         ss = fmaf(v.z, v.z, ss);
         ss = fmaf(v.w, v.w, ss);
-        *reinterpret_cast<uint2 *>(o + t) = pack_bf16x4(v);
+        const uint2 h = pack_bf16x4(v);
+        se += residual_sq(v, h);
+        *reinterpret_cast<uint2 *>(o + t) = h;
     }
     ss = wave_sum(ss);
+    se = wave_sum(se);
     // NaN orders above +inf as an unsigned pattern: a non-finite code poisons the bound of every row (-> exhaustive search)
-    if (lane == 0) atomicMax(cmax2_bits, __builtin_bit_cast(unsigned, ss));
+    if (lane == 0) {
+        atomicMax(cmax2_bits, __builtin_bit_cast(unsigned, ss));             // max |c|^2
+        atomicMax(cmax2_bits + 1, __builtin_bit_cast(unsigned, se));         // max |c - bf16(c)|^2
+    }
 }
 
 // sequential-chain code norms (the oracle's cn) and the accumulator seeds -cn / 2, padded to a multiple of the code tile with
@@ -124,8 +145,20 @@ __global__ void l2_screen_norms_kernel(const float *__restrict__ c, int k, int k
     cnh[j] = -0.5f * acc;
 }
 
+// E(n) of the header comment from |x_n|^2, |x_n - xh_n|^2, max |c|^2, max |c - ch|^2; NaN = no bound
+__device__ __forceinline__ float screen_bound(float ss, float se, float cmax2, float ecmax2, int d)
+{
+    const float nx = sqrtf(ss) * 1.001f, ex = sqrtf(se) * 1.001f;
+    const float cm = sqrtf(cmax2) * 1.001f, ecm = sqrtf(ecmax2) * 1.001f;
+    const float fd = (float)d;
+    const float e = 2.02f * (ex * cm + 1.004f * nx * ecm) + 2.02f * (fd * 4.76837158203125e-07f) * nx * cm +     // 2^-21
+                    (9.5367431640625e-07f + fd * 1.1920928955078125e-07f) * cm * cm + 1e-30f;                      // 2^-20, 2^-23
+    return (nx < 1e18f && cm < 1e18f) ? e : __builtin_nanf("");
+}
+
 // ------------------------------------------------------------------------------------------ 1. prep (x side, every call)
-// one wave per row: bf16 copy, |x_n|^2 -> E(n) in the units of a = -score / 2 (header comment); NaN = no bound
+// one wave per row: bf16 copy, |x_n|^2 -> E(n), the bound on |score - dist| = the threshold on a = -score / 2 (header comment);
+// NaN = no bound
 __global__ __launch_bounds__(256) void l2_screen_prep_kernel(const float *__restrict__ x, int64_t rows, int d,
                                                              unsigned short *__restrict__ xh, const float *__restrict__ cmax2,
                                                              float *__restrict__ bound, unsigned *__restrict__ gmax,
@@ -137,23 +170,23 @@ __global__ __launch_bounds__(256) void l2_screen_prep_kernel(const float *__rest
     if (row >= rows) return;
     const float *s = x + row * d;
     unsigned short *o = xh + row * d;
-    float ss = 0.f;
+    float ss = 0.f, se = 0.f;
     for (int t = lane * 4; t < d; t += 256) {
         const float4 v = *reinterpret_cast<const float4 *>(s + t);
         ss = fmaf(v.x, v.x, ss);
         ss = fmaf(v.y, v.y, ss);
         ss = fmaf(v.z, v.z, ss);
         ss = fmaf(v.w, v.w, ss);
-        *reinterpret_cast<uint2 *>(o + t) = pack_bf16x4(v);
+        const uint2 h = pack_bf16x4(v);
+        se += residual_sq(v, h);
+        *reinterpret_cast<uint2 *>(o + t) = h;
     }
     ss = wave_sum(ss);
+    se = wave_sum(se);
     if (lane != 0) return;
-    const float nx = sqrtf(ss) * 1.001f;
-    const float cm = sqrtf(cmax2[0]) * 1.001f;
-    const float delta = 1.02f * 0.0078125f + (float)d * 4.76837158203125e-07f;        // 2^-7, 2^-21
-    const float e2 = 2.02f * delta * nx * cm + (9.5367431640625e-07f + (float)d * 1.1920928955078125e-07f) * cm * cm + 1e-30f;
-    const bool ok = nx < 1e18f && cm < 1e18f && e2 < 1e30f;                           // false for NaN too
-    bound[row] = ok ? 0.5f * e2 : __builtin_nanf("");
+    const float e2 = screen_bound(ss, se, cmax2[0], cmax2[1], d);
+    const bool ok = e2 < 1e30f;                                                       // false for NaN too
+    bound[row] = ok ? e2 : __builtin_nanf("");
     gmax[row] = ord_f32(-INFINITY);                    // the row's running maximum, shared by the code splits (atomicMax)
 }
 
@@ -162,7 +195,7 @@ __global__ __launch_bounds__(256) void l2_screen_prep_kernel(const float *__rest
 // block tile as 2 x 2 MFMA tiles of 32 x 32 (v_mfma_f32_32x32x16_bf16, A = codes, B = rows).  Both operand tiles
 // (128 x 64 k's, 128-byte rows, 16-byte chunks XOR-swizzled with (row >> 1) & 7) are staged by LDS-DMA into a ring of two
 // stages (lane-linear destination: the swizzle is applied to the per-lane SOURCE address); the x tile is re-streamed from L2
-// for every code tile (D <= 512: 128 KB per block, it stays in L2).
+// for every code tile (D <= 512: 128 KB per block, it stays in L2; longer rows work and are tested, at whatever rate L2 misses leave).
 __global__ __launch_bounds__(256, 2) void l2_screen_kernel(const unsigned short *__restrict__ xh, const unsigned short *__restrict__ ch,
                                                            const float *__restrict__ cnh, const float *__restrict__ bound, int64_t n, int k,
                                                            int d, int tiles_per_split, int splits, uint2 *__restrict__ cand,

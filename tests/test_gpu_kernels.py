@@ -253,6 +253,49 @@ def test_l2_argmin_screened_adversarial_near_ties(env):
     np.testing.assert_array_equal(dist.cpu().numpy(), wdist)
 
 
+def test_l2_argmin_screened_worst_case_rounding(env):
+    """The geometry the error bound exists for (tests/vq_adversarial.py): bf16 rounding of the row and of two competing codes
+    lined up so that the screen prefers the wrong one by 0.6-0.67 E.  r5's threshold of E / 2 returned the wrong index on
+    these rows without any fallback firing; with the whole bound the winner is re-ranked.  Indices and distances equal the
+    oracle's, no row went through the exhaustive search (the cases are answered by screening + re-rank), and the winner's
+    score gap stays inside the bound."""
+    import vq_adversarial as A
+    from oracle import vq
+    ops = env
+    n_half = 0
+    for name, x, cb in A.cases():
+        n, d = x.shape
+        k = cb.shape[0]
+        xd, cd = t(x), t(cb)
+        ws = ops._ws_bytes(ops.L().mq_l2_screen_workspace(n, k, d), xd)
+        idx, dist = ops.l2_argmin_screened(xd, cd, return_dist=True, workspace=ws)
+        _, _, over = ops.l2_screen_stats(ws, n, k, d)
+        want, wdist = vq.l2_argmin(x, cb, return_dist=True)
+        np.testing.assert_array_equal(idx.cpu().numpy(), want, err_msg=name)
+        np.testing.assert_array_equal(dist.cpu().numpy(), wdist, err_msg=name)
+        assert over == 0, (name, over)
+        gap = A.bf16_gap(x, cb, want)
+        assert (gap / A.screen_bound(x, cb)).max() <= 1.0, name
+        n_half += int((gap > 0.5 * A.worst_case_bound(x, cb)).sum())
+    assert n_half >= 200                                   # rows r5's halved threshold lost
+
+
+def test_l2_argmin_screened_long_rows(env):
+    """d = 1024 and 2048: beyond the sizes the screen kernel's L2-residency argument was made for (d <= 512) - slower,
+    still exact.  (the shape check accepts them, so a test has to.)"""
+    from oracle import vq
+    ops = env
+    rng = np.random.default_rng(23)
+    for n, k, d in ((700, 300, 1024), (260, 513, 2048)):
+        x = rng.standard_normal((n, d)).astype(np.float32)
+        cb = rng.standard_normal((k, d)).astype(np.float32)
+        assert ops.l2_screen_supported(n, k, d)
+        idx, dist = ops.l2_argmin_screened(t(x), t(cb), return_dist=True)
+        want, wdist = vq.l2_argmin(x, cb, threads=4, return_dist=True)
+        np.testing.assert_array_equal(idx.cpu().numpy(), want)
+        np.testing.assert_array_equal(dist.cpu().numpy(), wdist)
+
+
 def test_l2_argmin_screened_rows_without_a_bound(env):
     """NaN / inf / huge rows have no error bound: they take the exhaustive exact path and still match the oracle; a NaN code
     or a huge codebook sends every row there.  (Rows that overflow their candidate slots take the same path: the zero rows of

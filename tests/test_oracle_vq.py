@@ -76,3 +76,26 @@ def test_fsq_thresholds_exact_vs_host_torch_tanh():
         assert p_row < 1e-7, (levels, p_row)
         if levels == [8, 5, 5, 5]:
             assert 1e-8 < p_row < 6e-8                       # ~3e-8: 1-2 flips in 2^26 rows, as measured
+
+
+def test_adversarial_rounding_cases_sit_between_half_and_the_whole_bound():
+    """The generator of tests/vq_adversarial.py (inputs of the GPU test of the screened search): in every case some rows'
+    exact winner trails the best bf16 score by MORE than half the bound - the threshold r5 shipped, which dropped them
+    silently - and none by more than the bound itself (numpy model of the screen's arithmetic and of its E(n))."""
+    import vq_adversarial as A
+    n_half = 0
+    for name, x, cb in A.cases():
+        want = vq.l2_argmin(x, cb)
+        gap = A.bf16_gap(x, cb, want)
+        r = gap / A.screen_bound(x, cb)
+        assert r.max() <= 0.75, (name, r.max())          # inside the bound, with the margin its slack factors give
+        r5 = gap / (0.5 * A.worst_case_bound(x, cb))     # what r5 compared against
+        assert (r5 > 1.0).sum() >= 5, (name, r5.max())   # ... and outside r5's halved threshold: it lost these rows
+        n_half += int((r5 > 1.0).sum())
+        assert np.all(A.screen_bound(x, cb) <= 1.01 * A.worst_case_bound(x, cb))
+    assert n_half >= 200
+    # random data: the measured-residual bound is about half the worst-case one
+    rng = np.random.default_rng(5)
+    x, cb = rng.standard_normal((64, 256)).astype(np.float32), rng.standard_normal((512, 256)).astype(np.float32)
+    ratio = A.screen_bound(x, cb) / A.worst_case_bound(x, cb)
+    assert 0.3 < ratio.min() and ratio.max() < 0.6, (ratio.min(), ratio.max())
