@@ -63,36 +63,17 @@ def kernel_build_id():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel_tag):
-    """HBM-side bytes per launch of `kernel_tag` from the last committed PMC pass (tools/pmc_traffic.sh: FETCH_SIZE
-    and WRITE_SIZE in separate rocprofv3 --pmc runs of this same bench, FETCH_SIZE x2 as the gfx950 note in
-    MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside the process, so the figure is taken
-    from profiles/; None when no pass covers this kernel or when the pass was taken on other kernel sources."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-    if not files:
-        return None, None
-    with open(files[-1]) as f:
-        t = json.load(f)
-    if t.get("_build") != kernel_build_id():
-        return None, os.path.relpath(files[-1], ROOT) + " (stale: measured on other kernel sources)"
-    e = t.get(kernel_tag)
-    if not e:
-        return None, None
-    return e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+def workload_key(config, batch, frames, precision):
+    """What a PMC pass was measured on / what this run is running: bytes per launch of one workload say nothing about another
+    (a batch-8 rehearsal was scored against batch-32 bytes and read 1.004 of the HBM peak)."""
+    return f"{config}/batch{batch}/frames{frames}/{precision}"
 
 
-HBM_FAMILIES = {"winograd_transforms": ("winon_", "wino1d_", "winow_"),
-                "pointwise_pool_upcat": ("pointwise_", "avgpool_", "upcat_"),
-                "fsq": ("fsq_",)}
+RUNNING_WORKLOAD = None        # set by main() before any traffic figure is looked up
 
 
-def pmc_family_bytes():
-    """Per step and per family of HBM-bound kernels (HBM_FAMILIES: kernel-name prefixes), the HBM-side bytes of the last committed
-    PMC pass (same file, same source-hash rule as pmc_traffic): sum over the family's kernels of bytes per launch x launches per
-    step.  The pass's step count comes from its own adam_kernel launches (two per step).  Also the bytes of the two-dimensional
-    Winograd layers as a whole - their transforms plus the dense 1x1 instantiations of the GEMM kernels, which only those layers
-    launch with more than a few MB - for the wasted-traffic ratio.  (None, source) when there is no valid pass."""
+def pmc_table():
+    """(kernel -> entry table of the committed PMC pass that matches the running build AND workload, source) or (None, reason)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
@@ -102,6 +83,42 @@ def pmc_family_bytes():
         t = json.load(f)
     if t.get("_build") != kernel_build_id():
         return None, src + " (stale: measured on other kernel sources)"
+    if t.get("_workload") == RUNNING_WORKLOAD:
+        return {k: v for k, v in t.items() if not k.startswith("_")}, src
+    other = (t.get("_passes") or {}).get(RUNNING_WORKLOAD)
+    if other:
+        return other, src + f" (pass {RUNNING_WORKLOAD})"
+    return None, src + f" (no pass for workload {RUNNING_WORKLOAD}; it holds {[t.get('_workload')] + sorted(t.get('_passes') or {})})"
+
+
+def pmc_traffic(kernel_tag):
+    """HBM-side bytes per launch of `kernel_tag` from the last committed PMC pass (tools/pmc_traffic.sh: FETCH_SIZE
+    and WRITE_SIZE in separate rocprofv3 --pmc runs of this same bench, FETCH_SIZE x2 as the gfx950 note in
+    MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside the process, so the figure is taken
+    from profiles/; None when no pass covers this kernel or when the pass was taken on other kernel sources."""
+    t, src = pmc_table()
+    if t is None:
+        return None, src
+    e = t.get(kernel_tag)
+    if not e:
+        return None, None
+    return e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"], src
+
+
+HBM_FAMILIES = {"winograd_transforms": ("winon_", "wino1d_", "winow_"),
+                "pointwise_pool_upcat": ("pointwise_", "avgpool_", "upcat_"),
+                "fsq": ("fsq_",)}
+
+
+def pmc_family_bytes():
+    """Per step and per family of HBM-bound kernels (HBM_FAMILIES: kernel-name prefixes), the HBM-side bytes of the last committed
+    PMC pass (same file, same source-hash and same-workload rule as pmc_traffic): sum over the family's kernels of bytes per launch x launches per
+    step.  The pass's step count comes from its own adam_kernel launches (two per step).  Also the bytes of the two-dimensional
+    Winograd layers as a whole - their transforms plus the dense 1x1 instantiations of the GEMM kernels, which only those layers
+    launch with more than a few MB - for the wasted-traffic ratio.  (None, source) when there is no valid pass."""
+    t, src = pmc_table()
+    if t is None:
+        return None, src
     adam = t.get("adam_kernel")
     if not adam or not adam.get("launches"):
         return None, src + " (no adam_kernel entry: step count unknown)"
@@ -110,7 +127,7 @@ def pmc_family_bytes():
     out = {fam: 0.0 for fam in HBM_FAMILIES}
     wino2d = 0.0
     for name, e in t.items():
-        if name.startswith("_") or "run" in e:
+        if name.startswith("_"):
             continue
         for fam, prefixes in HBM_FAMILIES.items():
             if name.startswith(prefixes):
@@ -497,13 +514,39 @@ def config3_line(device):
     B, T = cfg["data"]["batch_size"], cfg["data"]["crop_len"]
     steps, warmup = 3, 2          # two warm-up steps: the caching allocator has to grow to this config's footprint first
     tr, batches, lens, timer, elapsed, last = timed_run(cfg, "bf16", B, T, steps, warmup, device, 1, 0)
+    global RUNNING_WORKLOAD
+    keep, RUNNING_WORKLOAD = RUNNING_WORKLOAD, workload_key("hifimusic", B, T, "bf16")
+    try:
+        roof = roofline_of(timer, steps, elapsed, PEAK_BF16_MFMA_TFLOPS)
+    finally:
+        RUNNING_WORKLOAD = keep
     out = {"workload": f"hifimusic PreEncoder VQ-GAN train step, {cfg['model']['mel_channels']} mels x {T} frames, batch {B}, "
                        "bf16 convolutions with bf16 activation storage (refiner, discriminators), f32 accumulation, f32 VQ / losses / "
                        "optimiser", "dtype": "bf16 convs / f32 VQ", "value": B * T * steps / elapsed, "unit": "mel-frames/s",
            "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup,
            "losses_finite": all(np.isfinite(float(v)) for v in last.values()),
-           "roofline": roofline_of(timer, steps, elapsed, PEAK_BF16_MFMA_TFLOPS)}
+           "roofline": roof}
     del tr, batches
+    torch.cuda.empty_cache()
+    return out
+
+
+def forced_collectives_line(cfg, device, B, T, ms_plain):
+    """The cost of the N > 1 code path in the driver's N = 1 record: one forced RCCL rank - process group
+    of one, every gradient bucket all-reduced asynchronously on RCCL's own stream from the post-accumulate hooks, the three
+    loss-sum all-reduces per step - for 3 timed steps of the SAME workload after the main timed region.  Never `value`."""
+    steps, warmup = 3, 1
+    if not dist.is_initialized():
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+        dist.init_process_group("nccl", device_id=device)
+    try:
+        tr, batches, lens, timer, elapsed, last = timed_run(cfg, "fp32", B, T, steps, warmup, device, 1, 0, force=True)
+        out = collectives_of(tr, 1, True) or {}
+        out.update({"ms_per_step": elapsed / steps * 1e3, "ms_per_step_without_collectives": ms_plain, "steps": steps, "warmup": warmup,
+                    "losses_finite": all(np.isfinite(float(v)) for v in last.values())})
+        del tr, batches
+    finally:
+        dist.destroy_process_group()
     torch.cuda.empty_cache()
     return out
 
@@ -638,7 +681,9 @@ def main():
     ap.add_argument("--no-vq", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary fp32x3 / bf16 engine timings")
     ap.add_argument("--no-configs", action="store_true", help="skip the 3-step BASELINE config-3 (hifimusic, bf16) line")
-    ap.add_argument("--cpu-seconds", type=float, default=30.0)
+    ap.add_argument("--cpu-seconds", type=float, default=70.0,
+                    help="bound of the CPU baseline's timed steps: 70 s lets a 16-thread host take the 9 steps BASELINE.md section 3 "
+                         "asks for (about 6.5 s each); it stops earlier, at >= 3 steps, when they would not fit")
     ap.add_argument("--force-collectives", action="store_true",
                     help="issue every data-parallel collective (gradient buckets on RCCL's side stream, loss sums) even with one "
                          "rank: the N = 1 cost of the N > 1 code path")
@@ -752,6 +797,8 @@ def main():
     B = args.batch or cfg["data"]["batch_size"]
     T = args.frames or cfg["data"]["crop_len"]
     mel = cfg["model"]["mel_channels"]
+    global RUNNING_WORKLOAD
+    RUNNING_WORKLOAD = workload_key(args.config, B, T, args.precision)
     tr, batches, lens, timer, elapsed, last = timed_run(cfg, args.precision, B, T, args.steps, args.warmup, device, world, rank,
                                                         force=args.force_collectives)
     host_ms = host_ms_per_step(tr, batches, lens)
@@ -771,7 +818,7 @@ def main():
                 "data": "synthetic",
                 "config": {"workload": f"{args.config} PreEncoder VQ-GAN train step (G fwd + D step + G step + clip/Adam), "
                                        f"{mel} mels x {T} frames, batch {B}/GPU, FSQ {cfg['model']['generator']['fsq_levels']}, "
-                                       "D active, FM off, train-mode dropout", "global_batch": world * B, "frames": T,
+                                       "D active, FM off, train-mode dropout", "workload_key": RUNNING_WORKLOAD, "global_batch": world * B, "frames": T,
                            "parallelism": f"dp{world}",
                            "conv_algorithm": ("implicit GEMM; where a cheaper exact-f32 form exists, Winograd with f32 transforms, products on the same "
                                               "MFMA engine and f32 accumulation: 3x3 / stride-1 layers as F(4x5,3x3) / F(4x4) / F(3x3) (tile per "
@@ -805,6 +852,11 @@ def main():
             line["configs"]["reencode_n2_hifispeech_fp32"] = reencode_line()
             torch.cuda.empty_cache()
             line["configs"]["config2_through_the_loader"] = loader_line(device)
+        if world == 1 and not use_pg and not args.no_configs and args.config == "hifispeech" and args.precision == "fp32":
+            try:
+                line["collectives_forced_1rank"] = forced_collectives_line(cfg, device, B, T, line["ms_per_step"])
+            except Exception as e:          # a box without a usable RCCL must not cost the line its headline
+                line["collectives_forced_1rank"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if not args.no_vq:
             line["vq"] = bench_vq(device)
         if world == 1 and not args.no_cpu_baseline:
@@ -822,10 +874,20 @@ def main():
             summary["cpu_baseline_frames_per_s"] = line["cpu_baseline"].get("value")
         if line.get("collectives"):
             summary["exposed_comm_ms_per_step"] = line["collectives"].get("exposed_comm_ms_per_step")
+        fc = line.get("collectives_forced_1rank") or {}
+        if "ms_per_step" in fc:
+            summary["forced_1rank_collectives"] = {k: fc.get(k) for k in ("ms_per_step", "exposed_comm_ms_per_step", "ms_between_last_bucket_ready_and_clip", "bucket_MiB")}
+        ld = (line.get("configs") or {}).get("config2_through_the_loader")
+        if ld:
+            summary["config2_through_the_loader_ms_per_step"] = ld.get("ms_per_step")
+        for k, v in (line.get("vq") or {}).items():
+            if k.startswith("l2_argmin_screened_") and "rows" not in k:
+                summary[k + "_us"] = round(v["ms"] * 1e3, 1)
         front = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
         ordered = {k: line[k] for k in front if k in line}
         ordered["summary"] = summary
         ordered.update({k: v for k, v in line.items() if k not in ordered})
+        ordered["summary_tail"] = summary           # the same figures as the LAST key: a reader who only keeps the tail of the line
         emit(ordered)
     if use_pg:
         dist.barrier()
