@@ -638,9 +638,10 @@ def loader_line(device, n_files=576, file_frames=640):
     """The same config-2 step fed by the real input pipeline instead of resident batches (the reference's loop
     train.py:511-537): synthetic .npy files on disk -> DataLoader (num_workers 0, random 512-frame crops, collate) -> pinned
     staging -> H2D on a side stream (PrefetchLoader) -> train_step.  Trainer._train_epoch itself is timed: one warm-up epoch,
-    one timed epoch (18 steps; the epoch's start-up - the first batch cannot be prefetched - measured 146 ms, i.e. 8 ms per step
-    of this short epoch: 9- and 27-step epochs give 228.5 and 217.7 ms per step).  The PCIe-inclusive rate - reported beside
-    `value`, never as `value`."""
+    one timed epoch of 18 steps in the steady state of a run (r6: the loader lives across epochs, the first batches of an epoch are
+    staged during the last steps of the one before; the discriminators' first step of every epoch runs in train mode - one power
+    iteration, real and fake as separate batches - as in the reference, train.py:505-506).  The PCIe-inclusive rate - reported
+    beside `value`, never as `value`."""
     import copy
     import tempfile
     from mqgan_amd.train import Trainer, synthetic_mel
@@ -654,12 +655,13 @@ def loader_line(device, n_files=576, file_frames=640):
         cfg["data"]["validation_split"] = 0.0
         tr = Trainer(cfg, device=device, build_data=True)
         steps = len(tr.train_loader)
-        tr._train_epoch(1)                           # warm-up: allocator, kernels, page cache
+        tr._train_epoch(1, next_epoch=2)             # warm-up: allocator, kernels, page cache
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        tr._train_epoch(1)
-        torch.cuda.synchronize()
+        tr._train_epoch(2, next_epoch=3)             # a steady-state epoch: its first batches were staged during epoch 1's last
+        torch.cuda.synchronize()                     # steps, and it starts epoch 3's producer during its own
         dt = time.perf_counter() - t0
+        tr._prefetch.close()
         del tr
     torch.cuda.empty_cache()
     return {"workload": f"hifispeech train step fed by DataLoader + PrefetchLoader: {n_files} .npy files of {file_frames} x {mel}, "

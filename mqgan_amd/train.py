@@ -478,17 +478,21 @@ class Trainer:
         self.global_step += 1
         return out
 
-    def _train_epoch(self, epoch):
+    def _train_epoch(self, epoch, next_epoch=...):
         self.generator.train()
         self.patch_discriminator.train()
         self.multibin_discriminator.train()
         self.epoch = epoch
-        if self.world > 1 and hasattr(self.train_loader.sampler, "set_epoch"):
-            self.train_loader.sampler.set_epoch(epoch)
         log_every = self.config.get("logging", {}).get("log_interval", 50)
         frames, t0 = torch.zeros((), dtype=torch.int64, device=self.device), time.time()
         from .data import PrefetchLoader
-        for i, (real, lens, _) in enumerate(PrefetchLoader(self.train_loader, self.device, depth=2)):
+        if getattr(self, "_prefetch", None) is None or self._prefetch.loader is not self.train_loader:
+            self._prefetch = PrefetchLoader(self.train_loader, self.device, depth=2)      # lives across epochs (mqgan_amd/data.py)
+        # the sampler's shuffle (DistributedSampler.set_epoch) is set by the producer thread of each epoch; the next epoch's first
+        # batches are staged while this epoch's last steps run
+        last = self.config["training"].get("num_epochs", epoch)
+        nxt = (epoch + 1 if epoch < last else None) if next_epoch is Ellipsis else next_epoch
+        for i, (real, lens, _) in enumerate(self._prefetch.epoch(epoch, next_epoch=nxt)):
             empty = real is None or real.size(0) == 0   # every file of the batch failed to load (train.py:512-514)
             if self.comm.active:
                 # the step is full of collectives: either every rank takes it or none does.  Agreed on the HOST (gloo twin

@@ -57,6 +57,66 @@ def test_prefetch_loader_releases_its_thread_when_the_consumer_stops_early():
     assert threading.active_count() == before
 
 
+def test_prefetch_loader_stages_the_next_epoch_during_the_last_steps_of_this_one():
+    """Round 6: the loader lives across epochs.  epoch(e, next_epoch=e + 1) starts the producer of epoch
+    e + 1 when epoch e's last batch has been staged: while the consumer is still inside the last step of epoch e the first
+    `depth` batches of e + 1 are already produced; the sampler's set_epoch is called once per epoch, in order, by the producer
+    of that epoch, never while another epoch is being iterated; asking for another epoch than the staged one drops it; close()
+    leaves no thread behind."""
+    before = threading.active_count()
+
+    class Sampler:
+        def __init__(self):
+            self.calls = []
+
+        def set_epoch(self, e):
+            self.calls.append(e)
+
+    class Epochs:
+        def __init__(self, n):
+            self.n, self.sampler, self.active, self.iterated, self.max_active = n, Sampler(), 0, 0, 0
+
+        def __len__(self):
+            return self.n
+
+        def __iter__(self):
+            e = self.sampler.calls[-1] if self.sampler.calls else -1
+            self.active += 1
+            self.max_active = max(self.max_active, self.active)
+            self.iterated += 1
+            try:
+                for i in range(self.n):
+                    yield torch.full((1, 2, 3), float(100 * e + i)), torch.tensor([2], dtype=torch.int32), ("f",)
+            finally:
+                self.active -= 1
+
+    src = Epochs(5)
+    pl = PrefetchLoader(src, "cpu", depth=2)
+    seen = []
+    for e in (1, 2, 3):
+        for i, (x, _, _) in enumerate(pl.epoch(e, next_epoch=e + 1 if e < 3 else None)):
+            seen.append(int(x[0, 0, 0]))
+            if i == 4 and e < 3:
+                # inside the LAST step of epoch e: give the next producer a moment, then look - it must have staged batches already
+                deadline = time.time() + 5.0
+                while src.iterated < e + 1 and time.time() < deadline:
+                    time.sleep(0.01)
+                assert src.iterated == e + 1, "the next epoch's producer did not start during this epoch's last step"
+    assert seen == [100 * e + i for e in (1, 2, 3) for i in range(5)]
+    assert src.sampler.calls == [1, 2, 3] and src.max_active == 1
+    # a staged epoch nobody asks for: replaced by the one asked for, and close() joins whatever is left
+    for _ in pl.epoch(7, next_epoch=8):
+        pass
+    assert [int(x[0, 0, 0]) for x, _, _ in pl.epoch(9)][0] == 900          # epoch 8 was staged, 9 asked for
+    for _ in pl.epoch(10, next_epoch=11):
+        pass
+    pl.close()
+    deadline = time.time() + 5.0
+    while threading.active_count() > before and time.time() < deadline:
+        time.sleep(0.05)
+    assert threading.active_count() == before, "a producer thread outlived close()"
+
+
 def test_prefetch_loader_surfaces_loader_errors():
     class Bad:
         def __iter__(self):
