@@ -141,7 +141,7 @@ def pmc_family_bytes():
 def hbm_bound_of(tr, batches, lens, steps=2):
     """The HBM-bound half of the step ('HBM roof for FSQ streaming and the fused passes'), measured AFTER the timed
     region on `steps` further optimisation steps: HIP events on the launch stream around every launch of the Winograd transforms
-    (through mq_set_pass_hook), the pointwise / pool / upsample-concat passes and the FSQ kernels in situ (ops.pass_timing) give
+    (through mq_debug_set_pass_hook), the pointwise / pool / upsample-concat passes and the FSQ kernels in situ (ops.pass_timing) give
     ms per step per family; GB per step per family come from the committed PMC pass (null when it was taken on other kernel
     sources, as `traffic`); TB/s and the fraction of the 8 TB/s peak follow.  wasted_traffic_ratio: bytes the two-dimensional
     Winograd layers (refiner 3x3, patch discriminator 5x5 / stride 2) moved - transforms and Winograd-domain GEMMs, PMC - over

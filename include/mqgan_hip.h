@@ -28,6 +28,16 @@ extern "C" {
 
 typedef void *mqStream; /* hipStream_t */
 
+/* Building blocks behind the planned convolution calls (the Winograd / polyphase / row / column transforms) and the
+ * fused-Winograd prototype: libmqgan_hip.so - the PRODUCT library - uses them internally and does NOT export them; the test-variant
+ * build (make -C mqgan_amd/csrc variants -> libmqgan_hip_variants.so, -DMQ_VARIANTS=1) exports them for tests/, tools/ and
+ * micro-benchmarks.  A consumer of the product library reaches them through mq_conv_plan / mq_conv_*_planned. */
+#if defined(MQ_VARIANTS) && MQ_VARIANTS
+#define MQ_BLOCKS_API
+#else
+#define MQ_BLOCKS_API __attribute__((visibility("hidden")))
+#endif
+
 int mq_abi_version(void);
 const char *mq_last_error(void);
 /* Name of the kernel instantiation the last mq_conv_* / mq_gemm-type call on this thread launched, spelled as rocprofv3
@@ -457,18 +467,18 @@ int mq_masked_mae_bwd(const float *pred, const float *target, const uint8_t *pad
  * config 2 it takes the step from 191.7 to 187.7 ms at twice the rounding error of 4 x 5 (6.1e-6 against 3.2e-6 of the layer's output,
  * relative L2 against float64).  For that tile mq_winon_dy_fused is two launches (Z, then Vd as an input transform).
  * (ABI 8 folded the F(3x3) kernels of mq_wino3_* into these and removed F(2x2, 3x3), mq_wino_*: no configuration selected it.) */
-int mq_winon_input_transform(const float *x, int N, int H, int W, int C, float *V, int mh, int mw, mqStream stream);
-int mq_winon_output_transform(const float *M, const float *bias, int N, int H, int W, int K, int act, float slope, const uint8_t *padded,
+MQ_BLOCKS_API int mq_winon_input_transform(const float *x, int N, int H, int W, int C, float *V, int mh, int mw, mqStream stream);
+MQ_BLOCKS_API int mq_winon_output_transform(const float *M, const float *bias, int N, int H, int W, int K, int act, float slope, const uint8_t *padded,
                               int64_t d1, int64_t d2, int64_t d3, float *y, int mh, int mw, mqStream stream);
-int mq_winon_weight_transform(const float *w_krsc, int K, int C, int flip_transpose, float *U, int mh, int mw, mqStream stream);
-int mq_winon_wgrad_inverse(const float *P, int K, int C, float *dw_krsc, int mh, int mw, mqStream stream);
-int mq_winon_dy_fused_rows(int N, int H, int W, int K, int mh, int mw);
-int mq_winon_dy_fused(const float *dy, int N, int H, int W, int K, float *Z, float *Vd, float *bias_partial, int mh, int mw, mqStream stream);
-int mq_winon_input_transform_s2d(const float *x, int N, int H, int W, int C, float *V, int mh, int mw, mqStream stream);
-int mq_winon_weight_transform_s2d(const float *w_krsc, int K, int C, int flip_transpose, float *U, int mh, int mw, mqStream stream);
-int mq_winon_output_transform_d2s(const float *M, int N, int H, int W, int C, const float *gate, float slope, const uint8_t *padded_in,
+MQ_BLOCKS_API int mq_winon_weight_transform(const float *w_krsc, int K, int C, int flip_transpose, float *U, int mh, int mw, mqStream stream);
+MQ_BLOCKS_API int mq_winon_wgrad_inverse(const float *P, int K, int C, float *dw_krsc, int mh, int mw, mqStream stream);
+MQ_BLOCKS_API int mq_winon_dy_fused_rows(int N, int H, int W, int K, int mh, int mw);
+MQ_BLOCKS_API int mq_winon_dy_fused(const float *dy, int N, int H, int W, int K, float *Z, float *Vd, float *bias_partial, int mh, int mw, mqStream stream);
+MQ_BLOCKS_API int mq_winon_input_transform_s2d(const float *x, int N, int H, int W, int C, float *V, int mh, int mw, mqStream stream);
+MQ_BLOCKS_API int mq_winon_weight_transform_s2d(const float *w_krsc, int K, int C, int flip_transpose, float *U, int mh, int mw, mqStream stream);
+MQ_BLOCKS_API int mq_winon_output_transform_d2s(const float *M, int N, int H, int W, int C, const float *gate, float slope, const uint8_t *padded_in,
                                   int64_t d1, int64_t d2, int64_t d3, float *dx, int mh, int mw, mqStream stream);
-int mq_winon_wgrad_inverse_s2d(const float *P, int K, int C, float *dw_krsc, int mh, int mw, mqStream stream);
+MQ_BLOCKS_API int mq_winon_wgrad_inverse_s2d(const float *P, int K, int C, float *dw_krsc, int mh, int mw, mqStream stream);
 
 /* ------------------------------------------------------------------ one-dimensional Winograd F(m, 3) along the rows
  * The multi-bin discriminator's (3 x k) layers (discriminators.py:251-290: 3 taps and stride 1 along the bins, k taps and
@@ -486,15 +496,15 @@ int mq_winon_wgrad_inverse_s2d(const float *P, int K, int C, float *dw_krsc, int
  *             LeakyReLU'(gate) and zeroed where padded_in[...] (the producer layer's activation backward, mq_conv_dgrad_gated's
  *             contract);  dU = mq_conv_wgrad(that desc, V, Z);  dw_krsc = wgrad_inverse(dU). */
 int mq_wino1d_tile(int H);
-int mq_wino1d_input_transform(const float *x, int N, int H, int W, int C, int m, float *V, mqStream stream);
-int mq_wino1d_weight_transform(const float *w_krsc, int groups, int K, int C, int S, int m, float *U_krsc, float *U_crsk, mqStream stream);
-int mq_wino1d_output_transform(const float *M, const float *bias, int N, int H, int Q, int K, int groups, int m, int act, float slope,
+MQ_BLOCKS_API int mq_wino1d_input_transform(const float *x, int N, int H, int W, int C, int m, float *V, mqStream stream);
+MQ_BLOCKS_API int mq_wino1d_weight_transform(const float *w_krsc, int groups, int K, int C, int S, int m, float *U_krsc, float *U_crsk, mqStream stream);
+MQ_BLOCKS_API int mq_wino1d_output_transform(const float *M, const float *bias, int N, int H, int Q, int K, int groups, int m, int act, float slope,
                                const uint8_t *padded, int64_t d1, int64_t d2, int64_t d3, float *y, mqStream stream);
-int mq_wino1d_dy_rows(int N, int H, int Q, int K, int groups, int m);
-int mq_wino1d_dy_transform(const float *dy, int N, int H, int Q, int K, int groups, int m, float *Z, float *bias_partial, mqStream stream);
-int mq_wino1d_dx_transform(const float *dV, int N, int H, int W, int C, int m, const float *gate, float slope, const uint8_t *padded_in,
+MQ_BLOCKS_API int mq_wino1d_dy_rows(int N, int H, int Q, int K, int groups, int m);
+MQ_BLOCKS_API int mq_wino1d_dy_transform(const float *dy, int N, int H, int Q, int K, int groups, int m, float *Z, float *bias_partial, mqStream stream);
+MQ_BLOCKS_API int mq_wino1d_dx_transform(const float *dV, int N, int H, int W, int C, int m, const float *gate, float slope, const uint8_t *padded_in,
                            int64_t d1, int64_t d2, int64_t d3, float *dx, mqStream stream);
-int mq_wino1d_wgrad_inverse(const float *dU, int groups, int K, int C, int S, int m, float *dw_krsc, mqStream stream);
+MQ_BLOCKS_API int mq_wino1d_wgrad_inverse(const float *dU, int groups, int K, int C, int S, int m, float *dw_krsc, mqStream stream);
 
 /* ------------------------------------------------------------------ one-dimensional Winograd F(m, s) along the columns (time)
  * Convolutions with `taps` = 3, 5 or 7 column taps, stride 1 and no dilation along the columns, R row taps with any stride,
@@ -509,15 +519,15 @@ int mq_wino1d_wgrad_inverse(const float *dU, int groups, int K, int C, int S, in
  *             dx = dx_transform(dV) (gate / padded_in as mq_wino1d_dx_transform);  dU = mq_conv_wgrad(that desc, V, Z);
  *             dw_krsc = wgrad_inverse(dU). */
 int mq_winow_tile(int taps);
-int mq_winow_input_transform(const float *x, int N, int H, int W, int C, int taps, int Q, int pad_left, float *V, mqStream stream);
-int mq_winow_weight_transform(const float *w_krsc, int groups, int K, int C, int R, int taps, float *U_krsc, float *U_crsk, mqStream stream);
-int mq_winow_output_transform(const float *M, const float *bias, int N, int P, int Q, int K, int taps, int groups, int act, float slope,
+MQ_BLOCKS_API int mq_winow_input_transform(const float *x, int N, int H, int W, int C, int taps, int Q, int pad_left, float *V, mqStream stream);
+MQ_BLOCKS_API int mq_winow_weight_transform(const float *w_krsc, int groups, int K, int C, int R, int taps, float *U_krsc, float *U_crsk, mqStream stream);
+MQ_BLOCKS_API int mq_winow_output_transform(const float *M, const float *bias, int N, int P, int Q, int K, int taps, int groups, int act, float slope,
                               const uint8_t *padded, int64_t d1, int64_t d2, int64_t d3, float *y, mqStream stream);
-int mq_winow_dy_rows(int N, int P, int Q, int K, int taps, int groups);
-int mq_winow_dy_transform(const float *dy, int N, int P, int Q, int K, int taps, int groups, float *Z, float *bias_partial, mqStream stream);
-int mq_winow_dx_transform(const float *dV, int N, int H, int W, int C, int taps, int Q, int pad_left, const float *gate, float slope,
+MQ_BLOCKS_API int mq_winow_dy_rows(int N, int P, int Q, int K, int taps, int groups);
+MQ_BLOCKS_API int mq_winow_dy_transform(const float *dy, int N, int P, int Q, int K, int taps, int groups, float *Z, float *bias_partial, mqStream stream);
+MQ_BLOCKS_API int mq_winow_dx_transform(const float *dV, int N, int H, int W, int C, int taps, int Q, int pad_left, const float *gate, float slope,
                           const uint8_t *padded_in, int64_t d1, int64_t d2, int64_t d3, float *dx, mqStream stream);
-int mq_winow_wgrad_inverse(const float *dU, int groups, int K, int C, int R, int taps, float *dw_krsc, mqStream stream);
+MQ_BLOCKS_API int mq_winow_wgrad_inverse(const float *dU, int groups, int K, int C, int R, int taps, float *dw_krsc, mqStream stream);
 
 /* ------------------------------------------------------------------ optimiser
  * clip_grad_norm_ + Adam on flat arenas (train.py:401-407,485-492; torch.optim.Adam
@@ -540,12 +550,13 @@ int mq_multi_gather(const int64_t *table_dev, int n_tensors, int64_t total_block
  * the stream (what the data-parallel gradient exchange uses; train.py:140-197 makes shapes, hence addresses, vary per step). */
 int mq_multi_gather_args(const int64_t *table_host, int n_tensors, float *dst, mqStream stream);
 
-/* PROTOTYPE (csrc/winofused.hip, tools/winofused_micro.py; never chosen by mq_conv_plan): the 3x3 / stride-1 / pad-1 convolution
+/* PROTOTYPE (tools/microbench/winofused.hip, tools/winofused_micro.py; never chosen by mq_conv_plan; compiled into the test-variant
+ * library only - r5 shipped it in the product library): the 3x3 / stride-1 / pad-1 convolution
  * of the refiner's 64-channel level (preencoder.py:86-102) as F(4x5, 3x3) in ONE kernel - input transform in the MFMA's operand
  * registers, all 42 positions of a tile in one lane's accumulators, output transform lane-local; no V / M tensors in HBM.  U: the
  * transformed filters of mq_winon_weight_transform(w_krsc, K, C, 0, U, 4, 5); Ut: scratch of 42 * C * K floats; K % 16 == 0,
  * K <= 64, C % 4 == 0. */
-int mq_winofused_fprop(const float *x, const float *U, const float *bias, int N, int H, int W, int C, int K, float *Ut, float *y,
+MQ_BLOCKS_API int mq_winofused_fprop(const float *x, const float *U, const float *bias, int N, int H, int W, int C, int K, float *Ut, float *y,
                        mqStream stream);
 
 /* ------------------------------------------------------------------ algorithm choice and planned execution (csrc/plan.cpp)
@@ -622,16 +633,19 @@ int mq_conv_fprop_planned(const mqConvPlan *plan, const float *x, const float *w
 int mq_conv_backward_planned(const mqConvPlan *plan, const float *x, const void *keep, const float *w_krsc, const float *w_crsk,
                              const float *dy, const float *gate, float gate_slope, const uint8_t *gate_mask, int64_t g1, int64_t g2,
                              int64_t g3, float *dx, float *dw, float *db, void *workspace, size_t workspace_bytes, mqStream stream);
-/* Timing hook: called before (phase 0) and after (phase 1, with mq_last_kernel()) every GEMM launch of the planned calls, with
+/* DEBUG / MEASUREMENT ONLY - the one piece of process-global state in this ABI (everything else is per call and per stream):
+ * two function pointers, not thread-safe, meant for ONE measuring thread (bench.py, tools/layer_profile.py) and NULL otherwise;
+ * a production caller never sets them, and with both NULL the library keeps no state between calls.
+ * Timing hook: called before (phase 0) and after (phase 1, with mq_last_kernel()) every GEMM launch of the planned calls, with
  * the launch's algorithmic flop count - bench.py records HIP events on the launch stream from it.  NULL switches it off. */
 typedef void (*mqLaunchHook)(int phase, double flops, const char *kernel);
-void mq_set_launch_hook(mqLaunchHook hook);
+void mq_debug_set_launch_hook(mqLaunchHook hook);
 /* The HBM-bound half of the same calls ("HBM roof for ... the fused passes"): called before (phase 0) and after
  * (phase 1) every transform launch of the reduced forms with family = "winograd_transforms", and once per planned call of a reduced
  * form with phase 2, bytes = the layer's ALGORITHMIC activation bytes for that pass (each activation tensor it reads or writes,
  * once: x + y forward; dy + dx + x backward) and family = mq_form_name(form) - what bench.py's wasted-traffic ratio divides by. */
 typedef void (*mqPassHook)(int phase, double bytes, const char *family);
-void mq_set_pass_hook(mqPassHook hook);
+void mq_debug_set_pass_hook(mqPassHook hook);
 
 #ifdef __cplusplus
 }

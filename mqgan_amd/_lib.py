@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MQGAN_HIP_LIB: load another build of the same ABI (kernel experiments); the default is the in-tree library
 LIB_PATH = os.environ.get("MQGAN_HIP_LIB") or os.path.join(_HERE, "libmqgan_hip.so")
 _lib = None
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class MqganHipError(RuntimeError):
@@ -161,6 +161,25 @@ SIGNATURES = {
     "mq_lsgan_g_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "mq_masked_mae_sums": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "mq_masked_mae_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _F, _P, _P]),
+    "mq_wino1d_tile": (_I, [_I]),
+    "mq_winow_tile": (_I, [_I]),
+    "mq_plan_cfg_default": (None, [C.POINTER(PlanCfg)]),
+    "mq_form_name": (C.c_char_p, [_I]),
+    "mq_conv_plan": (_I, [C.POINTER(ConvDesc), _I, C.POINTER(PlanCfg), C.POINTER(ConvPlan)]),
+    "mq_conv_fprop_planned": (_I, [C.POINTER(ConvPlan), _P, _P, _P, _I, _F, _P, _L, _L, _L, _P, _P, _P, _Z, _P]),
+    "mq_conv_backward_planned": (_I, [C.POINTER(ConvPlan), _P, _P, _P, _P, _P, _P, _F, _P, _L, _L, _L, _P, _P, _P, _P, _Z, _P]),
+    "mq_debug_set_launch_hook": (None, [LaunchHook]),
+    "mq_debug_set_pass_hook": (None, [PassHook]),
+    "mq_sumsq": (_I, [_P, _L, _P, _P, _P]),
+    "mq_multi_gather": (_I, [_P, _I, _L, _P, _P]),
+    "mq_multi_gather_args": (_I, [_P, _I, _P, _P]),
+    "mq_adam_step": (_I, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _I, _P, _F, _F, _P]),
+}
+
+# Exported by the TEST-VARIANT build only (make -C mqgan_amd/csrc variants -> libmqgan_hip_variants.so): the transform building blocks
+# behind the planned convolution calls and the fused-Winograd prototype (include/mqgan_hip.h: MQ_BLOCKS_API).  Nothing in this package
+# calls them; tests/ and tools/ do, through load_variants().
+VARIANT_SIGNATURES = {
     "mq_winon_input_transform": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
     "mq_winon_output_transform": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _P, _L, _L, _L, _P, _I, _I, _P]),
     "mq_winon_input_transform_s2d": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
@@ -171,7 +190,6 @@ SIGNATURES = {
     "mq_winon_wgrad_inverse": (_I, [_P, _I, _I, _P, _I, _I, _P]),
     "mq_winon_dy_fused_rows": (_I, [_I, _I, _I, _I, _I, _I]),
     "mq_winon_dy_fused": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P]),
-    "mq_wino1d_tile": (_I, [_I]),
     "mq_wino1d_input_transform": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "mq_wino1d_weight_transform": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "mq_wino1d_output_transform": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _L, _L, _L, _P, _P]),
@@ -179,7 +197,6 @@ SIGNATURES = {
     "mq_wino1d_dy_transform": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "mq_wino1d_dx_transform": (_I, [_P, _I, _I, _I, _I, _I, _P, _F, _P, _L, _L, _L, _P, _P]),
     "mq_wino1d_wgrad_inverse": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
-    "mq_winow_tile": (_I, [_I]),
     "mq_winow_input_transform": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "mq_winow_weight_transform": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "mq_winow_output_transform": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _L, _L, _L, _P, _P]),
@@ -187,18 +204,7 @@ SIGNATURES = {
     "mq_winow_dy_transform": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "mq_winow_dx_transform": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _L, _L, _L, _P, _P]),
     "mq_winow_wgrad_inverse": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
-    "mq_plan_cfg_default": (None, [C.POINTER(PlanCfg)]),
-    "mq_form_name": (C.c_char_p, [_I]),
-    "mq_conv_plan": (_I, [C.POINTER(ConvDesc), _I, C.POINTER(PlanCfg), C.POINTER(ConvPlan)]),
-    "mq_conv_fprop_planned": (_I, [C.POINTER(ConvPlan), _P, _P, _P, _I, _F, _P, _L, _L, _L, _P, _P, _P, _Z, _P]),
-    "mq_conv_backward_planned": (_I, [C.POINTER(ConvPlan), _P, _P, _P, _P, _P, _P, _F, _P, _L, _L, _L, _P, _P, _P, _P, _Z, _P]),
     "mq_winofused_fprop": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
-    "mq_set_launch_hook": (None, [LaunchHook]),
-    "mq_set_pass_hook": (None, [PassHook]),
-    "mq_sumsq": (_I, [_P, _L, _P, _P, _P]),
-    "mq_multi_gather": (_I, [_P, _I, _L, _P, _P]),
-    "mq_multi_gather_args": (_I, [_P, _I, _P, _P]),
-    "mq_adam_step": (_I, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _I, _P, _F, _F, _P]),
 }
 
 
@@ -221,6 +227,46 @@ def load():
                             "(`make -C mqgan_amd/csrc`)")
     _lib = lib
     return lib
+
+
+VARIANTS_PATH = os.path.join(_HERE, "libmqgan_hip_variants.so")
+_variants = None
+
+
+def load_variants():
+    """The test-variant library (tests / tools / micro-benchmarks only): every entry point of the product library plus the
+    building blocks of VARIANT_SIGNATURES, and the measured-and-rejected kernel variants behind their MQGAN_* switches."""
+    global _variants
+    if _variants is not None:
+        return _variants
+    if not os.path.exists(VARIANTS_PATH):
+        raise MqganHipError(f"{VARIANTS_PATH} not found: build it with `make -C mqgan_amd/csrc variants` "
+                            "(python -c 'import __graft_entry__ as g; g.build_variants()')")
+    lib = C.CDLL(VARIANTS_PATH)
+    for name, (res, args) in {**SIGNATURES, **VARIANT_SIGNATURES}.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mq_abi_version() != ABI_VERSION:
+        raise MqganHipError(f"{VARIANTS_PATH} has ABI version {lib.mq_abi_version()}, this package needs {ABI_VERSION}: rebuild")
+    _variants = lib
+    return lib
+
+
+class use_variants:
+    """Context manager for tests: every call of the package goes to the test-variant library inside the block (the same process
+    keeps the product library for everything else)."""
+
+    def __enter__(self):
+        global _lib
+        self._keep = load()
+        _lib = load_variants()
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._keep
+        return False
 
 
 def check(rc, what=""):

@@ -7,6 +7,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#ifndef MQ_VARIANTS
+#define MQ_VARIANTS 0      // 1: the test-variant build (Makefile: make variants) - rejected kernel variants and the building blocks as exports
+#endif
 #include "../../include/mqgan_hip.h"
 
 namespace mq {

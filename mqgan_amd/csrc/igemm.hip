@@ -15,16 +15,22 @@ namespace mq {
 
 // LDS-DMA f32 kernels (igemm_h2.hip): fprop / dgrad of the layers with C % 16 == 0 and enough rows for 256-row tiles
 bool d32_nt_ok(const mqConvDesc *d, bool dgrad);
+#if MQ_VARIANTS
 int d32_nt_launch(const mqConvDesc *d, bool dgrad, const float *act, const float *w, const float *bias, const uint8_t *mask, int d1,
                   int d2, int d3, int act_kind, float slope, float *out, hipStream_t st);
+#endif
 // Measured (tools/f32_micro.py, round 2): on the f32 engine the LDS-DMA structure is SLOWER than the register-staged
 // kernels below (126-135 vs 131-142 TF/s on the 256-768 channel layers): f32 MFMA runs at the vector rate, so neither L2
 // bandwidth nor staging instructions bound it, and one 512-thread block per CU loses more to the tile tail than four
 // 256-thread blocks do.  The f32 instantiations stay available for A/B runs (MQGAN_D32=1) but are off by default.
 static bool use_d32()
 {
+#if MQ_VARIANTS
     static const bool on = getenv("MQGAN_D32") != nullptr;
     return on;
+#else
+    return false;                       // the LDS-DMA f32 kernels are compiled into the test-variant library only (make variants)
+#endif
 }
 
 struct ConvGeom {
@@ -1326,7 +1332,11 @@ static int launch_nt(const mqConvDesc *d, const float *act, const float *w, cons
     const bool want_x3 = d->precision == MQ_PRECISION_F32X3;
     if (use_d32() && epi.act != 3 && d->precision == MQ_PRECISION_F32 && !hmode && ((uintptr_t)act % 16 == 0) &&
         ((uintptr_t)w % 16 == 0) && d32_nt_ok(d, DGRAD))
+#if MQ_VARIANTS
         return d32_nt_launch(d, DGRAD, act, w, bias, epi.mask, epi.d1, epi.d2, epi.d3, epi.act, epi.slope, out, st);
+#else
+        return ::mq::fail("MQGAN_D32 needs the test-variant library");
+#endif
     ConvGeom g;
     const int ng = d->N / d->groups;
     if (!DGRAD) {

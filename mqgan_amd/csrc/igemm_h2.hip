@@ -2250,6 +2250,18 @@ static bool d32_shape_ok(const mqConvDesc *d, bool dgrad)
     return true;
 }
 
+// A/B switches of measured-and-rejected variants exist in the test-variant build only (make variants, -DMQ_VARIANTS=1): in the
+// product library the variant's code is not compiled and its switch reads as "not set".
+static inline bool variant_env(const char *name)
+{
+#if MQ_VARIANTS
+    return getenv(name) != nullptr;
+#else
+    (void)name;
+    return false;
+#endif
+}
+
 template <class ET, bool DGRAD>
 static int launch_h2(const mqConvDesc *d, const void *act, const void *w, void *out, const H2Epi &epi_in,
                      hipStream_t st, const char *who)
@@ -2286,13 +2298,15 @@ static int launch_h2(const mqConvDesc *d, const void *act, const void *w, void *
     // MFMA shape of the bf16 kernels: 16x16x32 by default - same LDS bytes and cycles per flop as 32x32x16, but the chip
     // holds a higher clock on it (measured +3..13 % on the 384-1152-channel layers, tools/h2_micro.py); MQGAN_H2_MF32=1
     // switches back for A/B runs
-    static const bool mf16 = getenv("MQGAN_H2_MF32") == nullptr;
+    static const bool mf16 = !variant_env("MQGAN_H2_MF32");
     (void)mf16;
     int TN = pick_tn(g.Ncols);
+#if MQ_VARIANTS
     if (const char *e = getenv("MQGAN_H2_TN")) {                 // experiments only
         const int v = atoi(e);
         if (v >= 1 && v <= 4) TN = v;
     }
+#endif
     const int BN = 64 * TN;
     g.nMt = (int)cdiv(g.Mtot, H2_BM);
     g.nNt = (int)cdiv(g.Ncols, BN);
@@ -2330,16 +2344,27 @@ static int launch_h2(const mqConvDesc *d, const void *act, const void *w, void *
         pi.tile0[pi.ncls] = t0;
         grid = dim3((unsigned)(t0 * g.nNt), d->groups);
     }
+#if MQ_VARIANTS
 #define MQ_H2(TN_, NS_, CB_, PAR_) do { kname("conv_h2_kernel<%d, %d, %d, %s, %s>", TN_, NS_, CB_, tf(PAR_), tf(mf16)); if (mf16) hipLaunchKernelGGL((conv_h2_kernel<TN_, NS_, CB_, PAR_, true>), grid, block, 0, st, reinterpret_cast<const unsigned short *>(act), \
                                                       reinterpret_cast<const unsigned short *>(w), out, g, pi, epi, act_gs); \
                                         else hipLaunchKernelGGL((conv_h2_kernel<TN_, NS_, CB_, PAR_, false>), grid, block, 0, st, reinterpret_cast<const unsigned short *>(act), \
                                                       reinterpret_cast<const unsigned short *>(w), out, g, pi, epi, act_gs); } while (0)
 #define MQ_D32(TN_, NS_, PAR_) do { kname("conv_d32_kernel<%d, %d, %s>", TN_, NS_, tf(PAR_)); hipLaunchKernelGGL((conv_d32_kernel<TN_, NS_, PAR_>), grid, block, 0, st, reinterpret_cast<const float *>(act), \
                                                   reinterpret_cast<const float *>(w), reinterpret_cast<float *>(out), g, pi, epi, act_gs); } while (0)
+#else          // product: the 16x16x32 instantiations only, no f32 LDS-DMA kernels
+#define MQ_H2(TN_, NS_, CB_, PAR_) do { kname("conv_h2_kernel<%d, %d, %d, %s, %s>", TN_, NS_, CB_, tf(PAR_), tf(true)); hipLaunchKernelGGL((conv_h2_kernel<TN_, NS_, CB_, PAR_, true>), grid, block, 0, st, reinterpret_cast<const unsigned short *>(act), \
+                                                      reinterpret_cast<const unsigned short *>(w), out, g, pi, epi, act_gs); } while (0)
+#define MQ_D32(TN_, NS_, PAR_) do { return ::mq::fail("%s: the LDS-DMA f32 kernels are in the test-variant library only", who); } while (0)
+#endif
 #define MQ_H2_CB(TN_, NS_, PAR_) do { if constexpr (ET::F32) MQ_D32(TN_, NS_, PAR_); else if (g.CB == 64) MQ_H2(TN_, NS_, 64, PAR_); else MQ_H2(TN_, NS_, 32, PAR_); } while (0)
+#if MQ_VARIANTS
     static const bool ns2 = getenv("MQGAN_H2_NS2") != nullptr;      // experiment: TN = 2 on a two-stage ring (A/B of the ring depth)
 #define MQ_H2_TN(PAR_) do { if (TN == 4) MQ_H2_CB(4, 2, PAR_); else if (TN == 3) MQ_H2_CB(3, 2, PAR_); \
                             else if (TN == 2) { if (ns2) MQ_H2_CB(2, 2, PAR_); else MQ_H2_CB(2, 3, PAR_); } else MQ_H2_CB(1, 2, PAR_); } while (0)
+#else
+#define MQ_H2_TN(PAR_) do { if (TN == 4) MQ_H2_CB(4, 2, PAR_); else if (TN == 3) MQ_H2_CB(3, 2, PAR_); \
+                            else if (TN == 2) MQ_H2_CB(2, 3, PAR_); else MQ_H2_CB(1, 2, PAR_); } while (0)
+#endif
     // three stride-1 column taps on 64-channel chunks: the shared-row kernel (one activation image per (chunk, tap row))
     const bool no_share = getenv("MQGAN_H2_NO_SHARE") != nullptr;      // read per call: tests switch it
     bool shared_rows = false;
@@ -2409,14 +2434,16 @@ static int launch_h2(const mqConvDesc *d, const void *act, const void *w, void *
         }
     } else if (shared96) {
         if constexpr (!ET::F32) {
-            const bool big = getenv("MQGAN_H2_96_BIG") != nullptr;        // A/B runs and the identity test: the 256-row kernel
+            const bool big = variant_env("MQGAN_H2_96_BIG");              // A/B runs and the identity test: the 256-row kernel
             g.nMt = (int)cdiv((int64_t)ng * g.OH * (g.OW + g.S - 1), big ? H2_BM : H96Q_BM);
             g.nNt = (int)cdiv(g.Ncols, H96_BN);
             grid = dim3((unsigned)(g.nMt * g.nNt), d->groups);
             if (big) {
+#if MQ_VARIANTS
                 kname("conv_h2s96_kernel<%d>", 3);
                 hipLaunchKernelGGL((conv_h2s96_kernel<3>), grid, block, 0, st, reinterpret_cast<const unsigned short *>(act),
                                    reinterpret_cast<const unsigned short *>(w), out, g, epi, act_gs);
+#endif
             } else {
                 kname("conv_h2s96q_kernel<%d>", 3);
                 hipLaunchKernelGGL((conv_h2s96q_kernel<3>), grid, dim3(256), 0, st, reinterpret_cast<const unsigned short *>(act),
@@ -2457,6 +2484,7 @@ static int launch_h2(const mqConvDesc *d, const void *act, const void *w, void *
 
 // hooks for igemm.hip's dispatcher (MQ_PRECISION_F32)
 bool d32_nt_ok(const mqConvDesc *d, bool dgrad) { return d32_shape_ok(d, dgrad); }
+#if MQ_VARIANTS
 int d32_nt_launch(const mqConvDesc *d, bool dgrad, const float *act, const float *w, const float *bias, const uint8_t *mask, int d1,
                   int d2, int d3, int act_kind, float slope, float *out, hipStream_t st)
 {
@@ -2464,6 +2492,7 @@ int d32_nt_launch(const mqConvDesc *d, bool dgrad, const float *act, const float
     if (dgrad) return launch_h2<ElemF32, true>(d, act, w, out, epi, st, "mq_conv_dgrad(lds-dma)");
     return launch_h2<ElemF32, false>(d, act, w, out, epi, st, "mq_conv_fprop(lds-dma)");
 }
+#endif
 
 }  // namespace mq
 
@@ -2669,15 +2698,19 @@ extern "C" int mq_conv_wgrad_h2(const mqConvDesc *d, const uint16_t *x, const ui
     dim3 grid(g.nKt * g.nCt, d->groups, g.splits), block(512);
     // the bias gradient rides on the dy tiles the kernel stages anyway: per-split column sums into bias_ws [splits][groups][K]
     // (MQGAN_H2_BIAS_PASS=1: the separate column-sum passes over dy of r2-r4, for A/B runs)
-    static const bool bias_pass = getenv("MQGAN_H2_BIAS_PASS") != nullptr;
+    static const bool bias_pass = variant_env("MQGAN_H2_BIAS_PASS");
     float *bias_slab = (dbias && !bias_pass) ? bias_ws : nullptr;
-    g.pipe = getenv("MQGAN_H2_WGRAD_NOPIPE") == nullptr;              // read per call: A/B runs
+    g.pipe = !variant_env("MQGAN_H2_WGRAD_NOPIPE");                  // read per call: A/B runs
     const int wraps = d->Q >= 64 ? 1 : 4;
     // the weight gradient stays on 32x32x16: its 16x16x32 instantiation (conflict-free too) measured 3-5 % slower
     // (twice the transposed LDS reads per flop); MQGAN_H2_WG16=1 selects it for A/B runs
+#if MQ_VARIANTS
     static const bool mf16 = getenv("MQGAN_H2_WG16") != nullptr;
 #define MQ_WH2(WM_, TM_, WR_) do { kname("conv_wgrad_h2_kernel<%d, %d, %d, %s>", WM_, TM_, WR_, tf(mf16)); if (mf16) hipLaunchKernelGGL((conv_wgrad_h2_kernel<WM_, TM_, WR_, true>), grid, block, 0, st, x, dy, target, bias_slab, g, d->groups); \
                                    else hipLaunchKernelGGL((conv_wgrad_h2_kernel<WM_, TM_, WR_, false>), grid, block, 0, st, x, dy, target, bias_slab, g, d->groups); } while (0)
+#else
+#define MQ_WH2(WM_, TM_, WR_) do { kname("conv_wgrad_h2_kernel<%d, %d, %d, %s>", WM_, TM_, WR_, tf(false)); hipLaunchKernelGGL((conv_wgrad_h2_kernel<WM_, TM_, WR_, false>), grid, block, 0, st, x, dy, target, bias_slab, g, d->groups); } while (0)
+#endif
 #define MQ_WH(WM_, TM_) do { if (wraps == 1) MQ_WH2(WM_, TM_, 1); else MQ_WH2(WM_, TM_, 4); } while (0)
     if (shared) {
         if (d->Q + 2 >= 64) { kname("conv_wgrad_h2s_kernel<%d>", 1); hipLaunchKernelGGL((conv_wgrad_h2s_kernel<1>), grid, block, 0, st, x, dy, target, bias_slab, g, d->groups); }

@@ -22,6 +22,10 @@ thread_local char g_kernel[128] = "";
 // 9: mq_set_pass_hook (HIP-event timing of the transform passes, algorithmic bytes per reduced-form layer); the screened codebook
 //    search is three launches with every bf16 score formed once (same entry points; any d % 8 == 0 - tuned for d <= 512, where a
 //    block's x tile stays in L2; longer rows are tested, not tuned)
-extern "C" int mq_abi_version(void) { return 9; }
+// 10: the product library exports only what mqgan_amd/ops.py calls (plus version / error / plan-configuration helpers): the transform
+//    building blocks mq_winon_* / mq_wino1d_* / mq_winow_* and mq_winofused_fprop are internal (MQ_BLOCKS_API) and exported by the
+//    test-variant build alone (make variants), which also carries the rejected kernel variants; the two hooks are named
+//    mq_debug_set_*_hook; the screened codebook search's bound comes from measured rounding residuals
+extern "C" int mq_abi_version(void) { return 10; }
 extern "C" const char *mq_last_error(void) { return mq::g_err; }
 extern "C" const char *mq_last_kernel(void) { return mq::g_kernel; }

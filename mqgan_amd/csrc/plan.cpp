@@ -224,8 +224,8 @@ int backward_impl(const mqConvPlan *p, const float *x, const void *keep, const f
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------- C ABI
-extern "C" void mq_set_launch_hook(mqLaunchHook hook) { g_hook = hook; }
-extern "C" void mq_set_pass_hook(mqPassHook hook) { g_pass = hook; }
+extern "C" void mq_debug_set_launch_hook(mqLaunchHook hook) { g_hook = hook; }
+extern "C" void mq_debug_set_pass_hook(mqPassHook hook) { g_pass = hook; }
 
 extern "C" void mq_plan_cfg_default(mqPlanCfg *c)
 {

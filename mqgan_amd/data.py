@@ -35,7 +35,7 @@ class PrefetchLoader:
                 continue
         return False
 
-    def _producer(self, q, stop, epoch=None):
+    def _producer(self, q, stop, epoch=None, done=None):
         put = lambda item: self._put(q, stop, item)
         try:
             sampler = getattr(self.loader, "sampler", None)
@@ -64,18 +64,20 @@ class PrefetchLoader:
         except BaseException as e:          # surface loader errors on the consumer side
             put(e)
         finally:
+            if done is not None:
+                done.set()                  # the loader of this epoch is exhausted: everything it produced is in the queue
             put(StopIteration)
 
     def _start(self, epoch):
-        q, stop = queue.Queue(maxsize=self.depth), threading.Event()
-        th = threading.Thread(target=self._producer, args=(q, stop, epoch), daemon=True)
+        q, stop, done = queue.Queue(maxsize=self.depth), threading.Event(), threading.Event()
+        th = threading.Thread(target=self._producer, args=(q, stop, epoch, done), daemon=True)
         th.start()
-        return (epoch, q, stop, th)
+        return (epoch, q, stop, th, done)
 
     @staticmethod
     def _release(run):
         """Stop a producer, drop what it staged (pinned buffers, device batches) and wait for it."""
-        _, q, stop, th = run
+        _, q, stop, th, _ = run
         stop.set()
         while True:
             try:
@@ -108,7 +110,12 @@ class PrefetchLoader:
             run = None
         if run is None:
             run = self._start(epoch)
-        _, q, stop, th = run
+        _, q, stop, th, done = run
+        try:
+            total = len(self.loader)
+        except TypeError:
+            total = None
+        got = 0
         try:
             while True:
                 item = q.get()
@@ -121,10 +128,13 @@ class PrefetchLoader:
                     torch.cuda.current_stream(self.device).wait_event(ev)
                     real.record_stream(torch.cuda.current_stream(self.device))
                     lens.record_stream(torch.cuda.current_stream(self.device))
-                if next_epoch is not None and self._ahead is None and not th.is_alive():
-                    # the producer has staged everything of this epoch (what is left sits in the queue): the next epoch's
-                    # producer may start now - one producer at a time, so sampler and dataset are never iterated concurrently
-                    self._ahead = self._start(next_epoch)
+                got += 1
+                if next_epoch is not None and self._ahead is None and (done.is_set() or (total is not None and got >= total)):
+                    # this is the epoch's last batch, or the producer has staged everything already (what is left sits in the
+                    # queue): the next epoch's producer starts now - after this epoch's loader is exhausted (a moment at most:
+                    # it has produced its last batch), so sampler and dataset are never iterated by two producers at once
+                    if done.wait(timeout=2.0):
+                        self._ahead = self._start(next_epoch)
                 yield real, lens, names
             if next_epoch is not None and self._ahead is None:
                 self._ahead = self._start(next_epoch)

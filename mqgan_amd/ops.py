@@ -25,7 +25,7 @@ def L():
 
 # ----------------------------------------------------------------------------- HBM-bound passes under HIP events (bench.py)
 # With a KernelTimer in ``PASS_TIMER`` every launch of the streaming kernels below, and every transform launch inside the
-# planned convolution calls (mq_set_pass_hook), is bracketed by two events and recorded under its FAMILY; ``records`` then holds
+# planned convolution calls (mq_debug_set_pass_hook), is bracketed by two events and recorded under its FAMILY; ``records`` then holds
 # (family, 0, start, end) and ``layer_bytes`` the algorithmic activation bytes the reduced-form layers reported.  Off (None) in
 # the timed region of the benchmark and everywhere else: L() then returns the library itself.
 PASS_TIMER = None
@@ -87,14 +87,14 @@ class pass_timing:
         global PASS_TIMER
         t = KernelTimer()
         t.layer_bytes = {}
-        _lib.load().mq_set_pass_hook(_PASS_HOOK)
+        _lib.load().mq_debug_set_pass_hook(_PASS_HOOK)
         PASS_TIMER = t
         return t
 
     def __exit__(self, *exc):
         global PASS_TIMER
         PASS_TIMER = None
-        _lib.load().mq_set_pass_hook(_lib.PassHook(0))
+        _lib.load().mq_debug_set_pass_hook(_lib.PassHook(0))
         return False
 
 
@@ -554,7 +554,7 @@ def _winow_ok(d: ConvDesc) -> bool:
     return conv_plan(d, False).form == FORM_WINOW or conv_plan(d, True).form == FORM_WINOW
 
 
-# HIP-event timing of the GEMM launches inside the planned calls: the library calls back around each of them (mq_set_launch_hook)
+# HIP-event timing of the GEMM launches inside the planned calls: the library calls back around each of them (mq_debug_set_launch_hook)
 _HOOK_STATE = {"start": None, "detail": None}
 
 
@@ -581,7 +581,7 @@ def _planned_call(key, fn):
     """Run a planned entry point; with a KernelTimer active the library reports every GEMM launch to it."""
     global _hook_installed
     if TIMER is not None and not _hook_installed:
-        L().mq_set_launch_hook(_LAUNCH_HOOK)
+        L().mq_debug_set_launch_hook(_LAUNCH_HOOK)
         _hook_installed = True
     _HOOK_STATE["detail"] = key
     fn()

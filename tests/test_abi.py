@@ -12,12 +12,16 @@ from conftest import ROOT
 HEADER = os.path.join(ROOT, "include", "mqgan_hip.h")
 
 
-def declared():
+def declared(blocks=None):
+    """name -> parameter count of every entry point the header declares; ``blocks`` True / False: only the building blocks
+    (MQ_BLOCKS_API: exported by the test-variant library alone) / only the product library's exports."""
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     out = {}
-    for m in re.finditer(r"\b(?:int|size_t|void|const char \*)\s*(mq_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
-        name, args = m.group(1), m.group(2).strip()
+    for m in re.finditer(r"(MQ_BLOCKS_API\s+)?\b(?:int|size_t|void|const char \*)\s*(mq_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        is_block, name, args = bool(m.group(1)), m.group(2), m.group(3).strip()
+        if blocks is not None and is_block != blocks:
+            continue
         n = 0 if args in ("", "void") else args.count(",") + 1
         out[name] = n
     return out
@@ -37,16 +41,39 @@ def test_header_parses():
 def test_library_exports_every_declared_symbol(built):
     from mqgan_amd import _lib
     lib = _lib.load()
-    d = declared()
+    d, blocks = declared(blocks=False), declared(blocks=True)
     assert set(d) == set(_lib.SIGNATURES), (set(d) ^ set(_lib.SIGNATURES))
+    assert set(blocks) == set(_lib.VARIANT_SIGNATURES), (set(blocks) ^ set(_lib.VARIANT_SIGNATURES))
     for name, nargs in d.items():
         assert hasattr(lib, name), name
         assert len(_lib.SIGNATURES[name][1]) == nargs, (name, nargs, len(_lib.SIGNATURES[name][1]))
-    assert lib.mq_abi_version() == 9 == _lib.ABI_VERSION
-    # nm agrees (extern "C", no mangling)
+    for name, nargs in blocks.items():
+        assert len(_lib.VARIANT_SIGNATURES[name][1]) == nargs, (name, nargs)
+    assert lib.mq_abi_version() == 10 == _lib.ABI_VERSION
+    # nm agrees (extern "C", no mangling) - in BOTH directions: the product library exports exactly the product section of the
+    # header, no building block, no prototype (r5 exported 25 transform entry points and mq_winofused_fprop that nothing in the
+    # package calls)
     syms = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
-    for name in d:
-        assert re.search(rf"\bT {name}\b", syms), name
+    exported = set(re.findall(r"\bT (mq_\w+)\b", syms))
+    assert exported == set(d), (sorted(exported - set(d)), sorted(set(d) - exported))
+
+
+def test_product_library_exports_only_what_the_package_calls(built):
+    """every exported entry point is one mqgan_amd/*.py calls - apart from a short list of helpers a C consumer
+    needs that the Python host has no use for."""
+    import glob
+    from mqgan_amd import _lib
+    used = set()
+    for f in glob.glob(os.path.join(ROOT, "mqgan_amd", "*.py")):
+        text = open(f).read()
+        if f.endswith("_lib.py"):
+            text = text.split("SIGNATURES = {")[0] + text.split("def load():")[1]        # the binding table itself is not a call
+        used |= set(re.findall(r"\b(mq_\w+)\b", text))
+    helpers = {"mq_abi_version", "mq_last_error",          # used by _lib.load() / check() (counted above) - listed for the C consumer
+               "mq_plan_cfg_default",                      # a C consumer's way to the defaults ops.py builds its mqPlanCfg from
+               "mq_wino1d_tile", "mq_winow_tile"}          # which tile mq_conv_plan will pick for a row / column form (host-side query)
+    unused = set(_lib.SIGNATURES) - used - helpers
+    assert not unused, sorted(unused)
 
 
 def test_host_side_validation_rejects_bad_shapes_without_a_gpu(built):

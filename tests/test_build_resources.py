@@ -1,4 +1,4 @@
-"""Register spills of the built kernels (no GPU needed: the code objects inside mqgan_amd/csrc/*.o carry them in their metadata).
+"""Register spills of the built kernels (no GPU needed: the code objects inside mqgan_amd/csrc/obj/*.o carry them in their metadata).
 
 Round 5 gave conv_wgrad_h2_kernel<2, 3> a second fragment set it had no registers for: 93 spilled VGPRs, 53 ms per step instead of
 14 - found by an A/B run, not by a test.  Bounds here: no VGPR spill at all in the bf16-storage kernels (igemm_h2.hip: they run at
@@ -43,7 +43,7 @@ def _kernels(obj):
 def test_no_kernel_spills_beyond_the_known_few():
     import __graft_entry__ as g
     g.build()
-    objs = sorted(glob.glob(os.path.join(ROOT, "mqgan_amd", "csrc", "*.o")))
+    objs = sorted(glob.glob(os.path.join(ROOT, "mqgan_amd", "csrc", "obj", "*.o")))
     assert objs, "build() left no object files"
     total = 0
     for obj in objs:

@@ -242,9 +242,10 @@ def test_h2_small_kernel_is_bit_identical(env, monkeypatch, c):
 @pytest.mark.parametrize("c", [dict(N=2, H=20, W=33, C=96, K=96, R=3, S=3, pad=(1, 1)), dict(N=1, H=9, W=31, C=288, K=288, R=3, S=3, pad=(1, 1)),
                                dict(N=4, H=3, W=50, C=96, K=96, R=1, S=3, pad=(0, 1), groups=2), dict(N=2, H=5, W=144, C=96, K=192, R=3, S=3, pad=(1, 1))],
                          ids=_ids)
-def test_h2_96_channel_kernels_agree_bit_for_bit(env, monkeypatch, c):
-    """conv_h2s96q_kernel (128-row tiles, no ring, three blocks per CU: the default) against conv_h2s96_kernel (256-row tiles, double
-    image buffer, three weight stages: MQGAN_H2_96_BIG=1): same reduction order, same MFMAs, same epilogue - forward (f32, bf16,
+def test_h2_96_channel_kernels_agree_bit_for_bit(env, monkeypatch, variants_lib, c):
+    """conv_h2s96q_kernel (128-row tiles, no ring, three blocks per CU: the default, run through the PRODUCT library) against
+    conv_h2s96_kernel (256-row tiles, double image buffer, three weight stages: the measured-and-rejected ring form, compiled into
+    the test-variant library only and selected there by MQGAN_H2_96_BIG=1): same reduction order, same MFMAs, same epilogue - forward (f32, bf16,
     LeakyReLU + mask) and input gradient (plain, gated) bit for bit."""
     ops = env
     x, w, b, desc, wk, wc = _setup(ops, c)
@@ -265,9 +266,13 @@ def test_h2_96_channel_kernels_agree_bit_for_bit(env, monkeypatch, c):
             outs.append(ops.conv_dgrad_h2(desc, dy, wth, out_dtype=torch.float32, gate=(xh, mask, dmap, 0.2)))
         torch.cuda.synchronize()
         return outs, name
+    from mqgan_amd import _lib
     small, k_s = run()
     monkeypatch.setenv("MQGAN_H2_96_BIG", "1")
-    big, k_b = run()
+    ign, k_i = run()                                         # the product library ignores the switch: the ring form is not in it
+    assert k_i == k_s
+    with _lib.use_variants():
+        big, k_b = run()
     monkeypatch.delenv("MQGAN_H2_96_BIG")
     assert k_s.startswith("conv_h2s96q_kernel<") and k_b.startswith("conv_h2s96_kernel<"), (k_s, k_b)
     for i, (a, bb) in enumerate(zip(small, big)):

@@ -141,12 +141,15 @@ def test_planned_calls_through_ctypes_equal_the_direct_form(lib, name, kw, leaky
         assert float(out["planned"][1][-1, :, d.W // 2:].abs().max()) == 0.0        # padded input frames of the gated gradient
 
 
-def test_fused_winograd_prototype_matches_float64(lib):
-    """csrc/winofused.hip (round-5 prototype, never chosen by mq_conv_plan): F(4x5, 3x3) with both transforms inside the GEMM kernel,
+def test_fused_winograd_prototype_matches_float64(lib, variants_lib):
+    """tools/microbench/winofused.hip (round-5 prototype, never chosen by mq_conv_plan; since round 6 compiled into the
+    test-variant library only - the product library neither contains nor exports it): F(4x5, 3x3) with both transforms inside the GEMM kernel,
     on a ragged image (H, W not multiples of the tile) with 64 output channels - against a float64 convolution at the bounds the
     separate Winograd sequence meets (relative L2 2e-5, no element off by more than 1e-4 of the rms), first / last rows and
     columns on their own."""
-    _lib, L = lib
+    _lib, Lp = lib
+    assert not hasattr(Lp, "mq_winofused_fprop") and not hasattr(Lp, "mq_winon_weight_transform")      # not in the product library
+    L = variants_lib
     torch.manual_seed(5)
     N, H, W, Cc, K = 3, 22, 33, 48, 64
     x = torch.randn(N, H, W, Cc, device=DEV)

@@ -23,6 +23,11 @@ import __graft_entry__ as ge  # noqa: E402
 
 ge.build()
 from mqgan_amd import ops  # noqa: E402
+from mqgan_amd import _lib as _mqlib  # noqa: E402
+
+ge.build_variants()          # the transform entry points / the prototype live in the test-variant library only (round 6)
+VL = _mqlib.load_variants
+
 from mqgan_amd.ops import L, check, fptr, ptr, stream  # noqa: E402
 
 DEV = "cuda"
@@ -80,12 +85,12 @@ for N, W, Cc, K in ((512, 512, 128, 256), (512, 256, 256, 256), (512, 128, 256, 
     # (c) the rate of the existing row transforms on this layer's tensors
     x = torch.randn(N, H, W, Cc, device=DEV)
     Vr = torch.empty(rows, 1, W, Cc, device=DEV)
-    ti = timeit(lambda: check(L().mq_wino1d_input_transform(fptr(x), N, H, W, Cc, m, fptr(Vr), stream()), "wino1d_input"))
+    ti = timeit(lambda: check(VL().mq_wino1d_input_transform(fptr(x), N, H, W, Cc, m, fptr(Vr), stream()), "wino1d_input"))
     gb_i = 4.0 * (x.numel() + Vr.numel()) / 1e9
     yb = torch.empty(N, H, Q, K, device=DEV)
     bias = torch.zeros(G * K, device=DEV)
     M = torch.randn(rows, 1, Q, K, device=DEV)
-    to = timeit(lambda: check(L().mq_wino1d_output_transform(fptr(M), fptr(bias), N, H, Q, K, G, m, 2, 0.2, None, 1, 0, 1, fptr(yb), stream()),
+    to = timeit(lambda: check(VL().mq_wino1d_output_transform(fptr(M), fptr(bias), N, H, Q, K, G, m, 2, 0.2, None, 1, 0, 1, fptr(yb), stream()),
                               "wino1d_output"))
     gb_o = 4.0 * (M.numel() + yb.numel()) / 1e9
     rate_i, rate_o = gb_i / ti, gb_o / to                  # GB/ms = TB/s

@@ -14,6 +14,11 @@ import __graft_entry__ as ge  # noqa: E402
 
 ge.build()
 from mqgan_amd import ops  # noqa: E402
+from mqgan_amd import _lib as _mqlib  # noqa: E402
+
+ge.build_variants()          # the transform entry points / the prototype live in the test-variant library only (round 6)
+VL = _mqlib.load_variants
+
 from mqgan_amd.ops import L, check, fptr, ptr, stream  # noqa: E402
 
 DEV = "cuda"
@@ -46,10 +51,10 @@ for N, H, W, Cc, K in ((32, 512, 90, 64, 64), (32, 512, 90, 192, 64), (32, 256, 
     planned = lambda: check(L().mq_conv_fprop_planned(C.byref(p), fptr(x), fptr(wk), fptr(bias), 0, 0.0, None, 1, 0, 1, fptr(y0), None,
                                                       ptr(ws), p.ws_fprop, stream()), "planned")
     U = torch.empty(42 * K * Cc, device=DEV)
-    check(L().mq_winon_weight_transform(fptr(wk), K, Cc, 0, fptr(U), 4, 5, stream()), "weight transform")
+    check(VL().mq_winon_weight_transform(fptr(wk), K, Cc, 0, fptr(U), 4, 5, stream()), "weight transform")
     Ut = torch.empty_like(U)
     y1 = torch.empty(N, H, W, K, device=DEV)
-    fused = lambda: check(L().mq_winofused_fprop(fptr(x), fptr(U), fptr(bias), N, H, W, Cc, K, fptr(Ut), fptr(y1), stream()), "fused")
+    fused = lambda: check(VL().mq_winofused_fprop(fptr(x), fptr(U), fptr(bias), N, H, W, Cc, K, fptr(Ut), fptr(y1), stream()), "fused")
     t0, t1 = timeit(planned), timeit(fused)
     planned(); fused()
     torch.cuda.synchronize()
