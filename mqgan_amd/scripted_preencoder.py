@@ -39,8 +39,14 @@ class ScriptedPreEncoder:
             raise FileNotFoundError(f"Model directory not found: {model_dir}")
         self.device = torch.device(device)
         if self.device.type != "cuda":
-            raise RuntimeError("mqgan_amd.ScriptedPreEncoder runs on the HIP device only (device='cuda'); "
-                               "there is no CPU path")
+            # the reference defaults to device='cpu' and falls back cuda -> cpu silently (scripted_preencoder.py:38-94); this
+            # package has no CPU path, so it says so instead of pretending
+            raise RuntimeError(f"mqgan_amd.ScriptedPreEncoder runs on the HIP device only, not on device={device!r}: pass device='cuda' "
+                               "(the default here; `reencode_spectrograms.py --device cuda`).  There is no CPU path - the reference's "
+                               "CPU default has no counterpart (INTEGRATION.md, section 1).")
+        if not torch.cuda.is_available():
+            raise RuntimeError("mqgan_amd.ScriptedPreEncoder needs an MI355X (torch.cuda.is_available() is False); unlike the reference "
+                               "it does not fall back to the CPU")
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         torch.cuda.set_device(self.device)               # kernels launch on the current device's stream

@@ -507,11 +507,56 @@ class Trainer:
                 rec.update(epoch=epoch, step=self.global_step, frames_per_s=int(frames.item()) / (time.time() - t0))
                 self.log_fn(rec)
 
+    def _evaluate(self, epoch):
+        """train.py:575-623 in numbers: the reference reconstructs ``num_plot_examples`` random utterances of the validation split
+        (whole files, generator in eval mode, no dropout) and logs pictures of them to wandb; the pictures are out of scope
+        (SURVEY 2), what they are looked at for is not - so the same samples are reconstructed the same way and the masked
+        reconstruction losses of both outputs (the training loss's terms, train.py:419-425) go to the log:
+        ``eval_loss_recon_pre / eval_loss_recon_post`` (mean over the samples), ``eval_frames``, ``eval_samples``.  Rank 0 only
+        (every rank holds the same weights); nothing is logged when the validation split is empty."""
+        from .losses import recon_loss
+        ds = self.eval_dataset
+        if ds is None or len(ds) == 0 or self.rank != 0:
+            return None
+        n = min(self.config.get("logging", {}).get("num_plot_examples", 3), len(ds))
+        was_training = self.generator.training
+        self.generator.eval()
+        pre, post, frames, used = 0.0, 0.0, 0, 0
+        try:
+            with torch.no_grad(), ops.conv_precision(self.conv_precision), ops.request_act_storage(self.use_bf16 and self.bf16_storage):
+                for idx in random.sample(range(len(ds)), n):
+                    item = ds.dataset[ds.indices[idx]]
+                    if item is None:                       # unreadable file: skipped, as in training
+                        continue
+                    mel, mel_len, _ = item
+                    x = mel.to(self.device).unsqueeze(0)
+                    lens = torch.tensor([mel_len], dtype=torch.int32, device=self.device)
+                    recon_pre, recon_post = self.generator(x, lens)
+                    pre += float(recon_loss(recon_pre, x, lens))
+                    post += float(recon_loss(recon_post, x, lens))
+                    frames += int(mel_len)
+                    used += 1
+        finally:
+            self.generator.train(was_training)
+        if used == 0:
+            return None
+        rec = {"epoch": epoch, "step": self.global_step, "eval_loss_recon_pre": pre / used, "eval_loss_recon_post": post / used,
+               "eval_samples": used, "eval_frames": frames}
+        if self.log_fn is not None:
+            self.log_fn(rec)
+        return rec
+
     def train(self):
-        for epoch in range(self.start_epoch, self.config["training"]["num_epochs"] + 1):
-            self._train_epoch(epoch)
+        last = self.config["training"]["num_epochs"]
+        eval_every = self.config.get("logging", {}).get("eval_interval", 0)
+        for epoch in range(self.start_epoch, last + 1):
+            self._train_epoch(epoch, next_epoch=epoch + 1 if epoch < last else None)
+            if eval_every and epoch % eval_every == 0:     # train.py:650-651
+                self._evaluate(epoch)
             if epoch % self.config["logging"]["save_interval"] == 0:
                 self._save_checkpoint(epoch)
+        if getattr(self, "_prefetch", None) is not None:
+            self._prefetch.close()
 
 
 def jsonl_logger(path):

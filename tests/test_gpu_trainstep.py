@@ -177,6 +177,39 @@ def test_trainer_epoch_on_npy_tree_with_bad_files(tmp_path):
     assert torch.equal(tr2.arena_d.flat_param, tr.arena_d.flat_param)
 
 
+def test_trainer_evaluates_the_validation_split_every_eval_interval(tmp_path):
+    """train.py:646-647, 575-623: every ``eval_interval`` epochs the reference reconstructs ``num_plot_examples`` random whole
+    utterances of the validation split with the generator in eval mode (and plots them); here the same samples give the masked
+    reconstruction losses of both outputs in the log.  Checked: one record per evaluated epoch, finite, the generator is back in
+    train mode afterwards, and the logged value equals the loss recomputed on the same file."""
+    from mqgan_amd.losses import recon_loss
+    from mqgan_amd.train import Trainer, synthetic_mel
+    data = tmp_path / "data"
+    data.mkdir()
+    for i, L in enumerate([64, 40, 96, 33, 70, 128, 50, 48, 61, 77]):
+        np.save(data / f"u{i}.npy", synthetic_mel(L, 16, i))
+    cfg = {"data": {"data_dir": str(data), "output_dir": str(tmp_path / "out"), "validation_split": 0.1, "crop_len": 32,
+                    "batch_size": 4, "num_workers": 0},
+           "model": TINY_CFG["model"], "training": dict(TINY_CFG["training"], num_epochs=4, pretrained=None),
+           "logging": {"eval_interval": 2, "save_interval": 100, "log_interval": 1000, "num_plot_examples": 3}}
+    logs = []
+    tr = Trainer(cfg, device=DEV, log_fn=logs.append)
+    assert len(tr.eval_dataset) == 1
+    tr.train()
+    ev = [r for r in logs if "eval_loss_recon_post" in r]
+    assert [r["epoch"] for r in ev] == [2, 4] and all(r["eval_samples"] == 1 for r in ev)
+    assert all(np.isfinite(r["eval_loss_recon_pre"]) and np.isfinite(r["eval_loss_recon_post"]) and r["eval_frames"] > 0 for r in ev)
+    assert tr.generator.training
+    mel, n, _ = tr.eval_dataset.dataset[tr.eval_dataset.indices[0]]
+    tr.generator.eval()
+    with torch.no_grad():
+        x, lens = mel.to(DEV).unsqueeze(0), torch.tensor([n], dtype=torch.int32, device=DEV)
+        _, post = tr.generator(x, lens)
+        want = float(recon_loss(post, x, lens))
+    np.testing.assert_allclose(ev[-1]["eval_loss_recon_post"], want, rtol=1e-6)          # same weights (last epoch), same file
+    assert ev[-1]["eval_frames"] == n
+
+
 @pytest.mark.parametrize("precision", ["fp32", "fp32x3", "bf16"])
 def test_full_size_hifimusic_step_runs_on_every_engine(precision):
     """BASELINE config 3 at full size (16 x 1024 frames x 128 mels; activations up to 9.7 GB, past 32-bit offsets):
