@@ -431,83 +431,28 @@ __device__ __forceinline__ float exact_dist(const float *__restrict__ xr, const 
 }
 
 
-// A block per RR_ROWS rows.  (a) the rows' state: final maximum over the code splits, bound, list lengths; (b) every list entry
-// against the final maximum, survivors compacted into an LDS table (LDS atomics: a counter per block and per row); (c) one lane
-// per survivor runs the exact chain and puts (distance, index) into the row's packed minimum in LDS; (d) rows without a bound,
-// with a list that ran over, with more survivors than the table takes or - defensively - with none are searched exhaustively
-// by the whole block, one after the other; (e) idx / best_dist.
-__global__ __launch_bounds__(256) void l2_rerank_kernel(const float *__restrict__ x, const float *__restrict__ cb, const float *__restrict__ cn,
-                                                        const uint2 *__restrict__ cand, const unsigned char *__restrict__ cntb,
-                                                        const unsigned *__restrict__ gmax, const float *__restrict__ bound, int64_t n, int k,
-                                                        int d, int splits, int32_t *__restrict__ idx, float *__restrict__ best_dist,
-                                                        unsigned *__restrict__ exhaustive_rows)
+// Phases (c)-(e) of the re-rank for the RR_ROWS rows from r0 on: survivors (s_pair, s_np) -> exact chains -> packed minima per row
+// (s_best), exhaustive rows (s_exh / no survivor), idx / best_dist.  Shared by l2_rerank_kernel (r5) and l2_search_kernel (r6).
+// s_ring: 4 * RR_NS * RR_STAGE bytes of LDS, 1 KB aligned.  The caller has filled the tables and synchronised the block.
+struct RerankTables {
+    unsigned long long *s_best;      // [RR_ROWS]
+    unsigned *s_rowcnt, *s_exh;      // [RR_ROWS]
+    unsigned *s_np;                  // [1]
+    unsigned long long *s_todo;      // [1]
+    uint2 *s_pair;                   // [RR_CAP]
+    unsigned long long *s_red;       // [4]
+    char *s_ring;
+};
+__device__ __forceinline__ void rerank_finish(const RerankTables &T, const float *__restrict__ x, const float *__restrict__ cb,
+                                              const float *__restrict__ cn, int64_t n, int k, int d, int64_t r0, int32_t *__restrict__ idx,
+                                              float *__restrict__ best_dist, unsigned *__restrict__ exhaustive_rows)
 {
-    __shared__ unsigned long long s_best[RR_ROWS];
-    __shared__ unsigned s_rowcnt[RR_ROWS];
-    __shared__ unsigned s_exh[RR_ROWS];
-    __shared__ unsigned s_np;
-    __shared__ unsigned long long s_todo;
-    __shared__ uint2 s_pair[RR_CAP];
-    __shared__ unsigned long long s_red[4];
-    __shared__ __attribute__((aligned(1024))) char s_ring[4 * RR_NS * RR_STAGE];  // per wave: four stages of (64 pairs x 64 B) x {code, x}
+    unsigned long long *s_best = T.s_best;
+    unsigned *s_rowcnt = T.s_rowcnt, *s_exh = T.s_exh;
+    uint2 *s_pair = T.s_pair;
+    unsigned long long *s_red = T.s_red;
+    char *s_ring = T.s_ring;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t r0 = (int64_t)blockIdx.x * RR_ROWS;
-    if (tid < RR_ROWS) {
-        s_best[tid] = ~0ull;
-        s_rowcnt[tid] = 0u;
-        s_exh[tid] = 0u;
-    }
-    if (tid == 0) s_np = 0u;
-    __syncthreads();
-    // ---- (a) + (b) lists -> survivors.  One thread per (row, list); everything a thread needs first - the row's final maximum and
-    // bound, the list's length - is requested at once, then the first two entries of every list (lists hold 1-2 entries on
-    // average), before anything is looked at: a kernel of 64-row blocks is a string of memory latencies, and r5's first version
-    // spent 16 us of them one after the other.
-    const int lists = splits * SC_LISTS;
-    for (int i0 = tid; i0 < RR_ROWS * lists; i0 += 4 * 256) {
-        int rl_[4], c_[4];
-        int64_t L_[4];
-        float thr_[4];
-        uint2 e0_[4], e1_[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * 256;
-            const bool v = i < RR_ROWS * lists;
-            rl_[u] = v ? i / lists : 0;
-            const int64_t row = r0 + rl_[u];
-            L_[u] = (v && row < n) ? row * lists + (i - rl_[u] * lists) : -1;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            c_[u] = L_[u] >= 0 ? (int)cntb[L_[u]] : 0;
-            thr_[u] = L_[u] >= 0 ? unord_f32(gmax[r0 + rl_[u]]) - bound[r0 + rl_[u]] : 0.f;      // NaN: no bound
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            e0_[u] = c_[u] > 0 ? cand[L_[u] * SC_PL] : make_uint2(0u, 0u);
-            e1_[u] = c_[u] > 1 ? cand[L_[u] * SC_PL + 1] : make_uint2(0u, 0u);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (L_[u] < 0) continue;
-            const int rl = rl_[u];
-            const float thr = thr_[u];
-            if (!(thr == thr) || c_[u] > SC_PL) {                   // no bound, or the list ran over: exhaustive search
-                s_exh[rl] = 1u;
-                continue;
-            }
-            for (int j = 0; j < c_[u]; ++j) {
-                const uint2 ent = j == 0 ? e0_[u] : j == 1 ? e1_[u] : cand[L_[u] * SC_PL + j];
-                if (__builtin_bit_cast(float, ent.y) >= thr) {
-                    const unsigned inrow = atomicAdd(&s_rowcnt[rl], 1u);
-                    const unsigned pos = inrow < (unsigned)RR_PER_ROW ? atomicAdd(&s_np, 1u) : (unsigned)RR_CAP;
-                    if (pos < (unsigned)RR_CAP) s_pair[pos] = make_uint2((unsigned)rl, ent.x);
-                    else s_exh[rl] = 1u;
-                }
-            }
-        }
-    }
-    __syncthreads();
     // ---- (c) exact chains, one lane per survivor, operands staged through LDS by LDS-DMA.
     // A lane that fetched its own two rows from global memory touched a different cache line per lane and instruction, each line
     // four times (16 bytes at a time): 23-33 us at 16,384 rows - the texture addresser, not the chain, was the cost.  Here a wave
@@ -517,7 +462,7 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(const float *__restrict_
     // pair p reads its 64-byte slots back (16-byte parts XOR-swizzled with (p >> 2) & 3, applied to the per-lane SOURCE part, as
     // the DMA writes lane-linear) and runs the 16 chain steps.  No block barrier: a wave waits for its own DMAs only.
     {
-        const unsigned np = min(s_np, (unsigned)RR_CAP);
+        const unsigned np = min(*T.s_np, (unsigned)RR_CAP);
         const __amdgpu_buffer_rsrc_t rcb = make_rsrc(cb, (size_t)k * d * 4);
         const int64_t rows_here = n - r0 < RR_ROWS ? n - r0 : RR_ROWS;
         const __amdgpu_buffer_rsrc_t rxb = make_rsrc(x + r0 * d, (size_t)rows_here * d * 4);
@@ -599,10 +544,10 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(const float *__restrict_
     if (wave == 0) {
         const bool need = r0 + lane < n && (s_exh[lane] != 0u || s_rowcnt[lane] == 0u);
         const unsigned long long mask = __ballot(need);
-        if (lane == 0) s_todo = mask;
+        if (lane == 0) *T.s_todo = mask;
     }
     __syncthreads();
-    unsigned long long todo = s_todo;
+    unsigned long long todo = *T.s_todo;
     while (todo) {
         const int rl = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
@@ -631,6 +576,411 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(const float *__restrict_
         const unsigned long long p = s_best[tid];
         idx[r0 + tid] = (int32_t)(p & 0xffffffffu);
         if (best_dist) best_dist[r0 + tid] = unord_f32((unsigned)(p >> 32));
+    }
+}
+
+// A block per RR_ROWS rows.  (a) the rows' state: final maximum over the code splits, bound, list lengths; (b) every list entry
+// against the final maximum, survivors compacted into an LDS table (LDS atomics: a counter per block and per row); (c) one lane
+// per survivor runs the exact chain and puts (distance, index) into the row's packed minimum in LDS; (d) rows without a bound,
+// with a list that ran over, with more survivors than the table takes or - defensively - with none are searched exhaustively
+// by the whole block, one after the other; (e) idx / best_dist.
+__global__ __launch_bounds__(256) void l2_rerank_kernel(const float *__restrict__ x, const float *__restrict__ cb, const float *__restrict__ cn,
+                                                        const uint2 *__restrict__ cand, const unsigned char *__restrict__ cntb,
+                                                        const unsigned *__restrict__ gmax, const float *__restrict__ bound, int64_t n, int k,
+                                                        int d, int splits, int32_t *__restrict__ idx, float *__restrict__ best_dist,
+                                                        unsigned *__restrict__ exhaustive_rows)
+{
+    __shared__ unsigned long long s_best[RR_ROWS];
+    __shared__ unsigned s_rowcnt[RR_ROWS];
+    __shared__ unsigned s_exh[RR_ROWS];
+    __shared__ unsigned s_np;
+    __shared__ unsigned long long s_todo;
+    __shared__ uint2 s_pair[RR_CAP];
+    __shared__ unsigned long long s_red[4];
+    __shared__ __attribute__((aligned(1024))) char s_ring[4 * RR_NS * RR_STAGE];  // per wave: four stages of (64 pairs x 64 B) x {code, x}
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * RR_ROWS;
+    if (tid < RR_ROWS) {
+        s_best[tid] = ~0ull;
+        s_rowcnt[tid] = 0u;
+        s_exh[tid] = 0u;
+    }
+    if (tid == 0) s_np = 0u;
+    __syncthreads();
+    // ---- (a) + (b) lists -> survivors.  One thread per (row, list); everything a thread needs first - the row's final maximum and
+    // bound, the list's length - is requested at once, then the first two entries of every list (lists hold 1-2 entries on
+    // average), before anything is looked at: a kernel of 64-row blocks is a string of memory latencies, and r5's first version
+    // spent 16 us of them one after the other.
+    const int lists = splits * SC_LISTS;
+    for (int i0 = tid; i0 < RR_ROWS * lists; i0 += 4 * 256) {
+        int rl_[4], c_[4];
+        int64_t L_[4];
+        float thr_[4];
+        uint2 e0_[4], e1_[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * 256;
+            const bool v = i < RR_ROWS * lists;
+            rl_[u] = v ? i / lists : 0;
+            const int64_t row = r0 + rl_[u];
+            L_[u] = (v && row < n) ? row * lists + (i - rl_[u] * lists) : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            c_[u] = L_[u] >= 0 ? (int)cntb[L_[u]] : 0;
+            thr_[u] = L_[u] >= 0 ? unord_f32(gmax[r0 + rl_[u]]) - bound[r0 + rl_[u]] : 0.f;      // NaN: no bound
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            e0_[u] = c_[u] > 0 ? cand[L_[u] * SC_PL] : make_uint2(0u, 0u);
+            e1_[u] = c_[u] > 1 ? cand[L_[u] * SC_PL + 1] : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (L_[u] < 0) continue;
+            const int rl = rl_[u];
+            const float thr = thr_[u];
+            if (!(thr == thr) || c_[u] > SC_PL) {                   // no bound, or the list ran over: exhaustive search
+                s_exh[rl] = 1u;
+                continue;
+            }
+            for (int j = 0; j < c_[u]; ++j) {
+                const uint2 ent = j == 0 ? e0_[u] : j == 1 ? e1_[u] : cand[L_[u] * SC_PL + j];
+                if (__builtin_bit_cast(float, ent.y) >= thr) {
+                    const unsigned inrow = atomicAdd(&s_rowcnt[rl], 1u);
+                    const unsigned pos = inrow < (unsigned)RR_PER_ROW ? atomicAdd(&s_np, 1u) : (unsigned)RR_CAP;
+                    if (pos < (unsigned)RR_CAP) s_pair[pos] = make_uint2((unsigned)rl, ent.x);
+                    else s_exh[rl] = 1u;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const RerankTables T{s_best, s_rowcnt, s_exh, &s_np, &s_todo, s_pair, s_red, s_ring};
+    rerank_finish(T, x, cb, cn, n, k, d, r0, idx, best_dist, exhaustive_rows);
+}
+
+
+// ============================================================================================== round 6: ONE kernel (d <= 512)
+// l2_search_kernel: conversion of x, the error bound, the bf16 scores, the candidate lists AND the exact re-rank in one launch
+// (one memset of 4 n + 4 row-tile bytes in front of it).  What changed against the three launches above, and why:
+//   * x never exists as a bf16 tensor in HBM.  A block owns RT rows for its whole life: it loads them as f32, rounds them to bf16
+//     into an LDS image (nk K-steps x RT rows x 128 bytes, the 16-byte chunk swizzle of the MFMA fragment reads), and sums |x|^2
+//     and |x - bf16(x)|^2 on the way - the bound E(n) of the header comment costs nothing extra.  RT = 128 for d <= 256, 64 for
+//     d <= 512 (64 KB of image either way).  l2_screen_prep_kernel's launch, its 24 MB round trip and the per-tile re-streaming of
+//     the x tile (half of the DMA bytes of l2_screen_kernel) are gone.
+//   * only code tiles are streamed: 128 codes x 64 k's = 16 KB per K-step by LDS-DMA into a ring of FOUR stages, three in flight.
+//     l2_screen_kernel had one 32 KB stage in flight per block (two blocks per CU): at 1024 x 256 every K-step cost one DMA
+//     latency - 20 us for 3.4 us of MFMA work.  The waits are COUNTED (vmcnt), which only holds if nothing else a wave
+//     issues to vector memory is in flight between them: the accumulator seeds (-cn / 2) therefore travel with the ks = 0 stage of
+//     a tile as a 512-byte DMA piece of wave 0, and the candidates stay in REGISTERS until the block's last K-step:
+//   * per (row, lane list) the LAST SR_CAP candidates (a >= running maximum - E at the time) and `lost` = the largest score ever
+//     pushed out of that window.  A list is complete if lost < g - E for the FINAL maximum g (checked by the re-rank; otherwise
+//     the row is searched exhaustively): the running maximum only rises, so what an over-collecting pass pushes out is almost
+//     always obsolete - it matters only when five candidates of one lane's 1 / (2 WC splits) share of the codes lie within E of
+//     each other.  No list stores, no atomics, no cross-split traffic inside the loop.
+//   * the re-rank runs in the block that finishes a row tile LAST (arrival counter per row tile after a device-scope fence): the
+//     final maxima, lists and bounds of its RT rows -> rerank_finish, in the LDS the main loop no longer needs.  No third launch,
+//     and the chains of early row tiles overlap the score pass of late ones.
+constexpr int SR_CT = 128;                 // codes per tile
+constexpr int SR_NST = 4;                  // code stages (SR_NST - 1 in flight)
+constexpr int SR_STAGE = SR_CT * 128 + 1024;   // 16 KB of codes + 512 B of seeds (+ 512 B the seed piece's idle lanes zero)
+constexpr int SR_CAP = 4;                  // entries per lane list
+
+template <int WC, int WR, int TM, int TN>  // waves along codes / rows, 32x32 MFMA tiles per wave along codes / rows
+__global__ __launch_bounds__(256) void l2_search_kernel(const float *__restrict__ x, const float *__restrict__ cb, const unsigned short *__restrict__ ch,
+                                                        const float *__restrict__ cn, const float *__restrict__ cnh, const float *__restrict__ cmax2,
+                                                        int64_t n, int k, int d, int tiles_per_split, int splits, uint2 *__restrict__ cand,
+                                                        float *__restrict__ lost, unsigned *__restrict__ gmax, unsigned *__restrict__ arrive,
+                                                        int32_t *__restrict__ idx, float *__restrict__ best_dist, unsigned *__restrict__ exhaustive_rows)
+{
+    static_assert(WC * WR == 4 && WC * TM * 32 == SR_CT, "four waves, 128 codes per tile");
+    constexpr int RT = WR * TN * 32;       // rows per block
+    constexpr int NPJ = RT / 32;           // 8-row pieces of the x tile per wave and K-step
+    constexpr int LPR = WC * 2;            // lists per (row, split)
+    extern __shared__ __attribute__((aligned(1024))) char dsm[];
+    __shared__ float s_rm[WC][RT];
+    __shared__ float s_bound[RT];
+    __shared__ unsigned long long s_best[RR_ROWS];
+    __shared__ unsigned s_rowcnt[RR_ROWS];
+    __shared__ unsigned s_exh[RR_ROWS];
+    __shared__ unsigned s_np, s_last;
+    __shared__ unsigned long long s_todo;
+    __shared__ uint2 s_pair[RR_CAP];
+    __shared__ unsigned long long s_red[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave / WR, wr = wave % WR;
+    const int li = lane & 31, lh = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * RT;
+    const int split = blockIdx.y;
+    const int ntiles = (k + SR_CT - 1) / SR_CT;
+    const int t_begin = split * tiles_per_split;
+    const int t_end = min(ntiles, t_begin + tiles_per_split);
+    const int nk = (d + 63) >> 6;
+    const int total = nk * (t_end - t_begin);
+    char *img = dsm;                                        // [nk][RT][128 B]
+    char *stages = dsm + (((size_t)nk * RT * 128 + 1023) & ~(size_t)1023);
+
+    // ---- code tiles by LDS-DMA: piece p = wave + 4 j covers tile rows 8 p .. 8 p + 7; lane -> row 8 p + (lane >> 3), physical chunk lane & 7
+    const int lc = (lane & 7) ^ ((((wave & 1) << 2) | (lane >> 4)) & 7);
+    const int64_t code0 = (int64_t)t_begin * SR_CT;
+    const int64_t codes_here = min((int64_t)k, (int64_t)t_end * SR_CT) - code0;
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc(ch + code0 * d, (size_t)(codes_here > 0 ? codes_here : 0) * d * 2);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(cnh + code0, (size_t)(t_end - t_begin > 0 ? t_end - t_begin : 0) * SR_CT * 4);   // cnh is padded to whole tiles
+    unsigned rowoff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rowoff[j] = (unsigned)(8 * (wave + 4 * j) + (lane >> 3)) * (unsigned)d * 2u + (unsigned)lc * 16u;
+    int is_tile = 0, is_ks = 0;                            // (tile, K-step) of the next stage to issue
+    auto issue = [&](int it) {
+        char *st = stages + (it & (SR_NST - 1)) * SR_STAGE;
+        const bool live = it < total;                       // past the end: out-of-range pieces (zeros into a free stage) keep the counts uniform
+        const bool kv = live && is_ks * 64 + lc * 8 < d;
+        const unsigned koff = (unsigned)is_ks * 128u;
+        const unsigned toff = (unsigned)is_tile * (unsigned)(SR_CT * 2) * (unsigned)d;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, lds_ptr_s(st + (wave + 4 * j) * 1024), 16, kv ? rowoff[j] + koff + toff : OOB, 0, 0, 0);
+        if (wave == 0)                                      // the tile's accumulator seeds ride with its first K-step (lanes 32-63 write zeros behind them)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds_ptr_s(st + SR_CT * 128), 16,
+                                                     (live && is_ks == 0 && lane < 32) ? (unsigned)is_tile * (unsigned)(SR_CT * 4) + (unsigned)lane * 16u : OOB, 0, 0, 0);
+        if (++is_ks == nk) { is_ks = 0; ++is_tile; }
+    };
+    if (total > 0) {
+#pragma unroll
+        for (int p = 0; p < SR_NST - 1; ++p) issue(p);
+    }
+
+    // ---- phase A: the block's rows, f32 -> bf16 image in LDS, |x|^2 and |x - xh|^2 on the way
+    {
+        const int c8 = lane & 7;
+        float ss[NPJ], se[NPJ];
+#pragma unroll
+        for (int j = 0; j < NPJ; ++j) ss[j] = se[j] = 0.f;
+        for (int ks = 0; ks < nk; ++ks) {
+            float4 v0[NPJ], v1[NPJ];
+            const bool kv = ks * 64 + c8 * 8 < d;
+#pragma unroll
+            for (int j = 0; j < NPJ; ++j) {
+                const int row = 8 * (wave + 4 * j) + (lane >> 3);
+                const bool ok = kv && m0 + row < n;
+                const float *src = x + (m0 + row) * d + ks * 64 + c8 * 8;
+                v0[j] = ok ? *reinterpret_cast<const float4 *>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+                v1[j] = ok ? *reinterpret_cast<const float4 *>(src + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < NPJ; ++j) {
+                const int row = 8 * (wave + 4 * j) + (lane >> 3);
+                ss[j] = fmaf(v0[j].x, v0[j].x, fmaf(v0[j].y, v0[j].y, fmaf(v0[j].z, v0[j].z, fmaf(v0[j].w, v0[j].w, ss[j]))));
+                ss[j] = fmaf(v1[j].x, v1[j].x, fmaf(v1[j].y, v1[j].y, fmaf(v1[j].z, v1[j].z, fmaf(v1[j].w, v1[j].w, ss[j]))));
+                const uint2 h0 = pack_bf16x4(v0[j]), h1 = pack_bf16x4(v1[j]);
+                se[j] += residual_sq(v0[j], h0) + residual_sq(v1[j], h1);
+                *reinterpret_cast<uint4 *>(img + ((size_t)ks * RT + row) * 128 + ((c8 ^ ((row >> 1) & 7)) << 4)) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NPJ; ++j) {
+            float a = ss[j], b = se[j];
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                a += __shfl_xor(a, o, 64);
+                b += __shfl_xor(b, o, 64);
+            }
+            const int row = 8 * (wave + 4 * j) + (lane >> 3);
+            if (c8 == 0) {
+                const float e = screen_bound(a, b, cmax2[0], cmax2[1], d);
+                s_bound[row] = (m0 + row < n && e < 1e30f) ? e : __builtin_nanf("");
+            }
+        }
+        if (tid < RT) {
+#pragma unroll
+            for (int w = 0; w < WC; ++w) s_rm[w][tid] = -INFINITY;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B: scores
+    const int sw = (li >> 1) & 7;
+    unsigned foff[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) foff[s4] = (unsigned)(li * 128 + ((((2 * s4) ^ (lh ^ sw)) & 7) << 4));
+    const unsigned a_base = (unsigned)reinterpret_cast<uintptr_t>(stages) + (unsigned)(wc * TM * 32) * 128u;
+    const unsigned b_base = (unsigned)reinterpret_cast<uintptr_t>(img) + (unsigned)(wr * TN * 32) * 128u;
+    const unsigned seed_base = (unsigned)reinterpret_cast<uintptr_t>(stages) + (unsigned)(SR_CT * 128) + (unsigned)(wc * TM * 32 + 4 * lh) * 4u;
+    const unsigned rm_base = (unsigned)reinterpret_cast<uintptr_t>(&s_rm[0][0]) + (unsigned)(wr * TN * 32 + li) * 4u;
+    f32x16 acc[TM][TN];
+    float rm[TN], ebound[TN], lostv[TN], la[TN][SR_CAP];
+    unsigned lcd[TN][SR_CAP];
+    bool rvalid[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int rl = wr * TN * 32 + tn * 32 + li;
+        rvalid[tn] = m0 + rl < n;
+        rm[tn] = -INFINITY;
+        lostv[tn] = -INFINITY;
+        ebound[tn] = s_bound[rl];
+#pragma unroll
+        for (int j = 0; j < SR_CAP; ++j) { la[tn][j] = -INFINITY; lcd[tn][j] = 0xFFFFFFFFu; }
+    }
+    int tile = 0, ks = 0;
+    for (int it = 0; it < total; ++it) {
+        // stage `it` has landed (the SR_NST - 2 younger ones may be in flight: 4 pieces each, 5 for wave 0 - waiting for one more than
+        // needed is safe), and every wave is done with stage it - 1, whose buffer the next issue overwrites
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (SR_NST - 2)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        issue(it + SR_NST - 1);
+        const unsigned st_off = (unsigned)((it & (SR_NST - 1)) * SR_STAGE);
+        if (ks == 0) {
+            // accumulator seeds of this tile: lane (li, lh) holds codes tm*32 + 8 (r >> 2) + 4 lh + (r & 3) -> one float4 per (tm, r >> 2)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4v sd;
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(sd) : "v"(seed_base + st_off + (unsigned)(tm * 32 + 8 * q) * 4u));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sd)::"memory");
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        acc[tm][tn][4 * q + 0] = sd[0];
+                        acc[tm][tn][4 * q + 1] = sd[1];
+                        acc[tm][tn][4 * q + 2] = sd[2];
+                        acc[tm][tn][4 * q + 3] = sd[3];
+                    }
+                }
+        }
+        const unsigned a_st = a_base + st_off, b_st = b_base + (unsigned)(ks * RT) * 128u;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[t]) : "v"(a_st + (unsigned)(t * 32 * 128) + foff[s4]));
+#pragma unroll
+            for (int t = 0; t < TN; ++t) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[t]) : "v"(b_st + (unsigned)(t * 32 * 128) + foff[s4]));
+            if constexpr (TM == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[TM - 1]), "+v"(fb[0]), "+v"(fb[TN - 1])::"memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fb[0]), "+v"(fb[TN - 1])::"memory");
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
+        }
+        if (++ks == nk) {
+            // ---- fold the finished code tile: running maximum of the row, candidates into the lane's register window
+            const unsigned cbase = (unsigned)((t_begin + tile) * SR_CT + wc * TM * 32);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                float tmax = -INFINITY;
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) tmax = fmaxf(tmax, fmaxf(acc[tm][tn][r], acc[tm][tn][r + 1]));
+                const float m = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                // what the other code slices of the block had reached a tile ago (a lower bound of g).  LDS access by inline asm: in
+                // front of a C++ load from LDS the compiler drains every LDS-DMA in flight (vmcnt(0)) - the ring's whole point
+                float other = -INFINITY;
+#pragma unroll
+                for (int w = 0; w < WC; ++w) {
+                    float o;
+                    asm volatile("ds_read_b32 %0, %1" : "=v"(o) : "v"(rm_base + (unsigned)((w * RT + tn * 32) * 4)));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o)::"memory");
+                    other = fmaxf(other, o);
+                }
+                rm[tn] = fmaxf(fmaxf(rm[tn], m), other);
+                if (lh == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(rm_base + (unsigned)((wc * RT + tn * 32) * 4)), "v"(rm[tn]) : "memory");
+                const float thr = rm[tn] - ebound[tn];        // NaN for rows without a bound: nothing compares >= against it
+                if (__any(tmax >= thr)) {                    // wave-uniform
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float a0 = acc[tm][tn][4 * q], a1 = acc[tm][tn][4 * q + 1], a2 = acc[tm][tn][4 * q + 2], a3 = acc[tm][tn][4 * q + 3];
+                            if (fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)) >= thr) {
+                                const float av[4] = {a0, a1, a2, a3};
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (av[e] >= thr) {
+                                        // the lane's list holds its LAST SR_CAP candidates; what it pushes out is remembered by value
+                                        lostv[tn] = fmaxf(lostv[tn], la[tn][SR_CAP - 1]);
+#pragma unroll
+                                        for (int j = SR_CAP - 1; j > 0; --j) { la[tn][j] = la[tn][j - 1]; lcd[tn][j] = lcd[tn][j - 1]; }
+                                        la[tn][0] = av[e];
+                                        lcd[tn][0] = cbase + (unsigned)(tm * 32 + 8 * q + 4 * lh + e);
+                                    }
+                            }
+                        }
+                }
+            }
+            ks = 0;
+            ++tile;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the trailing out-of-range pieces must not outlive the ring
+    // ---- the lists and the row maxima of this (row tile, split) -> global memory
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int rl = wr * TN * 32 + tn * 32 + li;
+        if (rvalid[tn]) {
+            const int64_t L = (((m0 + rl) * splits + split) * LPR + wc * 2 + lh);
+#pragma unroll
+            for (int j = 0; j < SR_CAP; ++j) cand[L * SR_CAP + j] = make_uint2(lcd[tn][j], __builtin_bit_cast(unsigned, la[tn][j]));
+            lost[L] = lostv[tn];
+        }
+    }
+    __syncthreads();
+    if (tid < RT && m0 + tid < n && total > 0) {
+        float g = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < WC; ++w) g = fmaxf(g, s_rm[w][tid]);
+        atomicMax(&gmax[m0 + tid], ord_f32(g));
+    }
+    __threadfence();                                          // lists and maxima visible device-wide before the arrival is
+    __syncthreads();
+    if (tid == 0) s_last = (atomicAdd(&arrive[blockIdx.x], 1u) == (unsigned)(splits - 1)) ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+
+    // ---- phase C: this block closed the row tile - exact re-rank of its RT rows, 64 at a time, in the LDS the main loop is done with
+    const int lists = splits * LPR;
+    for (int half = 0; half < RT / RR_ROWS; ++half) {
+        const int64_t r0 = m0 + half * RR_ROWS;
+        if (r0 >= n) break;                                   // block-uniform
+        __syncthreads();
+        if (tid < RR_ROWS) {
+            s_best[tid] = ~0ull;
+            s_rowcnt[tid] = 0u;
+            s_exh[tid] = 0u;
+        }
+        if (tid == 0) s_np = 0u;
+        __syncthreads();
+        for (int i = tid; i < RR_ROWS * lists; i += 256) {
+            const int rl = i / lists;
+            const int64_t row = r0 + rl;
+            if (row >= n) continue;
+            const int64_t L = row * lists + (i - rl * lists);
+            const float g = unord_f32(__hip_atomic_load(gmax + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const float thr = g - s_bound[half * RR_ROWS + rl];
+            const float lv = __hip_atomic_load(lost + L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!(thr == thr) || lv >= thr) {                // no bound, or an entry that may matter fell off this list: exhaustive search
+                s_exh[rl] = 1u;
+                continue;
+            }
+            const unsigned long long *cl = reinterpret_cast<const unsigned long long *>(cand + L * SR_CAP);
+#pragma unroll
+            for (int j = 0; j < SR_CAP; ++j) {
+                const unsigned long long e = __hip_atomic_load(cl + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned code = (unsigned)(e & 0xffffffffull);
+                const float a = __builtin_bit_cast(float, (unsigned)(e >> 32));
+                if (a >= thr && code != 0xFFFFFFFFu) {
+                    const unsigned inrow = atomicAdd(&s_rowcnt[rl], 1u);
+                    const unsigned pos = inrow < (unsigned)RR_PER_ROW ? atomicAdd(&s_np, 1u) : (unsigned)RR_CAP;
+                    if (pos < (unsigned)RR_CAP) s_pair[pos] = make_uint2((unsigned)rl, code);
+                    else s_exh[rl] = 1u;
+                }
+            }
+        }
+        __syncthreads();
+        const RerankTables T{s_best, s_rowcnt, s_exh, &s_np, &s_todo, s_pair, s_red, dsm};
+        rerank_finish(T, x, cb, cn, n, k, d, r0, idx, best_dist, exhaustive_rows);
     }
 }
 
@@ -669,6 +1019,38 @@ static ScreenLayout screen_layout(int64_t n, int k, int d)
     return L;
 }
 
+struct SearchLayout {              // workspace of the one-kernel path (l2_search_kernel)
+    size_t cand, lost, gmax, arrive, counters, zero_bytes, ws, dyn_lds;
+    int splits, tiles_per_split, rt, lpr;
+};
+static SearchLayout search_layout(int64_t n, int k, int d)
+{
+    SearchLayout L;
+    L.rt = d <= 256 ? 128 : 64;
+    L.lpr = (L.rt == 128 ? 2 : 4) * 2;
+    const int64_t row_tiles = cdiv(n > 0 ? n : 1, L.rt);
+    const int ntiles = (int)cdiv(k, SR_CT);
+    // one block per CU (130 KB of LDS): enough code splits for one round of 256 blocks, no more - a split re-converts its rows
+    int splits = (int)cdiv(256, row_tiles);
+    if (splits > ntiles) splits = ntiles;
+    if (splits < 1) splits = 1;
+    L.tiles_per_split = (int)cdiv(ntiles, splits);
+    L.splits = (int)cdiv(ntiles, L.tiles_per_split);
+    size_t o = 0;
+    L.cand = o; o += al256((size_t)n * L.splits * L.lpr * SR_CAP * 8);
+    L.lost = o; o += al256((size_t)n * L.splits * L.lpr * 4);
+    L.gmax = o; o += al256((size_t)n * 4);                       // zeroed per call from here ...
+    L.arrive = o; o += al256((size_t)row_tiles * 4);
+    L.counters = o; o += 256;                                    // ... to here
+    L.zero_bytes = o - L.gmax;
+    L.ws = o;
+    const size_t nk = (size_t)(d + 63) / 64;
+    const size_t main_lds = ((nk * L.rt * 128 + 1023) & ~(size_t)1023) + (size_t)SR_NST * SR_STAGE;
+    const size_t ring = (size_t)4 * RR_NS * RR_STAGE;
+    L.dyn_lds = main_lds > ring ? main_lds : ring;
+    return L;
+}
+
 }  // namespace mq
 
 using namespace mq;
@@ -683,9 +1065,16 @@ extern "C" int mq_l2_screen_supported(int64_t n, int k, int d) { return screen_s
 
 extern "C" size_t mq_l2_screen_codebook_bytes(int k, int d) { return screen_shape_ok(0, k, d) ? screen_layout(0, k, d).blob : 0; }
 
+// d <= 512: the one-kernel search (round 6); longer rows keep the three launches of round 5 (MQGAN_VQ_3LAUNCH=1 forces them: A/B runs and
+// the bit-identity test of the two paths)
+static bool search_one_kernel(int d) { return d <= 512 && getenv("MQGAN_VQ_3LAUNCH") == nullptr; }
+
 extern "C" size_t mq_l2_screen_workspace(int64_t n, int k, int d)
 {
-    return screen_shape_ok(n, k, d) ? screen_layout(n > 0 ? n : 0, k, d).ws : 0;
+    if (!screen_shape_ok(n, k, d)) return 0;
+    const size_t a = screen_layout(n > 0 ? n : 0, k, d).ws;
+    const size_t b = d <= 512 ? search_layout(n > 0 ? n : 0, k, d).ws : 0;
+    return a > b ? a : b;
 }
 
 extern "C" int mq_l2_screen_prepare(const float *codebook, int k, int d, void *prepared, mqStream stream)
@@ -715,8 +1104,39 @@ extern "C" int mq_l2_argmin_screened(const float *x, const float *codebook, cons
     MQ_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)codebook % 16 == 0 && (uintptr_t)prepared % 256 == 0 && (uintptr_t)workspace % 256 == 0,
                "mq_l2_argmin_screened: alignment (x / codebook 16, blob / workspace 256)");
     if (n == 0) return 0;
+    MQ_REQUIRE(workspace_bytes >= mq_l2_screen_workspace(n, k, d), "mq_l2_argmin_screened: workspace too small (%zu < %zu)", workspace_bytes,
+               mq_l2_screen_workspace(n, k, d));
     const ScreenLayout L = screen_layout(n, k, d);
-    MQ_REQUIRE(workspace_bytes >= L.ws, "mq_l2_argmin_screened: workspace too small (%zu < %zu)", workspace_bytes, L.ws);
+    if (search_one_kernel(d)) {
+        const SearchLayout Q = search_layout(n, k, d);
+        const char *pb = reinterpret_cast<const char *>(prepared);
+        char *w = reinterpret_cast<char *>(workspace);
+        hipStream_t st = S(stream);
+        hipError_t e = hipMemsetAsync(w + Q.gmax, 0, Q.zero_bytes, st);       // row maxima (0 orders below every float), arrival counters, statistics
+        MQ_REQUIRE(e == hipSuccess, "mq_l2_argmin_screened: memset failed: %s", hipGetErrorString(e));
+        const dim3 grid((unsigned)cdiv(n, Q.rt), (unsigned)Q.splits);
+#define MQ_SEARCH(WC_, WR_, TM_, TN_)                                                                                                        \
+    do {                                                                                                                                     \
+        static bool attr_done = false;                                                                                                       \
+        if (!attr_done) {                                                                                                                    \
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&l2_search_kernel<WC_, WR_, TM_, TN_>),                                   \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);                                                \
+            MQ_REQUIRE(e == hipSuccess, "mq_l2_argmin_screened: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));             \
+            attr_done = true;                                                                                                                \
+        }                                                                                                                                    \
+        hipLaunchKernelGGL((l2_search_kernel<WC_, WR_, TM_, TN_>), grid, dim3(256), Q.dyn_lds, st, x, codebook,                             \
+                           reinterpret_cast<const unsigned short *>(pb + L.ch), reinterpret_cast<const float *>(pb + L.cn),                \
+                           reinterpret_cast<const float *>(pb + L.cnh), reinterpret_cast<const float *>(pb + L.cmax2), n, k, d,            \
+                           Q.tiles_per_split, Q.splits, reinterpret_cast<uint2 *>(w + Q.cand), reinterpret_cast<float *>(w + Q.lost),     \
+                           reinterpret_cast<unsigned *>(w + Q.gmax), reinterpret_cast<unsigned *>(w + Q.arrive), idx, best_dist,           \
+                           reinterpret_cast<unsigned *>(w + Q.counters));                                                                    \
+    } while (0)
+        if (Q.rt == 128) MQ_SEARCH(2, 2, 2, 2);
+        else MQ_SEARCH(4, 1, 1, 2);
+#undef MQ_SEARCH
+        MQ_LAUNCH_CHECK("mq_l2_argmin_screened");
+        return 0;
+    }
     const char *pb = reinterpret_cast<const char *>(prepared);
     const float *cn = reinterpret_cast<const float *>(pb + L.cn);
     const float *cnh = reinterpret_cast<const float *>(pb + L.cnh);
@@ -745,6 +1165,29 @@ extern "C" int mq_l2_screen_stats(const void *workspace, int64_t n, int k, int d
                                   uint64_t *rows_over, mqStream stream)
 {
     MQ_REQUIRE(workspace && appended && slots && rows_over && n > 0 && screen_shape_ok(n, k, d), "mq_l2_screen_stats: bad arguments");
+    if (search_one_kernel(d)) {
+        // one-kernel path: the lists hold the last SR_CAP candidates of a lane (code 0xffffffff = empty slot)
+        const SearchLayout Q = search_layout(n, k, d);
+        const size_t ne = (size_t)n * Q.splits * Q.lpr * SR_CAP;
+        uint2 *h = reinterpret_cast<uint2 *>(malloc(ne * 8 + 8));
+        MQ_REQUIRE(h != nullptr, "mq_l2_screen_stats: out of host memory");
+        const char *w = reinterpret_cast<const char *>(workspace);
+        unsigned over = 0;
+        hipError_t e = hipMemcpyAsync(h, w + Q.cand, ne * 8, hipMemcpyDeviceToHost, S(stream));
+        if (e == hipSuccess) e = hipMemcpyAsync(&over, w + Q.counters, 4, hipMemcpyDeviceToHost, S(stream));
+        if (e == hipSuccess) e = hipStreamSynchronize(S(stream));
+        if (e != hipSuccess) {
+            free(h);
+            return ::mq::fail("mq_l2_screen_stats: copy failed: %s", hipGetErrorString(e));
+        }
+        uint64_t a = 0;
+        for (size_t i = 0; i < ne; ++i) a += h[i].x != 0xFFFFFFFFu;
+        free(h);
+        *appended = a;
+        *slots = ne;
+        *rows_over = over;
+        return 0;
+    }
     const ScreenLayout L = screen_layout(n, k, d);
     const size_t nl = (size_t)n * L.splits * SC_LISTS;
     unsigned char *h = reinterpret_cast<unsigned char *>(malloc(nl + 4));

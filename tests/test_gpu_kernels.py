@@ -253,6 +253,39 @@ def test_l2_argmin_screened_adversarial_near_ties(env):
     np.testing.assert_array_equal(dist.cpu().numpy(), wdist)
 
 
+@pytest.mark.parametrize("n,k,d", [(16384, 1024, 256), (5000, 2048, 512), (333, 8192, 512), (130, 700, 200), (16384, 64, 64), (4097, 1025, 8)])
+def test_l2_argmin_one_kernel_equals_three_launches(env, monkeypatch, n, k, d):
+    """Round 6: for d <= 512 the screened search is ONE kernel (x converted and bounded inside it, candidate windows in registers,
+    the re-rank run by the block that closes a row tile).  Same indices and distances, bit for bit, as the three launches of round
+    5 (MQGAN_VQ_3LAUNCH=1) and as the oracle - on full and ragged row tiles, one and several code splits, both row-tile sizes
+    (128 rows for d <= 256, 64 above), a reduction that is not a multiple of the 64-wide K-step - three times on one workspace
+    (the per-call memset must leave nothing behind)."""
+    from oracle import vq
+    ops = env
+    rng = np.random.default_rng(19)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    cb = rng.standard_normal((k, d)).astype(np.float32)
+    x[min(7, n - 1), 0] = np.nan                          # a row without a bound: exhaustive search inside the same kernel
+    xd, cd = t(x), t(cb)
+    prep = ops.l2_screen_prepare(cd)
+    ws = ops._ws_bytes(ops.L().mq_l2_screen_workspace(n, k, d), xd)
+    ws.fill_(0xAB)                                        # the workspace arrives dirty
+    runs = [ops.l2_argmin_screened(xd, cd, prep, return_dist=True, workspace=ws) for _ in range(3)]
+    assert ops.L().mq_last_kernel() is not None
+    monkeypatch.setenv("MQGAN_VQ_3LAUNCH", "1")
+    i3, d3 = ops.l2_argmin_screened(xd, cd, prep, return_dist=True, workspace=ws)
+    monkeypatch.delenv("MQGAN_VQ_3LAUNCH")
+    want, wdist = vq.l2_argmin(x, cb, threads=8, return_dist=True)
+    for i1, d1 in runs:
+        np.testing.assert_array_equal(i1.cpu().numpy(), want)
+        np.testing.assert_array_equal(d1.cpu().numpy(), wdist)
+        assert torch.equal(i1, i3) and torch.equal(d1.view(torch.int32), d3.view(torch.int32))
+    emitted, cap, over = ops.l2_screen_stats(ws, n, k, d)      # stats of the LAST call on ws: the three-launch one ran last - rerun
+    i1, d1 = ops.l2_argmin_screened(xd, cd, prep, return_dist=True, workspace=ws)
+    emitted, cap, over = ops.l2_screen_stats(ws, n, k, d)
+    assert over <= 1 and emitted >= n - 1, (emitted, cap, over)                 # only the NaN row took the exhaustive path
+
+
 def test_l2_argmin_screened_worst_case_rounding(env):
     """The geometry the error bound exists for (tests/vq_adversarial.py): bf16 rounding of the row and of two competing codes
     lined up so that the screen prefers the wrong one by 0.6-0.67 E.  r5's threshold of E / 2 returned the wrong index on
