@@ -231,16 +231,21 @@ def bench_vq(device):
         out["l2_argmin_screened_" + tag] = {"n": rows, "ms": ms2, "algorithmic_TFLOPs": flops / (ms2 / 1e3) / 1e12,
                                             "peak_TFLOPs": PEAK_BF16_MFMA_TFLOPS,
                                             "frac": flops / (ms2 / 1e3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
-                                            "executed_bf16_TFLOPs": flops / (ms2 / 1e3) / 1e12, "launches": 3,
+                                            "executed_bf16_TFLOPs": flops / (ms2 / 1e3) / 1e12, "launches": 2 if d <= 256 else 3,
                                             "speedup_vs_f32_kernel": ms / ms2, "identical_to_f32_kernel": same,
                                             "list_entries_per_row": emitted / rows, "list_capacity_per_row": cap / rows,
                                             "rows_searched_exhaustively": over,
                                             "algorithmic_GBps": byts / (ms2 / 1e3) / 1e9, "bound": "mfma (bf16 pipe)",
-                                            "kernel": "l2_screen_prep_kernel (x -> bf16, per-row error bound) + l2_screen_kernel (bf16 "
-                                                      "MFMA scores formed once, code norm as the accumulator seed, candidates within the "
-                                                      "bound of the running row maximum into private lists) + l2_rerank_kernel (lists "
-                                                      "filtered against the final maximum, exact k-ordered f32 chain out of LDS-DMA staged "
-                                                      "rows, idx / distance written); codebook prepared once, x prepared inside the timed call"}
+                                            "kernel": ("l2_search_kernel (d <= 256: the block's rows rounded to bf16 into an LDS image and bounded from their "
+                                                       "measured rounding residuals in the kernel, code tiles streamed through a four-stage LDS-DMA ring, "
+                                                       "scores formed once on the bf16 MFMA, candidate windows in registers) + l2_rerank2_kernel (windows "
+                                                       "against the final maximum, exact k-ordered f32 chain out of LDS-DMA staged rows, idx / distance "
+                                                       "written)" if d <= 256 else
+                                                       "l2_screen_prep_kernel (x -> bf16, per-row error bound from the measured rounding residuals) + "
+                                                       "l2_screen_kernel (bf16 MFMA scores formed once, code norm as the accumulator seed, candidates within "
+                                                       "the bound of the running row maximum into private lists) + l2_rerank_kernel (lists filtered against "
+                                                       "the final maximum, exact k-ordered f32 chain out of LDS-DMA staged rows, idx / distance written)")
+                                                      + "; codebook prepared once, x prepared inside the timed call"}
     return out
 
 

@@ -661,9 +661,8 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(const float *__restrict_
 }
 
 
-// ============================================================================================== round 6: ONE kernel (d <= 512)
-// l2_search_kernel: conversion of x, the error bound, the bf16 scores, the candidate lists AND the exact re-rank in one launch
-// (one memset of 4 n + 4 row-tile bytes in front of it).  What changed against the three launches above, and why:
+// ============================================================================================== round 6: two launches (d <= 256; built for d <= 512)
+// l2_search_kernel + l2_rerank2_kernel.  What changed against the three launches above, and why:
 //   * x never exists as a bf16 tensor in HBM.  A block owns RT rows for its whole life: it loads them as f32, rounds them to bf16
 //     into an LDS image (nk K-steps x RT rows x 128 bytes, the 16-byte chunk swizzle of the MFMA fragment reads), and sums |x|^2
 //     and |x - bf16(x)|^2 on the way - the bound E(n) of the header comment costs nothing extra.  RT = 128 for d <= 256, 64 for
@@ -677,37 +676,36 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(const float *__restrict_
 //   * per (row, lane list) the LAST SR_CAP candidates (a >= running maximum - E at the time) and `lost` = the largest score ever
 //     pushed out of that window.  A list is complete if lost < g - E for the FINAL maximum g (checked by the re-rank; otherwise
 //     the row is searched exhaustively): the running maximum only rises, so what an over-collecting pass pushes out is almost
-//     always obsolete - it matters only when five candidates of one lane's 1 / (2 WC splits) share of the codes lie within E of
-//     each other.  No list stores, no atomics, no cross-split traffic inside the loop.
-//   * the re-rank runs in the block that finishes a row tile LAST (arrival counter per row tile after a device-scope fence): the
-//     final maxima, lists and bounds of its RT rows -> rerank_finish, in the LDS the main loop no longer needs.  No third launch,
-//     and the chains of early row tiles overlap the score pass of late ones.
+//     always obsolete - it matters only when nine candidates of one lane's share of the codes lie within E of each other.  No list
+//     stores, no atomics, no cross-split traffic inside the loop; the row maxima are per (row, split) - plain stores, nothing to
+//     initialise, so no memset in front of the kernel.
+//   * 512 threads: one block per CU (132 KB of LDS), so the block itself has to bring two waves per SIMD - with four waves every
+//     K-step was five DMA issues + twenty fragment reads + sixteen MFMAs one after the other on each SIMD (measured: 1.4 us per
+//     K-step at 1024 x 256 where the MFMAs are 0.2 us).
+// Tried first and measured (tools/vq_stamp.py): the re-rank INSIDE the score kernel, run by the block that closes a row tile (arrival
+// counter behind a device-scope fence): the two fences cost 25-30 us EACH (on this chip a device-scope release is an L2 write-back,
+// as r3 found for a fence per candidate), and with one block per CU every row tile closes at the same moment, so nothing overlaps
+// anyway: 88 / 157 / 370 us against 47 / 84 / 200 for the three launches.  Removed.
 constexpr int SR_CT = 128;                 // codes per tile
 constexpr int SR_NST = 4;                  // code stages (SR_NST - 1 in flight)
 constexpr int SR_STAGE = SR_CT * 128 + 1024;   // 16 KB of codes + 512 B of seeds (+ 512 B the seed piece's idle lanes zero)
-constexpr int SR_CAP = 4;                  // entries per lane list
+constexpr int SR_CAP = 8;                  // entries per lane list (five candidates within E of each other in one list are a 1e-6 event per
+                                           // list, i.e. one exhaustive row per call at 16,384 rows x 8 lists with a window of four: measured)
+constexpr int SR_NW = 8;                   // waves per block
 
 template <int WC, int WR, int TM, int TN>  // waves along codes / rows, 32x32 MFMA tiles per wave along codes / rows
-__global__ __launch_bounds__(256) void l2_search_kernel(const float *__restrict__ x, const float *__restrict__ cb, const unsigned short *__restrict__ ch,
-                                                        const float *__restrict__ cn, const float *__restrict__ cnh, const float *__restrict__ cmax2,
-                                                        int64_t n, int k, int d, int tiles_per_split, int splits, uint2 *__restrict__ cand,
-                                                        float *__restrict__ lost, unsigned *__restrict__ gmax, unsigned *__restrict__ arrive,
-                                                        int32_t *__restrict__ idx, float *__restrict__ best_dist, unsigned *__restrict__ exhaustive_rows)
+__global__ __launch_bounds__(512) void l2_search_kernel(const float *__restrict__ x, const unsigned short *__restrict__ ch, const float *__restrict__ cnh,
+                                                        const float *__restrict__ cmax2, int64_t n, int k, int d, int tiles_per_split, int splits,
+                                                        uint2 *__restrict__ cand, uint2 *__restrict__ head, float *__restrict__ gsplit,
+                                                        float *__restrict__ bound, unsigned *__restrict__ exhaustive_rows)
 {
-    static_assert(WC * WR == 4 && WC * TM * 32 == SR_CT, "four waves, 128 codes per tile");
+    static_assert(WC * WR == SR_NW && WC * TM * 32 == SR_CT, "eight waves, 128 codes per tile");
     constexpr int RT = WR * TN * 32;       // rows per block
-    constexpr int NPJ = RT / 32;           // 8-row pieces of the x tile per wave and K-step
+    constexpr int NPJ = RT / 64;           // 8-row pieces of the x tile per wave and K-step
     constexpr int LPR = WC * 2;            // lists per (row, split)
     extern __shared__ __attribute__((aligned(1024))) char dsm[];
     __shared__ float s_rm[WC][RT];
     __shared__ float s_bound[RT];
-    __shared__ unsigned long long s_best[RR_ROWS];
-    __shared__ unsigned s_rowcnt[RR_ROWS];
-    __shared__ unsigned s_exh[RR_ROWS];
-    __shared__ unsigned s_np, s_last;
-    __shared__ unsigned long long s_todo;
-    __shared__ uint2 s_pair[RR_CAP];
-    __shared__ unsigned long long s_red[4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wc = wave / WR, wr = wave % WR;
@@ -721,16 +719,17 @@ __global__ __launch_bounds__(256) void l2_search_kernel(const float *__restrict_
     const int total = nk * (t_end - t_begin);
     char *img = dsm;                                        // [nk][RT][128 B]
     char *stages = dsm + (((size_t)nk * RT * 128 + 1023) & ~(size_t)1023);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *exhaustive_rows = 0u;     // the re-rank launch counts them
 
-    // ---- code tiles by LDS-DMA: piece p = wave + 4 j covers tile rows 8 p .. 8 p + 7; lane -> row 8 p + (lane >> 3), physical chunk lane & 7
+    // ---- code tiles by LDS-DMA: piece p = wave + 8 j (j = 0, 1) covers tile rows 8 p .. 8 p + 7; lane -> row 8 p + (lane >> 3), physical chunk lane & 7
     const int lc = (lane & 7) ^ ((((wave & 1) << 2) | (lane >> 4)) & 7);
     const int64_t code0 = (int64_t)t_begin * SR_CT;
     const int64_t codes_here = min((int64_t)k, (int64_t)t_end * SR_CT) - code0;
     const __amdgpu_buffer_rsrc_t rc = make_rsrc(ch + code0 * d, (size_t)(codes_here > 0 ? codes_here : 0) * d * 2);
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(cnh + code0, (size_t)(t_end - t_begin > 0 ? t_end - t_begin : 0) * SR_CT * 4);   // cnh is padded to whole tiles
-    unsigned rowoff[4];
+    unsigned rowoff[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) rowoff[j] = (unsigned)(8 * (wave + 4 * j) + (lane >> 3)) * (unsigned)d * 2u + (unsigned)lc * 16u;
+    for (int j = 0; j < 2; ++j) rowoff[j] = (unsigned)(8 * (wave + 8 * j) + (lane >> 3)) * (unsigned)d * 2u + (unsigned)lc * 16u;
     int is_tile = 0, is_ks = 0;                            // (tile, K-step) of the next stage to issue
     auto issue = [&](int it) {
         char *st = stages + (it & (SR_NST - 1)) * SR_STAGE;
@@ -739,8 +738,8 @@ __global__ __launch_bounds__(256) void l2_search_kernel(const float *__restrict_
         const unsigned koff = (unsigned)is_ks * 128u;
         const unsigned toff = (unsigned)is_tile * (unsigned)(SR_CT * 2) * (unsigned)d;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, lds_ptr_s(st + (wave + 4 * j) * 1024), 16, kv ? rowoff[j] + koff + toff : OOB, 0, 0, 0);
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, lds_ptr_s(st + (wave + 8 * j) * 1024), 16, kv ? rowoff[j] + koff + toff : OOB, 0, 0, 0);
         if (wave == 0)                                      // the tile's accumulator seeds ride with its first K-step (lanes 32-63 write zeros behind them)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds_ptr_s(st + SR_CT * 128), 16,
                                                      (live && is_ks == 0 && lane < 32) ? (unsigned)is_tile * (unsigned)(SR_CT * 4) + (unsigned)lane * 16u : OOB, 0, 0, 0);
@@ -762,7 +761,7 @@ __global__ __launch_bounds__(256) void l2_search_kernel(const float *__restrict_
             const bool kv = ks * 64 + c8 * 8 < d;
 #pragma unroll
             for (int j = 0; j < NPJ; ++j) {
-                const int row = 8 * (wave + 4 * j) + (lane >> 3);
+                const int row = 8 * (wave + 8 * j) + (lane >> 3);
                 const bool ok = kv && m0 + row < n;
                 const float *src = x + (m0 + row) * d + ks * 64 + c8 * 8;
                 v0[j] = ok ? *reinterpret_cast<const float4 *>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -770,7 +769,7 @@ __global__ __launch_bounds__(256) void l2_search_kernel(const float *__restrict_
             }
 #pragma unroll
             for (int j = 0; j < NPJ; ++j) {
-                const int row = 8 * (wave + 4 * j) + (lane >> 3);
+                const int row = 8 * (wave + 8 * j) + (lane >> 3);
                 ss[j] = fmaf(v0[j].x, v0[j].x, fmaf(v0[j].y, v0[j].y, fmaf(v0[j].z, v0[j].z, fmaf(v0[j].w, v0[j].w, ss[j]))));
                 ss[j] = fmaf(v1[j].x, v1[j].x, fmaf(v1[j].y, v1[j].y, fmaf(v1[j].z, v1[j].z, fmaf(v1[j].w, v1[j].w, ss[j]))));
                 const uint2 h0 = pack_bf16x4(v0[j]), h1 = pack_bf16x4(v1[j]);
@@ -786,10 +785,12 @@ __global__ __launch_bounds__(256) void l2_search_kernel(const float *__restrict_
                 a += __shfl_xor(a, o, 64);
                 b += __shfl_xor(b, o, 64);
             }
-            const int row = 8 * (wave + 4 * j) + (lane >> 3);
+            const int row = 8 * (wave + 8 * j) + (lane >> 3);
             if (c8 == 0) {
                 const float e = screen_bound(a, b, cmax2[0], cmax2[1], d);
-                s_bound[row] = (m0 + row < n && e < 1e30f) ? e : __builtin_nanf("");
+                const float eb = (m0 + row < n && e < 1e30f) ? e : __builtin_nanf("");
+                s_bound[row] = eb;
+                if (split == 0 && m0 + row < n) bound[m0 + row] = eb;
             }
         }
         if (tid < RT) {
@@ -810,7 +811,7 @@ __global__ __launch_bounds__(256) void l2_search_kernel(const float *__restrict_
     const unsigned rm_base = (unsigned)reinterpret_cast<uintptr_t>(&s_rm[0][0]) + (unsigned)(wr * TN * 32 + li) * 4u;
     f32x16 acc[TM][TN];
     float rm[TN], ebound[TN], lostv[TN], la[TN][SR_CAP];
-    unsigned lcd[TN][SR_CAP];
+    unsigned lcd[TN][SR_CAP], lcnt[TN];
     bool rvalid[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
@@ -818,52 +819,68 @@ __global__ __launch_bounds__(256) void l2_search_kernel(const float *__restrict_
         rvalid[tn] = m0 + rl < n;
         rm[tn] = -INFINITY;
         lostv[tn] = -INFINITY;
+        lcnt[tn] = 0u;
         ebound[tn] = s_bound[rl];
 #pragma unroll
         for (int j = 0; j < SR_CAP; ++j) { la[tn][j] = -INFINITY; lcd[tn][j] = 0xFFFFFFFFu; }
     }
-    int tile = 0, ks = 0;
-    for (int it = 0; it < total; ++it) {
-        // stage `it` has landed (the SR_NST - 2 younger ones may be in flight: 4 pieces each, 5 for wave 0 - waiting for one more than
-        // needed is safe), and every wave is done with stage it - 1, whose buffer the next issue overwrites
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (SR_NST - 2)) : "memory");
-        __builtin_amdgcn_s_barrier();
-        issue(it + SR_NST - 1);
-        const unsigned st_off = (unsigned)((it & (SR_NST - 1)) * SR_STAGE);
-        if (ks == 0) {
-            // accumulator seeds of this tile: lane (li, lh) holds codes tm*32 + 8 (r >> 2) + 4 lh + (r & 3) -> one float4 per (tm, r >> 2)
+    int it = 0;
+    for (int tile = 0; tile < t_end - t_begin; ++tile) {
+        // The accumulators are touched by MFMAs only inside the K loop (zeroed here, read by the fold): seeding them element by
+        // element at ks == 0 made the compiler carry all of them through VGPR <-> AGPR copies in EVERY K-step (128 moves per 16
+        // MFMAs in the first version of this kernel).  The seeds -cn / 2 are read at ks == 0 into registers and ADDED by the fold -
+        // another summation order for the same sum, inside the bound E.
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+        f32x4v sd[TM][4];
+        for (int ks = 0; ks < nk; ++ks, ++it) {
+            // stage `it` has landed (the SR_NST - 2 younger ones may be in flight: 2 pieces each, 3 for wave 0 - waiting for one more
+            // than needed is safe), and every wave is done with stage it - 1, whose buffer the next issue overwrites
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (SR_NST - 2)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            issue(it + SR_NST - 1);
+            const unsigned st_off = (unsigned)((it & (SR_NST - 1)) * SR_STAGE);
+            if (ks == 0) {
+                // the tile's seeds: lane (li, lh) holds codes tm*32 + 8 (r >> 2) + 4 lh + (r & 3) -> one float4 per (tm, r >> 2)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(sd[tm][q]) : "v"(seed_base + st_off + (unsigned)(tm * 32 + 8 * q) * 4u));
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sd[tm][0]), "+v"(sd[tm][1]), "+v"(sd[tm][2]), "+v"(sd[tm][3])::"memory");
+            }
+            const unsigned a_st = a_base + st_off, b_st = b_base + (unsigned)(ks * RT) * 128u;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                bf16x8 fa[TM], fb[TN];
+#pragma unroll
+                for (int t = 0; t < TM; ++t) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[t]) : "v"(a_st + (unsigned)(t * 32 * 128) + foff[s4]));
+#pragma unroll
+                for (int t = 0; t < TN; ++t) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[t]) : "v"(b_st + (unsigned)(t * 32 * 128) + foff[s4]));
+                // every fragment register is tied to the wait ONCE (the same variable twice would make the compiler copy a register
+                // whose data has not landed yet)
+                static_assert(TM == 1 && (TN == 1 || TN == 2), "fragment ties below");
+                if constexpr (TN == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fb[0]), "+v"(fb[1])::"memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fb[0])::"memory");
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
+            }
+        }
+        {
+            // scores of the tile: accumulator + seed
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4v sd;
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(sd) : "v"(seed_base + st_off + (unsigned)(tm * 32 + 8 * q) * 4u));
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sd)::"memory");
+                for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-                    for (int tn = 0; tn < TN; ++tn) {
-                        acc[tm][tn][4 * q + 0] = sd[0];
-                        acc[tm][tn][4 * q + 1] = sd[1];
-                        acc[tm][tn][4 * q + 2] = sd[2];
-                        acc[tm][tn][4 * q + 3] = sd[3];
-                    }
-                }
-        }
-        const unsigned a_st = a_base + st_off, b_st = b_base + (unsigned)(ks * RT) * 128u;
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            bf16x8 fa[TM], fb[TN];
-#pragma unroll
-            for (int t = 0; t < TM; ++t) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[t]) : "v"(a_st + (unsigned)(t * 32 * 128) + foff[s4]));
-#pragma unroll
-            for (int t = 0; t < TN; ++t) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[t]) : "v"(b_st + (unsigned)(t * 32 * 128) + foff[s4]));
-            if constexpr (TM == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[TM - 1]), "+v"(fb[0]), "+v"(fb[TN - 1])::"memory");
-            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fb[0]), "+v"(fb[TN - 1])::"memory");
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
-        }
-        if (++ks == nk) {
+                    for (int r = 0; r < 16; ++r) acc[tm][tn][r] += sd[tm][r >> 2][r & 3];
             // ---- fold the finished code tile: running maximum of the row, candidates into the lane's register window
             const unsigned cbase = (unsigned)((t_begin + tile) * SR_CT + wc * TM * 32);
 #pragma unroll
@@ -904,13 +921,12 @@ __global__ __launch_bounds__(256) void l2_search_kernel(const float *__restrict_
                                         for (int j = SR_CAP - 1; j > 0; --j) { la[tn][j] = la[tn][j - 1]; lcd[tn][j] = lcd[tn][j - 1]; }
                                         la[tn][0] = av[e];
                                         lcd[tn][0] = cbase + (unsigned)(tm * 32 + 8 * q + 4 * lh + e);
+                                        ++lcnt[tn];
                                     }
                             }
                         }
                 }
             }
-            ks = 0;
-            ++tile;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the trailing out-of-range pieces must not outlive the ring
@@ -920,68 +936,81 @@ __global__ __launch_bounds__(256) void l2_search_kernel(const float *__restrict_
         const int rl = wr * TN * 32 + tn * 32 + li;
         if (rvalid[tn]) {
             const int64_t L = (((m0 + rl) * splits + split) * LPR + wc * 2 + lh);
+            const unsigned c = lcnt[tn] < (unsigned)SR_CAP ? lcnt[tn] : (unsigned)SR_CAP;       // the window's newest c entries are slots 0 .. c - 1
 #pragma unroll
-            for (int j = 0; j < SR_CAP; ++j) cand[L * SR_CAP + j] = make_uint2(lcd[tn][j], __builtin_bit_cast(unsigned, la[tn][j]));
-            lost[L] = lostv[tn];
+            for (int j = 0; j < SR_CAP; ++j)
+                if ((unsigned)j < c) cand[L * SR_CAP + j] = make_uint2(lcd[tn][j], __builtin_bit_cast(unsigned, la[tn][j]));
+            head[L] = make_uint2(__builtin_bit_cast(unsigned, lostv[tn]), c);
         }
     }
     __syncthreads();
-    if (tid < RT && m0 + tid < n && total > 0) {
+    if (tid < RT && m0 + tid < n) {
         float g = -INFINITY;
 #pragma unroll
         for (int w = 0; w < WC; ++w) g = fmaxf(g, s_rm[w][tid]);
-        atomicMax(&gmax[m0 + tid], ord_f32(g));
+        gsplit[(m0 + tid) * splits + split] = g;
     }
-    __threadfence();                                          // lists and maxima visible device-wide before the arrival is
-    __syncthreads();
-    if (tid == 0) s_last = (atomicAdd(&arrive[blockIdx.x], 1u) == (unsigned)(splits - 1)) ? 1u : 0u;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
+}
 
-    // ---- phase C: this block closed the row tile - exact re-rank of its RT rows, 64 at a time, in the LDS the main loop is done with
-    const int lists = splits * LPR;
-    for (int half = 0; half < RT / RR_ROWS; ++half) {
-        const int64_t r0 = m0 + half * RR_ROWS;
-        if (r0 >= n) break;                                   // block-uniform
-        __syncthreads();
-        if (tid < RR_ROWS) {
-            s_best[tid] = ~0ull;
-            s_rowcnt[tid] = 0u;
-            s_exh[tid] = 0u;
+// The re-rank of the two-launch path: a block per RR_ROWS rows.  Final maximum of a row = the largest of its splits' maxima; a list
+// whose pushed-out score reaches g - E sends the row to the exhaustive search; the windows' entries against g - E -> survivors ->
+// rerank_finish (exact chains, packed minima, idx / best_dist).
+__global__ __launch_bounds__(256) void l2_rerank2_kernel(const float *__restrict__ x, const float *__restrict__ cb, const float *__restrict__ cn,
+                                                         const uint2 *__restrict__ cand, const uint2 *__restrict__ head, const float *__restrict__ gsplit,
+                                                         const float *__restrict__ bound, int64_t n, int k, int d, int splits, int lpr,
+                                                         int32_t *__restrict__ idx, float *__restrict__ best_dist, unsigned *__restrict__ exhaustive_rows)
+{
+    __shared__ unsigned long long s_best[RR_ROWS];
+    __shared__ unsigned s_rowcnt[RR_ROWS];
+    __shared__ unsigned s_exh[RR_ROWS];
+    __shared__ float s_thr[RR_ROWS];
+    __shared__ unsigned s_np;
+    __shared__ unsigned long long s_todo;
+    __shared__ uint2 s_pair[RR_CAP];
+    __shared__ unsigned long long s_red[4];
+    __shared__ __attribute__((aligned(1024))) char s_ring[4 * RR_NS * RR_STAGE];
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * RR_ROWS;
+    if (tid < RR_ROWS) {
+        s_best[tid] = ~0ull;
+        s_rowcnt[tid] = 0u;
+        s_exh[tid] = 0u;
+        float thr = __builtin_nanf("");
+        if (r0 + tid < n) {
+            float g = -INFINITY;
+            for (int sp = 0; sp < splits; ++sp) g = fmaxf(g, gsplit[(r0 + tid) * splits + sp]);
+            thr = g - bound[r0 + tid];                          // NaN: no bound
         }
-        if (tid == 0) s_np = 0u;
-        __syncthreads();
-        for (int i = tid; i < RR_ROWS * lists; i += 256) {
-            const int rl = i / lists;
-            const int64_t row = r0 + rl;
-            if (row >= n) continue;
-            const int64_t L = row * lists + (i - rl * lists);
-            const float g = unord_f32(__hip_atomic_load(gmax + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            const float thr = g - s_bound[half * RR_ROWS + rl];
-            const float lv = __hip_atomic_load(lost + L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (!(thr == thr) || lv >= thr) {                // no bound, or an entry that may matter fell off this list: exhaustive search
-                s_exh[rl] = 1u;
-                continue;
-            }
-            const unsigned long long *cl = reinterpret_cast<const unsigned long long *>(cand + L * SR_CAP);
-#pragma unroll
-            for (int j = 0; j < SR_CAP; ++j) {
-                const unsigned long long e = __hip_atomic_load(cl + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned code = (unsigned)(e & 0xffffffffull);
-                const float a = __builtin_bit_cast(float, (unsigned)(e >> 32));
-                if (a >= thr && code != 0xFFFFFFFFu) {
-                    const unsigned inrow = atomicAdd(&s_rowcnt[rl], 1u);
-                    const unsigned pos = inrow < (unsigned)RR_PER_ROW ? atomicAdd(&s_np, 1u) : (unsigned)RR_CAP;
-                    if (pos < (unsigned)RR_CAP) s_pair[pos] = make_uint2((unsigned)rl, code);
-                    else s_exh[rl] = 1u;
-                }
-            }
-        }
-        __syncthreads();
-        const RerankTables T{s_best, s_rowcnt, s_exh, &s_np, &s_todo, s_pair, s_red, dsm};
-        rerank_finish(T, x, cb, cn, n, k, d, r0, idx, best_dist, exhaustive_rows);
+        s_thr[tid] = thr;
     }
+    if (tid == 0) s_np = 0u;
+    __syncthreads();
+    const int lists = splits * lpr;
+    for (int i = tid; i < RR_ROWS * lists; i += 256) {
+        const int rl = i / lists;
+        const int64_t row = r0 + rl;
+        if (row >= n) continue;
+        const int64_t L = row * lists + (i - rl * lists);
+        const uint2 hd = head[L];
+        const float thr = s_thr[rl];
+        if (!(thr == thr) || __builtin_bit_cast(float, hd.x) >= thr) {       // no bound, or an entry that may matter fell out of this window
+            s_exh[rl] = 1u;
+            continue;
+        }
+        const int cnt = (int)hd.y;
+        for (int j = 0; j < cnt; ++j) {
+            const uint2 ent = cand[L * SR_CAP + j];
+            if (__builtin_bit_cast(float, ent.y) >= thr) {
+                const unsigned inrow = atomicAdd(&s_rowcnt[rl], 1u);
+                const unsigned pos = inrow < (unsigned)RR_PER_ROW ? atomicAdd(&s_np, 1u) : (unsigned)RR_CAP;
+                if (pos < (unsigned)RR_CAP) s_pair[pos] = make_uint2((unsigned)rl, ent.x);
+                else s_exh[rl] = 1u;
+            }
+        }
+    }
+    __syncthreads();
+    const RerankTables T{s_best, s_rowcnt, s_exh, &s_np, &s_todo, s_pair, s_red, s_ring};
+    rerank_finish(T, x, cb, cn, n, k, d, r0, idx, best_dist, exhaustive_rows);
 }
 
 struct ScreenLayout {              // byte offsets inside the prepared-codebook blob and the workspace
@@ -1020,14 +1049,14 @@ static ScreenLayout screen_layout(int64_t n, int k, int d)
 }
 
 struct SearchLayout {              // workspace of the one-kernel path (l2_search_kernel)
-    size_t cand, lost, gmax, arrive, counters, zero_bytes, ws, dyn_lds;
+    size_t cand, head, gsplit, bound, counters, ws, dyn_lds;
     int splits, tiles_per_split, rt, lpr;
 };
 static SearchLayout search_layout(int64_t n, int k, int d)
 {
     SearchLayout L;
     L.rt = d <= 256 ? 128 : 64;
-    L.lpr = (L.rt == 128 ? 2 : 4) * 2;
+    L.lpr = 4 * 2;                                               // four waves along the codes, two lane halves
     const int64_t row_tiles = cdiv(n > 0 ? n : 1, L.rt);
     const int ntiles = (int)cdiv(k, SR_CT);
     // one block per CU (130 KB of LDS): enough code splits for one round of 256 blocks, no more - a split re-converts its rows
@@ -1038,16 +1067,14 @@ static SearchLayout search_layout(int64_t n, int k, int d)
     L.splits = (int)cdiv(ntiles, L.tiles_per_split);
     size_t o = 0;
     L.cand = o; o += al256((size_t)n * L.splits * L.lpr * SR_CAP * 8);
-    L.lost = o; o += al256((size_t)n * L.splits * L.lpr * 4);
-    L.gmax = o; o += al256((size_t)n * 4);                       // zeroed per call from here ...
-    L.arrive = o; o += al256((size_t)row_tiles * 4);
-    L.counters = o; o += 256;                                    // ... to here
-    L.zero_bytes = o - L.gmax;
+    L.head = o; o += al256((size_t)n * L.splits * L.lpr * 8);            // per list: {largest score pushed out of the window, entries}
+    L.gsplit = o; o += al256((size_t)n * L.splits * 4);          // per (row, split): the largest score
+    L.bound = o; o += al256((size_t)n * 4);
+    L.counters = o; o += 256;
     L.ws = o;
     const size_t nk = (size_t)(d + 63) / 64;
     const size_t main_lds = ((nk * L.rt * 128 + 1023) & ~(size_t)1023) + (size_t)SR_NST * SR_STAGE;
-    const size_t ring = (size_t)4 * RR_NS * RR_STAGE;
-    L.dyn_lds = main_lds > ring ? main_lds : ring;
+    L.dyn_lds = main_lds;
     return L;
 }
 
@@ -1065,9 +1092,20 @@ extern "C" int mq_l2_screen_supported(int64_t n, int k, int d) { return screen_s
 
 extern "C" size_t mq_l2_screen_codebook_bytes(int k, int d) { return screen_shape_ok(0, k, d) ? screen_layout(0, k, d).blob : 0; }
 
-// d <= 512: the one-kernel search (round 6); longer rows keep the three launches of round 5 (MQGAN_VQ_3LAUNCH=1 forces them: A/B runs and
+// d <= 256: the two-launch search (round 6); longer rows keep the three launches of round 5 (MQGAN_VQ_3LAUNCH=1 forces them: A/B runs and
 // the bit-identity test of the two paths)
-static bool search_one_kernel(int d) { return d <= 512 && getenv("MQGAN_VQ_3LAUNCH") == nullptr; }
+// Measured (16,384 rows, same box, profiles/r6_vq_*): 1024 x 256  42.8 us against 46.8 (score kernel 24 us where prep + screen took 26, and one
+// launch fewer); 2048 x 512  92.7 against 83.5, 8192 x 512  254 against 200 - with 64-row tiles (the 64 KB image limit at d = 512) a
+// wave's 32 x 32 tile reads two LDS fragments per MFMA and the kernel is LDS-bound where l2_screen_kernel's 64 x 64 wave tiles are
+// not.  So: d <= 256 takes the two launches, longer rows keep the three.  (MQGAN_VQ_2LAUNCH_MAXD overrides the limit for A/B runs, up
+// to 512.)
+static int search_maxd()
+{
+    const char *e = getenv("MQGAN_VQ_2LAUNCH_MAXD");             // read per call: tests switch it
+    const int q = e ? atoi(e) : 256;
+    return q < 0 ? 0 : (q > 512 ? 512 : q);
+}
+static bool search_one_kernel(int d) { return d <= search_maxd() && getenv("MQGAN_VQ_3LAUNCH") == nullptr; }
 
 extern "C" size_t mq_l2_screen_workspace(int64_t n, int k, int d)
 {
@@ -1112,8 +1150,7 @@ extern "C" int mq_l2_argmin_screened(const float *x, const float *codebook, cons
         const char *pb = reinterpret_cast<const char *>(prepared);
         char *w = reinterpret_cast<char *>(workspace);
         hipStream_t st = S(stream);
-        hipError_t e = hipMemsetAsync(w + Q.gmax, 0, Q.zero_bytes, st);       // row maxima (0 orders below every float), arrival counters, statistics
-        MQ_REQUIRE(e == hipSuccess, "mq_l2_argmin_screened: memset failed: %s", hipGetErrorString(e));
+        hipError_t e = hipSuccess;
         const dim3 grid((unsigned)cdiv(n, Q.rt), (unsigned)Q.splits);
 #define MQ_SEARCH(WC_, WR_, TM_, TN_)                                                                                                        \
     do {                                                                                                                                     \
@@ -1124,16 +1161,19 @@ extern "C" int mq_l2_argmin_screened(const float *x, const float *codebook, cons
             MQ_REQUIRE(e == hipSuccess, "mq_l2_argmin_screened: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));             \
             attr_done = true;                                                                                                                \
         }                                                                                                                                    \
-        hipLaunchKernelGGL((l2_search_kernel<WC_, WR_, TM_, TN_>), grid, dim3(256), Q.dyn_lds, st, x, codebook,                             \
-                           reinterpret_cast<const unsigned short *>(pb + L.ch), reinterpret_cast<const float *>(pb + L.cn),                \
-                           reinterpret_cast<const float *>(pb + L.cnh), reinterpret_cast<const float *>(pb + L.cmax2), n, k, d,            \
-                           Q.tiles_per_split, Q.splits, reinterpret_cast<uint2 *>(w + Q.cand), reinterpret_cast<float *>(w + Q.lost),     \
-                           reinterpret_cast<unsigned *>(w + Q.gmax), reinterpret_cast<unsigned *>(w + Q.arrive), idx, best_dist,           \
-                           reinterpret_cast<unsigned *>(w + Q.counters));                                                                    \
+        hipLaunchKernelGGL((l2_search_kernel<WC_, WR_, TM_, TN_>), grid, dim3(512), Q.dyn_lds, st, x,                                       \
+                           reinterpret_cast<const unsigned short *>(pb + L.ch), reinterpret_cast<const float *>(pb + L.cnh),               \
+                           reinterpret_cast<const float *>(pb + L.cmax2), n, k, d, Q.tiles_per_split, Q.splits,                            \
+                           reinterpret_cast<uint2 *>(w + Q.cand), reinterpret_cast<uint2 *>(w + Q.head), reinterpret_cast<float *>(w + Q.gsplit), \
+                           reinterpret_cast<float *>(w + Q.bound), reinterpret_cast<unsigned *>(w + Q.counters));                          \
     } while (0)
-        if (Q.rt == 128) MQ_SEARCH(2, 2, 2, 2);
-        else MQ_SEARCH(4, 1, 1, 2);
+        if (Q.rt == 128) MQ_SEARCH(4, 2, 1, 2);
+        else MQ_SEARCH(4, 2, 1, 1);
 #undef MQ_SEARCH
+        hipLaunchKernelGGL(l2_rerank2_kernel, dim3((unsigned)cdiv(n, RR_ROWS)), dim3(256), 0, st, x, codebook, reinterpret_cast<const float *>(pb + L.cn),
+                           reinterpret_cast<const uint2 *>(w + Q.cand), reinterpret_cast<const uint2 *>(w + Q.head),
+                           reinterpret_cast<const float *>(w + Q.gsplit), reinterpret_cast<const float *>(w + Q.bound), n, k, d, Q.splits, Q.lpr, idx,
+                           best_dist, reinterpret_cast<unsigned *>(w + Q.counters));
         MQ_LAUNCH_CHECK("mq_l2_argmin_screened");
         return 0;
     }
@@ -1166,14 +1206,14 @@ extern "C" int mq_l2_screen_stats(const void *workspace, int64_t n, int k, int d
 {
     MQ_REQUIRE(workspace && appended && slots && rows_over && n > 0 && screen_shape_ok(n, k, d), "mq_l2_screen_stats: bad arguments");
     if (search_one_kernel(d)) {
-        // one-kernel path: the lists hold the last SR_CAP candidates of a lane (code 0xffffffff = empty slot)
+        // one-kernel path: a list's header holds {largest score pushed out of the lane's window, entries in the window}
         const SearchLayout Q = search_layout(n, k, d);
-        const size_t ne = (size_t)n * Q.splits * Q.lpr * SR_CAP;
+        const size_t ne = (size_t)n * Q.splits * Q.lpr;
         uint2 *h = reinterpret_cast<uint2 *>(malloc(ne * 8 + 8));
         MQ_REQUIRE(h != nullptr, "mq_l2_screen_stats: out of host memory");
         const char *w = reinterpret_cast<const char *>(workspace);
         unsigned over = 0;
-        hipError_t e = hipMemcpyAsync(h, w + Q.cand, ne * 8, hipMemcpyDeviceToHost, S(stream));
+        hipError_t e = hipMemcpyAsync(h, w + Q.head, ne * 8, hipMemcpyDeviceToHost, S(stream));
         if (e == hipSuccess) e = hipMemcpyAsync(&over, w + Q.counters, 4, hipMemcpyDeviceToHost, S(stream));
         if (e == hipSuccess) e = hipStreamSynchronize(S(stream));
         if (e != hipSuccess) {
@@ -1181,10 +1221,10 @@ extern "C" int mq_l2_screen_stats(const void *workspace, int64_t n, int k, int d
             return ::mq::fail("mq_l2_screen_stats: copy failed: %s", hipGetErrorString(e));
         }
         uint64_t a = 0;
-        for (size_t i = 0; i < ne; ++i) a += h[i].x != 0xFFFFFFFFu;
+        for (size_t i = 0; i < ne; ++i) a += h[i].y;
         free(h);
         *appended = a;
-        *slots = ne;
+        *slots = ne * SR_CAP;
         *rows_over = over;
         return 0;
     }
