@@ -172,7 +172,16 @@ def hbm_bound_of(tr, batches, lens, steps=2):
     return out
 
 
-def time_events(fn, iters):
+def time_events(fn, iters, warm_s=0.25):
+    """Mean milliseconds of `iters` back-to-back calls (HIP events) in the STEADY state: the chip's clock ramps over tens of
+    milliseconds (tools/microbench/f32_gemm_lab.hip, profiles/r6_f32_gemm_lab.txt: a 0.5 ms kernel measured after one warm-up
+    call reads 1.5 GHz, the steady state 2.3-2.4), and these kernels live inside a 190 ms step, so the calls are repeated for
+    `warm_s` seconds first."""
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < warm_s:
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(iters):
