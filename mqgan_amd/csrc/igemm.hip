@@ -493,6 +493,194 @@ __global__ __launch_bounds__(256, (BN == 128 ? 3 : 4)) void conv_nt_bf16_kernel(
     conv_nt_body<EngBF16, BN, DGRAD, MODE>(act, wgt, bias, out, g, wg, act_group_stride, w_group_stride, smem, epi);
 }
 
+
+// ------------------------------------------------------------------------------------------ dense 256 x 128 tile (round 6)
+// The Winograd-domain products (MODE 4) with >= 128 output columns on a 256 x 128 block tile: four waves as 2 x 2, wave tile 128 x 64
+// (eight 32 x 32 accumulators), two blocks per CU.  What changed against nt_gemm_mainloop (tools/microbench/f32_gemm_lab.hip measured
+// each step, profiles/r6_f32_gemm_lab.txt): LDS rows of 16 floats without padding, the 16-byte chunk c of row r stored at chunk
+// c ^ ((r >> 2) & 3) - fragment reads (ds_read_b128: four k's per lane and read, half the LDS instructions) and staging writes
+// (ds_write_b128) are both conflict-free; and the K-step is software-pipelined: two groups of 32 MFMAs (the lane's two float4
+// fragments), the fragments of the NEXT group and the LDS writes of the NEXT tile issued between the MFMAs of this one, the K-step's
+// one barrier between its two groups, so no MFMA waits for an LDS read issued right in front of it.  Steady state, same box:
+// 512 -> 512  140.4-141.5 TF/s against 135.6-138.7, 256 -> 256  132.6 against 127.9 (+2.0 ... +3.7 %).
+// Accumulation order per accumulator: k = (j, 4 + j), j = 0 .. 3, then (8 + j, 12 + j) of every 16 - another order than the
+// 128-row kernel's, the same exact f32 products (the convolutions are held to float64 at 2e-5, not to a bit pattern).
+struct DenseRow4 {             // rows of a dense [rows][Kdim] f32 matrix: slot j = tile rows 64 j + (tid >> 2), the thread's 16-byte k-quad
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned row_[4], off_[4];
+    int Kdim, soff;
+    __device__ __forceinline__ void init(const float *base, int rows, int Kdim_)
+    {
+        Kdim = Kdim_;
+        rsrc = make_rsrc(base, (size_t)(rows < 0 ? 0 : rows) * Kdim_ * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = (threadIdx.x >> 2) + 64 * j;
+            row_[j] = r < rows ? (unsigned)r * (unsigned)Kdim_ * 4u + 16u * (threadIdx.x & 3) : OOB;
+        }
+        soff = 0;
+    }
+    __device__ __forceinline__ void stage(int k0)
+    {
+        const bool kv = k0 < Kdim;                     // wave-uniform
+        soff = kv ? k0 * 4 : 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) off_[j] = kv ? row_[j] : OOB;
+    }
+    __device__ __forceinline__ float4 fetch(int j) const { return buf_load4s(rsrc, off_[j], soff); }
+};
+
+__global__ __launch_bounds__(256, 2) void conv_nt_dense256_kernel(const float *__restrict__ act, const float *__restrict__ wgt,
+                                                                 const float *__restrict__ bias, float *__restrict__ out, ConvGeom g,
+                                                                 size_t act_group_stride, size_t w_group_stride)
+{
+    constexpr int BM = 256, BN = 128, TM = 4, TN = 2, AS = 4, BS = 2;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * 16];
+    const int grp = blockIdx.y;
+    const int tile = xcd_remap(blockIdx.x, g.nMt * g.nNt);
+    const int mt = tile / g.nNt, nt = tile - mt * g.nNt;
+    const int m0 = mt * BM, n0 = nt * BN;
+    DenseRow4 la, lb;
+    la.init(act + (size_t)grp * act_group_stride + (size_t)m0 * g.Kdim, g.Mtot - m0, g.Kdim);
+    lb.init(wgt + (size_t)grp * w_group_stride + (size_t)n0 * g.Kdim, g.Ncols - n0, g.Kdim);
+    const int nk = g.Kdim / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    float *As = smem, *Bs = smem + 2 * BM * 16;
+    const int ld_row = tid >> 2, ld_kq = tid & 3;
+    const int st_off = ld_row * 16 + 4 * (ld_kq ^ ((ld_row >> 2) & 3));            // rows ld_row + 64 j share (row >> 2) & 3
+    const int sw = (li >> 2) & 3;
+    const int fo[2] = {4 * ((0 + lh) ^ sw), 4 * ((2 + lh) ^ sw)};
+    const float *Ar = As + (wm * 128 + li) * 16, *Br = Bs + (wn * 64 + li) * 16;
+    float4 ra[AS], rb[BS];
+    float4 fa[2][TM], fb[2][TN];
+    f32x16 acc[TM][TN];
+    auto frag_a = [&](int buf, int s_, int t) { fa[s_][t] = *reinterpret_cast<const float4 *>(Ar + buf * BM * 16 + t * 32 * 16 + fo[s_]); };
+    auto frag_b = [&](int buf, int s_, int t) { fb[s_][t] = *reinterpret_cast<const float4 *>(Br + buf * BN * 16 + t * 32 * 16 + fo[s_]); };
+    auto put_a = [&](int buf, int j) { *reinterpret_cast<float4 *>(&As[buf * BM * 16 + st_off + 64 * 16 * j]) = ra[j]; };
+    auto put_b = [&](int buf, int j) { *reinterpret_cast<float4 *>(&Bs[buf * BN * 16 + st_off + 64 * 16 * j]) = rb[j]; };
+    // prologue: tile 0 -> LDS buffer 0, tile 1 -> staging registers, fragments (0, 0)
+    la.stage(0);
+    lb.stage(0);
+#pragma unroll
+    for (int j = 0; j < AS; ++j) ra[j] = la.fetch(j);
+#pragma unroll
+    for (int j = 0; j < BS; ++j) rb[j] = lb.fetch(j);
+#pragma unroll
+    for (int j = 0; j < AS; ++j) put_a(0, j);
+#pragma unroll
+    for (int j = 0; j < BS; ++j) put_b(0, j);
+    la.stage(16);
+    lb.stage(16);
+#pragma unroll
+    for (int j = 0; j < AS; ++j) ra[j] = la.fetch(j);
+#pragma unroll
+    for (int j = 0; j < BS; ++j) rb[j] = lb.fetch(j);
+    la.stage(32);
+    lb.stage(32);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < TM; ++t) frag_a(0, 0, t);
+#pragma unroll
+    for (int t = 0; t < TN; ++t) frag_b(0, 0, t);
+
+    // 8 MFMAs of one k pair (element e of fragment s) over the wave tile
+    auto mfma8 = [&](int s_, int e, bool zero_first) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const float av = e == 0 ? fa[s_][tm].x : e == 1 ? fa[s_][tm].y : e == 2 ? fa[s_][tm].z : fa[s_][tm].w;
+                const float bv = e == 0 ? fb[s_][tn].x : e == 1 ? fb[s_][tn].y : e == 2 ? fb[s_][tn].z : fb[s_][tn].w;
+                if (zero_first) {
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, zero, 0, 0, 0);
+                } else {
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tm][tn], 0, 0, 0);
+                }
+            }
+    };
+    auto k_step = [&](int kt, auto cur_tag, auto first_tag) {
+        constexpr int cur = decltype(cur_tag)::value;
+        constexpr bool first = decltype(first_tag)::value;
+        // ---- group 0: MFMAs on (kt, 0); fragments (kt, 1) early, the LDS writes of tile kt + 1 late
+        mfma8(0, 0, first);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TM; ++t) frag_a(cur, 1, t);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(0, 1, false);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TN; ++t) frag_b(cur, 1, t);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(0, 2, false);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < AS; ++j) put_a(cur ^ 1, j);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(0, 3, false);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < BS; ++j) put_b(cur ^ 1, j);
+        __syncthreads();                                   // tile kt + 1 is in LDS; every read of tile kt has been issued and awaited
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- group 1: MFMAs on (kt, 1); global loads of tile kt + 2, fragments (kt + 1, 0) a whole chunk of MFMAs ahead of their use
+        mfma8(1, 0, false);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < AS; ++j) ra[j] = la.fetch(j);
+#pragma unroll
+        for (int t = 0; t < TM; ++t) frag_a(cur ^ 1, 0, t);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(1, 1, false);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < BS; ++j) rb[j] = lb.fetch(j);
+#pragma unroll
+        for (int t = 0; t < TN; ++t) frag_b(cur ^ 1, 0, t);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(1, 2, false);
+        __builtin_amdgcn_sched_barrier(0);
+        la.stage((kt + 3) * 16);
+        lb.stage((kt + 3) * 16);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(1, 3, false);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using c0 = std::integral_constant<int, 0>;
+    using c1 = std::integral_constant<int, 1>;
+    k_step(0, c0{}, std::true_type{});
+    int kt = 1;
+    for (; kt + 1 < nk; kt += 2) {
+        k_step(kt, c1{}, std::false_type{});
+        k_step(kt + 1, c0{}, std::false_type{});
+    }
+    if (kt < nk) k_step(kt, c1{}, std::false_type{});
+
+    // plain store (+ bias) through a buffer descriptor that ends behind the tile's last valid row, as conv_nt_body's
+    float *o = out + (size_t)grp * g.Mtot * g.Ncols;
+    const int rows_left = g.Mtot - m0 < BM ? g.Mtot - m0 : BM;
+    const unsigned pitch = (unsigned)g.Ncols * 4u;
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(o + (size_t)m0 * g.Ncols, (size_t)rows_left * pitch);
+    const int lane_row = wm * 128 + 4 * lh;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + wn * 64 + tn * 32 + li;
+        const bool colok = n < g.Ncols;
+        const float bv = (bias && colok) ? bias[(size_t)grp * g.Ncols + n] : 0.f;
+        const unsigned voff = colok ? (unsigned)lane_row * pitch + (unsigned)n * 4u : 0x80000000u;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned rstep = (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * pitch;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[tm][tn][r] + bv), ro, (int)(voff + rstep), 0, 0);
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ dgrad by stride parity
 // For stride > 1 only the taps with (ih + ph - r*dh) % sh == 0 contribute to input pixel ih: 1/sh of
 // the rows of the filter (and 1/sw of its columns).  The input pixels are therefore partitioned into
@@ -1452,6 +1640,17 @@ static int launch_nt(const mqConvDesc *d, const float *act, const float *w, cons
     if (!DGRAD && mode == 3 && !hmode && d->R == 1 && d->S == 1 && d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 0 && d->pad_w == 0 &&
         d->P == d->H && d->Q == d->W && (size_t)GEMM_BM * g.Kdim * sizeof(float) < 0x7FFFFFF0ull && getenv("MQGAN_NO_DENSE") == nullptr)
         mode = 4;
+    // round 6: the dense products with >= 128 output columns and enough rows for 256-row tiles on the pipelined 256 x 128 kernel
+    // (MQGAN_NO_DENSE256=1: the 128-row kernel, for A/B runs and the tests that compare the two)
+    if (!DGRAD && mode == 4 && BN == 128 && !x3 && !bf16 && !hmode && epi.act == 0 && g.Kdim % 16 == 0 && g.Mtot >= 1024 &&
+        (size_t)256 * g.Kdim * sizeof(float) < 0x7FFFFFF0ull && getenv("MQGAN_NO_DENSE256") == nullptr) {
+        ConvGeom g2 = g;
+        g2.nMt = (int)cdiv(g.Mtot, 256);
+        kname("conv_nt_dense256_kernel<%d>", 128);
+        hipLaunchKernelGGL(conv_nt_dense256_kernel, dim3(g2.nMt * g2.nNt, d->groups), dim3(256), 0, st, act, w, bias, out, g2, act_gs, w_gs);
+        MQ_LAUNCH_CHECK("mq_conv_fprop(dense256)");
+        return 0;
+    }
     dim3 grid(g.nMt * g.nNt, d->groups), block(256);
 #define MQ_NT(BN_, M_) do { kname("conv_nt_kernel<%d, %s, %d>", BN_, tf(DGRAD), M_); hipLaunchKernelGGL((conv_nt_kernel<BN_, DGRAD, M_>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs, epi); } while (0)
 #define MQ_NTH(BN_, M_) do { kname("conv_nt_bf16_kernel<%d, %s, %d>", BN_, tf(DGRAD), M_); hipLaunchKernelGGL((conv_nt_bf16_kernel<BN_, DGRAD, M_>), grid, block, 0, st, act, w, bias, out, g, wg, act_gs, w_gs, epi); } while (0)

@@ -548,6 +548,38 @@ POLY_CMAX = 2e-4
 WINO1D_CMAX = 2e-4
 WINOW_CMAX = 5e-5
 
+@pytest.mark.parametrize("G,M,N,K", [(3, 1024, 128, 64), (2, 1333, 250, 144), (1, 4096, 512, 512), (5, 1100, 200, 16), (2, 2049, 256, 80)])
+def test_dense256_gemm_vs_float64_and_the_128_row_kernel(env, monkeypatch, G, M, N, K):
+    """conv_nt_dense256_kernel (round 6: the Winograd-domain products with >= 128 output columns and >= 1024 rows per group on a
+    pipelined 256 x 128 tile) through mq_conv_fprop on a batch-grouped 1 x 1 convolution: against a float64 matrix product at the
+    direct kernels' bound, and against the 128-row kernel it replaces (MQGAN_NO_DENSE256=1; another accumulation order, so not
+    bit for bit) - whole and ragged row / column tiles, one and several K-steps, an odd K-step count, groups, bias."""
+    import ctypes as C
+    ops = env
+    torch.manual_seed(G * 1000 + M)
+    x = torch.randn(G * M, K, device=DEV)                   # (N = G * M images of 1 x 1 pixels, C = K)
+    w = torch.randn(G * N, K, device=DEV) / K ** 0.5        # KRSC with R = S = 1, per group N filters
+    b = torch.randn(G * N, device=DEV)
+    d = ops.conv_desc(G * M, 1, 1, K, N, 1, 1, groups=G, precision="f32")
+
+    def run():
+        y = torch.full((G * M, N), float("nan"), device=DEV)
+        ops.check(ops.L().mq_conv_fprop(C.byref(d), ops.fptr(x), ops.fptr(w), ops.fptr(b), ops.fptr(y), ops.stream()), "mq_conv_fprop")
+        return y, ops.L().mq_last_kernel().decode()
+
+    y, name = run()
+    assert name == "conv_nt_dense256_kernel<128>", name
+    monkeypatch.setenv("MQGAN_NO_DENSE256", "1")
+    y0, name0 = run()
+    monkeypatch.delenv("MQGAN_NO_DENSE256")
+    assert name0 == "conv_nt_kernel<128, false, 4>", name0
+    ref = torch.stack([x[g * M:(g + 1) * M].double().cpu() @ w[g * N:(g + 1) * N].double().cpu().T + b[g * N:(g + 1) * N].double().cpu()
+                       for g in range(G)]).reshape(G * M, N)
+    assert_elem(y, ref, 2e-6, 2e-5, f"dense256 G{G} M{M} N{N} K{K}")
+    assert_elem(y0, ref, 2e-6, 2e-5, f"dense128 G{G} M{M} N{N} K{K}")
+    assert_elem(y, y0.double().cpu(), 2e-6, 2e-5, "dense256 against the 128-row kernel")
+
+
 WINO_CASES = [
     dict(N=2, H=8, W=10, C=128, K=128, R=3, S=3, pad=(1, 1)),
     dict(N=1, H=7, W=9, C=144, K=128, R=3, S=3, pad=(1, 1)),          # odd height and width: half-used edge tiles

@@ -550,8 +550,10 @@ def test_hifispeech_architecture_step_matches_oracle(monkeypatch, wino_tile, win
     else:
         assert len(cols) >= 12 and any(q[13] for q in rows)                  # 1-D blocks, stride-(2, 1) layers; the nested (3 x 5) layer
     names = set(timer.summary().keys())
-    dense = "conv_nt_x3_kernel<128, false, 4>" if precision == "fp32x3" else "conv_nt_kernel<128, false, 4>"
-    assert dense in names, sorted(names)                                     # the Winograd-domain GEMM instantiation
+    # the Winograd-domain GEMM instantiations: at this test's image sizes the wide layers' products have < 1024 rows per group and
+    # stay on the 128-row kernel; full-size runs take conv_nt_dense256_kernel (test_full_size_config2_winograd_against_direct_kernels)
+    dense = ("conv_nt_x3_kernel<128, false, 4>",) if precision == "fp32x3" else ("conv_nt_kernel<128, false, 4>", "conv_nt_dense256_kernel<128>")
+    assert any(dn in names for dn in dense), sorted(names)
 
     # ---- weights after the first Adam step
     sd = tr.generator.state_dict()
@@ -740,7 +742,8 @@ def test_hifimusic_architecture_step_matches_oracle(monkeypatch):
         _compare_all_grads("oracle-step hifimusic fp32", tr, otr, arch=arch, gates=gates)
         # the forms this architecture's layers take (7 x 7 / stride 2 has no reduced form: direct kernels; the 96-multiple levels
         # take the Winograd form like any 3 x 3 layer)
-        assert any(k.startswith("conv_nt_kernel<") and k.rstrip(">").endswith(", 4") for k in res["fp32"]["kernels"]), sorted(res["fp32"]["kernels"])
+        assert any((k.startswith("conv_nt_kernel<") and k.rstrip(">").endswith(", 4")) or k.startswith("conv_nt_dense256_kernel<")
+                   for k in res["fp32"]["kernels"]), sorted(res["fp32"]["kernels"])
         sd = tr.generator.state_dict()
         for k in ("refiner.ups.0.conv.conv1.parametrizations.weight.original1", "refiner.pre.conv2.bias", "post.conv_out.weight",
                   "refiner.reproj.weight"):
