@@ -132,7 +132,7 @@ def pmc_family_bytes():
         for fam, prefixes in HBM_FAMILIES.items():
             if name.startswith(prefixes):
                 out[fam] += per_step(e)
-        if name.startswith(("winon_", "conv_nt_dense256_kernel<")) or (name.startswith(("conv_nt_kernel<", "conv_wgrad_kernel<")) and name.rstrip(">").endswith(", 4")):
+        if name.startswith(("winon_", "conv_nt_dense256_kernel")) or (name.startswith(("conv_nt_kernel<", "conv_wgrad_kernel<")) and name.rstrip(">").endswith(", 4")):
             wino2d += per_step(e)
     out["_wino2d_layers"] = wino2d
     return out, src

@@ -1646,7 +1646,7 @@ static int launch_nt(const mqConvDesc *d, const float *act, const float *w, cons
         (size_t)256 * g.Kdim * sizeof(float) < 0x7FFFFFF0ull && getenv("MQGAN_NO_DENSE256") == nullptr) {
         ConvGeom g2 = g;
         g2.nMt = (int)cdiv(g.Mtot, 256);
-        kname("conv_nt_dense256_kernel<%d>", 128);
+        kname("conv_nt_dense256_kernel");
         hipLaunchKernelGGL(conv_nt_dense256_kernel, dim3(g2.nMt * g2.nNt, d->groups), dim3(256), 0, st, act, w, bias, out, g2, act_gs, w_gs);
         MQ_LAUNCH_CHECK("mq_conv_fprop(dense256)");
         return 0;

@@ -568,7 +568,7 @@ def test_dense256_gemm_vs_float64_and_the_128_row_kernel(env, monkeypatch, G, M,
         return y, ops.L().mq_last_kernel().decode()
 
     y, name = run()
-    assert name == "conv_nt_dense256_kernel<128>", name
+    assert name == "conv_nt_dense256_kernel", name
     monkeypatch.setenv("MQGAN_NO_DENSE256", "1")
     y0, name0 = run()
     monkeypatch.delenv("MQGAN_NO_DENSE256")

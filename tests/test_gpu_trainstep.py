@@ -552,7 +552,7 @@ def test_hifispeech_architecture_step_matches_oracle(monkeypatch, wino_tile, win
     names = set(timer.summary().keys())
     # the Winograd-domain GEMM instantiations: at this test's image sizes the wide layers' products have < 1024 rows per group and
     # stay on the 128-row kernel; full-size runs take conv_nt_dense256_kernel (test_full_size_config2_winograd_against_direct_kernels)
-    dense = ("conv_nt_x3_kernel<128, false, 4>",) if precision == "fp32x3" else ("conv_nt_kernel<128, false, 4>", "conv_nt_dense256_kernel<128>")
+    dense = ("conv_nt_x3_kernel<128, false, 4>",) if precision == "fp32x3" else ("conv_nt_kernel<128, false, 4>", "conv_nt_dense256_kernel")
     assert any(dn in names for dn in dense), sorted(names)
 
     # ---- weights after the first Adam step
@@ -742,7 +742,7 @@ def test_hifimusic_architecture_step_matches_oracle(monkeypatch):
         _compare_all_grads("oracle-step hifimusic fp32", tr, otr, arch=arch, gates=gates)
         # the forms this architecture's layers take (7 x 7 / stride 2 has no reduced form: direct kernels; the 96-multiple levels
         # take the Winograd form like any 3 x 3 layer)
-        assert any((k.startswith("conv_nt_kernel<") and k.rstrip(">").endswith(", 4")) or k.startswith("conv_nt_dense256_kernel<")
+        assert any((k.startswith("conv_nt_kernel<") and k.rstrip(">").endswith(", 4")) or k.startswith("conv_nt_dense256_kernel")
                    for k in res["fp32"]["kernels"]), sorted(res["fp32"]["kernels"])
         sd = tr.generator.state_dict()
         for k in ("refiner.ups.0.conv.conv1.parametrizations.weight.original1", "refiner.pre.conv2.bias", "post.conv_out.weight",
