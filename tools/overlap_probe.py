@@ -38,7 +38,13 @@ def stream_pass(st):
     check(L().mq_axpby(fptr(big), fptr(big), 0.5, 0.5, big.numel(), fptr(out), C.c_void_p(st.cuda_stream)), "axpby")
 
 
-sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+# argv[1]: "equal" (default) or "prio" - the streaming pass on a HIGH-priority stream, the GEMM on a low-priority one.  The streaming
+# pass's grid is capped by MQGAN_EW_CAP (read once per process by the library): with a few hundred looping blocks it can only ever hold
+# a slot or two per CU, whatever the dispatcher does.
+mode = sys.argv[1] if len(sys.argv) > 1 else "equal"
+lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+sa = torch.cuda.Stream(priority=0) if mode == "equal" else torch.cuda.Stream(priority=0)
+sb = torch.cuda.Stream(priority=0) if mode == "equal" else torch.cuda.Stream(priority=-1)
 
 
 def run(fa, fb, reps=30):
@@ -57,5 +63,5 @@ for _ in range(2):
     run(gemm, stream_pass, 5)
 a, b, ab = run(gemm, None), run(None, stream_pass), run(gemm, stream_pass)
 flop = 2.0 * G * M * Cc * K
-print(f"GEMM alone {a:.3f} ms ({flop / a / 1e9:.0f} TF/s); streaming pass alone {b:.3f} ms ({3 * 4 * big.numel() / b / 1e9:.2f} TB/s); "
+print(f"[{mode}, MQGAN_EW_CAP={os.environ.get('MQGAN_EW_CAP', 'default')}] GEMM alone {a:.3f} ms ({flop / a / 1e9:.0f} TF/s); streaming pass alone {b:.3f} ms ({3 * 4 * big.numel() / b / 1e9:.2f} TB/s); "
       f"both on two streams {ab:.3f} ms (sum {a + b:.3f}, max {max(a, b):.3f}): overlap saves {100 * (a + b - ab) / min(a, b):.0f} % of the shorter one")
