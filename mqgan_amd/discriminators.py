@@ -167,7 +167,7 @@ def _run_discriminators(bands, x, x_lengths, return_features, need_input_grad, d
         N, H, W, Cin = out.shape
         if i == n - 1:                                                        # masked SE before the logits conv (:216-217)
             out = ops.to_f32(out)
-            sq = ops.SeSqueezeFn.apply(out, mask)                             # (G*B, C)
+            out, sq = ops.SeSqueezeSkipFn.apply(out, mask)                    # (G*B, C); `out` itself, its gradient summed in place
             w1k, w1c, b1 = _stacked(bands, lambda d: d.se_block.fc1, detach=detach_params)
             w2k, w2c, b2 = _stacked(bands, lambda d: d.se_block.fc2, detach=detach_params)
             r = b1.numel() // G

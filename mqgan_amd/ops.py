@@ -1402,7 +1402,13 @@ class CbamApplyFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------- masked SE
-class SeSqueezeFn(torch.autograd.Function):
+class SeSqueezeSkipFn(torch.autograd.Function):
+    """Masked mean over (H, W) for the squeeze-excite block, for the usual case that x goes on to SeScaleFn: returns (x, squeeze(x)) and, in backward, ADDS the squeeze's
+    broadcast gradient into the gradient that arrived for x (mq_se_squeeze_bwd accumulates) instead of handing autograd a second
+    full-size tensor to sum - one fill and one three-stream add over the discriminator's widest feature map less per pass, same
+    two-operand additions (bit-identical).  The incoming gradient is updated in place: it is the tensor SeScaleFn.backward (or
+    autograd's own accumulation, with several consumers) produced for this edge alone."""
+
     @staticmethod
     def forward(ctx, x, mask):
         B, H, W, Cc = x.shape
@@ -1410,13 +1416,18 @@ class SeSqueezeFn(torch.autograd.Function):
         check(L().mq_se_squeeze(fptr(x), ptr(mask, torch.uint8), B, H, W, Cc, fptr(sq), stream()), "mq_se_squeeze")
         ctx.save_for_backward(mask)
         ctx.dims = (B, H, W, Cc)
-        return sq
+        return x, sq
 
     @staticmethod
-    def backward(ctx, dsq):
+    def backward(ctx, dx, dsq):
         (mask,) = ctx.saved_tensors
         B, H, W, Cc = ctx.dims
-        dx = torch.zeros(ctx.dims, dtype=F32, device=dsq.device)
+        if dsq is None:
+            return dx, None
+        if dx is None:
+            dx = torch.zeros(ctx.dims, dtype=F32, device=dsq.device)
+        elif not dx.is_contiguous() or dx.dtype != F32:
+            dx = dx.to(F32).contiguous()
         check(L().mq_se_squeeze_bwd(fptr(dsq.contiguous()), ptr(mask, torch.uint8), B, H, W, Cc, fptr(dx), stream()),
               "mq_se_squeeze_bwd")
         return dx, None
