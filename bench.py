@@ -432,7 +432,8 @@ def collectives_of(tr, world, forced):
     if not (world > 1 or forced):
         return None
     out = dict(tr.bench_comm or {})          # exposed communication and per-rank step times of the timed region (timed_run)
-    out.update({"backend": dist.get_backend(), "ranks_counted_by_all_reduce": world, "forced_on_one_rank": bool(forced and world == 1),
+    abi = bool(getattr(tr.comm, "buckets_async", False))
+    out.update({"backend": "rccl behind the C ABI (mq_allreduce_bucket)" if abi else dist.get_backend(), "ranks_counted_by_all_reduce": world, "forced_on_one_rank": bool(forced and world == 1),
             "gradient_buckets_per_step": len(tr.reducer_g.buckets) + len(tr.reducer_d.buckets),
             "bucket_MiB": [round((e - s) * 4 / 2**20, 1) for red in (tr.reducer_d, tr.reducer_g) for (s, e, _) in red.buckets],
             # the bucket whose gradients are ready LAST (the first layers: backward has ended, nothing is left to hide its
@@ -447,7 +448,7 @@ def collectives_of(tr, world, forced):
     return out
 
 
-def timed_run(cfg, precision, B, T, steps, warmup, device, world, rank, force=False):
+def timed_run(cfg, precision, B, T, steps, warmup, device, world, rank, force=False, abi=False):
     """W untimed + K timed optimisation steps of one configuration; returns the trainer, inputs, kernel timer, wall
     seconds of the timed region (max over ranks) and the last step's losses."""
     import copy
@@ -457,7 +458,11 @@ def timed_run(cfg, precision, B, T, steps, warmup, device, world, rank, force=Fa
     cfg["training"]["precision"] = precision
     mel = cfg["model"]["mel_channels"]
     _trace(rank, "building the trainer")
-    tr = Trainer(cfg, device=device, build_data=False, force_collectives=force)
+    comm = None
+    if abi:                                  # device collectives through include/mqgan_hip.h's own RCCL entry points
+        from mqgan_amd.comm import RcclAbiComm
+        comm = RcclAbiComm(force=force)
+    tr = Trainer(cfg, device=device, build_data=False, comm=comm, force_collectives=force)
     tr.generator.train()
     tr.patch_discriminator.train()
     tr.multibin_discriminator.train()
@@ -561,6 +566,18 @@ def forced_collectives_line(cfg, device, B, T, ms_plain):
         del tr, batches
     finally:
         dist.destroy_process_group()
+    torch.cuda.empty_cache()
+    # the same three steps with the collectives behind the C ABI (mq_comm_init / mq_allreduce_bucket, no torch.distributed)
+    try:
+        tr, batches, lens, timer, elapsed, last = timed_run(cfg, "fp32", B, T, steps, warmup, device, 1, 0, force=True, abi=True)
+        out["through_the_c_abi"] = {"ms_per_step": elapsed / steps * 1e3, "exposed_comm_ms_per_step": (tr.bench_comm or {}).get("exposed_comm_ms_per_step"),
+                                    "ms_between_last_bucket_ready_and_clip": (tr.bench_comm or {}).get("ms_between_last_bucket_ready_and_clip"),
+                                    "collective_calls": tr.comm.calls, "losses_finite": all(np.isfinite(float(v)) for v in last.values()),
+                                    "entry_points": "mq_comm_unique_id / mq_comm_init / mq_allreduce_bucket / mq_comm_destroy"}
+        tr.comm.close()
+        del tr, batches
+    except Exception as e:                   # noqa: BLE001 - a secondary block must not take the line down
+        out["through_the_c_abi"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     torch.cuda.empty_cache()
     return out
 

@@ -633,6 +633,25 @@ int mq_conv_fprop_planned(const mqConvPlan *plan, const float *x, const float *w
 int mq_conv_backward_planned(const mqConvPlan *plan, const float *x, const void *keep, const float *w_krsc, const float *w_crsk,
                              const float *dy, const float *gate, float gate_slope, const uint8_t *gate_mask, int64_t g1, int64_t g2,
                              int64_t g3, float *dx, float *dw, float *db, void *workspace, size_t workspace_bytes, mqStream stream);
+/* ------------------------------------------------------------------ data-parallel exchange (SURVEY.md 8b `allreduce_bucket`, 8e)
+ * The reference trains on ONE device (train.py:229-233) and has no collective; under data parallelism the gradients that
+ * train.py:400-404 (discriminators) and :489-493 (generator) clip and apply are the SUMS over the ranks of the per-rank gradients
+ * (the 1 / world factor goes into mq_clip_adam's grad_scale; the loss normalisers are global sums, mqgan_amd/comm.py).  RCCL is
+ * resolved at run time (dlopen: a copy the process already maps - PyTorch-ROCm's own - wins, else the system librccl.so, or the
+ * file MQGAN_RCCL_LIB names); the library has no link-time dependency on it and nothing here is touched by a single-GPU run.
+ *   mq_comm_unique_id   rank 0 fills MQ_COMM_ID_BYTES host bytes (ncclUniqueId) and hands them to every rank over any host channel
+ *   mq_comm_init        collective over the `world` ranks; the calling thread's current HIP device is the rank's GPU (one per rank)
+ *   mq_allreduce_bucket in-place SUM of n floats over the ranks, asynchronous on `stream` (a side stream, so that a bucket's exchange
+ *                       runs behind the rest of backward: the caller orders it after the bucket's last gradient with an event and
+ *                       makes the compute stream wait for it before mq_clip_adam); one call at a time per communicator
+ *   mq_comm_destroy     after the last collective has completed */
+#define MQ_COMM_ID_BYTES 128
+typedef struct mqComm mqComm;
+int mq_comm_unique_id(void *id_host);
+int mq_comm_init(mqComm **comm, int world, int rank, const void *id_host);
+int mq_allreduce_bucket(mqComm *comm, float *buf, size_t n, mqStream stream);
+int mq_comm_destroy(mqComm *comm);
+
 /* DEBUG / MEASUREMENT ONLY - the one piece of process-global state in this ABI (everything else is per call and per stream):
  * two function pointers, not thread-safe, meant for ONE measuring thread (bench.py, tools/layer_profile.py) and NULL otherwise;
  * a production caller never sets them, and with both NULL the library keeps no state between calls.

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MQGAN_HIP_LIB: load another build of the same ABI (kernel experiments); the default is the in-tree library
 LIB_PATH = os.environ.get("MQGAN_HIP_LIB") or os.path.join(_HERE, "libmqgan_hip.so")
 _lib = None
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class MqganHipError(RuntimeError):
@@ -174,6 +174,10 @@ SIGNATURES = {
     "mq_multi_gather": (_I, [_P, _I, _L, _P, _P]),
     "mq_multi_gather_args": (_I, [_P, _I, _P, _P]),
     "mq_adam_step": (_I, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _I, _P, _F, _F, _P]),
+    "mq_comm_unique_id": (_I, [_P]),
+    "mq_comm_init": (_I, [C.POINTER(_P), _I, _I, _P]),
+    "mq_allreduce_bucket": (_I, [_P, _P, _Z, _P]),
+    "mq_comm_destroy": (_I, [_P]),
 }
 
 # Exported by the TEST-VARIANT build only (make -C mqgan_amd/csrc variants -> libmqgan_hip_variants.so): the transform building blocks

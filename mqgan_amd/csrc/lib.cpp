@@ -26,6 +26,8 @@ thread_local char g_kernel[128] = "";
 //    building blocks mq_winon_* / mq_wino1d_* / mq_winow_* and mq_winofused_fprop are internal (MQ_BLOCKS_API) and exported by the
 //    test-variant build alone (make variants), which also carries the rejected kernel variants; the two hooks are named
 //    mq_debug_set_*_hook; the screened codebook search's bound comes from measured rounding residuals
-extern "C" int mq_abi_version(void) { return 10; }
+// 11: mq_comm_unique_id / mq_comm_init / mq_allreduce_bucket / mq_comm_destroy (the gradient-bucket all-reduce over RCCL, resolved
+//    with dlopen at first use: csrc/collective.cpp)
+extern "C" int mq_abi_version(void) { return 11; }
 extern "C" const char *mq_last_error(void) { return mq::g_err; }
 extern "C" const char *mq_last_kernel(void) { return mq::g_kernel; }

@@ -155,8 +155,13 @@ class GradReducer:
         self.pg = process_group
         # ``comm``: a non-torch.distributed communicator (mqgan_amd.comm.Comm with world > 1, e.g. a test double): the whole
         # gradient arena is then summed in finish() with one blocking call instead of hooked, bucketed async all-reduces
-        self.comm = comm if (comm is not None and comm.world > 1 and not dist.is_initialized()) else None
-        self.world = self.comm.world if self.comm is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
+        # ``comm.buckets_async`` (comm.RcclAbiComm): the buckets go through the communicator's own asynchronous all-reduce - the
+        # C ABI's mq_allreduce_bucket on a side stream - from the same hooks, instead of torch.distributed's
+        self._abi = comm if getattr(comm, "buckets_async", False) else None
+        self.comm = comm if (comm is not None and comm.world > 1 and not dist.is_initialized() and self._abi is None) else None
+        self.world = (self._abi.world if self._abi is not None else self.comm.world if self.comm is not None
+                      else (dist.get_world_size(process_group) if dist.is_initialized() else 1))
+        self._rank = self._abi.rank if self._abi is not None else (dist.get_rank(process_group) if dist.is_initialized() else 0)
         self.average = average
         self.buckets = []                      # (start, end) element ranges of flat_grad, reverse order
         self.bucket_members = []               # positions in arena.params, per bucket
@@ -185,7 +190,8 @@ class GradReducer:
         self._hooks = []
         self._last_launch_event = None         # HIP event at the launch of the step's last bucket (while the StallClock runs)
         self._tail_pairs = []                  # (that event, event behind finish()'s waits) per step
-        self.enabled = (self.world > 1 or (force and dist.is_initialized())) and self.comm is None
+        self.enabled = ((self.world > 1 or (force and dist.is_initialized())) and self.comm is None) if self._abi is None \
+            else self._abi.active
         # gloo with DEVICE tensors (only the one-GPU rehearsal of the multi-rank path uses it): ProcessGroupGloo stages every
         # collective through a private HIGH-PRIORITY stream that waits ON THE DEVICE for the compute stream.  With several
         # ranks sharing one GPU those waiting high-priority queues starve the normal-priority compute queues they wait for
@@ -194,7 +200,8 @@ class GradReducer:
         # asynchronous, issued from the hooks and waited in finish() exactly as under RCCL (whose stream has normal priority
         # and whose ranks own their GPU).
         self.clock = getattr(comm, "clock", None)       # StallClock of the trainer's communicator: exposed waits on the buckets
-        self._drain_first = (not _ASYNC and self.enabled and arena.flat_grad.is_cuda and dist.get_backend(process_group) == "gloo")
+        self._drain_first = (not _ASYNC and self.enabled and self._abi is None and arena.flat_grad.is_cuda
+                             and dist.get_backend(process_group) == "gloo")
         self._blocking = _BLOCKING
         if self.enabled:
             for p in arena.params:
@@ -236,13 +243,16 @@ class GradReducer:
         self._launched[b] = True
         if _TRACE:
             import sys, threading
-            print(f"[ddp rank {dist.get_rank(self.pg)}] launch bucket {b} of {len(self.buckets)} [{s}:{e}) from "
+            print(f"[ddp rank {self._rank}] launch bucket {b} of {len(self.buckets)} [{s}:{e}) from "
                   f"{threading.current_thread().name}", file=sys.stderr, flush=True)
         self.arena.gather(self.bucket_members[b])      # gather mode: the bucket's gradients move into the arena now
         if self.clock is not None and self.clock.enabled and self.arena.flat_grad.is_cuda:
             ev = torch.cuda.Event(enable_timing=True)   # overwritten by every launch: what is left is the step's last one
             ev.record()
             self._last_launch_event = ev
+        if self._abi is not None:
+            self._handles.append(self._abi.all_reduce_async(self.arena.flat_grad[s:e]))
+            return
         if self._drain_first:
             torch.cuda.current_stream().synchronize()
         if self._blocking:
@@ -281,7 +291,7 @@ class GradReducer:
                 h.wait()
             if _TRACE:
                 import sys
-                print(f"[ddp rank {dist.get_rank(self.pg)}] handle {i} of {len(self._handles)} done", file=sys.stderr, flush=True)
+                print(f"[ddp rank {self._rank}] handle {i} of {len(self._handles)} done", file=sys.stderr, flush=True)
         self._handles = []
         if self._last_launch_event is not None:
             done = torch.cuda.Event(enable_timing=True)

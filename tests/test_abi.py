@@ -49,7 +49,7 @@ def test_library_exports_every_declared_symbol(built):
         assert len(_lib.SIGNATURES[name][1]) == nargs, (name, nargs, len(_lib.SIGNATURES[name][1]))
     for name, nargs in blocks.items():
         assert len(_lib.VARIANT_SIGNATURES[name][1]) == nargs, (name, nargs)
-    assert lib.mq_abi_version() == 10 == _lib.ABI_VERSION
+    assert lib.mq_abi_version() == 11 == _lib.ABI_VERSION
     # nm agrees (extern "C", no mangling) - in BOTH directions: the product library exports exactly the product section of the
     # header, no building block, no prototype (r5 exported 25 transform entry points and mq_winofused_fprop that nothing in the
     # package calls)
@@ -86,6 +86,25 @@ def test_host_side_validation_rejects_bad_shapes_without_a_gpu(built):
     rc = lib.mq_conv_fprop(C.byref(d), C.c_void_p(16), C.c_void_p(16), None, C.c_void_p(16), None)
     assert rc != 0 and b"groups" in lib.mq_last_error()
     assert lib.mq_conv_wgrad_workspace(C.byref(d)) == 0
+
+
+def test_collective_entry_points_resolve_rccl_and_validate_on_the_host(built):
+    """mq_comm_* / mq_allreduce_bucket (SURVEY 8b `allreduce_bucket`): RCCL is resolved with dlopen at the first call - the copy
+    this process already maps (PyTorch-ROCm's own) and no second one - and bad arguments are refused before RCCL sees them."""
+    import ctypes as C
+    import torch  # noqa: F401 - maps torch's librccl.so
+    from mqgan_amd import _lib
+    lib = _lib.load()
+    assert lib.mq_allreduce_bucket(None, C.c_void_p(16), 4, None) != 0 and b"comm is NULL" in lib.mq_last_error()
+    comm, ident = C.c_void_p(), C.create_string_buffer(128)
+    assert lib.mq_comm_init(C.byref(comm), 2, 2, ident) != 0 and b"rank 2 of 2" in lib.mq_last_error()
+    assert lib.mq_comm_init(None, 1, 0, ident) != 0 and b"NULL" in lib.mq_last_error()
+    assert lib.mq_comm_destroy(None) == 0
+    mapped = {line.split()[-1] for line in open(f"/proc/{os.getpid()}/maps") if "rccl" in line}
+    assert len(mapped) == 1, mapped
+    # no link-time dependency: a single-GPU consumer never touches RCCL
+    needed = subprocess.run(["readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rccl" not in needed and "nccl" not in needed
 
 
 def test_planned_calls_validate_on_the_host(built):

@@ -140,6 +140,103 @@ def test_rccl_single_rank_step_is_bit_identical_to_no_collectives():
         assert np.array_equal(plain[i], forced[i]), what
 
 
+# ----------------------------------------------------------------------------------------- RCCL behind the C ABI, one rank
+def _abi_rank(q):
+    try:
+        import ctypes as C
+        torch.cuda.set_device(0)
+        import __graft_entry__ as ge
+        ge.build()
+        from mqgan_amd import _lib, ddp
+        from mqgan_amd.comm import RcclAbiComm
+        import torch.distributed as dist
+        assert not dist.is_initialized()                               # nothing but the library's own entry points
+        lib = _lib.load()
+        # raw ctypes, as INTEGRATION.md section 2 binds it: id -> communicator -> in-place sum on a stream -> destroy
+        ident = C.create_string_buffer(128)
+        assert lib.mq_comm_unique_id(ident) == 0, lib.mq_last_error()
+        assert any(ident.raw)
+        comm = C.c_void_p()
+        assert lib.mq_comm_init(C.byref(comm), 1, 0, ident) == 0, lib.mq_last_error()
+        v = torch.randn(1 << 20, device=DEV)
+        ref = v.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        assert lib.mq_allreduce_bucket(comm, C.c_void_p(v.data_ptr()), v.numel(), C.c_void_p(side.cuda_stream)) == 0, lib.mq_last_error()
+        assert lib.mq_allreduce_bucket(comm, None, 0, None) == 0       # an empty bucket launches nothing
+        torch.cuda.synchronize()
+        assert torch.equal(v, ref)                                     # a sum over one rank
+        assert lib.mq_allreduce_bucket(None, C.c_void_p(v.data_ptr()), 4, None) != 0 and b"comm is NULL" in lib.mq_last_error()
+        assert lib.mq_comm_init(C.byref(comm), 2, 2, ident) != 0 and b"rank 2 of 2" in lib.mq_last_error()
+        assert lib.mq_comm_destroy(comm) == 0
+
+        g = load_golden("g7_trainstep.npz")
+        Ts = [40, 24, 48, 32]
+        batches = [_batch(T, 700 + 10 * i) for i, T in enumerate(Ts)]
+
+        def run(abi):
+            c = RcclAbiComm(force=True) if abi else None
+            tr = _trainer(g, comm=c, force_collectives=abi)
+            launched = []
+            if abi:
+                assert tr.comm is c and c.active and tr.world == 1 and c.any_rank(True) and not c.any_rank(False)
+                tr.reducer_g.remove()
+                tr.reducer_d.remove()
+                tr.reducer_g = ddp.GradReducer(tr.arena_g, bucket_bytes=64 << 10, comm=c, force=True)
+                tr.reducer_d = ddp.GradReducer(tr.arena_d, bucket_bytes=64 << 10, comm=c, force=True)
+                for red in (tr.reducer_g, tr.reducer_d):
+                    assert red.enabled and red._abi is c and len(red.buckets) >= 2
+                    orig = red._launch
+                    red._launch = (lambda o: (lambda b: (launched.append(b), o(b))[1]))(orig)
+            else:
+                assert not tr.reducer_g.enabled and not tr.comm.active
+            res = []
+            for x, lens in batches:             # no host synchronisation between the steps
+                out = tr.train_step(x, lens)
+                res.append((out, tr.arena_g.flat_grad.clone(), tr.arena_d.flat_grad.clone()))
+            torch.cuda.synchronize()
+            res = [({k: float(v) for k, v in o.items()}, a.cpu().numpy(), b.cpu().numpy()) for o, a, b in res]
+            n_buckets = len(tr.reducer_g.buckets) + len(tr.reducer_d.buckets)
+            calls = c.calls if abi else 0
+            out = (res, tr.arena_g.flat_param.cpu().numpy(), tr.arena_d.flat_param.cpu().numpy(), tr.gan_loss._state.cpu().numpy(),
+                   len(launched), n_buckets, calls)
+            if abi:
+                c.close()
+            return out
+
+        q.put(("ok", run(False), run(True)))
+    except BaseException as e:                 # noqa: BLE001 - reported by the parent
+        import traceback
+        q.put(("error", repr(e), traceback.format_exc()))
+
+
+def test_rccl_behind_the_c_abi_single_rank_step_is_bit_identical_to_no_collectives():
+    """include/mqgan_hip.h: mq_comm_unique_id / mq_comm_init / mq_allreduce_bucket / mq_comm_destroy (SURVEY 8b `allreduce_bucket`),
+    first through raw ctypes, then as the Trainer's communicator (comm.RcclAbiComm, NO torch.distributed in the process): the
+    gradient hooks hand every bucket to mq_allreduce_bucket on the communicator's side stream behind an event, finish() makes the
+    compute stream wait for the handles, the loss sums go through the same entry point on the compute stream.  One rank, every
+    collective forced: four unsynchronised steps must equal the plain step bit for bit."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_abi_rank, args=(q,))
+    p.start()
+    msg = q.get(timeout=420)
+    p.join(timeout=120)
+    assert msg[0] == "ok", msg[1:]
+    assert p.exitcode == 0
+    _, plain, abi = msg
+    n_steps = len(plain[0])
+    assert abi[4] == n_steps * abi[5] and abi[5] >= 4                  # every bucket, every step
+    assert abi[6] >= n_steps * (abi[5] + 3)                            # buckets + loss sums, all through mq_allreduce_bucket
+    for s in range(n_steps):
+        assert plain[0][s][0] == abi[0][s][0], f"step {s}: losses differ"
+        assert np.array_equal(plain[0][s][1], abi[0][s][1]), f"step {s}: generator gradient arena"
+        assert np.array_equal(plain[0][s][2], abi[0][s][2]), f"step {s}: discriminator gradient arena"
+    for i, what in ((1, "generator weights"), (2, "discriminator weights"), (3, "LeCam state")):
+        assert np.array_equal(plain[i], abi[i]), what
+
+
 # ----------------------------------------------------------------------------------------- host far ahead of the stream
 def test_arena_fill_rows_are_captured_at_launch():
     """Stall the stream, then enqueue 40 arena fills (each with freshly allocated gradient tensors, > 120 rows so that one fill
