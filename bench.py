@@ -569,8 +569,10 @@ def forced_collectives_line(cfg, device, B, T, ms_plain):
     torch.cuda.empty_cache()
     # the same three steps with the collectives behind the C ABI (mq_comm_init / mq_allreduce_bucket, no torch.distributed)
     try:
-        tr, batches, lens, timer, elapsed, last = timed_run(cfg, "fp32", B, T, steps, warmup, device, 1, 0, force=True, abi=True)
-        out["through_the_c_abi"] = {"ms_per_step": elapsed / steps * 1e3, "exposed_comm_ms_per_step": (tr.bench_comm or {}).get("exposed_comm_ms_per_step"),
+        # two warm-up steps: the allocator regrows after empty_cache() and the first step of an epoch is the long one (train-mode
+        # discriminators); with one, this block read 262 ms where the same trainer then runs at the plain step's rate
+        tr, batches, lens, timer, elapsed, last = timed_run(cfg, "fp32", B, T, steps, 2, device, 1, 0, force=True, abi=True)
+        out["through_the_c_abi"] = {"ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": 2, "exposed_comm_ms_per_step": (tr.bench_comm or {}).get("exposed_comm_ms_per_step"),
                                     "ms_between_last_bucket_ready_and_clip": (tr.bench_comm or {}).get("ms_between_last_bucket_ready_and_clip"),
                                     "collective_calls": tr.comm.calls, "losses_finite": all(np.isfinite(float(v)) for v in last.values()),
                                     "entry_points": "mq_comm_unique_id / mq_comm_init / mq_allreduce_bucket / mq_comm_destroy"}

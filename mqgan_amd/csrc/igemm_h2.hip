@@ -2080,6 +2080,260 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_h2s_kernel(const unsigned s
     conv_wgrad_h2s_body<WRAPS>(x, dy, out, bias_slab, g, groups, smem);
 }
 
+// ------------------------------------------------------------------------------------------ shared-row weight gradient, 96-channel chunks (r6)
+// The refiner's outer levels at config 3 have 96 / 192 / 288 / 576 input channels and 96 / 192 / 384 filters (hifimusic: base 96).
+// No multiple of 128, so their weight gradients ran on conv_wgrad_h2_kernel<2, 2> / <2, 3> with gathered 256-column tiles: K = 96
+// filled 96 of the 128 tile rows and 96 of the 256 channels of every staged dy row - 49 useful flop per DMA byte, 0.16 of the bf16
+// peak on 5 ms of the step (the r5 review's "kernel furthest below its roofline with >= 4 ms").  Here, as in conv_h2s96_kernel on
+// the forward side, an LDS row is one pixel's 96-channel chunk (192 bytes):
+//   block tile  96 RG filters x (one tap row, one 96-channel chunk, the three column taps = 288 columns), 3 RG waves, each 96 x 96
+//               (3 x 3 MFMA tiles of 32 x 32 x 16: the same per-wave work as conv_wgrad_h2s_kernel)
+//   per 64-pixel K-step: RG dy images of 64 pixels x 96 filters (12 KB each) + ONE x image of 66 pixels x 96 channels (12.4 KB),
+//               shared by the three column taps at pixel offsets 0, 1, 2 over the width padded by two (dy is zero at the two
+//               extra positions of a row): 141 (RG = 1) / 191 (RG = 2) flop per DMA byte
+// 192-byte rows need no bank swizzle for the transposed reads: the four pixel rows a half-wave addresses start 192 bytes apart,
+// i.e. at 0, 192, 128, 64 mod 256 - four disjoint 64-byte windows at every row offset (column-tap shifts included).  The LDS-DMA
+// writes whole 1 KB pieces (5 1/3 rows), so each lane derives (row, 16-byte chunk) from its linear chunk index once, before the
+// loop.  Two (RG = 1: 51 KB) / one (RG = 2: 75 KB) blocks per CU by registers (144 accumulators).
+// S = 3, stride 1, column dilation 1, C % 96 == 0, K % 96 == 0 (RG = 2 when K % 192 == 0), Q >= 14.  Pixel sums in the order of
+// conv_wgrad_h2s_kernel (groups of 16 over the padded width): equal to conv_wgrad_h2_kernel within rounding, not bit for bit.
+constexpr int W96_ROWB = 192, W96_DYP = 12, W96_XP = 13;          // bytes per LDS row; 1 KB pieces of a dy image (64 rows) / the x image (66 rows)
+constexpr int W96_BSR = 4;                                        // bias-sum items per thread: 12 RG chunks x 64 pixels / (192 RG threads)
+
+template <int RG, int WRAPS>
+__device__ __forceinline__ void conv_wgrad_h2s96_body(const unsigned short *__restrict__ x, const unsigned short *__restrict__ dy,
+                                                      float *__restrict__ out, float *__restrict__ bias_slab, const H2Wgrad &g, int groups,
+                                                      char *smem)
+{
+    constexpr int NW = 3 * RG, NT = 64 * NW;
+    constexpr int BMK = 96 * RG;
+    constexpr int IMGA = RG * W96_DYP * 1024;                      // the dy images of a stage
+    constexpr int STAGE = IMGA + W96_XP * 1024;
+    constexpr int XS = (W96_XP + NW - 1) / NW;                     // x slots per wave: 5 (three waves) / 3 (six)
+    char *const dummy = smem + 2 * STAGE;                          // 1 KB every out-of-range x slot zero-fills (zeros over zeros)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / 3, wn = wave - 3 * wm;
+    const int li = lane & 31, lh = lane >> 5;
+    const int ntile = gridDim.x;
+    const int lin = blockIdx.x + ntile * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int virt = xcd_remap(lin, ntile * gridDim.y * gridDim.z);
+    const int tile = virt % ntile, sg = virt / ntile;
+    const int grp = sg % gridDim.y, split = sg / gridDim.y;
+    const int kt = tile / g.nCt, ct = tile - kt * g.nCt;
+    const int nchunk = g.IC / 96;
+    const int tap_r = ct / nchunk, chunk = ct - tap_r * nchunk;
+    const int k0 = kt * BMK;
+    const int OWp = g.OW + 2;
+    const int Mp = g.Mtot;                                         // pixels of a group over the padded width (host: ng OH (OW + 2))
+    const int m_begin = split * g.chunk;
+    const int m_end = min(Mp, m_begin + g.chunk);
+    const int ng = Mp / (g.OH * OWp);
+    const int row0 = m_begin / OWp;                                // first (image, output row) of the split: offsets are relative to it
+    const int img0 = row0 / g.OH;
+
+    // ---- dy slots: piece p = wave + NW j, j = 0 .. 3, of the 12 RG pieces; piece p is image p / 12 (filters 96 (p / 12) ...), linear
+    // 16-byte chunks 64 (p % 12) + lane of that image's 64 rows x 12 chunks.  The descriptor ends at the split's last real pixel:
+    // positions past m_end read zeros without a test (a valid position q < m_end has a real index below that of m_end)
+    const unsigned short *dyg = dy + ((size_t)grp * ng * g.OH + row0) * g.OW * g.K;
+    const int row_e = m_end / OWp, owp_e = m_end - row_e * OWp;
+    const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(dyg, ((size_t)(row_e - row0) * g.OW + (owp_e < g.OW ? owp_e : g.OW)) * g.K * 2);
+    int a_owp[4], a_off[4];                                        // padded column; byte offset of (real pixel, filter chunk)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = wave + NW * j;
+        const int rgi = p / W96_DYP;
+        const int L = 64 * (p - rgi * W96_DYP) + lane;
+        const int pix = L / 12, c = L - 12 * pix;
+        const int q = m_begin + pix;
+        const int row = q / OWp;
+        const int ch = k0 + rgi * 96 + 8 * c;
+        a_owp[j] = ch < g.K ? q - row * OWp : (1 << 30);           // a filter chunk beyond K: never a valid column
+        a_off[j] = (((row - row0) * g.OW + q - row * OWp) * g.K + ch) * 2;
+    }
+    // ---- x slots: piece p = wave + NW j of the 13; linear chunk 64 p + lane of the image's 66 rows x 12 chunks
+    const unsigned short *xg = x + ((size_t)grp * ng + img0) * g.IH * g.IW * g.IC;
+    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(xg, (size_t)(ng - img0) * g.IH * g.IW * g.IC * 2);
+    const int tap_h = tap_r * g.dh - g.ph;
+    int b_owp[XS], b_oh[XS], b_base[XS];
+#pragma unroll
+    for (int j = 0; j < XS; ++j) {
+        const int p = wave + NW * j;
+        const int L = 64 * p + lane;
+        const int e = L / 12, c = L - 12 * e;                      // image row, chunk
+        const int q = m_begin + e;
+        const int row = q / OWp;
+        b_owp[j] = (p < W96_XP && e < 66) ? q - row * OWp : -(1 << 30);      // rows the image does not have: never a valid column
+        const int n = row / g.OH;
+        b_oh[j] = row - n * g.OH;
+        b_base[j] = ((((n - img0) * g.IH + b_oh[j] + tap_h) * g.IW + q - row * OWp - g.pw) * g.IC + chunk * 96 + 8 * c) * 2;
+    }
+    auto issue = [&](int stage) {
+        char *st = smem + stage * STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned vo = (unsigned)a_owp[j] < (unsigned)g.OW ? (unsigned)a_off[j] : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, lds_ptr(st + (wave + NW * j) * 1024), 16, vo, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < XS; ++j) {
+            const bool ok = (unsigned)(b_oh[j] + tap_h) < (unsigned)g.IH && (unsigned)(b_owp[j] - g.pw) < (unsigned)g.IW;
+            const unsigned vo = ok ? (unsigned)b_base[j] : OOB;
+            // pieces past the 13th do not exist: those waves issue the same instruction out of range into the shared patch (no branch)
+            char *dst = wave + NW * j < W96_XP ? st + IMGA + (wave + NW * j) * 1024 : dummy;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, lds_ptr(dst), 16, vo, 0, 0, 0);
+        }
+        // advance by 64 positions of the padded enumeration
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a_owp[j] += 64;
+            a_off[j] += 64 * g.K * 2;
+#pragma unroll
+            for (int i = 0; i < WRAPS; ++i) {
+                const bool w1 = a_owp[j] >= OWp;
+                a_owp[j] -= w1 ? OWp : 0;
+                a_off[j] -= w1 ? 2 * g.K * 2 : 0;                    // next row: + OW, column - (OW + 2)
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < XS; ++j) {
+            b_owp[j] += 64;
+            b_base[j] += 64 * g.IC * 2;
+#pragma unroll
+            for (int i = 0; i < WRAPS; ++i) {
+                const bool w1 = b_owp[j] >= OWp;
+                b_owp[j] -= w1 ? OWp : 0;
+                b_oh[j] += w1 ? 1 : 0;
+                b_base[j] += w1 ? (g.IW - OWp) * g.IC * 2 : 0;
+                const bool w2 = b_oh[j] >= g.OH;
+                b_oh[j] -= w2 ? g.OH : 0;
+                b_base[j] += w2 ? (g.IH - g.OH) * g.IW * g.IC * 2 : 0;
+            }
+        }
+    };
+
+    f32x16 acc[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // transposed-read lane constants (conv_wgrad_h2_body, 32x32x16): lane 4 q + p of a 16-lane group addresses pixel row q,
+    // channels 4 p .. 4 p + 3; group gsel = (lane >> 4) & 1 -> channels + 16, lane half lh -> pixels + 8.  No swizzle (192-byte rows)
+    const int trq = (lane & 15) >> 2, trp = lane & 3, gsel = (lane >> 4) & 1;
+    int aad[3], bad[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) aad[t] = wm * W96_DYP * 1024 + (8 * lh + trq) * W96_ROWB + (t * 32 + 16 * gsel + 4 * trp) * 2;
+#pragma unroll
+    for (int sft = 0; sft < 3; ++sft) bad[sft] = IMGA + (8 * lh + trq + sft) * W96_ROWB + (wn * 32 + 16 * gsel + 4 * trp) * 2;
+    const int nsteps = (m_end - m_begin + 63) / 64;
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    auto tr8 = [&](const char *p0, int row_off) {                   // 8 pixels of one channel per lane: two transposed reads
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)lds_ptr(p0 + row_off * W96_ROWB));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)lds_ptr(p0 + (row_off + 4) * W96_ROWB));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto compute = [&](int stage) {
+        const char *base = smem + stage * STAGE;
+#pragma unroll
+        for (int sx = 0; sx < 4; ++sx) {
+            bf16x8 a[3], b[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) a[t] = tr8(base + aad[t], 16 * sx);
+#pragma unroll
+            for (int sft = 0; sft < 3; ++sft) b[sft] = tr8(base + bad[sft], 16 * sx);
+#pragma unroll
+            for (int tm = 0; tm < 3; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 3; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+        }
+    };
+    // bias gradient (see h2_dy_colsum_step): column tile ct owns the 8-filter chunks ct, ct + nCt, ... of the 12 RG; item = (owned
+    // chunk, pixel).  Inline asm: in front of a C++ LDS load the compiler would drain the DMA of the NEXT stage
+    const bool sum_dy = bias_slab != nullptr && ct < 12 * RG;      // block-uniform; dy is zero at the padded positions
+    float bs[W96_BSR][8] = {};
+    auto colsum_step = [&](const char *img) {
+#pragma unroll
+        for (int r = 0; r < W96_BSR; ++r) {
+            const int item = tid + NT * r;
+            const int c16 = ct + g.nCt * (item >> 6), p = item & 63;
+            if (c16 < 12 * RG) {                                   // wave-uniform: a wave's 64 items share the chunk
+                const int rgi = c16 / 12;
+                const unsigned a = (unsigned)reinterpret_cast<uintptr_t>(img + rgi * W96_DYP * 1024 + p * W96_ROWB + ((c16 - 12 * rgi) << 4));
+                u32x4 v;
+                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bs[r][2 * e] += __builtin_bit_cast(float, v[e] << 16);
+                    bs[r][2 * e + 1] += __builtin_bit_cast(float, v[e] & 0xFFFF0000u);
+                }
+            }
+        }
+    };
+    int st_c = 0;
+    for (int t = 0; t < nsteps; ++t) {
+        issue(st_c ^ 1);                 // past the end of the split: dy out of range (zeros); the x image is whatever follows
+        compute(st_c);
+        if (sum_dy) colsum_step(smem + st_c * STAGE);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        st_c ^= 1;
+    }
+    if (sum_dy) {                        // the 64 pixels' sums of a filter are added in a fixed order (h2_dy_colsum_store)
+        float *sp = reinterpret_cast<float *>(smem);               // [owned chunk][8 filters][64 pixels]: <= 24 KB RG
+        float *bias_row = bias_slab + ((size_t)split * groups + grp) * g.K;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < W96_BSR; ++r) {
+            const int item = tid + NT * r;
+            const int slot = item >> 6, p = item & 63;
+            if (ct + g.nCt * slot < 12 * RG) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sp[(slot * 8 + e) * 64 + p] = bs[r][e];
+            }
+        }
+        __syncthreads();
+        const int slot = tid >> 3, e = tid & 7;                    // 24 RG slots x 8 filters = NT threads >= the 12 RG chunks
+        const int c16 = ct + g.nCt * slot;
+        const int ch = c16 * 8 + e;
+        if (c16 < 12 * RG && k0 + ch < g.K) {
+            float tsum = 0.f;
+            for (int q = 0; q < 64; ++q) tsum += sp[(slot * 8 + e) * 64 + q];
+            bias_row[k0 + ch] = tsum;
+        }
+    }
+
+    // slab [split][group][K][RSC]; the tile's columns (tap col s, channel) go to (tap, channel) of the channel-blocked filter layout
+    float *o = out + ((size_t)split * groups + grp) * (size_t)g.K * g.RSC;
+    const int cbs = chan_block(g.IC);
+#pragma unroll
+    for (int sft = 0; sft < 3; ++sft) {
+        const int tap = tap_r * 3 + sft;
+        const int col = kidx(tap, chunk * 96 + wn * 32 + li, g.RS, cbs);
+#pragma unroll
+        for (int tm = 0; tm < 3; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = k0 + wm * 96 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < g.K) o[(size_t)row * g.RSC + col] = acc[tm][sft][r];
+            }
+    }
+}
+
+template <int RG, int WRAPS>
+__global__ __launch_bounds__(192 * RG, 2) void conv_wgrad_h2s96_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ dy,
+                                                                       float *__restrict__ out, float *__restrict__ bias_slab, H2Wgrad g,
+                                                                       int groups)
+{
+    __shared__ __attribute__((aligned(1024))) char smem[2 * (RG * W96_DYP + W96_XP) * 1024 + 1024];
+    conv_wgrad_h2s96_body<RG, WRAPS>(x, dy, out, bias_slab, g, groups, smem);
+}
+
 // out[i] = sum_k slabs[k][i] in the fixed order k = 0, 1, ... (deterministic)
 __global__ void h2_slab_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ out, size_t n4, int splits)
 {
@@ -2625,7 +2879,14 @@ static bool h2_wgrad_shared_shape(const mqConvDesc *d)
 {
     return d->S == 3 && d->stride_w == 1 && d->stride_h == 1 && d->dil_w == 1 && d->C % 128 == 0 && d->K % 192 == 0 && d->Q >= 14;
 }
-static void h2_wgrad_plan_shared(const mqConvDesc *d, H2Wgrad &g)
+// the 96-channel-chunk form (conv_wgrad_h2s96_kernel): what the 128-channel form does not take of the layers with C % 96 == 0 and
+// K % 96 == 0; tiles of 96 RG rows x (tap row, 96-channel chunk), RG = 2 when K % 192 == 0
+static bool h2_wgrad_shared96_shape(const mqConvDesc *d)
+{
+    return d->S == 3 && d->stride_w == 1 && d->stride_h == 1 && d->dil_w == 1 && d->C % 96 == 0 && d->K % 96 == 0 && d->Q >= 14 &&
+           !h2_wgrad_shared_shape(d);
+}
+static void h2_wgrad_plan_shared(const mqConvDesc *d, H2Wgrad &g, int bmk = 192, int chk = 128, int64_t slots = 256)
 {
     const int ng = d->N / d->groups;
     g.OH = d->P; g.OW = d->Q; g.IH = d->H; g.IW = d->W; g.IC = d->C;
@@ -2634,10 +2895,9 @@ static void h2_wgrad_plan_shared(const mqConvDesc *d, H2Wgrad &g)
     g.K = d->K;
     g.RS = d->R * d->S;
     g.RSC = g.RS * d->C;
-    g.nKt = (int)cdiv(g.K, 192);
-    g.nCt = d->R * (d->C / 128);
+    g.nKt = (int)cdiv(g.K, bmk);
+    g.nCt = d->R * (d->C / chk);
     const int64_t tiles = (int64_t)g.nKt * g.nCt * d->groups;
-    const int64_t slots = 256;
     int64_t max_splits = cdiv(g.Mtot, 64 * 16);
     if (max_splits > 512) max_splits = 512;
     if (max_splits < 1) max_splits = 1;
@@ -2674,6 +2934,12 @@ extern "C" size_t mq_conv_wgrad_h2_workspace(const mqConvDesc *d)
         h2_wgrad_plan_shared(d, gs);
         if (gs.splits > g.splits) g.splits = gs.splits;
     }
+    if (h2_wgrad_shared96_shape(d)) {
+        H2Wgrad gs;
+        const int rg = d->K % 192 == 0 ? 2 : 1;
+        h2_wgrad_plan_shared(d, gs, 96 * rg, 96, rg == 1 ? 512 : 256);
+        if (gs.splits > g.splits) g.splits = gs.splits;
+    }
     const size_t slabs = g.splits > 1 ? (size_t)g.splits * d->groups * g.K * g.RSC * sizeof(float) : 0;
     return slabs + (size_t)1024 * d->groups * g.K * sizeof(float);          // + column-sum partials of the bias gradient
 }
@@ -2689,7 +2955,11 @@ extern "C" int mq_conv_wgrad_h2(const mqConvDesc *d, const uint16_t *x, const ui
     H2Wgrad g;
     int wm = 0, tm = 0;
     const bool shared = h2_wgrad_shared_shape(d) && getenv("MQGAN_H2_NO_SHARE") == nullptr && getenv("MQGAN_H2_NO_SHARE_WGRAD") == nullptr;
+    // MQGAN_H2_NO_WGRAD96=1: the 96-channel layers back on the gathered tiles of conv_wgrad_h2_kernel (A/B runs; read per call)
+    const bool shared96 = h2_wgrad_shared96_shape(d) && getenv("MQGAN_H2_NO_SHARE") == nullptr && getenv("MQGAN_H2_NO_WGRAD96") == nullptr;
+    const int rg96 = d->K % 192 == 0 ? 2 : 1;
     if (shared) h2_wgrad_plan_shared(d, g);
+    else if (shared96) h2_wgrad_plan_shared(d, g, 96 * rg96, 96, rg96 == 1 ? 512 : 256);
     else h2_wgrad_plan(d, g, wm, tm);
     hipStream_t st = S(stream);
     const size_t n = (size_t)d->groups * g.K * g.RSC;
@@ -2712,7 +2982,13 @@ extern "C" int mq_conv_wgrad_h2(const mqConvDesc *d, const uint16_t *x, const ui
 #define MQ_WH2(WM_, TM_, WR_) do { kname("conv_wgrad_h2_kernel<%d, %d, %d, %s>", WM_, TM_, WR_, tf(false)); hipLaunchKernelGGL((conv_wgrad_h2_kernel<WM_, TM_, WR_, false>), grid, block, 0, st, x, dy, target, bias_slab, g, d->groups); } while (0)
 #endif
 #define MQ_WH(WM_, TM_) do { if (wraps == 1) MQ_WH2(WM_, TM_, 1); else MQ_WH2(WM_, TM_, 4); } while (0)
-    if (shared) {
+    if (shared96) {
+        const dim3 blk(192 * rg96);
+#define MQ_W96(RG_, WR_) do { kname("conv_wgrad_h2s96_kernel<%d, %d>", RG_, WR_); hipLaunchKernelGGL((conv_wgrad_h2s96_kernel<RG_, WR_>), grid, blk, 0, st, x, dy, target, bias_slab, g, d->groups); } while (0)
+        if (rg96 == 1) { if (d->Q + 2 >= 64) MQ_W96(1, 1); else MQ_W96(1, 4); }
+        else { if (d->Q + 2 >= 64) MQ_W96(2, 1); else MQ_W96(2, 4); }
+#undef MQ_W96
+    } else if (shared) {
         if (d->Q + 2 >= 64) { kname("conv_wgrad_h2s_kernel<%d>", 1); hipLaunchKernelGGL((conv_wgrad_h2s_kernel<1>), grid, block, 0, st, x, dy, target, bias_slab, g, d->groups); }
         else { kname("conv_wgrad_h2s_kernel<%d>", 4); hipLaunchKernelGGL((conv_wgrad_h2s_kernel<4>), grid, block, 0, st, x, dy, target, bias_slab, g, d->groups); }
     } else if (wm == 4) MQ_WH(4, 2);

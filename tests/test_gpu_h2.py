@@ -114,8 +114,14 @@ def test_h2_fprop_dgrad_wgrad_vs_float64(env, c):
         dw, db = ops.conv_wgrad_h2(desc, xh, rh, tuple(wk.shape), True)
         shared = (c["S"] == 3 and c.get("stride", (1, 1)) == (1, 1) and c.get("dil", (1, 1))[1] == 1 and c["C"] % 128 == 0 and
                   c["K"] % 192 == 0 and desc.Q >= 14)
+        # r6: what the 128-channel form does not take of the 96-channel-chunk layers goes to conv_wgrad_h2s96_kernel<RG, .>
+        shared96 = (c["S"] == 3 and c.get("stride", (1, 1)) == (1, 1) and c.get("dil", (1, 1))[1] == 1 and c["C"] % 96 == 0 and
+                    c["K"] % 96 == 0 and desc.Q >= 14 and not shared)
         last = ops.L().mq_last_kernel().decode()
         assert last.startswith("conv_wgrad_h2s_kernel") == shared, (last, shared)       # the shared-row kernel takes exactly these
+        assert last.startswith("conv_wgrad_h2s96_kernel") == shared96, (last, shared96)
+        if shared96:
+            assert last.startswith("conv_wgrad_h2s96_kernel<%d, " % (2 if c["K"] % 192 == 0 else 1)), last
         # bring dw (KRSC, channel-blocked) back to the reference layout through the weight-prep backward
         G = c.get("groups", 1)
         dws = []
@@ -379,8 +385,17 @@ def test_h2_full_size_96_channel_level(env, Cc, K):
     assert ops.L().mq_last_kernel().decode().startswith("conv_h2s96") == (K % 96 == 0 and K % 64 != 0)
     assert torch.equal(dx[N - 1], dx[0])
     xf = x.float().requires_grad_(True)
-    (ops.conv(xf, wk, wc, None, d) * r.float()).sum().backward()
+    wkf = wk.clone().requires_grad_(True)
+    (ops.conv(xf, wkf, wc, None, d) * r.float()).sum().backward()
     assert float((dx - xf.grad).abs().max()) / float(xf.grad.pow(2).mean().sqrt()) < 2e-5
+    # the weight gradient of the level: conv_wgrad_h2s96_kernel<1, 1> (K = 96: 96-row tiles, one-wrap walk over 146 padded columns,
+    # hundreds of splits) against the f32-tensor engine's, 2.36 M pixel terms per weight; and its bias gradient against a plain sum
+    dw, db = ops.conv_wgrad_h2(d, x, r, tuple(wk.shape), True)
+    assert ops.L().mq_last_kernel().decode() == "conv_wgrad_h2s96_kernel<1, 1>"
+    assert float((dw - wkf.grad).abs().max()) / float(wkf.grad.pow(2).mean().sqrt()) < 1e-3
+    assert float((dw - wkf.grad).pow(2).sum().sqrt()) / float(wkf.grad.pow(2).sum().sqrt()) < 1e-4
+    db_ref = r.float().sum(dim=(0, 1, 2), dtype=torch.float64)
+    assert float((db.double() - db_ref).abs().max()) / float(db_ref.pow(2).mean().sqrt()) < 1e-4
 
 
 def test_h2_random_shapes_against_float64():

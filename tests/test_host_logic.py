@@ -166,7 +166,7 @@ def test_bench_traffic_lookup_is_tied_to_the_kernel_sources(tmp_path, monkeypatc
     assert t is None and "stale" in src
     assert bench.peak_of("conv_h2_kernel<3, 2, 64, false, true>") == bench.PEAK_BF16_MFMA_TFLOPS
     for name in ("conv_h2s_kernel<3, 3, false>", "conv_h2s96q_kernel<3>", "conv_h2s96_kernel<3>", "conv_h2_small_kernel<2, 32>",
-                 "conv_wgrad_h2s_kernel<1>"):
+                 "conv_wgrad_h2s_kernel<1>", "conv_wgrad_h2s96_kernel<1, 1>"):
         assert bench.peak_of(name) == bench.PEAK_BF16_MFMA_TFLOPS, name
     assert bench.peak_of("conv_nt_kernel<128, false, 3>") == bench.PEAK_F32_MFMA_TFLOPS
 
