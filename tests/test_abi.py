@@ -107,6 +107,23 @@ def test_collective_entry_points_resolve_rccl_and_validate_on_the_host(built):
     assert "rccl" not in needed and "nccl" not in needed
 
 
+def test_header_is_strict_c99_and_the_plain_c_consumer_builds(built, tmp_path):
+    """The boundary is a C ABI: include/mqgan_hip.h compiles as ISO C99 (-pedantic -Werror, gcc - no C++, no HIP, no torch in it),
+    and examples/c_consumer (codebook search + planned convolution + the RCCL exchange from a C program) builds against the
+    library with gcc.  tests/test_gpu_c_consumer.py runs it."""
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "mqgan_hip.h"\nint main(void) { mqConvPlan p; (void)p; return mq_abi_version() == 11 ? 0 : 1; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), "-fsyntax-only", str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    ex = os.path.join(ROOT, "examples", "c_consumer")
+    subprocess.run(["make", "-s", "-C", ex, "clean"], check=True)
+    r = subprocess.run(["make", "-s", "-C", ex], capture_output=True, text=True)
+    assert r.returncode == 0 and os.path.exists(os.path.join(ex, "c_consumer")), r.stderr[-2000:]
+    needed = subprocess.run(["readelf", "-d", os.path.join(ex, "c_consumer")], capture_output=True, text=True).stdout
+    assert "libmqgan_hip.so" in needed and "torch" not in needed and "python" not in needed and "stdc++" not in needed, needed
+
+
 def test_planned_calls_validate_on_the_host(built):
     """mq_conv_plan / mq_conv_*_planned: struct layouts agree between the header and ctypes (the plan echoes the descriptor),
     and the planned calls refuse a short workspace or a plan / epilogue mismatch before any launch."""
