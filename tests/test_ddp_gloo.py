@@ -32,7 +32,26 @@ class Net(torch.nn.Module):
         return self.c(torch.tanh(self.b(torch.relu(self.a(x))))) * self.scale
 
 
-def _worker(rank, world, port, out_q, gather=False):
+class AsyncBucketDouble:
+    """A communicator with comm.RcclAbiComm's BUCKET interface (``buckets_async``, ``all_reduce_async`` -> handle with wait()),
+    carried by gloo so that two CPU ranks can drive the branch of GradReducer that hands its buckets to mq_allreduce_bucket on
+    the GPU (one forced rank there: tests/test_gpu_exchange.py)."""
+    buckets_async = True
+
+    def __init__(self):
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.calls = 0
+
+    @property
+    def active(self):
+        return self.world > 1
+
+    def all_reduce_async(self, t):
+        self.calls += 1
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+
+
+def _worker(rank, world, port, out_q, gather=False, abi=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -41,8 +60,10 @@ def _worker(rank, world, port, out_q, gather=False):
         net = Net()
         arena = FlatArena([net], gather=gather)
         broadcast_arena(arena)
-        red = GradReducer(arena, bucket_bytes=1024, tail_bytes=64)  # several buckets, tapering towards the front of the arena
+        double = AsyncBucketDouble() if abi else None
+        red = GradReducer(arena, bucket_bytes=1024, tail_bytes=64, comm=double)  # several buckets, tapering towards the front of the arena
         assert len(red.buckets) >= 3
+        assert red.enabled and (red._abi is double) and red.world == world and red.comm is None
         launched_during_backward = []
         orig = red._launch
         red._launch = lambda b: (launched_during_backward.append(b), orig(b))[1]
@@ -56,6 +77,8 @@ def _worker(rank, world, port, out_q, gather=False):
             n_hook = len(launched_during_backward)
             red.finish()
             results.append((arena.flat_grad.clone(), n_hook))
+        if abi:                                      # every bucket of both steps went through the communicator's own all-reduce
+            assert double.calls == 2 * len(red.buckets), (double.calls, len(red.buckets))
         # every parameter still aliases the arena and .grad views were filled in place (gather mode: the gradients stay in
         # autograd's own tensors and were copied into the arena bucket by bucket)
         for p, o in zip(arena.params, arena.offsets):
@@ -67,13 +90,14 @@ def _worker(rank, world, port, out_q, gather=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("gather", [False, True])
-def test_bucketed_allreduce_world2(gather):
+@pytest.mark.parametrize("gather,abi", [(False, False), (True, False), (True, True)],
+                         ids=["torch.distributed", "torch.distributed-gather", "async-bucket communicator (the C ABI route)"])
+def test_bucketed_allreduce_world2(gather, abi):
     world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, gather)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, gather, abi)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=60) for _ in range(world)]
